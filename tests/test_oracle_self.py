@@ -1,0 +1,135 @@
+"""Oracle self-consistency: each restated function against an independent
+brute-force statement of the same definition (numpy / pure Python, small sizes)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from phylonium_amd import synth
+
+
+def brute_longest_match(S: bytes, q: bytes):
+    """(l, count, first position) of the longest prefix of q occurring in S."""
+    best = 0
+    for l in range(len(q), 0, -1):
+        if S.find(q[:l]) >= 0:
+            best = l
+            break
+    if best == 0:
+        return 0, len(S), -1
+    cnt, pos, start = 0, -1, 0
+    while True:
+        k = S.find(q[:best], start)
+        if k < 0:
+            break
+        cnt += 1
+        pos = k if pos < 0 else pos
+        start = k + 1
+    return best, cnt, pos
+
+
+def test_seqcmp_against_numpy():
+    rng = np.random.default_rng(1)
+    alpha = np.frombuffer(b"ACGT!", np.uint8)
+    a = rng.choice(alpha, 5000, p=[.24, .24, .24, .24, .04])
+    b = a.copy()
+    idx = rng.random(5000) < 0.2
+    b[idx] = rng.choice(alpha, int(idx.sum()))
+    for n in list(range(0, 70)) + [255, 256, 257, 1000, 4999]:
+        for off in (0, 1, 3):
+            x, y = a[off:off + n], b[off:off + n]
+            n = len(x)
+            assert O.seqcmp(x, y, n) == int((x != y).sum())
+            want = int((((x ^ y[::-1]) & 6) != 4).sum())
+            assert O.revseqcmp(x, y, n) == want
+
+
+def test_bang_is_A_under_revseqcmp():
+    # '!' & 6 == 'A' & 6 == 0: revseqcmp treats '!' like 'A' (libs/revseqcmp.h:19-23)
+    assert O.revseqcmp(b"!", b"T", 1) == 0
+    assert O.revseqcmp(b"T", b"!", 1) == 0
+    assert O.revseqcmp(b"!", b"!", 1) == 1
+    assert O.seqcmp(b"!", b"A", 1) == 1 and O.seqcmp(b"!", b"!", 1) == 0
+
+
+def test_suffix_array_sorted():
+    rng = np.random.default_rng(2)
+    for n in (1, 2, 50, 3000):
+        s = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), n))
+        S = s + b"#" + O.revcomp(s)
+        sa = O.suffix_array(S)
+        assert sorted(sa.tolist()) == list(range(len(S)))
+        for a, b in zip(sa[:-1], sa[1:]):
+            assert S[a:] < S[b:]
+    # low complexity + contig separators
+    S = b"AAAAAAAAAA!AAAAACCCCC!AAAA" + b"#" + O.revcomp(b"AAAAAAAAAA!AAAAACCCCC!AAAA")
+    sa = O.suffix_array(S)
+    for a, b in zip(sa[:-1], sa[1:]):
+        assert S[a:] < S[b:]
+
+
+@pytest.mark.parametrize("seed,n,contigs", [(3, 400, 1), (4, 2000, 1), (5, 1500, 4)])
+def test_esa_match_is_longest_prefix(seed, n, contigs):
+    rng = np.random.default_rng(seed)
+    ref = synth.split_contigs(synth.random_base(n, rng), contigs, rng).tobytes()
+    e = O.Esa(ref)
+    S = ref + b"#" + O.revcomp(ref)
+    quirks = e.cache_quirks()
+    qs = synth.mutate(np.frombuffer(ref.replace(b"!", b""), np.uint8), 0.1, rng).tobytes()
+    qs = qs[:300] + O.revcomp(qs[300:600]) + b"!" + qs[600:]
+    for start in range(0, len(qs), 7):
+        q = qs[start:start + 200]
+        for cached in (False, True):
+            l, i, j, pos = e.match(q, cached)
+            bl, cnt, bpos = brute_longest_match(S, q)
+            if cached and quirks:
+                continue  # reference quirk esa.cxx:174-199 may lengthen cached matches
+            assert l == bl, (start, cached)
+            if bl > 0:
+                assert j - i + 1 == cnt
+                assert S[pos:pos + l] == q[:l]
+                if cnt == 1:
+                    assert pos == bpos
+    e.close()
+
+
+def test_min_anchor_length_values():
+    # probe values from SURVEY §3.2: 13 @ L=300k, 14 @ L=1M (|S| = 2L+1), gc≈0.5
+    assert O.min_anchor_length(0.025, 0.5, 600001) == 13
+    assert O.min_anchor_length(0.025, 0.5, 2000001) == 14
+
+
+def test_pair_tally_equals_position_pileup():
+    """compare(list,list) == #reference positions covered by both, and mismatches there
+    (SURVEY §3.4 equivalent formulation), incl. reverse hits and '!'."""
+    gs = synth.make_genomes(4, 6000, seed=11, d_range=(0.02, 0.15), indel_per_mbp=800,
+                            inv_frac=0.15, contigs=3, inv_len=(100, 400))
+    r = O.Run(gs, 0).process()
+    L = len(gs[0])
+    s, h = r.matrix()
+    planes = []
+    for g in range(4):
+        cov = np.zeros(L, bool)
+        raw = np.zeros(L, np.uint8)
+        rv = np.zeros(L, bool)
+        for hm in r.homologies(g):
+            ps, ln, iq = int(hm["iproj"]), int(hm["len"]), int(hm["iq"])
+            assert not cov[ps:ps + ln].any()
+            cov[ps:ps + ln] = True
+            seg = gs[g][iq:iq + ln]
+            if hm["rev"]:
+                raw[ps:ps + ln] = seg[::-1]
+                rv[ps:ps + ln] = True
+            else:
+                raw[ps:ps + ln] = seg
+        planes.append((cov, raw, rv))
+    saw_rev = any(p[2].any() for p in planes)
+    assert saw_rev
+    for i in range(4):
+        for j in range(i + 1, 4):
+            ci, ri, di = planes[i]
+            cj, rj, dj = planes[j]
+            both = ci & cj
+            same_dir = di == dj
+            mm = np.where(same_dir, ri != rj, ((ri ^ rj) & 6) != 4)
+            assert int(both.sum()) == int(h[i, j])
+            assert int((mm & both).sum()) == int(s[i, j])
