@@ -1,0 +1,137 @@
+/* phylonium_amd.h — C ABI of the MI355X-native anchor + pairwise-compare path.
+ *
+ * Drop-in boundary for phylonium's hot path.  The reference has no FFI; its
+ * natural seams and what replaces each one here:
+ *
+ *   B2  std::vector<evo_model> process(const sequence &subject,
+ *                                      const std::vector<sequence> &queries)
+ *       /root/reference/src/process.h:12, src/process.cxx:408-556
+ *         → phylo_set_genomes + phylo_set_reference + phylo_anchor +
+ *           phylo_compare_all   (or phylo_process, all four in one call)
+ *   B1  evo_model::{account, account_rev, operator+=, estimate_*}
+ *       src/evo_model.h:27-36, src/evo_model.cxx:53-131
+ *         → the two uint64 tallies per pair written by phylo_compare_*;
+ *           phylo_estimate for the host-side distance formulas
+ *   B0  size_t seqcmp(const char*, const char*, size_t)      libs/seqcmp.h:14
+ *       size_t revseqcmp(const char*, const char*, size_t)   libs/revseqcmp.h:25
+ *         → phylo_seqcmp / phylo_revseqcmp (same signature, host pointers) and
+ *           phylo_seqcmp_batch over device-resident genomes
+ *
+ * Conventions: plain pointers and sizes, no C++ or torch types.  Every int
+ * function returns 0 on success and nonzero on error; the library never calls
+ * exit().  phylo_last_error() gives the message.  One host thread drives a
+ * context; the library owns its HIP stream; contexts are independent.
+ * All compute runs on the GPU — there is no CPU fallback; without a usable
+ * device phylo_ctx_create fails.
+ */
+#ifndef PHYLONIUM_AMD_H
+#define PHYLONIUM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct phylo_ctx phylo_ctx;
+
+/* Same fields as class homology, src/process.h:18-26. direction: 0 forward,
+ * 1 reverse (homology::dir). */
+typedef struct phylo_homology {
+	uint64_t index_reference;
+	uint64_t index_reference_projected;
+	uint64_t index_query;
+	uint64_t length;
+	int32_t direction;
+	int32_t _pad;
+} phylo_homology;
+
+/* flags for phylo_process (src/global.h:7-16) */
+#define PHYLO_COMPLETE_DELETION 4
+
+/* ── context ── */
+int phylo_ctx_create(phylo_ctx **out, int device);
+void phylo_ctx_destroy(phylo_ctx *ctx);
+/* ctx may be NULL: last error of a failed phylo_ctx_create on this thread. */
+const char *phylo_last_error(const phylo_ctx *ctx);
+/* Tunables, mostly for tests: "chunk" (phase-A chunk length, power of two),
+ * "kmer" (bucket k), "profile" (1: time every kernel with HIP events),
+ * "compare_backend" (0 pileup, 1 segment list). */
+int phylo_set_option(phylo_ctx *ctx, const char *key, long value);
+/* Accumulated since the last phylo_reset_stats: "ms:<kernel>", "n:<kernel>"
+ * (HIP-event time and launch count per kernel when profiling is on),
+ * "ms:anchor_total", "ms:compare_total", "ms:host_sort_filter",
+ * "bytes:compare_sites", ... Returns nonzero for an unknown key. */
+int phylo_get_stat(phylo_ctx *ctx, const char *key, double *out);
+int phylo_reset_stats(phylo_ctx *ctx);
+/* NUL-separated list of stat keys, double-NUL terminated; returns bytes needed. */
+size_t phylo_stat_keys(phylo_ctx *ctx, char *buf, size_t cap);
+
+/* ── genomes: `queries` of process(), src/process.cxx:408-409 ──
+ * Bytes are the joined sequences as phylonium holds them: A,C,G,T with '!'
+ * between contigs (src/sequence.cxx:171-199). Copied to the device. */
+int phylo_set_genomes(phylo_ctx *ctx, size_t n, const char *const *seq, const size_t *len);
+/* Same, for genomes already resident in device memory (one allocation;
+ * genome j at dev_base+offsets[j], offsets multiples of 64, each genome
+ * followed by at least 64 zero bytes). Borrowed until the next set_genomes
+ * or destroy. */
+int phylo_set_genomes_device(phylo_ctx *ctx, size_t n, const void *dev_base, const uint64_t *offsets,
+							 const uint64_t *lens);
+
+/* ── reference: `esa ref(subject)` + threshold, src/process.cxx:413-417 ──
+ * sa: suffix array of S = subject + '#' + revcomp(subject), 2L+1 entries,
+ * exactly what divsufsort64 returns at src/esa.cxx:74; NULL builds it on the
+ * host cores (SA-IS). threshold 0 computes
+ * min_anchor_length(0.025, gc, 2L+1) as src/process.cxx:416-417. */
+int phylo_set_reference(phylo_ctx *ctx, size_t ref_idx, const int64_t *sa, size_t threshold);
+size_t phylo_threshold(const phylo_ctx *ctx);
+
+/* ── phase A: anchor_homologies + sort + filter_overlaps_max for queries
+ * [q_begin, q_end), src/process.cxx:433-458 ── */
+int phylo_anchor(phylo_ctx *ctx, size_t q_begin, size_t q_end);
+/* ctx-owned result of phase A (or of phylo_set_homologies) for genome j. */
+int phylo_get_homologies(phylo_ctx *ctx, size_t j, const phylo_homology **h, size_t *n);
+/* Install lists computed elsewhere (another rank). */
+int phylo_set_homologies(phylo_ctx *ctx, size_t j, const phylo_homology *h, size_t n);
+/* complete_delete over all genomes' lists, src/process.cxx:467-469,725-776 (host). */
+int phylo_complete_delete(phylo_ctx *ctx);
+
+/* ── phase B: the pair grid, src/process.cxx:517-549 ──
+ * subst / homologs: caller-owned N*N row-major; every pair (i<j) of this part
+ * is written at [i*N+j] and [j*N+i]; everything else is set to 0. Parts
+ * partition the pair grid (part in [0,nparts)); summing the outputs of all
+ * parts gives the full matrix. */
+int phylo_compare(phylo_ctx *ctx, size_t part, size_t nparts, uint64_t *subst, uint64_t *homologs);
+int phylo_compare_all(phylo_ctx *ctx, uint64_t *subst, uint64_t *homologs);
+
+/* ── B2 in one call ── */
+int phylo_process(phylo_ctx *ctx, size_t ref_idx, int flags, uint64_t *subst, uint64_t *homologs);
+
+/* ── B0 ── */
+size_t phylo_seqcmp(const char *begin, const char *other, size_t length);
+size_t phylo_revseqcmp(const char *begin, const char *other, size_t length);
+/* n segments over the resident genomes: compare genome ga[s] at offa[s] with
+ * genome gb[s] at offb[s] for len[s] bytes; rev[s] != 0 uses revseqcmp
+ * semantics (offb is the start of the reversed window, as in
+ * evo_model::account_rev, src/evo_model.cxx:68-75). */
+int phylo_seqcmp_batch(phylo_ctx *ctx, size_t n, const uint32_t *ga, const uint64_t *offa,
+					   const uint32_t *gb, const uint64_t *offb, const uint64_t *len, const uint8_t *rev,
+					   uint64_t *out);
+
+/* ── host-side helpers (no GPU) ── */
+int phylo_host_suffix_array(const char *s, size_t n, int64_t *sa);
+size_t phylo_host_min_anchor_length(double p, double gc, size_t l);
+/* std::sort by projected start + filter_overlaps_max, in place; returns new n */
+size_t phylo_host_sort_filter(phylo_homology *h, size_t n, int do_sort);
+/* kind: 0 Jukes-Cantor, 1 raw, 2 ANI (src/evo_model.cxx:100-131) */
+double phylo_estimate(int kind, uint64_t subst, uint64_t homologs, int zero_on_error);
+/* PHYLIP text of src/io.cxx:141-163; returns bytes needed including NUL */
+size_t phylo_format_phylip(size_t n, const char *const *names, const uint64_t *subst,
+						   const uint64_t *homologs, int kind, char *out, size_t cap);
+const char *phylo_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,456 @@
+// hostlogic.hpp — host-side (CPU) pieces of the path that the north star keeps
+// on the host cores: suffix-array construction, the index tables derived from
+// it, the anchor threshold, and the per-query sort + chain filter whose result
+// depends on libstdc++'s std::sort tie order.
+//
+// Citations are to /root/reference.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/phylonium_amd.h"
+#include "anchor_core.h"
+
+namespace phy {
+
+// ───────────────────────── suffix array: SA-IS ─────────────────────────
+// Induced sorting (Nong, Zhang & Chan 2009).  Stands in for
+// divsufsort64 (src/esa.cxx:74); the suffix array of a string is unique, so the
+// result is the same array.  Text must end in a unique smallest symbol 0.
+
+template <class Ch>
+static void sais_buckets(const Ch *s, int32_t n, int32_t K, std::vector<int32_t> &bkt, bool end)
+{
+	std::fill(bkt.begin(), bkt.begin() + K, 0);
+	for (int32_t i = 0; i < n; i++) bkt[(size_t)s[i]]++;
+	int32_t sum = 0;
+	for (int32_t c = 0; c < K; c++) {
+		sum += bkt[(size_t)c];
+		bkt[(size_t)c] = end ? sum : sum - bkt[(size_t)c];
+	}
+}
+
+template <class Ch>
+static void sais_induce(const Ch *s, int32_t *SA, int32_t n, int32_t K, const std::vector<uint8_t> &stype,
+						std::vector<int32_t> &bkt)
+{
+	sais_buckets(s, n, K, bkt, false);
+	for (int32_t i = 0; i < n; i++) { // L-type, left to right
+		int32_t j = SA[i] - 1;
+		if (SA[i] > 0 && !stype[(size_t)j]) SA[bkt[(size_t)s[j]]++] = j;
+	}
+	sais_buckets(s, n, K, bkt, true);
+	for (int32_t i = n - 1; i >= 0; i--) { // S-type, right to left
+		int32_t j = SA[i] - 1;
+		if (SA[i] > 0 && stype[(size_t)j]) SA[--bkt[(size_t)s[j]]] = j;
+	}
+}
+
+template <class Ch> static void sais_main(const Ch *s, int32_t *SA, int32_t n, int32_t K)
+{
+	if (n == 1) {
+		SA[0] = 0;
+		return;
+	}
+	std::vector<uint8_t> stype((size_t)n);
+	stype[(size_t)n - 1] = 1;
+	for (int32_t i = n - 2; i >= 0; i--)
+		stype[(size_t)i] = (s[i] < s[i + 1] || (s[i] == s[i + 1] && stype[(size_t)i + 1])) ? 1 : 0;
+	auto is_lms = [&](int32_t i) { return i > 0 && stype[(size_t)i] && !stype[(size_t)i - 1]; };
+
+	std::vector<int32_t> bkt((size_t)K);
+	// 1. sort LMS substrings
+	sais_buckets(s, n, K, bkt, true);
+	std::fill(SA, SA + n, -1);
+	for (int32_t i = 1; i < n; i++)
+		if (is_lms(i)) SA[--bkt[(size_t)s[i]]] = i;
+	sais_induce(s, SA, n, K, stype, bkt);
+	int32_t n1 = 0;
+	for (int32_t i = 0; i < n; i++)
+		if (is_lms(SA[i])) SA[n1++] = SA[i];
+	std::fill(SA + n1, SA + n, -1);
+	int32_t name = 0, prev = -1;
+	for (int32_t i = 0; i < n1; i++) {
+		int32_t pos = SA[i];
+		bool diff = false;
+		if (prev < 0) {
+			diff = true;
+		} else {
+			for (int32_t d = 0;; d++) {
+				if (s[pos + d] != s[prev + d] || stype[(size_t)(pos + d)] != stype[(size_t)(prev + d)]) {
+					diff = true;
+					break;
+				}
+				if (d > 0 && (is_lms(pos + d) || is_lms(prev + d))) break;
+			}
+		}
+		if (diff) {
+			name++;
+			prev = pos;
+		}
+		SA[n1 + (pos >> 1)] = name - 1;
+	}
+	for (int32_t i = n - 1, j = n - 1; i >= n1; i--)
+		if (SA[i] >= 0) SA[j--] = SA[i];
+	// 2. order the LMS suffixes
+	int32_t *SA1 = SA, *s1 = SA + n - n1;
+	if (name < n1) {
+		sais_main<int32_t>(s1, SA1, n1, name);
+	} else {
+		for (int32_t i = 0; i < n1; i++) SA1[s1[i]] = i;
+	}
+	// 3. induce the full order
+	sais_buckets(s, n, K, bkt, true);
+	for (int32_t i = 1, j = 0; i < n; i++)
+		if (is_lms(i)) s1[j++] = i;
+	for (int32_t i = 0; i < n1; i++) SA1[i] = s1[SA1[i]];
+	std::fill(SA + n1, SA + n, -1);
+	for (int32_t i = n1 - 1; i >= 0; i--) {
+		int32_t j = SA[i];
+		SA[i] = -1;
+		SA[--bkt[(size_t)s[j]]] = j;
+	}
+	sais_induce(s, SA, n, K, stype, bkt);
+}
+
+// Suffix array of the n bytes of `s` in unsigned-byte order (shorter suffix
+// first), as divsufsort returns it.  n < 2^31 - 1.
+static inline void suffix_array_u32(const uint8_t *s, uint32_t n, uint32_t *sa_out)
+{
+	if (n == 0) return;
+	// dense-rank the alphabet so the bucket array stays small; 0 = sentinel
+	int32_t rank[256];
+	bool seen[256] = {false};
+	for (uint32_t i = 0; i < n; i++) seen[s[i]] = true;
+	int32_t K = 1;
+	for (int c = 0; c < 256; c++) rank[c] = seen[c] ? K++ : 0;
+	std::vector<uint8_t> t((size_t)n + 1);
+	for (uint32_t i = 0; i < n; i++) t[i] = (uint8_t)rank[s[i]];
+	t[n] = 0;
+	std::vector<int32_t> SA((size_t)n + 1);
+	sais_main<uint8_t>(t.data(), SA.data(), (int32_t)n + 1, K);
+	for (uint32_t i = 0; i < n; i++) sa_out[i] = (uint32_t)SA[(size_t)i + 1]; // SA[0] is the sentinel
+}
+
+// LCP[r] = lcp(suffix SA[r-1], suffix SA[r]) for r in 1..n-1, LCP[0] = LCP[n] = 0
+// (Kasai et al.; the reference's init_LCP, src/esa.cxx:305-347, computes the same
+// values with the Φ variant and stores -1 at both ends).
+static inline void lcp_kasai(const uint8_t *s, uint32_t n, const uint32_t *sa, uint32_t *lcp)
+{
+	std::vector<uint32_t> rnk((size_t)n);
+	for (uint32_t r = 0; r < n; r++) rnk[sa[r]] = r;
+	uint32_t h = 0;
+	lcp[0] = 0;
+	lcp[n] = 0;
+	for (uint32_t i = 0; i < n; i++) {
+		uint32_t r = rnk[i];
+		if (r == 0) {
+			h = 0;
+			continue;
+		}
+		uint32_t j = sa[r - 1];
+		while (i + h < n && j + h < n && s[i + h] == s[j + h]) h++;
+		lcp[r] = h;
+		if (h) h--;
+	}
+}
+
+// Bucket table: T[c] = number of suffixes of s lexicographically smaller than
+// the k-mer with code c (A<C<G<T, 2 bits each), c in [0,4^k]; T[4^k] = n.
+// Suffixes that hit a non-ACGT byte ('!', '#') or the end of s inside their
+// first k bytes sort before every k-mer sharing their ACGT prefix, because
+// those bytes are < 'A'.
+static inline void kmer_table(const uint8_t *s, uint32_t n, uint32_t k, std::vector<uint32_t> &T)
+{
+	size_t buckets = (size_t)1 << (2 * k);
+	T.assign(buckets + 1, 0);
+	uint32_t code = 0, run = 0;
+	for (uint32_t ii = n; ii-- > 0;) {
+		uint32_t v = nuc_code(s[ii]);
+		if (v > 3) {
+			run = 0;
+			v = 0;
+		} else if (run < k) {
+			run++;
+		}
+		code = (v << (2 * (k - 1))) | (code >> 2);
+		if (run >= k) {
+			T[(size_t)code + 1]++;
+		} else {
+			uint32_t low = 2 * (k - run);
+			uint32_t b = (low >= 32) ? 0u : (code >> low) << low;
+			T[b]++;
+		}
+	}
+	uint32_t sum = 0;
+	for (size_t c = 0; c <= buckets; c++) {
+		sum += T[c];
+		T[c] = sum;
+	}
+}
+
+static inline uint32_t choose_k(uint32_t n)
+{
+	// about one suffix per bucket, capped so the table (4^k+1 u32) stays modest
+	uint32_t k = 1;
+	while (k < 13 && ((uint64_t)1 << (2 * (k + 1))) <= (uint64_t)n) k++;
+	return k;
+}
+
+// ───────────────────────── anchor threshold ─────────────────────────
+// src/process.cxx:77-161 (Haubold et al. 2009 shustring distribution).
+
+static inline size_t binomial_coefficient(size_t n, size_t k)
+{
+	if (n <= 0 || k > n) return 0;
+	if (k == 0 || k == n) return 1;
+	if (k > n - k) k = n - k;
+	size_t res = 1;
+	for (size_t i = 1; i <= k; i++) {
+		res *= n - k + i;
+		res /= i;
+	}
+	return res;
+}
+
+static inline double shuprop(size_t x, double p, size_t l)
+{
+	double xx = (double)x, ll = (double)l, s = 0.0;
+	for (size_t k = 0; k <= x; k++) {
+		double kk = (double)k;
+		double t = pow(p, kk) * pow(0.5 - p, xx - kk);
+		s += pow(2, xx) * (t * pow(1 - t, ll)) * (double)binomial_coefficient(x, k);
+		if (s >= 1.0) {
+			s = 1.0;
+			break;
+		}
+	}
+	return s;
+}
+
+static inline size_t min_anchor_length(double p, double g, size_t l)
+{
+	size_t x = 1;
+	while (shuprop(x, g / 2, l) < 1 - p) x++;
+	return x;
+}
+
+// src/sequence.cxx:152-165
+static inline double gc_content(const uint8_t *s, size_t n)
+{
+	size_t gc = 0;
+	for (size_t i = 0; i < n; i++)
+		if ((s[i] & 'G' & 'C') == ('G' & 'C')) gc++;
+	return (double)gc / (double)n;
+}
+
+// src/sequence.cxx:73-103
+static inline void revcomp(const uint8_t *in, size_t n, uint8_t *out)
+{
+	for (size_t k = 0; k < n; k++) {
+		uint8_t c = in[n - k - 1];
+		out[k] = (c < 'A') ? c : (uint8_t)(c ^ ((c & 2) ? 4 : 21));
+	}
+}
+
+// ───────────────────────── homologies on the host ─────────────────────────
+
+// homology::reverseEh, src/process.h:72-80. `border` = L = ref.size()/2.
+static inline phylo_homology project_homology(const RawHom &r, uint64_t border)
+{
+	phylo_homology h;
+	h.index_reference = r.iref;
+	h.index_reference_projected = r.iref;
+	h.index_query = r.iq;
+	h.length = r.len;
+	h.direction = 0;
+	h._pad = 0;
+	if (h.index_reference >= border) {
+		h.index_reference_projected = 2 * border + 1 - h.length - h.index_reference;
+		h.direction = 1;
+	}
+	return h;
+}
+
+// filter_overlaps_max, src/process.cxx:354-401, in O(n log n).
+// The reference's O(n²) scan picks, for each i, the smallest k with the largest
+// score among {k < i : end[k] <= start[i]}.  Because the pile is sorted by start
+// and every length is positive, end[k] <= start[i] already implies k < i, so the
+// candidates are a prefix of the pile ordered by end; a running (max score,
+// smallest index) over that order gives the same predecessor.
+static inline void filter_overlaps_max(std::vector<phylo_homology> &pile)
+{
+	size_t n = pile.size();
+	if (n < 2) return;
+	std::vector<uint32_t> by_end(n);
+	for (size_t i = 0; i < n; i++) by_end[i] = (uint32_t)i;
+	std::stable_sort(by_end.begin(), by_end.end(), [&](uint32_t a, uint32_t b) {
+		return pile[a].index_reference_projected + pile[a].length <
+			   pile[b].index_reference_projected + pile[b].length;
+	});
+	std::vector<int64_t> score(n), pred(n);
+	int64_t best = 0, best_k = -1;
+	size_t p = 0;
+	for (size_t i = 0; i < n; i++) {
+		uint64_t start_i = pile[i].index_reference_projected;
+		while (p < n) {
+			uint32_t k = by_end[p];
+			if (pile[k].index_reference_projected + pile[k].length > start_i) break;
+			if (score[k] > best || (score[k] == best && (int64_t)k < best_k)) {
+				best = score[k];
+				best_k = k;
+			}
+			p++;
+		}
+		pred[i] = best_k;
+		score[i] = (best_k >= 0 ? score[(size_t)best_k] : 0) + (int64_t)pile[i].length;
+	}
+	// std::max_element over (0, score[0..n)): first maximum
+	int64_t top = 0, idx = -1;
+	for (size_t i = 0; i < n; i++)
+		if (score[i] > top) {
+			top = score[i];
+			idx = (int64_t)i;
+		}
+	std::vector<uint8_t> keep(n, 0);
+	while (idx >= 0) {
+		keep[(size_t)idx] = 1;
+		idx = pred[(size_t)idx];
+	}
+	size_t w = 0;
+	for (size_t r = 0; r < n; r++)
+		if (keep[r]) pile[w++] = pile[r];
+	pile.resize(w);
+}
+
+// src/process.cxx:438-443 — same std::sort call on the same input order.
+static inline void sort_and_filter(std::vector<phylo_homology> &hv)
+{
+	std::sort(hv.begin(), hv.end(), [](const phylo_homology &a, const phylo_homology &b) {
+		return a.index_reference_projected < b.index_reference_projected;
+	});
+	filter_overlaps_max(hv);
+}
+
+// homology::trim, src/process.h:119-143
+static inline phylo_homology trim_homology(const phylo_homology &h, uint64_t s, uint64_t e)
+{
+	if (e <= s) return h;
+	phylo_homology t = h;
+	uint64_t hs = h.index_reference_projected, he = hs + h.length;
+	uint64_t offset = (s > hs && s < he) ? s - hs : 0;
+	uint64_t drift = (he > e && e > hs) ? he - e : 0;
+	t.index_reference_projected += offset;
+	if (h.direction == 0) {
+		t.index_reference += offset;
+		t.index_query += offset;
+	} else {
+		t.index_reference += drift;
+		t.index_query += drift;
+	}
+	t.length = h.length - offset - drift;
+	return t;
+}
+
+// complete_delete, src/process.cxx:725-776
+static inline std::vector<std::vector<phylo_homology>>
+complete_delete(const std::vector<std::vector<phylo_homology>> &H)
+{
+	size_t n = H.size();
+	std::vector<std::vector<phylo_homology>> core(n);
+	std::vector<size_t> front(n, 0);
+	for (;;) {
+		bool open = true;
+		for (size_t g = 0; g < n; g++)
+			if (front[g] >= H[g].size()) open = false;
+		if (!open || n == 0) break;
+		uint64_t cs = 0, ce = 0;
+		size_t arg = 0;
+		for (size_t g = 0; g < n; g++) {
+			const phylo_homology &h = H[g][front[g]];
+			uint64_t s = h.index_reference_projected, e = s + h.length;
+			if (g == 0 || s > cs) cs = s;
+			if (g == 0 || e < ce) {
+				ce = e;
+				arg = g;
+			}
+		}
+		if (cs < ce)
+			for (size_t g = 0; g < n; g++) core[g].push_back(trim_homology(H[g][front[g]], cs, ce));
+		front[arg]++;
+	}
+	return core;
+}
+
+// evo_model::estimate_*, src/evo_model.cxx:100-131
+static inline double estimate_raw(uint64_t s, uint64_t h, bool zero_on_error)
+{
+	if (h == 0) return zero_on_error ? 0.0 : NAN;
+	return s / (double)h;
+}
+static inline double estimate_ani(uint64_t s, uint64_t h, bool zero_on_error)
+{
+	if (h == 0) return zero_on_error ? 0.0 : NAN;
+	return (1.0 - s / (double)h) * 100;
+}
+static inline double estimate_jc(uint64_t s, uint64_t h, bool zero_on_error)
+{
+	double d = estimate_raw(s, h, zero_on_error);
+	d = -0.75 * log(1.0 - (4.0 / 3.0) * d);
+	return d <= 0.0 ? 0.0 : d;
+}
+
+// ───────────────────────── phase-A work layout ─────────────────────────
+
+struct ChunkPlan {
+	uint32_t C = 0, logC = 0, cap = 0, nchunks = 0;
+	std::vector<uint32_t> qchunk0;     // [nq+1]
+	std::vector<uint32_t> chunk_query; // [nchunks]
+	std::vector<uint32_t> items;       // [nchunks] round-robin over queries
+};
+
+// Chunks of C positions per query; the work order interleaves queries so the 64
+// lanes of a wavefront hold chunks of different genomes (a near-identical
+// genome's long matches are then spread over many wavefronts).
+static inline ChunkPlan plan_chunks(const std::vector<uint32_t> &qlen, uint32_t threshold, uint32_t forced_C)
+{
+	ChunkPlan P;
+	uint64_t total = 0;
+	for (uint32_t l : qlen) total += l;
+	uint32_t C = forced_C;
+	if (C == 0) {
+		// aim for ~512k chains, 512 <= C <= 8192
+		C = 512;
+		while (C < 8192 && total / C > 512 * 1024) C <<= 1;
+	}
+	while (C <= 2 * threshold + 32) C <<= 1; // chunk starts must be lucky-ineligible from (0,0,0)
+	P.C = C;
+	P.logC = 0;
+	while ((1u << P.logC) < C) P.logC++;
+	P.cap = C / (threshold + 1) + 2;
+	size_t nq = qlen.size();
+	P.qchunk0.resize(nq + 1);
+	uint32_t acc = 0, maxc = 0;
+	for (size_t j = 0; j < nq; j++) {
+		P.qchunk0[j] = acc;
+		uint32_t c = (uint32_t)(((uint64_t)qlen[j] + C - 1) / C);
+		acc += c;
+		maxc = std::max(maxc, c);
+	}
+	P.qchunk0[nq] = acc;
+	P.nchunks = acc;
+	P.chunk_query.resize(acc);
+	for (size_t j = 0; j < nq; j++)
+		for (uint32_t c = P.qchunk0[j]; c < P.qchunk0[j + 1]; c++) P.chunk_query[c] = (uint32_t)j;
+	P.items.reserve(acc);
+	for (uint32_t r = 0; r < maxc; r++)
+		for (size_t j = 0; j < nq; j++)
+			if (P.qchunk0[j] + r < P.qchunk0[j + 1]) P.items.push_back(P.qchunk0[j] + r);
+	return P;
+}
+
+} // namespace phy

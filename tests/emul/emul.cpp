@@ -1,0 +1,219 @@
+// emul.cpp — TEST INFRASTRUCTURE. Compiles the product's host/device chain code
+// (phylonium_amd/csrc/anchor_core.h, hostlogic.hpp) with g++ and runs the
+// phase-A pipeline (speculative chunks → bridges → walk + fold → sort + filter)
+// serially on the CPU, so the algorithm can be checked against the oracle in
+// the GPU-less build container.  The product library never links this file.
+#include <cstdio>
+#include <vector>
+
+#include "../../phylonium_amd/csrc/hostlogic.hpp"
+
+using namespace phy;
+
+struct EmulOut {
+	std::vector<std::vector<RawHom>> raw;
+	std::vector<std::vector<phylo_homology>> filtered;
+	uint32_t threshold, k, C, nchunks;
+	uint64_t steps_spec = 0, steps_bridge = 0, cmp_calls = 0, pool_used = 0;
+	int error = 0;
+};
+
+static CmpRes full_cmp(const CmpReq &r, uint64_t *calls)
+{
+	CmpRes out;
+	uint32_t pos = r.from;
+	(*calls)++;
+	while (!cmp_some(r, 64, &pos, &out)) {
+	}
+	return out;
+}
+
+extern "C" {
+
+void *emul_run(size_t n, const char *const *seq, const size_t *len, size_t ref_idx, size_t threshold,
+			   unsigned forced_C, unsigned forced_k)
+{
+	EmulOut *E = new EmulOut();
+	// reference index
+	size_t L = len[ref_idx];
+	uint32_t ns = (uint32_t)(2 * L + 1);
+	std::vector<uint8_t> S((size_t)ns + 64, 0);
+	memcpy(S.data(), seq[ref_idx], L);
+	S[L] = '#';
+	revcomp((const uint8_t *)seq[ref_idx], L, S.data() + L + 1);
+	std::vector<uint32_t> SA(ns), LCP((size_t)ns + 1), T;
+	suffix_array_u32(S.data(), ns, SA.data());
+	lcp_kasai(S.data(), ns, SA.data(), LCP.data());
+	uint32_t k = forced_k ? forced_k : choose_k(ns);
+	kmer_table(S.data(), ns, k, T);
+	if (threshold == 0) threshold = min_anchor_length(0.025, gc_content((const uint8_t *)seq[ref_idx], L), ns);
+	RefIndex R = {S.data(), SA.data(), LCP.data(), T.data(), ns, k, (uint32_t)threshold};
+	E->threshold = (uint32_t)threshold;
+	E->k = k;
+
+	// genomes, padded
+	std::vector<uint64_t> qoff(n);
+	std::vector<uint32_t> qlen(n);
+	uint64_t tot = 0;
+	for (size_t j = 0; j < n; j++) {
+		qoff[j] = tot;
+		qlen[j] = (uint32_t)len[j];
+		tot += ((len[j] + 63) / 64) * 64 + 64;
+	}
+	std::vector<uint8_t> qbase(tot, 0);
+	for (size_t j = 0; j < n; j++) memcpy(qbase.data() + qoff[j], seq[j], len[j]);
+
+	ChunkPlan P = plan_chunks(qlen, (uint32_t)threshold, forced_C);
+	E->C = P.C;
+	E->nchunks = P.nchunks;
+	std::vector<Anchor> spec_anchors((size_t)P.nchunks * P.cap);
+	std::vector<uint32_t> spec_cnt(P.nchunks, 0), visited((size_t)P.nchunks * (P.C / 32), 0);
+	std::vector<SpecExit> spec_exit(P.nchunks);
+	std::vector<BridgeRec> bridge(P.nchunks);
+	uint32_t pool_blocks = 1024 + P.nchunks;
+	std::vector<PoolBlock> pool(pool_blocks);
+	uint32_t pool_next = 0, error = 0, fetch[2] = {0, 0};
+	PhaseA A;
+	A.qbase = qbase.data();
+	A.qoff = qoff.data();
+	A.qlen = qlen.data();
+	A.qchunk0 = P.qchunk0.data();
+	A.items = P.items.data();
+	A.chunk_query = P.chunk_query.data();
+	A.nchunks = P.nchunks;
+	A.C = P.C;
+	A.logC = P.logC;
+	A.cap = P.cap;
+	A.spec_anchors = spec_anchors.data();
+	A.spec_cnt = spec_cnt.data();
+	A.spec_exit = spec_exit.data();
+	A.visited = visited.data();
+	A.bridge = bridge.data();
+	A.pool = pool.data();
+	A.pool_blocks = pool_blocks;
+	A.pool_next = &pool_next;
+	A.error = &error;
+	A.fetch = fetch;
+
+	CmpRes res = {0, false};
+	CmpReq req;
+	// K1: speculative chains
+	for (uint32_t it = 0; it < P.nchunks; it++) {
+		SpecLane ln;
+		ln.start(A, P.items[it]);
+		for (;;) {
+			if (ln.ch.st == ST_STEP && !ln.begin_step(A)) break;
+			if (ln.ch.advance(R, res, &req) == ADV_NEED_CMP) {
+				res = full_cmp(req, &E->cmp_calls);
+			} else {
+				ln.step_done(A);
+				E->steps_spec++;
+			}
+		}
+	}
+	// K2: bridges
+	auto alloc = [&]() -> uint32_t {
+		if (pool_next >= pool_blocks) return NO_BLOCK;
+		return pool_next++;
+	};
+	for (uint32_t it = 0; it < P.nchunks; it++) {
+		BridgeLane ln;
+		ln.start(A, P.items[it]);
+		for (;;) {
+			if (ln.ch.st == ST_STEP && !ln.begin_step(A, R)) break;
+			if (ln.ch.advance(R, res, &req) == ADV_NEED_CMP) {
+				res = full_cmp(req, &E->cmp_calls);
+			} else {
+				ln.step_done(A, alloc);
+				E->steps_bridge++;
+			}
+		}
+	}
+	E->pool_used = pool_next;
+	E->error = (int)error;
+	// K3: walk + fold, then host sort + filter
+	uint32_t border = (uint32_t)L;
+	E->raw.resize(n);
+	E->filtered.resize(n);
+	for (size_t j = 0; j < n; j++) {
+		FoldState f;
+		fold_init(&f);
+		RawHom h;
+		std::vector<RawHom> &out = E->raw[j];
+		if (P.qchunk0[j] < P.qchunk0[j + 1]) {
+			uint32_t gc = P.qchunk0[j], idx = 0;
+			for (;;) {
+				for (uint32_t t = idx; t < spec_cnt[gc]; t++)
+					if (fold_anchor(&f, spec_anchors[(size_t)gc * P.cap + t], border, R.threshold, &h))
+						out.push_back(h);
+				const BridgeRec &b = bridge[gc];
+				uint32_t blk = b.block;
+				for (uint32_t t = 0; t < b.n; t++) {
+					Anchor a;
+					if (t < BRIDGE_INLINE) {
+						a = b.a[t];
+					} else {
+						uint32_t kk = (t - BRIDGE_INLINE) % POOL_BLOCK;
+						if (kk == 0 && t != BRIDGE_INLINE) blk = pool[blk].next;
+						a = pool[blk].a[kk];
+					}
+					if (fold_anchor(&f, a, border, R.threshold, &h)) out.push_back(h);
+				}
+				if (b.target == BRIDGE_END) break;
+				gc = b.target;
+				idx = b.idx_m;
+			}
+		}
+		if (fold_finish(&f, qlen[j], R.threshold, &h)) out.push_back(h);
+		std::vector<phylo_homology> hv;
+		for (const RawHom &r : out) hv.push_back(project_homology(r, border));
+		sort_and_filter(hv);
+		E->filtered[j] = hv;
+	}
+	return E;
+}
+
+void emul_free(void *e) { delete (EmulOut *)e; }
+size_t emul_count(void *e, size_t j, int filtered)
+{
+	EmulOut *E = (EmulOut *)e;
+	return filtered ? E->filtered[j].size() : E->raw[j].size();
+}
+void emul_get_filtered(void *e, size_t j, phylo_homology *out)
+{
+	EmulOut *E = (EmulOut *)e;
+	std::copy(E->filtered[j].begin(), E->filtered[j].end(), out);
+}
+void emul_get_raw(void *e, size_t j, uint32_t *out)
+{
+	EmulOut *E = (EmulOut *)e;
+	for (size_t i = 0; i < E->raw[j].size(); i++) {
+		out[3 * i] = E->raw[j][i].iref;
+		out[3 * i + 1] = E->raw[j][i].iq;
+		out[3 * i + 2] = E->raw[j][i].len;
+	}
+}
+void emul_info(void *e, uint64_t out[8])
+{
+	EmulOut *E = (EmulOut *)e;
+	out[0] = E->threshold;
+	out[1] = E->k;
+	out[2] = E->C;
+	out[3] = E->nchunks;
+	out[4] = E->steps_spec;
+	out[5] = E->steps_bridge;
+	out[6] = E->cmp_calls;
+	out[7] = ((uint64_t)E->error << 32) | E->pool_used;
+}
+
+// host-logic entry points for CPU tests
+void emul_suffix_array(const uint8_t *s, uint32_t n, uint32_t *sa) { suffix_array_u32(s, n, sa); }
+void emul_lcp(const uint8_t *s, uint32_t n, const uint32_t *sa, uint32_t *lcp) { lcp_kasai(s, n, sa, lcp); }
+size_t emul_kmer_table(const uint8_t *s, uint32_t n, uint32_t k, uint32_t *out)
+{
+	std::vector<uint32_t> T;
+	kmer_table(s, n, k, T);
+	if (out) std::copy(T.begin(), T.end(), out);
+	return T.size();
+}
+}
