@@ -1,0 +1,282 @@
+"""ctypes binding over the C ABI (include/phylonium_amd.h).
+
+Host-side mirror of the reference's interface for the path:
+`process(subject, queries)` of /root/reference/src/process.h:12 becomes
+`Context.process(ref_idx)` returning the two N×N tallies that the reference's
+`std::vector<evo_model>` holds (src/evo_model.h:15-19).  Everything that
+computes goes through libphylonium_amd.so; if the library (or a GPU) is
+missing this module raises — there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libphylonium_amd.so")
+
+PHOM = np.dtype([("index_reference", "<u8"), ("index_reference_projected", "<u8"), ("index_query", "<u8"),
+                 ("length", "<u8"), ("direction", "<i4"), ("_pad", "<i4")])
+
+# every symbol include/phylonium_amd.h declares
+SYMBOLS = [
+    "phylo_ctx_create", "phylo_ctx_destroy", "phylo_last_error", "phylo_set_option", "phylo_get_stat",
+    "phylo_reset_stats", "phylo_stat_keys", "phylo_set_genomes", "phylo_set_genomes_device",
+    "phylo_set_reference", "phylo_threshold", "phylo_anchor", "phylo_get_homologies", "phylo_set_homologies",
+    "phylo_complete_delete", "phylo_compare", "phylo_compare_all", "phylo_process", "phylo_seqcmp",
+    "phylo_revseqcmp", "phylo_seqcmp_batch", "phylo_host_suffix_array", "phylo_host_min_anchor_length",
+    "phylo_host_sort_filter", "phylo_estimate", "phylo_format_phylip", "phylo_version",
+]
+
+_LIB = None
+
+
+class PhyloniumError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libphylonium_amd.so; raises if it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise PhyloniumError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, u64p = C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)
+    L.phylo_ctx_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.phylo_ctx_destroy.argtypes = [vp]
+    L.phylo_last_error.restype = C.c_char_p
+    L.phylo_last_error.argtypes = [vp]
+    L.phylo_set_option.argtypes = [vp, C.c_char_p, C.c_long]
+    L.phylo_get_stat.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double)]
+    L.phylo_reset_stats.argtypes = [vp]
+    L.phylo_stat_keys.restype = sz
+    L.phylo_stat_keys.argtypes = [vp, vp, sz]
+    L.phylo_set_genomes.argtypes = [vp, sz, vp, vp]
+    L.phylo_set_genomes_device.argtypes = [vp, sz, vp, vp, vp]
+    L.phylo_set_reference.argtypes = [vp, sz, vp, sz]
+    L.phylo_threshold.restype = sz
+    L.phylo_threshold.argtypes = [vp]
+    L.phylo_anchor.argtypes = [vp, sz, sz]
+    L.phylo_get_homologies.argtypes = [vp, sz, C.POINTER(vp), C.POINTER(sz)]
+    L.phylo_set_homologies.argtypes = [vp, sz, vp, sz]
+    L.phylo_complete_delete.argtypes = [vp]
+    L.phylo_compare.argtypes = [vp, sz, sz, vp, vp]
+    L.phylo_compare_all.argtypes = [vp, vp, vp]
+    L.phylo_process.argtypes = [vp, sz, C.c_int, vp, vp]
+    L.phylo_seqcmp.restype = sz
+    L.phylo_seqcmp.argtypes = [vp, vp, sz]
+    L.phylo_revseqcmp.restype = sz
+    L.phylo_revseqcmp.argtypes = [vp, vp, sz]
+    L.phylo_seqcmp_batch.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp]
+    L.phylo_host_suffix_array.argtypes = [vp, sz, vp]
+    L.phylo_host_min_anchor_length.restype = sz
+    L.phylo_host_min_anchor_length.argtypes = [C.c_double, C.c_double, sz]
+    L.phylo_host_sort_filter.restype = sz
+    L.phylo_host_sort_filter.argtypes = [vp, sz, C.c_int]
+    L.phylo_estimate.restype = C.c_double
+    L.phylo_estimate.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_int]
+    L.phylo_format_phylip.restype = sz
+    L.phylo_format_phylip.argtypes = [sz, vp, vp, vp, C.c_int, vp, sz]
+    L.phylo_version.restype = C.c_char_p
+    _LIB = L
+    return L
+
+
+def _u8(x):
+    if isinstance(x, (bytes, bytearray)):
+        return np.frombuffer(bytes(x), dtype=np.uint8)
+    return np.ascontiguousarray(x, dtype=np.uint8)
+
+
+KIND = {"jc": 0, "raw": 1, "ani": 2}
+
+
+class Context:
+    """One GPU context: genomes, a reference index, homology lists, tallies."""
+
+    def __init__(self, device=0):
+        self.L = load()
+        h = C.c_void_p()
+        if self.L.phylo_ctx_create(C.byref(h), device):
+            raise PhyloniumError(self.L.phylo_last_error(None).decode())
+        self.h = h
+        self.n = 0
+
+    def _chk(self, rc):
+        if rc:
+            raise PhyloniumError(self.L.phylo_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.phylo_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # options / stats
+    def set_option(self, key, value):
+        self._chk(self.L.phylo_set_option(self.h, key.encode(), int(value)))
+
+    def stat(self, key, default=None):
+        v = C.c_double()
+        if self.L.phylo_get_stat(self.h, key.encode(), C.byref(v)):
+            return default
+        return v.value
+
+    def stats(self):
+        need = self.L.phylo_stat_keys(self.h, None, 0)
+        buf = C.create_string_buffer(need)
+        self.L.phylo_stat_keys(self.h, buf, need)
+        keys = [k.decode() for k in buf.raw[:need].split(b"\0") if k]
+        return {k: self.stat(k) for k in keys}
+
+    def reset_stats(self):
+        self._chk(self.L.phylo_reset_stats(self.h))
+
+    # genomes
+    def set_genomes(self, genomes):
+        arrs = [_u8(g) for g in genomes]
+        n = len(arrs)
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        lens = (C.c_size_t * n)(*[a.size for a in arrs])
+        self._chk(self.L.phylo_set_genomes(self.h, n, ptrs, lens))
+        self.n = n
+        self.lengths = [a.size for a in arrs]
+
+    def set_genomes_device(self, dev_ptr, offsets, lens):
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        ln = np.ascontiguousarray(lens, dtype=np.uint64)
+        self._chk(self.L.phylo_set_genomes_device(self.h, off.size, C.c_void_p(int(dev_ptr)),
+                                                  off.ctypes.data_as(C.c_void_p), ln.ctypes.data_as(C.c_void_p)))
+        self.n = off.size
+        self.lengths = [int(x) for x in ln]
+
+    def set_reference(self, ref_idx, sa=None, threshold=0):
+        sap = None
+        if sa is not None:
+            self._sa = np.ascontiguousarray(sa, dtype=np.int64)
+            sap = self._sa.ctypes.data_as(C.c_void_p)
+        self._chk(self.L.phylo_set_reference(self.h, ref_idx, sap, threshold))
+        self.ref_idx = ref_idx
+
+    @property
+    def threshold(self):
+        return self.L.phylo_threshold(self.h)
+
+    # phase A
+    def anchor(self, q_begin=0, q_end=None):
+        self._chk(self.L.phylo_anchor(self.h, q_begin, self.n if q_end is None else q_end))
+
+    def homologies(self, j):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._chk(self.L.phylo_get_homologies(self.h, j, C.byref(p), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, PHOM)
+        buf = (C.c_char * (n.value * PHOM.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=PHOM).copy()
+
+    def set_homologies(self, j, h):
+        h = np.ascontiguousarray(h, dtype=PHOM)
+        self._chk(self.L.phylo_set_homologies(self.h, j, h.ctypes.data_as(C.c_void_p), h.size))
+
+    def complete_delete(self):
+        self._chk(self.L.phylo_complete_delete(self.h))
+
+    # phase B
+    def compare(self, part=0, nparts=1):
+        s = np.zeros((self.n, self.n), np.uint64)
+        h = np.zeros((self.n, self.n), np.uint64)
+        self._chk(self.L.phylo_compare(self.h, part, nparts, s.ctypes.data_as(C.c_void_p),
+                                       h.ctypes.data_as(C.c_void_p)))
+        return s, h
+
+    def process(self, ref_idx, complete_deletion=False):
+        """process(queries[ref_idx], queries), src/process.cxx:408-556."""
+        s = np.zeros((self.n, self.n), np.uint64)
+        h = np.zeros((self.n, self.n), np.uint64)
+        self._chk(self.L.phylo_process(self.h, ref_idx, 4 if complete_deletion else 0,
+                                       s.ctypes.data_as(C.c_void_p), h.ctypes.data_as(C.c_void_p)))
+        self.ref_idx = ref_idx
+        return s, h
+
+    # B0, batched over resident genomes
+    def seqcmp_batch(self, ga, offa, gb, offb, length, rev):
+        ga = np.ascontiguousarray(ga, np.uint32)
+        gb = np.ascontiguousarray(gb, np.uint32)
+        offa = np.ascontiguousarray(offa, np.uint64)
+        offb = np.ascontiguousarray(offb, np.uint64)
+        length = np.ascontiguousarray(length, np.uint64)
+        rev = np.ascontiguousarray(rev, np.uint8)
+        out = np.zeros(ga.size, np.uint64)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._chk(self.L.phylo_seqcmp_batch(self.h, ga.size, p(ga), p(offa), p(gb), p(offb), p(length), p(rev), p(out)))
+        return out
+
+
+# ── B0 with the reference's signatures ──
+def seqcmp(a, b, n=None):
+    a, b = _u8(a), _u8(b)
+    n = min(a.size, b.size) if n is None else n
+    return load().phylo_seqcmp(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), n)
+
+
+def revseqcmp(a, b, n=None):
+    a, b = _u8(a), _u8(b)
+    n = min(a.size, b.size) if n is None else n
+    return load().phylo_revseqcmp(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), n)
+
+
+# ── host helpers ──
+def host_suffix_array(s):
+    s = _u8(s)
+    sa = np.zeros(s.size, np.int64)
+    if load().phylo_host_suffix_array(s.ctypes.data_as(C.c_void_p), s.size, sa.ctypes.data_as(C.c_void_p)):
+        raise PhyloniumError("phylo_host_suffix_array failed")
+    return sa
+
+
+def host_min_anchor_length(p, gc, l):
+    return load().phylo_host_min_anchor_length(p, gc, l)
+
+
+def host_sort_filter(h, do_sort=True):
+    h = np.ascontiguousarray(h.copy(), dtype=PHOM)
+    n = load().phylo_host_sort_filter(h.ctypes.data_as(C.c_void_p), h.size, int(do_sort))
+    return h[:n].copy()
+
+
+def estimate(kind, subst, homologs, zero_on_error=False):
+    return load().phylo_estimate(KIND[kind], int(subst), int(homologs), int(zero_on_error))
+
+
+def format_phylip(names, subst, homologs, kind="jc"):
+    n = len(names)
+    enc = [x.encode() for x in names]
+    arr = (C.c_char_p * n)(*enc)
+    s = np.ascontiguousarray(subst, np.uint64)
+    h = np.ascontiguousarray(homologs, np.uint64)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    need = load().phylo_format_phylip(n, arr, p(s), p(h), KIND[kind], None, 0)
+    buf = C.create_string_buffer(need)
+    load().phylo_format_phylip(n, arr, p(s), p(h), KIND[kind], buf, need)
+    return buf.value.decode()
+
+
+def process(genomes, ref_idx, device=0, complete_deletion=False):
+    """Convenience wrapper: genomes (bytes/uint8 arrays) → (substitutions, homologs)."""
+    with Context(device) as ctx:
+        ctx.set_genomes(genomes)
+        return ctx.process(ref_idx, complete_deletion)

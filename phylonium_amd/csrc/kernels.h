@@ -1,0 +1,49 @@
+// kernels.h — launch wrappers shared between the .hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include "anchor_core.h"
+
+namespace phy {
+
+// anchor_kernels.hip
+void launch_spec(const PhaseA &A, const RefIndex &R, int blocks, hipStream_t st);
+void launch_bridge(const PhaseA &A, const RefIndex &R, int blocks, hipStream_t st);
+void launch_fold(const PhaseA &A, uint32_t nq, uint32_t border, uint32_t thr, RawHom *out,
+				 const uint64_t *out_base, const uint32_t *out_cap, uint32_t *out_cnt, hipStream_t st);
+
+// seqcmp_kernels.hip
+struct Segment {
+	uint64_t a;   // byte offset of the first string in the genome buffer
+	uint64_t b;   // byte offset of the second string (start of the window, also when rev)
+	uint32_t len;
+	uint32_t rev; // 0: seqcmp, 1: revseqcmp
+};
+void launch_seqcmp_batch(const uint8_t *base, const Segment *segs, uint32_t nseg, uint64_t *out, int blocks,
+						 hipStream_t st);
+
+// pileup_kernels.hip
+struct DevHom {
+	uint32_t start; // index_reference_projected
+	uint32_t iq;    // index_query
+	uint32_t len;
+	uint32_t rev;
+};
+struct Pileup {
+	uint32_t *plane[5]; // V, N0, N1, D (reverse), B ('!'); each [W][Npad]
+	uint32_t W;         // words of 32 reference positions
+	uint32_t N, Npad;
+	uint32_t L;
+};
+void launch_project(const Pileup &P, const uint8_t *gbase, const uint64_t *goff, const DevHom *homs,
+					const uint32_t *hom_off, uint32_t *bang_flag, hipStream_t st);
+// tiles: list of (ig, jt) pairs packed as ig<<16|jt
+void launch_pairs(const Pileup &P, bool with_bang, const uint32_t *tiles, uint32_t ntiles, uint32_t wchunk,
+				  unsigned long long *subst, unsigned long long *homologs, hipStream_t st);
+
+static const uint32_t PAIR_IG = 16; // i-genomes per block (scalar side)
+static const uint32_t PAIR_JT = 64; // j-genomes per block (one per lane)
+
+} // namespace phy

@@ -1,0 +1,1012 @@
+// phylo_abi.hip — the C ABI (include/phylonium_amd.h): context, device memory,
+// orchestration of the phase-A and phase-B kernels, and the host-side steps
+// that stay on the CPU cores (suffix array, sort + chain filter).
+//
+// Mirrors process() of /root/reference/src/process.cxx:408-556.  There is no
+// CPU compute fallback: every entry point that does the path's arithmetic
+// launches HIP kernels and fails if no device is usable.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <map>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/phylonium_amd.h"
+#include "hostlogic.hpp"
+#include "kernels.h"
+
+using namespace phy;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+double now_ms()
+{
+	using namespace std::chrono;
+	return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+template <class T> struct DevBuf {
+	T *p = nullptr;
+	size_t cap = 0; // elements
+	hipError_t ensure(size_t n)
+	{
+		if (n <= cap) return hipSuccess;
+		if (p) (void)hipFree(p);
+		p = nullptr;
+		cap = 0;
+		size_t want = n + n / 8 + 16;
+		hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+		if (e == hipSuccess) cap = want;
+		return e;
+	}
+	void release()
+	{
+		if (p) (void)hipFree(p);
+		p = nullptr;
+		cap = 0;
+	}
+};
+
+struct TimedSpan {
+	std::string name;
+	hipEvent_t a, b;
+};
+
+} // namespace
+
+struct phylo_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	std::string err;
+	int n_cu = 256;
+
+	// options
+	uint32_t opt_chunk = 0, opt_kmer = 0;
+	bool profile = false;
+	int backend = 0;
+	int host_threads = 0;
+
+	// genomes
+	size_t n = 0;
+	std::vector<uint64_t> goff, glen;
+	uint8_t *d_genomes = nullptr;
+	bool own_genomes = false;
+	DevBuf<uint8_t> genomes_store;
+	DevBuf<uint64_t> d_goff;
+	DevBuf<uint32_t> d_glen;
+
+	// reference index
+	bool have_ref = false;
+	size_t ref_idx = 0;
+	uint32_t L = 0, ns = 0, k = 0, threshold = 0;
+	DevBuf<uint8_t> d_S;
+	DevBuf<uint32_t> d_SA, d_LCP, d_T;
+
+	// phase A scratch
+	DevBuf<uint64_t> a_qoff;
+	DevBuf<uint32_t> a_qlen, a_qchunk0, a_items, a_chunk_query, a_spec_cnt, a_visited, a_misc;
+	DevBuf<Anchor> a_spec_anchors;
+	DevBuf<SpecExit> a_spec_exit;
+	DevBuf<BridgeRec> a_bridge;
+	DevBuf<PoolBlock> a_pool;
+	DevBuf<RawHom> a_raw, a_raw_compact;
+	DevBuf<uint64_t> a_out_base, a_cmp_base;
+	DevBuf<uint32_t> a_out_cap, a_out_cnt;
+
+	// homologies (host, ctx-owned)
+	std::vector<std::vector<phylo_homology>> homs;
+
+	// phase B scratch
+	DevBuf<uint32_t> b_planes, b_hom_off, b_tiles, b_flag;
+	DevBuf<DevHom> b_homs;
+	DevBuf<unsigned long long> b_subst, b_homologs;
+	DevBuf<Segment> s_segs;
+	DevBuf<uint64_t> s_out;
+
+	// stats
+	std::map<std::string, double> stats;
+	std::vector<TimedSpan> spans;
+	std::vector<hipEvent_t> event_pool;
+
+	int fail(const char *fmt, ...)
+	{
+		char buf[1024];
+		va_list ap;
+		va_start(ap, fmt);
+		vsnprintf(buf, sizeof buf, fmt, ap);
+		va_end(ap);
+		err = buf;
+		g_last_error = buf;
+		return 1;
+	}
+};
+
+#define HIPOK(ctx, call)                                                                                         \
+	do {                                                                                                         \
+		hipError_t e__ = (call);                                                                                 \
+		if (e__ != hipSuccess) return (ctx)->fail("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+	} while (0)
+
+namespace {
+
+hipEvent_t get_event(phylo_ctx *c)
+{
+	if (!c->event_pool.empty()) {
+		hipEvent_t e = c->event_pool.back();
+		c->event_pool.pop_back();
+		return e;
+	}
+	hipEvent_t e;
+	(void)hipEventCreate(&e);
+	return e;
+}
+
+// Times one kernel launch with HIP events on the context's stream.
+struct KernelSpan {
+	phylo_ctx *c;
+	hipEvent_t a = nullptr, b = nullptr;
+	const char *name;
+	KernelSpan(phylo_ctx *ctx, const char *nm) : c(ctx), name(nm)
+	{
+		if (c->profile) {
+			a = get_event(c);
+			b = get_event(c);
+			(void)hipEventRecord(a, c->stream);
+		}
+	}
+	~KernelSpan()
+	{
+		if (c->profile) {
+			(void)hipEventRecord(b, c->stream);
+			c->spans.push_back(TimedSpan{name, a, b});
+		}
+	}
+};
+
+// Call after the stream has been synchronised.
+void harvest_spans(phylo_ctx *c)
+{
+	for (TimedSpan &s : c->spans) {
+		float ms = 0;
+		if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+			c->stats["ms:" + s.name] += ms;
+			c->stats["n:" + s.name] += 1;
+		}
+		c->event_pool.push_back(s.a);
+		c->event_pool.push_back(s.b);
+	}
+	c->spans.clear();
+}
+
+int sync_stream(phylo_ctx *c)
+{
+	HIPOK(c, hipStreamSynchronize(c->stream));
+	harvest_spans(c);
+	return 0;
+}
+
+template <class F> void parallel_for(size_t n, int threads, F f)
+{
+	if (threads <= 1 || n <= 1) {
+		for (size_t i = 0; i < n; i++) f(i);
+		return;
+	}
+	std::atomic<size_t> next{0};
+	std::vector<std::thread> pool;
+	size_t nt = std::min<size_t>((size_t)threads, n);
+	for (size_t t = 0; t < nt; t++)
+		pool.emplace_back([&]() {
+			for (;;) {
+				size_t i = next.fetch_add(1);
+				if (i >= n) break;
+				f(i);
+			}
+		});
+	for (auto &t : pool) t.join();
+}
+
+int host_threads(const phylo_ctx *c)
+{
+	if (c->host_threads > 0) return c->host_threads;
+	unsigned h = std::thread::hardware_concurrency();
+	return h ? (int)std::min(h, 64u) : 1;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *phylo_version(void) { return "phylonium_amd 0.1 (gfx950)"; }
+
+const char *phylo_last_error(const phylo_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int phylo_ctx_create(phylo_ctx **out, int device)
+{
+	if (!out) return 1;
+	*out = nullptr;
+	int count = 0;
+	hipError_t e = hipGetDeviceCount(&count);
+	if (e != hipSuccess || count <= 0) {
+		g_last_error = std::string("no usable HIP device: ") + hipGetErrorString(e);
+		return 2;
+	}
+	if (device < 0 || device >= count) {
+		g_last_error = "device ordinal out of range";
+		return 3;
+	}
+	phylo_ctx *c = new phylo_ctx();
+	c->device = device;
+	if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess) {
+		g_last_error = std::string("cannot initialise device: ") + hipGetErrorString(e);
+		delete c;
+		return 4;
+	}
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+	*out = c;
+	return 0;
+}
+
+void phylo_ctx_destroy(phylo_ctx *c)
+{
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	(void)hipStreamSynchronize(c->stream);
+	c->genomes_store.release();
+	c->d_goff.release();
+	c->d_glen.release();
+	c->d_S.release();
+	c->d_SA.release();
+	c->d_LCP.release();
+	c->d_T.release();
+	c->a_qoff.release();
+	c->a_qlen.release();
+	c->a_qchunk0.release();
+	c->a_items.release();
+	c->a_chunk_query.release();
+	c->a_spec_cnt.release();
+	c->a_visited.release();
+	c->a_misc.release();
+	c->a_spec_anchors.release();
+	c->a_spec_exit.release();
+	c->a_bridge.release();
+	c->a_pool.release();
+	c->a_raw.release();
+	c->a_raw_compact.release();
+	c->a_out_base.release();
+	c->a_cmp_base.release();
+	c->a_out_cap.release();
+	c->a_out_cnt.release();
+	c->b_planes.release();
+	c->b_hom_off.release();
+	c->b_tiles.release();
+	c->b_flag.release();
+	c->b_homs.release();
+	c->b_subst.release();
+	c->b_homologs.release();
+	c->s_segs.release();
+	c->s_out.release();
+	for (TimedSpan &s : c->spans) {
+		(void)hipEventDestroy(s.a);
+		(void)hipEventDestroy(s.b);
+	}
+	for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+	(void)hipStreamDestroy(c->stream);
+	delete c;
+}
+
+int phylo_set_option(phylo_ctx *c, const char *key, long value)
+{
+	if (!c || !key) return 1;
+	std::string k = key;
+	if (k == "chunk") {
+		if (value != 0 && (value < 64 || (value & (value - 1)))) return c->fail("chunk must be 0 or a power of two >= 64");
+		c->opt_chunk = (uint32_t)value;
+	} else if (k == "kmer") {
+		if (value < 0 || value > 14) return c->fail("kmer must be in 0..14");
+		c->opt_kmer = (uint32_t)value;
+		c->have_ref = false;
+	} else if (k == "profile") {
+		c->profile = value != 0;
+	} else if (k == "compare_backend") {
+		if (value != 0 && value != 1) return c->fail("compare_backend must be 0 (pileup) or 1 (segments)");
+		c->backend = (int)value;
+	} else if (k == "host_threads") {
+		c->host_threads = (int)value;
+	} else {
+		return c->fail("unknown option '%s'", key);
+	}
+	return 0;
+}
+
+int phylo_get_stat(phylo_ctx *c, const char *key, double *out)
+{
+	if (!c || !key || !out) return 1;
+	auto it = c->stats.find(key);
+	if (it == c->stats.end()) return 1;
+	*out = it->second;
+	return 0;
+}
+
+int phylo_reset_stats(phylo_ctx *c)
+{
+	if (!c) return 1;
+	c->stats.clear();
+	return 0;
+}
+
+size_t phylo_stat_keys(phylo_ctx *c, char *buf, size_t cap)
+{
+	if (!c) return 0;
+	size_t need = 1;
+	for (auto &kv : c->stats) need += kv.first.size() + 1;
+	if (buf && cap >= need) {
+		char *w = buf;
+		for (auto &kv : c->stats) {
+			memcpy(w, kv.first.c_str(), kv.first.size() + 1);
+			w += kv.first.size() + 1;
+		}
+		*w = '\0';
+	}
+	return need;
+}
+
+// ───────────────────────── genomes ─────────────────────────
+
+static int install_layout(phylo_ctx *c)
+{
+	size_t n = c->n;
+	std::vector<uint32_t> l32(n);
+	for (size_t j = 0; j < n; j++) {
+		if (c->glen[j] >= 0xfff00000ull) return c->fail("genome %zu is too long (%llu >= 2^32-2^20)", j, (unsigned long long)c->glen[j]);
+		l32[j] = (uint32_t)c->glen[j];
+	}
+	HIPOK(c, c->d_goff.ensure(n + 1));
+	HIPOK(c, c->d_glen.ensure(n + 1));
+	HIPOK(c, hipMemcpyAsync(c->d_goff.p, c->goff.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+	HIPOK(c, hipMemcpyAsync(c->d_glen.p, l32.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+	HIPOK(c, hipStreamSynchronize(c->stream));
+	c->homs.assign(n, {});
+	c->have_ref = false;
+	return 0;
+}
+
+int phylo_set_genomes(phylo_ctx *c, size_t n, const char *const *seq, const size_t *len)
+{
+	if (!c) return 1;
+	if (n && (!seq || !len)) return c->fail("null genome arrays");
+	HIPOK(c, hipSetDevice(c->device));
+	c->n = n;
+	c->goff.assign(n, 0);
+	c->glen.assign(n, 0);
+	uint64_t tot = 64; // leading pad
+	for (size_t j = 0; j < n; j++) {
+		c->goff[j] = tot;
+		c->glen[j] = len[j];
+		tot += ((len[j] + 63) / 64) * 64 + 64;
+	}
+	HIPOK(c, c->genomes_store.ensure(tot));
+	HIPOK(c, hipMemsetAsync(c->genomes_store.p, 0, tot, c->stream));
+	for (size_t j = 0; j < n; j++)
+		if (len[j])
+			HIPOK(c, hipMemcpyAsync(c->genomes_store.p + c->goff[j], seq[j], len[j], hipMemcpyHostToDevice, c->stream));
+	c->d_genomes = c->genomes_store.p;
+	c->own_genomes = true;
+	return install_layout(c);
+}
+
+int phylo_set_genomes_device(phylo_ctx *c, size_t n, const void *dev_base, const uint64_t *offsets,
+							 const uint64_t *lens)
+{
+	if (!c) return 1;
+	if (n && (!dev_base || !offsets || !lens)) return c->fail("null genome arrays");
+	HIPOK(c, hipSetDevice(c->device));
+	for (size_t j = 0; j < n; j++)
+		if (offsets[j] % 64) return c->fail("genome %zu: device offset must be a multiple of 64", j);
+	c->n = n;
+	c->goff.assign(offsets, offsets + n);
+	c->glen.assign(lens, lens + n);
+	c->d_genomes = (uint8_t *)dev_base;
+	c->own_genomes = false;
+	return install_layout(c);
+}
+
+// ───────────────────────── reference index ─────────────────────────
+
+int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t threshold)
+{
+	if (!c) return 1;
+	if (ref_idx >= c->n) return c->fail("reference index %zu out of range (n=%zu)", ref_idx, c->n);
+	HIPOK(c, hipSetDevice(c->device));
+	double t0 = now_ms();
+	uint64_t L = c->glen[ref_idx];
+	if (2 * L + 1 >= 0x7fffffffull) return c->fail("reference too long: 2L+1 must be < 2^31 (src/esa.cxx:374-375)");
+	if (L == 0) return c->fail("reference genome is empty");
+	uint32_t ns = (uint32_t)(2 * L + 1);
+	std::vector<uint8_t> S((size_t)ns + 64, 0);
+	HIPOK(c, hipMemcpy(S.data(), c->d_genomes + c->goff[ref_idx], L, hipMemcpyDeviceToHost));
+	S[L] = '#';
+	revcomp(S.data(), L, S.data() + L + 1);
+	std::vector<uint32_t> SA(ns), LCP((size_t)ns + 1), T;
+	double t1 = now_ms();
+	if (sa) {
+		for (uint32_t i = 0; i < ns; i++) {
+			if (sa[i] < 0 || sa[i] >= (int64_t)ns) return c->fail("suffix array entry %u out of range", i);
+			SA[i] = (uint32_t)sa[i];
+		}
+	} else {
+		suffix_array_u32(S.data(), ns, SA.data());
+	}
+	double t2 = now_ms();
+	lcp_kasai(S.data(), ns, SA.data(), LCP.data());
+	uint32_t k = c->opt_kmer ? c->opt_kmer : choose_k(ns);
+	kmer_table(S.data(), ns, k, T);
+	double t3 = now_ms();
+	if (threshold == 0) threshold = min_anchor_length(0.025, gc_content(S.data(), L), ns);
+	HIPOK(c, c->d_S.ensure(S.size()));
+	HIPOK(c, c->d_SA.ensure(ns));
+	HIPOK(c, c->d_LCP.ensure((size_t)ns + 1));
+	HIPOK(c, c->d_T.ensure(T.size()));
+	HIPOK(c, hipMemcpy(c->d_S.p, S.data(), S.size(), hipMemcpyHostToDevice));
+	HIPOK(c, hipMemcpy(c->d_SA.p, SA.data(), (size_t)ns * 4, hipMemcpyHostToDevice));
+	HIPOK(c, hipMemcpy(c->d_LCP.p, LCP.data(), ((size_t)ns + 1) * 4, hipMemcpyHostToDevice));
+	HIPOK(c, hipMemcpy(c->d_T.p, T.data(), T.size() * 4, hipMemcpyHostToDevice));
+	c->ref_idx = ref_idx;
+	c->L = (uint32_t)L;
+	c->ns = ns;
+	c->k = k;
+	c->threshold = (uint32_t)threshold;
+	c->have_ref = true;
+	c->stats["ms:ref_fetch"] += t1 - t0;
+	c->stats["ms:ref_suffix_array"] += t2 - t1;
+	c->stats["ms:ref_lcp_table"] += t3 - t2;
+	c->stats["ms:ref_total"] += now_ms() - t0;
+	c->stats["ref:k"] = k;
+	c->stats["ref:threshold"] = (double)threshold;
+	c->stats["ref:size"] = ns;
+	return 0;
+}
+
+size_t phylo_threshold(const phylo_ctx *c) { return c ? c->threshold : 0; }
+
+// ───────────────────────── phase A ─────────────────────────
+
+__global__ void compact_raw_kernel(const RawHom *__restrict__ src, const uint64_t *__restrict__ src_base,
+								   const uint32_t *__restrict__ cnt, const uint64_t *__restrict__ dst_base,
+								   RawHom *__restrict__ dst)
+{
+	const uint32_t j = blockIdx.x;
+	const RawHom *s = src + src_base[j];
+	RawHom *d = dst + dst_base[j];
+	for (uint32_t t = threadIdx.x; t < cnt[j]; t += blockDim.x) d[t] = s[t];
+}
+
+int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
+{
+	if (!c) return 1;
+	if (!c->have_ref) return c->fail("phylo_anchor: no reference set");
+	if (q_begin > q_end || q_end > c->n) return c->fail("phylo_anchor: bad query range");
+	HIPOK(c, hipSetDevice(c->device));
+	size_t nq = q_end - q_begin;
+	if (nq == 0) return 0;
+	double t0 = now_ms();
+
+	std::vector<uint32_t> qlen(nq);
+	std::vector<uint64_t> qoff(nq);
+	uint64_t total = 0;
+	for (size_t j = 0; j < nq; j++) {
+		qlen[j] = (uint32_t)c->glen[q_begin + j];
+		qoff[j] = c->goff[q_begin + j];
+		total += qlen[j];
+	}
+	ChunkPlan P = plan_chunks(qlen, c->threshold, c->opt_chunk);
+	uint32_t nch = P.nchunks;
+
+	// output capacities: an emitted homology spans >= 2*threshold query positions
+	std::vector<uint64_t> out_base(nq + 1);
+	std::vector<uint32_t> out_cap(nq);
+	uint64_t raw_total = 0;
+	for (size_t j = 0; j < nq; j++) {
+		out_base[j] = raw_total;
+		out_cap[j] = qlen[j] / (2 * c->threshold) + 2;
+		raw_total += out_cap[j];
+	}
+	out_base[nq] = raw_total;
+	uint32_t pool_blocks = nch / 4 + 4096;
+
+	HIPOK(c, c->a_qoff.ensure(nq));
+	HIPOK(c, c->a_qlen.ensure(nq));
+	HIPOK(c, c->a_qchunk0.ensure(nq + 1));
+	HIPOK(c, c->a_items.ensure(nch + 1));
+	HIPOK(c, c->a_chunk_query.ensure(nch + 1));
+	HIPOK(c, c->a_spec_cnt.ensure(nch + 1));
+	HIPOK(c, c->a_visited.ensure((size_t)nch * (P.C / 32) + 1));
+	HIPOK(c, c->a_misc.ensure(16));
+	HIPOK(c, c->a_spec_anchors.ensure((size_t)nch * P.cap + 1));
+	HIPOK(c, c->a_spec_exit.ensure(nch + 1));
+	HIPOK(c, c->a_bridge.ensure(nch + 1));
+	HIPOK(c, c->a_pool.ensure(pool_blocks));
+	HIPOK(c, c->a_raw.ensure(raw_total + 1));
+	HIPOK(c, c->a_out_base.ensure(nq + 1));
+	HIPOK(c, c->a_cmp_base.ensure(nq + 1));
+	HIPOK(c, c->a_out_cap.ensure(nq));
+	HIPOK(c, c->a_out_cnt.ensure(nq));
+
+	hipStream_t st = c->stream;
+	HIPOK(c, hipMemcpyAsync(c->a_qoff.p, qoff.data(), nq * 8, hipMemcpyHostToDevice, st));
+	HIPOK(c, hipMemcpyAsync(c->a_qlen.p, qlen.data(), nq * 4, hipMemcpyHostToDevice, st));
+	HIPOK(c, hipMemcpyAsync(c->a_qchunk0.p, P.qchunk0.data(), (nq + 1) * 4, hipMemcpyHostToDevice, st));
+	if (nch) {
+		HIPOK(c, hipMemcpyAsync(c->a_items.p, P.items.data(), (size_t)nch * 4, hipMemcpyHostToDevice, st));
+		HIPOK(c, hipMemcpyAsync(c->a_chunk_query.p, P.chunk_query.data(), (size_t)nch * 4, hipMemcpyHostToDevice, st));
+	}
+	HIPOK(c, hipMemcpyAsync(c->a_out_base.p, out_base.data(), (nq + 1) * 8, hipMemcpyHostToDevice, st));
+	HIPOK(c, hipMemcpyAsync(c->a_out_cap.p, out_cap.data(), nq * 4, hipMemcpyHostToDevice, st));
+	HIPOK(c, hipMemsetAsync(c->a_misc.p, 0, 16 * 4, st));
+	if (nch) HIPOK(c, hipMemsetAsync(c->a_visited.p, 0, (size_t)nch * (P.C / 32) * 4, st));
+
+	PhaseA A;
+	A.qbase = c->d_genomes;
+	A.qoff = c->a_qoff.p;
+	A.qlen = c->a_qlen.p;
+	A.qchunk0 = c->a_qchunk0.p;
+	A.items = c->a_items.p;
+	A.chunk_query = c->a_chunk_query.p;
+	A.nchunks = nch;
+	A.C = P.C;
+	A.logC = P.logC;
+	A.cap = P.cap;
+	A.spec_anchors = c->a_spec_anchors.p;
+	A.spec_cnt = c->a_spec_cnt.p;
+	A.spec_exit = c->a_spec_exit.p;
+	A.visited = c->a_visited.p;
+	A.bridge = c->a_bridge.p;
+	A.pool = c->a_pool.p;
+	A.pool_blocks = pool_blocks;
+	A.fetch = c->a_misc.p;          // [0] spec, [1] bridge
+	A.pool_next = c->a_misc.p + 2;
+	A.error = c->a_misc.p + 3;
+	RefIndex R = {c->d_S.p, c->d_SA.p, c->d_LCP.p, c->d_T.p, c->ns, c->k, c->threshold};
+
+	// persistent lanes: enough waves to cover latency, never more lanes than chunks
+	int blocks = c->n_cu * 8;
+	int need_blocks = (int)((nch + 255) / 256);
+	if (need_blocks < blocks) blocks = need_blocks > 0 ? need_blocks : 1;
+	double t1 = now_ms();
+	if (nch) {
+		{
+			KernelSpan s(c, "anchor_spec");
+			launch_spec(A, R, blocks, st);
+		}
+		{
+			KernelSpan s(c, "anchor_bridge");
+			launch_bridge(A, R, blocks, st);
+		}
+	}
+	{
+		KernelSpan s(c, "anchor_fold");
+		launch_fold(A, (uint32_t)nq, c->L, c->threshold, c->a_raw.p, c->a_out_base.p, c->a_out_cap.p, c->a_out_cnt.p, st);
+	}
+	HIPOK(c, hipGetLastError());
+	std::vector<uint32_t> cnt(nq);
+	uint32_t misc[4];
+	HIPOK(c, hipMemcpyAsync(cnt.data(), c->a_out_cnt.p, nq * 4, hipMemcpyDeviceToHost, st));
+	HIPOK(c, hipMemcpyAsync(misc, c->a_misc.p, 16, hipMemcpyDeviceToHost, st));
+	if (sync_stream(c)) return 1;
+	double t2 = now_ms();
+	if (misc[3]) return c->fail("phase A scratch overflow (code %u: 1 chunk log, 2 bridge pool, 3 homology buffer)", misc[3]);
+
+	std::vector<uint64_t> cbase(nq + 1);
+	uint64_t ctot = 0;
+	for (size_t j = 0; j < nq; j++) {
+		cbase[j] = ctot;
+		ctot += cnt[j];
+	}
+	cbase[nq] = ctot;
+	std::vector<RawHom> raw(ctot);
+	if (ctot) {
+		HIPOK(c, c->a_raw_compact.ensure(ctot));
+		HIPOK(c, hipMemcpyAsync(c->a_cmp_base.p, cbase.data(), (nq + 1) * 8, hipMemcpyHostToDevice, st));
+		{
+			KernelSpan s(c, "anchor_compact");
+			hipLaunchKernelGGL(compact_raw_kernel, dim3((uint32_t)nq), dim3(256), 0, st, c->a_raw.p, c->a_out_base.p,
+							   c->a_out_cnt.p, c->a_cmp_base.p, c->a_raw_compact.p);
+		}
+		HIPOK(c, hipMemcpyAsync(raw.data(), c->a_raw_compact.p, ctot * sizeof(RawHom), hipMemcpyDeviceToHost, st));
+		if (sync_stream(c)) return 1;
+	}
+	double t3 = now_ms();
+	// reverseEh + std::sort + filter_overlaps_max on the host cores (process.cxx:438-443)
+	uint64_t border = c->L;
+	parallel_for(nq, host_threads(c), [&](size_t j) {
+		std::vector<phylo_homology> hv(cnt[j]);
+		for (uint32_t t = 0; t < cnt[j]; t++) hv[t] = project_homology(raw[cbase[j] + t], border);
+		sort_and_filter(hv);
+		c->homs[q_begin + j] = std::move(hv);
+	});
+	double t4 = now_ms();
+	c->stats["ms:anchor_setup"] += t1 - t0;
+	c->stats["ms:anchor_gpu"] += t2 - t1;
+	c->stats["ms:anchor_copyback"] += t3 - t2;
+	c->stats["ms:host_sort_filter"] += t4 - t3;
+	c->stats["ms:anchor_total"] += t4 - t0;
+	c->stats["n:anchor_calls"] += 1;
+	c->stats["count:query_bases"] += (double)total;
+	c->stats["count:chunks"] += nch;
+	c->stats["count:raw_homologies"] += (double)ctot;
+	c->stats["count:pool_blocks_used"] += misc[2];
+	c->stats["anchor:chunk"] = P.C;
+	return 0;
+}
+
+int phylo_get_homologies(phylo_ctx *c, size_t j, const phylo_homology **h, size_t *n)
+{
+	if (!c || !h || !n) return 1;
+	if (j >= c->n) return c->fail("genome index out of range");
+	*h = c->homs[j].data();
+	*n = c->homs[j].size();
+	return 0;
+}
+
+int phylo_set_homologies(phylo_ctx *c, size_t j, const phylo_homology *h, size_t n)
+{
+	if (!c) return 1;
+	if (j >= c->n) return c->fail("genome index out of range");
+	if (n && !h) return c->fail("null homology list");
+	c->homs[j].assign(h, h + n);
+	return 0;
+}
+
+int phylo_complete_delete(phylo_ctx *c)
+{
+	if (!c) return 1;
+	c->homs = complete_delete(c->homs);
+	return 0;
+}
+
+// ───────────────────────── phase B ─────────────────────────
+
+// compare(list, list) of process.cxx:566-611 as a segment generator (host):
+// every overlapping (ha, hb) pair becomes one seqcmp / revseqcmp segment
+// (process.cxx:620-658).  Used by the segment-list backend.
+static void pair_segments(const phylo_ctx *c, size_t i, size_t j, std::vector<Segment> &out)
+{
+	const auto &ha = c->homs[i], &hb = c->homs[j];
+	size_t right = 0;
+	for (const phylo_homology &h : ha) {
+		uint64_t hs = h.index_reference_projected, he = hs + h.length;
+		while (right < hb.size() && hb[right].index_reference_projected + hb[right].length <= hs) right++;
+		for (size_t r = right; r < hb.size(); r++) {
+			const phylo_homology &o = hb[r];
+			uint64_t os = o.index_reference_projected, oe = os + o.length;
+			if (os >= he) break;
+			uint64_t cs = std::max(hs, os), ce = std::min(he, oe);
+			if (cs >= ce) continue;
+			phylo_homology hat = trim_homology(h, cs, ce), hbt = trim_homology(o, cs, ce);
+			Segment sg;
+			sg.len = (uint32_t)(ce - cs);
+			if (h.direction == o.direction) {
+				sg.a = c->goff[i] + hat.index_query;
+				sg.b = c->goff[j] + hbt.index_query;
+				sg.rev = 0;
+			} else if (o.direction == 1) { // account_rev(sa + hat.start_query(), sb, hbt.end_query(), n)
+				sg.a = c->goff[i] + hat.index_query;
+				sg.b = c->goff[j] + hbt.index_query + hbt.length - sg.len;
+				sg.rev = 1;
+			} else {
+				sg.a = c->goff[j] + hbt.index_query;
+				sg.b = c->goff[i] + hat.index_query + hat.length - sg.len;
+				sg.rev = 1;
+			}
+			out.push_back(sg);
+		}
+	}
+}
+
+static int compare_segments(phylo_ctx *c, size_t part, size_t nparts, uint64_t *subst, uint64_t *homologs)
+{
+	size_t N = c->n;
+	std::vector<Segment> segs;
+	std::vector<uint32_t> seg_pair; // pair index of each segment
+	std::vector<std::pair<uint32_t, uint32_t>> pairs;
+	size_t pid = 0;
+	for (size_t i = 0; i < N; i++)
+		for (size_t j = i + 1; j < N; j++, pid++) {
+			if (pid % nparts != part) continue;
+			size_t before = segs.size();
+			pair_segments(c, i, j, segs);
+			pairs.emplace_back((uint32_t)i, (uint32_t)j);
+			seg_pair.resize(segs.size(), (uint32_t)(pairs.size() - 1));
+			(void)before;
+		}
+	std::vector<uint64_t> out(segs.size());
+	if (!segs.empty()) {
+		HIPOK(c, c->s_segs.ensure(segs.size()));
+		HIPOK(c, c->s_out.ensure(segs.size()));
+		HIPOK(c, hipMemcpyAsync(c->s_segs.p, segs.data(), segs.size() * sizeof(Segment), hipMemcpyHostToDevice, c->stream));
+		int blocks = std::min<int>(c->n_cu * 8, (int)((segs.size() + 3) / 4));
+		{
+			KernelSpan s(c, "seqcmp_batch");
+			launch_seqcmp_batch(c->d_genomes, c->s_segs.p, (uint32_t)segs.size(), c->s_out.p, blocks, c->stream);
+		}
+		HIPOK(c, hipGetLastError());
+		HIPOK(c, hipMemcpyAsync(out.data(), c->s_out.p, segs.size() * 8, hipMemcpyDeviceToHost, c->stream));
+		if (sync_stream(c)) return 1;
+	}
+	double sites = 0;
+	for (size_t s = 0; s < segs.size(); s++) {
+		auto pr = pairs[seg_pair[s]];
+		size_t a = (size_t)pr.first * N + pr.second, b = (size_t)pr.second * N + pr.first;
+		subst[a] += out[s];
+		homologs[a] += segs[s].len;
+		subst[b] = subst[a];
+		homologs[b] = homologs[a];
+		sites += segs[s].len;
+	}
+	c->stats["count:compare_sites"] += sites;
+	c->stats["count:segments"] += (double)segs.size();
+	return 0;
+}
+
+static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *subst, uint64_t *homologs)
+{
+	size_t N = c->n;
+	hipStream_t st = c->stream;
+	Pileup P;
+	P.N = (uint32_t)N;
+	P.Npad = (uint32_t)((N + 63) / 64 * 64);
+	P.L = c->L;
+	P.W = (c->L + 31) / 32;
+	size_t plane_words = (size_t)P.W * P.Npad;
+	HIPOK(c, c->b_planes.ensure(plane_words * 5));
+	for (int p = 0; p < 5; p++) P.plane[p] = c->b_planes.p + plane_words * p;
+
+	// filtered homologies → device
+	std::vector<uint32_t> hom_off(N + 1);
+	size_t tot = 0;
+	for (size_t g = 0; g < N; g++) {
+		hom_off[g] = (uint32_t)tot;
+		tot += c->homs[g].size();
+	}
+	hom_off[N] = (uint32_t)tot;
+	std::vector<DevHom> dh(tot);
+	for (size_t g = 0; g < N; g++) {
+		size_t o = hom_off[g];
+		for (const phylo_homology &h : c->homs[g]) {
+			if (h.index_reference_projected + h.length > c->L)
+				return c->fail("genome %zu: homology reaches beyond the reference", g);
+			dh[o++] = DevHom{(uint32_t)h.index_reference_projected, (uint32_t)h.index_query, (uint32_t)h.length,
+							 (uint32_t)h.direction};
+		}
+	}
+	HIPOK(c, c->b_hom_off.ensure(N + 1));
+	HIPOK(c, c->b_homs.ensure(tot + 1));
+	HIPOK(c, c->b_flag.ensure(4));
+	HIPOK(c, c->b_subst.ensure(N * N));
+	HIPOK(c, c->b_homologs.ensure(N * N));
+	HIPOK(c, hipMemcpyAsync(c->b_hom_off.p, hom_off.data(), (N + 1) * 4, hipMemcpyHostToDevice, st));
+	if (tot) HIPOK(c, hipMemcpyAsync(c->b_homs.p, dh.data(), tot * sizeof(DevHom), hipMemcpyHostToDevice, st));
+	HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 16, st));
+	HIPOK(c, hipMemsetAsync(c->b_subst.p, 0, N * N * 8, st));
+	HIPOK(c, hipMemsetAsync(c->b_homologs.p, 0, N * N * 8, st));
+	{
+		KernelSpan s(c, "pileup_project");
+		launch_project(P, c->d_genomes, c->d_goff.p, c->b_homs.p, c->b_hom_off.p, c->b_flag.p, st);
+	}
+	HIPOK(c, hipGetLastError());
+	uint32_t flag = 0;
+	HIPOK(c, hipMemcpyAsync(&flag, c->b_flag.p, 4, hipMemcpyDeviceToHost, st));
+	if (sync_stream(c)) return 1;
+
+	// tiles of this part: (ig, jt) with at least one pair i<j, dealt round-robin
+	std::vector<uint32_t> tiles;
+	uint32_t nig = (uint32_t)((N + PAIR_IG - 1) / PAIR_IG), njt = (uint32_t)((N + PAIR_JT - 1) / PAIR_JT);
+	size_t tid = 0;
+	for (uint32_t ig = 0; ig < nig; ig++)
+		for (uint32_t jt = 0; jt < njt; jt++) {
+			if ((uint64_t)ig * PAIR_IG >= (uint64_t)jt * PAIR_JT + PAIR_JT - 1) continue; // no i<j inside
+			if (tid++ % nparts == part) tiles.push_back((ig << 16) | jt);
+		}
+	if (!tiles.empty()) {
+		HIPOK(c, c->b_tiles.ensure(tiles.size()));
+		HIPOK(c, hipMemcpyAsync(c->b_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, st));
+		// enough blocks to fill the chip several times over, chunks of >= 64 windows
+		uint32_t want_blocks = (uint32_t)c->n_cu * 32;
+		uint32_t nwc = std::max<uint32_t>(1, want_blocks / (uint32_t)tiles.size());
+		uint32_t wchunk = std::max<uint32_t>(64, (P.W + nwc - 1) / nwc);
+		{
+			KernelSpan s(c, flag ? "pileup_pairs_bang" : "pileup_pairs");
+			launch_pairs(P, flag != 0, c->b_tiles.p, (uint32_t)tiles.size(), wchunk, c->b_subst.p, c->b_homologs.p, st);
+		}
+		HIPOK(c, hipGetLastError());
+	}
+	std::vector<uint64_t> hs(N * N), hh(N * N);
+	HIPOK(c, hipMemcpyAsync(hs.data(), c->b_subst.p, N * N * 8, hipMemcpyDeviceToHost, st));
+	HIPOK(c, hipMemcpyAsync(hh.data(), c->b_homologs.p, N * N * 8, hipMemcpyDeviceToHost, st));
+	if (sync_stream(c)) return 1;
+	double sites = 0;
+	for (size_t i = 0; i < N; i++)
+		for (size_t j = i + 1; j < N; j++) {
+			size_t a = i * N + j, b = j * N + i;
+			subst[a] = subst[b] = hs[a];
+			homologs[a] = homologs[b] = hh[a];
+			sites += (double)hh[a];
+		}
+	c->stats["count:compare_sites"] += sites;
+	c->stats["pileup:bang"] = flag;
+	return 0;
+}
+
+int phylo_compare(phylo_ctx *c, size_t part, size_t nparts, uint64_t *subst, uint64_t *homologs)
+{
+	if (!c) return 1;
+	if (!subst || !homologs) return c->fail("null output matrix");
+	if (nparts == 0 || part >= nparts) return c->fail("bad part %zu of %zu", part, nparts);
+	if (!c->have_ref) return c->fail("phylo_compare: no reference set");
+	HIPOK(c, hipSetDevice(c->device));
+	double t0 = now_ms();
+	size_t N = c->n;
+	std::fill(subst, subst + N * N, 0);
+	std::fill(homologs, homologs + N * N, 0);
+	int rc = c->backend == 1 ? compare_segments(c, part, nparts, subst, homologs)
+							 : compare_pileup(c, part, nparts, subst, homologs);
+	c->stats["ms:compare_total"] += now_ms() - t0;
+	c->stats["n:compare_calls"] += 1;
+	return rc;
+}
+
+int phylo_compare_all(phylo_ctx *c, uint64_t *subst, uint64_t *homologs)
+{
+	return phylo_compare(c, 0, 1, subst, homologs);
+}
+
+int phylo_process(phylo_ctx *c, size_t ref_idx, int flags, uint64_t *subst, uint64_t *homologs)
+{
+	if (!c) return 1;
+	int rc = phylo_set_reference(c, ref_idx, nullptr, 0);
+	if (rc) return rc;
+	rc = phylo_anchor(c, 0, c->n);
+	if (rc) return rc;
+	if (flags & PHYLO_COMPLETE_DELETION) {
+		rc = phylo_complete_delete(c);
+		if (rc) return rc;
+	}
+	return phylo_compare_all(c, subst, homologs);
+}
+
+// ───────────────────────── B0 ─────────────────────────
+
+int phylo_seqcmp_batch(phylo_ctx *c, size_t n, const uint32_t *ga, const uint64_t *offa, const uint32_t *gb,
+					   const uint64_t *offb, const uint64_t *len, const uint8_t *rev, uint64_t *out)
+{
+	if (!c) return 1;
+	if (n == 0) return 0;
+	if (!ga || !offa || !gb || !offb || !len || !out) return c->fail("null segment arrays");
+	HIPOK(c, hipSetDevice(c->device));
+	std::vector<Segment> segs(n);
+	for (size_t s = 0; s < n; s++) {
+		if (ga[s] >= c->n || gb[s] >= c->n) return c->fail("segment %zu: genome index out of range", s);
+		if (offa[s] + len[s] > c->glen[ga[s]] || offb[s] + len[s] > c->glen[gb[s]])
+			return c->fail("segment %zu reaches beyond its genome", s);
+		if (len[s] > 0xffffffffull) return c->fail("segment %zu too long", s);
+		segs[s] = Segment{c->goff[ga[s]] + offa[s], c->goff[gb[s]] + offb[s], (uint32_t)len[s], rev && rev[s] ? 1u : 0u};
+	}
+	HIPOK(c, c->s_segs.ensure(n));
+	HIPOK(c, c->s_out.ensure(n));
+	HIPOK(c, hipMemcpyAsync(c->s_segs.p, segs.data(), n * sizeof(Segment), hipMemcpyHostToDevice, c->stream));
+	int blocks = std::min<int>(c->n_cu * 8, (int)((n + 3) / 4));
+	{
+		KernelSpan s(c, "seqcmp_batch");
+		launch_seqcmp_batch(c->d_genomes, c->s_segs.p, (uint32_t)n, c->s_out.p, blocks, c->stream);
+	}
+	HIPOK(c, hipGetLastError());
+	HIPOK(c, hipMemcpyAsync(out, c->s_out.p, n * 8, hipMemcpyDeviceToHost, c->stream));
+	return sync_stream(c);
+}
+
+// seqcmp / revseqcmp with the reference's signature (libs/seqcmp.h:14,
+// libs/revseqcmp.h:25): host buffers in, count out, computed on device 0.
+static size_t b0_call(const char *a, const char *b, size_t length, int rev)
+{
+	static phylo_ctx *ctx = nullptr;
+	if (!ctx && phylo_ctx_create(&ctx, 0)) {
+		fprintf(stderr, "phylonium_amd: %s\n", g_last_error.c_str());
+		abort(); // the reference signature has no error channel; never fall back to the CPU
+	}
+	if (length == 0) return 0;
+	const char *seqs[2] = {a, b};
+	size_t lens[2] = {length, length};
+	uint64_t total = 0;
+	if (phylo_set_genomes(ctx, 2, seqs, lens)) goto fail;
+	{
+		// pieces of < 2^32 bytes
+		const uint64_t piece = 1ull << 30;
+		std::vector<uint32_t> ga, gb;
+		std::vector<uint64_t> oa, ob, ln, out;
+		std::vector<uint8_t> rv;
+		for (uint64_t o = 0; o < length; o += piece) {
+			uint64_t m = std::min<uint64_t>(piece, length - o);
+			ga.push_back(0);
+			gb.push_back(1);
+			oa.push_back(o);
+			ob.push_back(rev ? length - o - m : o);
+			ln.push_back(m);
+			rv.push_back((uint8_t)rev);
+		}
+		out.resize(ga.size());
+		if (phylo_seqcmp_batch(ctx, ga.size(), ga.data(), oa.data(), gb.data(), ob.data(), ln.data(), rv.data(), out.data()))
+			goto fail;
+		for (uint64_t v : out) total += v;
+	}
+	return (size_t)total;
+fail:
+	fprintf(stderr, "phylonium_amd: %s\n", ctx->err.c_str());
+	abort();
+}
+
+size_t phylo_seqcmp(const char *begin, const char *other, size_t length) { return b0_call(begin, other, length, 0); }
+size_t phylo_revseqcmp(const char *begin, const char *other, size_t length) { return b0_call(begin, other, length, 1); }
+
+// ───────────────────────── host-side helpers ─────────────────────────
+
+int phylo_host_suffix_array(const char *s, size_t n, int64_t *sa)
+{
+	if (!s || !sa || n >= 0x7fffffffull) return 1;
+	std::vector<uint32_t> tmp(n);
+	suffix_array_u32((const uint8_t *)s, (uint32_t)n, tmp.data());
+	for (size_t i = 0; i < n; i++) sa[i] = tmp[i];
+	return 0;
+}
+
+size_t phylo_host_min_anchor_length(double p, double gc, size_t l) { return min_anchor_length(p, gc, l); }
+
+size_t phylo_host_sort_filter(phylo_homology *h, size_t n, int do_sort)
+{
+	std::vector<phylo_homology> v(h, h + n);
+	if (do_sort) sort_and_filter(v);
+	else filter_overlaps_max(v);
+	std::copy(v.begin(), v.end(), h);
+	return v.size();
+}
+
+double phylo_estimate(int kind, uint64_t subst, uint64_t homologs, int zero_on_error)
+{
+	switch (kind) {
+		case 0: return estimate_jc(subst, homologs, zero_on_error != 0);
+		case 1: return estimate_raw(subst, homologs, zero_on_error != 0);
+		default: return estimate_ani(subst, homologs, zero_on_error != 0);
+	}
+}
+
+// src/io.cxx:141-163
+size_t phylo_format_phylip(size_t n, const char *const *names, const uint64_t *subst, const uint64_t *homologs,
+						   int kind, char *out, size_t cap)
+{
+	std::ostringstream o;
+	o << n << std::endl;
+	o.precision(4);
+	if (kind == 2) o << std::dec;
+	else o << std::scientific;
+	for (size_t i = 0; i < n; i++) {
+		o << names[i];
+		for (size_t j = 0; j < n; j++) {
+			double d = (i == j) ? 0.0 : phylo_estimate(kind, subst[i * n + j], homologs[i * n + j], 0);
+			o << "  " << d;
+		}
+		o << std::endl;
+	}
+	std::string s = o.str();
+	if (out && cap >= s.size() + 1) memcpy(out, s.c_str(), s.size() + 1);
+	return s.size() + 1;
+}
+
+} // extern "C"

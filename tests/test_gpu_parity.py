@@ -1,0 +1,233 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU
+oracle on the same seeded inputs.  Integer tallies, thresholds and homology
+lists must be bit-exact; distances are computed from the integers with the
+same libm, so they are compared with == (tolerance stated by the north star:
+1e-12)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from phylonium_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def hom_tuples_gpu(h):
+    return [(int(b["direction"]), int(b["index_reference"]), int(b["index_reference_projected"]),
+             int(b["index_query"]), int(b["length"])) for b in h]
+
+
+def hom_tuples_orc(h):
+    return [(int(a["rev"]), int(a["iref"]), int(a["iproj"]), int(a["iq"]), int(a["len"])) for a in h]
+
+
+def check_process(ctx, gs, ref, chunk=0, kmer=0, backend=0, complete_deletion=False):
+    ctx.set_option("chunk", chunk)
+    ctx.set_option("kmer", kmer)
+    ctx.set_option("compare_backend", backend)
+    ctx.set_genomes(gs)
+    ctx.set_reference(ref)
+    r = O.Run(gs, ref).process(complete_deletion=complete_deletion)
+    assert ctx.threshold == r.threshold
+    ctx.anchor()
+    if complete_deletion:
+        ctx.complete_delete()
+    for j in range(len(gs)):
+        assert hom_tuples_gpu(ctx.homologies(j)) == hom_tuples_orc(r.homologies(j)), f"homologies of genome {j}"
+    s, h = ctx.compare()
+    so, ho = r.matrix()
+    assert (h == ho).all(), "homologs differ"
+    assert (s == so).all(), "substitutions differ"
+    for i in range(len(gs)):
+        for j in range(len(gs)):
+            a, b = api.estimate("jc", s[i, j], h[i, j]), O.estimate("jc", so[i, j], ho[i, j])
+            assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= 1e-12
+    ctx.set_option("chunk", 0)
+    ctx.set_option("kmer", 0)
+    ctx.set_option("compare_backend", 0)
+    return s, h
+
+
+# ── B0: seqcmp / revseqcmp ──
+def test_seqcmp_batch_all_lengths_and_alignments(ctx):
+    rng = np.random.default_rng(1)
+    alpha = np.frombuffer(b"ACGT!", np.uint8)
+    a = rng.choice(alpha, 6000, p=[.24, .24, .24, .24, .04])
+    b = a.copy()
+    idx = rng.random(6000) < 0.2
+    b[idx] = rng.choice(alpha, int(idx.sum()))
+    ctx.set_genomes([a, b])
+    ga, oa, gb, ob, ln, rv, want = [], [], [], [], [], [], []
+    for n in list(range(0, 301)) + [511, 512, 513, 1023, 1024, 1025, 4096, 5000]:
+        for offa, offb in ((0, 0), (1, 0), (3, 7), (13, 2), (64, 65)):
+            if max(offa, offb) + n > 6000:
+                continue
+            for rev in (0, 1):
+                ga.append(0); gb.append(1); oa.append(offa); ob.append(offb); ln.append(n); rv.append(rev)
+                x, y = a[offa:offa + n], b[offb:offb + n]
+                want.append(O.revseqcmp(x, y, n) if rev else O.seqcmp(x, y, n))
+    got = ctx.seqcmp_batch(ga, oa, gb, ob, ln, rv)
+    assert got.tolist() == want
+
+
+def test_b0_reference_signatures(ctx):
+    rng = np.random.default_rng(2)
+    a = rng.integers(0, 256, 100000, dtype=np.uint8)  # arbitrary bytes, like any char*
+    b = a.copy()
+    b[rng.random(100000) < 0.3] = 7
+    for n in (0, 1, 15, 16, 17, 99999, 100000):
+        assert api.seqcmp(a, b, n) == O.seqcmp(a, b, n)
+        assert api.revseqcmp(a, b, n) == O.revseqcmp(a, b, n)
+
+
+# ── the path ──
+@pytest.mark.parametrize("chunk", [0, 64, 256])
+def test_process_star(ctx, chunk):
+    gs = synth.make_genomes(6, 30000, seed=3, d_range=(0.01, 0.25))
+    check_process(ctx, gs, 0, chunk=chunk)
+    check_process(ctx, gs, 4, chunk=chunk, backend=1)
+
+
+@pytest.mark.parametrize("seed", [5, 6])
+def test_process_indels_inversions_contigs(ctx, seed):
+    gs = synth.make_genomes(7, 40000, seed=seed, d_range=(0.01, 0.3), indel_per_mbp=500, inv_frac=0.1,
+                            contigs=3, inv_len=(100, 1500))
+    for ref in (0, 5):
+        if O.Esa(gs[ref]).cache_quirks():
+            continue
+        s, h = check_process(ctx, gs, ref, chunk=128)
+        s1, h1 = check_process(ctx, gs, ref, chunk=64, kmer=3, backend=1)
+        assert (s == s1).all() and (h == h1).all()
+
+
+def test_process_tree_low_divergence(ctx):
+    gs = synth.make_genomes(9, 80000, seed=9, d_range=(0.0005, 0.03), tree=True, indel_per_mbp=200, inv_frac=0.05)
+    check_process(ctx, gs, 0)
+    check_process(ctx, gs, 7, chunk=128)
+
+
+def test_process_bang_inside_homology(ctx):
+    """A contig break inside a homologous stretch: '!' is projected, so the
+    five-plane pair kernel has to run (seqcmp: '!'!='A'; revseqcmp: '!' acts as 'A')."""
+    rng = np.random.default_rng(31)
+    base = synth.random_base(30000, rng)
+    gs = [base.copy()]
+    for g in range(4):
+        s = synth.mutate(base, 0.02, rng)
+        if g % 2:
+            s = synth.revcomp(s)
+        s = s.copy()
+        for pos in rng.integers(1000, 29000, 6):
+            s[pos] = ord("!")
+        gs.append(s)
+    ref = base.copy()
+    ref[15000] = ord("!")
+    gs.append(ref)
+    s, h = check_process(ctx, gs, 0, chunk=128)
+    check_process(ctx, gs, 5, chunk=128)
+    s1, h1 = check_process(ctx, gs, 0, backend=1)
+    assert (s == s1).all() and (h == h1).all()
+    assert ctx.stat("pileup:bang") is not None
+
+
+def test_process_edge_cases(ctx):
+    rng = np.random.default_rng(24)
+    a = synth.random_base(5000, rng)
+    gs = [a, a.copy(), a[:5].copy(), a[10:11].copy(), np.zeros(0, np.uint8), a[200:230].copy(),
+          np.frombuffer(b"!!!!", np.uint8).copy(), np.frombuffer(b"ACGT!ACGT", np.uint8).copy(),
+          synth.random_base(3000, rng), synth.revcomp(a)]
+    check_process(ctx, gs, 0, chunk=64)
+    check_process(ctx, gs, 1)
+
+
+def test_process_complete_deletion(ctx):
+    gs = synth.make_genomes(5, 30000, seed=12, d_range=(0.01, 0.1), indel_per_mbp=600, inv_frac=0.05)
+    check_process(ctx, gs, 1, complete_deletion=True)
+
+
+def test_process_repeats(ctx):
+    rng = np.random.default_rng(23)
+    unit = synth.random_base(700, rng)
+    sp = [synth.random_base(1500, rng) for _ in range(5)]
+    a = np.concatenate([sp[0], unit, sp[1], unit, sp[2], synth.revcomp(unit), sp[3],
+                        np.frombuffer(b"A" * 300 + b"AC" * 200 + b"T" * 100, np.uint8), sp[4]])
+    b = synth.mutate(a, 0.02, rng)
+    c = synth.mutate(np.concatenate([sp[2], unit, unit, sp[0], np.frombuffer(b"A" * 500, np.uint8)]), 0.01, rng)
+    for ref in (0, 1, 2):
+        check_process(ctx, [a, b, c], ref, chunk=64)
+
+
+def test_external_suffix_array_is_accepted(ctx):
+    gs = synth.make_genomes(3, 20000, seed=41, d_range=(0.02, 0.1))
+    S = gs[1].tobytes() + b"#" + O.revcomp(gs[1].tobytes())
+    ctx.set_genomes(gs)
+    ctx.set_reference(1, sa=O.suffix_array(S))  # what divsufsort64 would hand over
+    ctx.anchor()
+    s, h = ctx.compare()
+    so, ho = O.Run(gs, 1).process().matrix()
+    assert (s == so).all() and (h == ho).all()
+
+
+def test_sharded_compare_sums_to_full(ctx):
+    gs = synth.make_genomes(70, 6000, seed=43, d_range=(0.01, 0.2))
+    ctx.set_genomes(gs)
+    ctx.set_reference(3)
+    ctx.anchor(0, 30)
+    ctx.anchor(30, 70)
+    s, h = ctx.compare()
+    acc_s, acc_h = np.zeros_like(s), np.zeros_like(h)
+    for part in range(3):
+        ps, ph = ctx.compare(part, 3)
+        acc_s += ps
+        acc_h += ph
+    assert (acc_s == s).all() and (acc_h == h).all()
+    so, ho = O.Run(gs, 3).process(threads=4).matrix()
+    assert (s == so).all() and (h == ho).all()
+
+
+# ── golden fixtures: known answers of the compiled reference ──
+def test_golden_simple_and_cfg1(ctx, golden_dir):
+    known = json.load(open(os.path.join(golden_dir, "known_answers.json")))
+    g = [O.read_fasta_genome(os.path.join(golden_dir, f"simple{i}.fasta.gz")) for i in (0, 1)]
+    ctx.set_genomes(g)
+    s, h = ctx.process(1)
+    assert api.format_phylip(["simple0", "simple1"], s, h) == \
+        "2\nsimple0  0.0000e+00  9.7004e-02\nsimple1  9.7004e-02  0.0000e+00\n"
+    k = known["cfg1"]
+    g = [O.read_fasta_genome(os.path.join(golden_dir, f"cfg1_{i}.fasta.gz")) for i in (0, 1)]
+    ctx.set_genomes(g)
+    s, h = ctx.process(k["ref"])
+    assert ctx.threshold == k["threshold"]
+    hv = ctx.homologies(0)
+    assert len(hv) == k["n_homologies_q0"] and int(hv["length"].sum()) == k["covered_q0"]
+    assert [[int(x["index_reference"]), int(x["index_query"]), int(x["length"])] for x in hv[:3]] == \
+        k["first_homologies_q0"]
+    assert int(s[0, 1]) == k["substitutions"] and int(h[0, 1]) == k["homologs"]
+    assert "%.17g" % api.estimate("jc", s[0, 1], h[0, 1]) == k["jc"]
+    names = ["cfg1_0", "cfg1_1"]
+    assert api.format_phylip(names, s, h, "jc").split()[3] == k["phylip_jc"]
+    assert api.format_phylip(names, s, h, "raw").split()[3] == k["phylip_raw"]
+    assert api.format_phylip(names, s, h, "ani").split()[3] == k["phylip_ani"]
+
+
+def test_medium_scale_parity_and_properties(ctx):
+    """24 x 400 kbp with structure: oracle-checked; plus size-independent
+    properties (symmetry, homologs <= min genome length, self-row coverage)."""
+    gs = synth.make_genomes(24, 400000, seed=51, d_range=(0.01, 0.3), indel_per_mbp=100, inv_frac=0.02)
+    ctx.set_genomes(gs)
+    s, h = ctx.process(11)
+    r = O.Run(gs, 11).process(threads=8)
+    so, ho = r.matrix()
+    assert (s == so).all() and (h == ho).all()
+    assert (s == s.T).all() and (h == h.T).all() and (s <= h).all()
+    assert (np.diag(h) == 0).all()
