@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the anchor + pairwise-compare path on MI355X.
+
+One "step" = one pass of the hot path (phase A anchor chains + host sort/filter
++ phase B pair grid) over the resident synthetic genome set, i.e. one
+`process(subject, queries)` of /root/reference/src/process.cxx:408-556 minus
+the suffix-array build (which the north star keeps on the host and the metric
+excludes).  Inputs (genomes, reference index) are resident in HBM before the
+timed region.  Prints ONE JSON line (see the task contract).
+
+Run:  python bench.py [--gpus N --steps K --warmup W --workload c3]
+N>1:  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (genomes, length, d_range, indel_per_mbp, inv_frac, description)
+    "c1": (2, 1_000_000, (0.1, 0.1), 0, 0.0, "configs[0]: 2 x 1 Mbp, d=0.1, substitutions only"),
+    "c2like": (29, 5_000_000, (0.0002, 0.03), 20, 0.005, "configs[1] stand-in (eco29 data absent): 29 x 5 Mbp, d in [0.0002,0.03]"),
+    "c3": (256, 5_000_000, (0.01, 0.3), 100, 0.02, "configs[2]: 256 x 5 Mbp, d in [0.01,0.3] from the reference, 100 indels/Mbp, 2% inverted"),
+    "c4": (1024, 5_000_000, (0.01, 0.3), 100, 0.02, "configs[3]: 1024 x 5 Mbp, same distribution as c3"),
+    "small": (32, 1_000_000, (0.01, 0.3), 100, 0.02, "dev: 32 x 1 Mbp"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+
+
+def make_genomes_gpu(torch, n, length, seed, device, d_range, indel_per_mbp, inv_frac, inv_len=(1000, 5000)):
+    """Synthetic genome set on the GPU. Genome 0 is the unmutated base (the reference,
+    like simf's S0, test/simf.cxx:32); genome g>0 = base at JC distance d_g ~ U(d_range),
+    plus indel events and inverted blocks. Returns (buffer, offsets, lengths)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    base = torch.randint(0, 4, (length,), dtype=torch.uint8, generator=g, device=device)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    codes = []
+    for k in range(n):
+        if k == 0:
+            code = base
+        else:
+            d = float(rng.uniform(*d_range))
+            p = 0.75 - 0.75 * math.exp(-(4.0 / 3.0) * d)
+            hit = torch.rand(length, generator=g, device=device) < p
+            shift = torch.randint(1, 4, (length,), dtype=torch.uint8, generator=g, device=device)
+            code = (base + hit.to(torch.uint8) * shift) & 3
+            n_indel = int(round(indel_per_mbp * length / 1e6))
+            n_inv = int(round(inv_frac * length / (0.5 * (inv_len[0] + inv_len[1]))))
+            if n_indel or n_inv:
+                ev = [(int(x), 0) for x in rng.integers(0, length, n_indel)] + \
+                     [(int(x), 1) for x in rng.integers(0, length, n_inv)]
+                ev.sort()
+                pieces, pos = [], 0
+                for at, kind in ev:
+                    if at < pos:
+                        continue
+                    pieces.append(code[pos:at])
+                    if kind == 0:
+                        ln = int(rng.integers(1, 51))
+                        if rng.random() < 0.5:
+                            pos = min(length, at + ln)
+                        else:
+                            pieces.append(torch.randint(0, 4, (ln,), dtype=torch.uint8, generator=g, device=device))
+                            pos = at
+                    else:
+                        ln = int(rng.integers(inv_len[0], inv_len[1] + 1))
+                        end = min(length, at + ln)
+                        pieces.append(3 - torch.flip(code[at:end], dims=(0,)))  # reverse complement
+                        pos = end
+                pieces.append(code[pos:])
+                code = torch.cat(pieces)
+        codes.append(code)
+    lens = [int(c.numel()) for c in codes]
+    offs, tot = [], 64
+    for l in lens:
+        offs.append(tot)
+        tot += (l + 63) // 64 * 64 + 64
+    buf = torch.zeros(tot, dtype=torch.uint8, device=device)
+    for c, o, l in zip(codes, offs, lens):
+        buf[o:o + l] = lut[c.long()]
+    del codes
+    return buf, offs, lens
+
+
+def cpu_baseline(torch, buf, offs, lens, ref_idx, sa_ref, sample_queries, threads):
+    """The oracle (CPU port of the reference path) on a bounded sample of the same
+    workload: the reference genome plus `sample_queries` others, anchor + compare
+    timed, ESA construction excluded (as the suffix-array build is on the GPU side)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    idx = [ref_idx] + [j for j in range(len(lens)) if j != ref_idx][:sample_queries]
+    gs = [buf[offs[j]:offs[j] + lens[j]].cpu().numpy() for j in idx]
+    r = O.Run(gs, 0)
+    r.process(sa=sa_ref, threads=threads)
+    t_esa, t_a, t_b = r.times()
+    bases = float(sum(len(g) for g in gs))
+    return {"value": bases / (t_a + t_b) / 1e9, "unit": "Gbp/s", "cores": threads, "kind": "port",
+            "sample": f"oracle (C++ restatement of process.cxx/esa.cxx, OpenMP over queries and pair rows) on "
+                      f"{len(gs)} of the workload's genomes ({bases / 1e6:.0f} Mbp): anchor {t_a:.2f}s + compare "
+                      f"{t_b:.2f}s; ESA build {t_esa:.1f}s excluded"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--genomes", type=int, default=0, help="override genome count")
+    ap.add_argument("--length", type=int, default=0, help="override genome length")
+    ap.add_argument("--seed", type=int, default=20260101)
+    ap.add_argument("--cpu-sample", type=int, default=7, help="queries in the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not time kernels with HIP events")
+    ap.add_argument("--check", action="store_true", help="verify a sample of the result against the oracle")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as td
+    from phylonium_amd import api, dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        td.init_process_group(backend="nccl", device_id=device)
+
+    n, length, d_range, indel, inv, desc = WORKLOADS[args.workload]
+    n = args.genomes or n
+    length = args.length or length
+    t_gen = time.time()
+    buf, offs, lens = make_genomes_gpu(torch, n, length, args.seed, device, d_range, indel, inv)
+    torch.cuda.synchronize()
+    t_gen = time.time() - t_gen
+    ref_idx = 0
+
+    ctx = api.Context(local)
+    ctx.set_option("profile", 0 if args.no_profile else 1)
+    ctx.set_genomes_device(buf.data_ptr(), offs, lens)
+    t_ref = time.time()
+    ctx.set_reference(ref_idx)  # host suffix array + tables: outside the metric
+    t_ref = time.time() - t_ref
+    ref_stats = {k: ctx.stat(k) for k in ("ms:ref_suffix_array", "ms:ref_lcp_table", "ms:ref_total")}
+    total_bases = float(sum(lens))
+
+    def step():
+        return dist.process_sharded(ctx, ref_idx, rank, world, device=device, lengths=lens, set_reference=False)
+
+    for _ in range(args.warmup):
+        s, h = step()
+    ctx.reset_stats()
+    if world > 1:
+        td.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        s, h = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        td.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        dt = float(t.item())
+
+    stats = ctx.stats()
+    if rank == 0:
+        K = args.steps
+        P = n * (n - 1) // 2
+        ns = 2 * lens[ref_idx] + 1
+        sites = float(np.triu(h.astype(np.float64), 1).sum())
+        bytes_a = total_bases + 26.0 * ns          # each query byte once + one pass over the reference-layout ESA
+        bytes_b = 2.0 * sites + 16.0 * P           # two 1-byte nucleotides per compared site + one 16 B tally per pair
+        kern = {k[3:]: v for k, v in stats.items() if k.startswith("ms:") and ("n:" + k[3:]) in stats}
+        launches = {k: stats["n:" + k] for k in kern}
+        roof = None
+        kernels = {}
+        if kern:
+            alg = {"anchor_spec": bytes_a / world, "anchor_bridge": 0.0, "anchor_fold": 0.0, "anchor_compact": 0.0,
+                   "pileup_project": total_bases, "pileup_pairs": bytes_b / world, "pileup_pairs_bang": bytes_b / world,
+                   "seqcmp_batch": bytes_b / world}
+            for k in kern:
+                avg_ms = kern[k] / launches[k]
+                kernels[k] = {"avg_ms": round(avg_ms, 4), "launches_per_step": launches[k] / K,
+                              "alg_GBps": round(alg.get(k, 0.0) / (avg_ms * 1e-3) / 1e9, 2)}
+            dom = max(kern, key=lambda k: kern[k])
+            avg_ms = kern[dom] / launches[dom]
+            achieved = alg.get(dom, 0.0) / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get(args.workload, {}).get(dom)
+                except Exception:
+                    traffic = None
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "alg_bytes_per_launch": alg.get(dom, 0.0), "avg_launch_ms": round(avg_ms, 4),
+                    "note": "anchor_* kernels are latency/random-access bound (gathers over SA/LCP/T/S), not HBM-streaming; "
+                            "pileup_pairs moves far fewer HBM bytes than the reference layout's algorithmic 2 B/site"}
+        cpu = None
+        if world == 1 and args.cpu_sample > 0:
+            try:
+                sa_ref = None
+                S = None
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import oracle_lib as O
+                refb = buf[offs[ref_idx]:offs[ref_idx] + lens[ref_idx]].cpu().numpy().tobytes()
+                S = refb + b"#" + O.revcomp(refb)
+                sa_ref = api.host_suffix_array(S)  # the suffix array is unique; saves the oracle's slow sorter
+                threads = min(os.cpu_count() or 1, 1 + min(args.cpu_sample, n - 1))
+                cpu = cpu_baseline(torch, buf, offs, lens, ref_idx, sa_ref, min(args.cpu_sample, n - 1), threads)
+            except Exception as e:  # the baseline is a report, never a reason to lose the bench line
+                cpu = {"value": None, "unit": "Gbp/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
+        if args.check:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O
+            m = min(n, 6)
+            gs = [buf[offs[j]:offs[j] + lens[j]].cpu().numpy() for j in range(m)]
+            so, ho = O.Run(gs, 0).process(threads=os.cpu_count() or 1).matrix()
+            ok = bool((s[:m, :m] == so).all() and (h[:m, :m] == ho).all())
+            print(f"# check vs oracle on the first {m} genomes: {'OK' if ok else 'MISMATCH'}", file=sys.stderr)
+            if not ok:
+                raise SystemExit(2)
+        out = {
+            "metric": "Gbp/s through anchor+seqcmp", "value": round(total_bases * K / dt / 1e9, 4), "unit": "Gbp/s",
+            "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {desc}", "genomes": n, "genome_length": length,
+                       "query_bases": total_bases, "pairs": P, "reference": "genome 0 (unmutated base)",
+                       "threshold": ctx.threshold, "seed": args.seed,
+                       "parallelism": f"queries and pair tiles sharded over {world} GPU(s)"},
+            "roofline": roof, "cpu_baseline": cpu,
+            "phases_ms_per_step": {k[3:]: round(v / K, 3) for k, v in stats.items()
+                                   if k in ("ms:anchor_total", "ms:anchor_gpu", "ms:anchor_setup", "ms:anchor_copyback",
+                                            "ms:host_sort_filter", "ms:compare_total")},
+            "kernels": kernels,
+            "compared_sites": sites, "alg_bytes": {"anchor": bytes_a, "compare": bytes_b},
+            "path_alg_GBps": round((bytes_a + bytes_b) * K / dt / 1e9, 2),
+            "setup_s": {"generate": round(t_gen, 2), "reference_index": round(t_ref, 2),
+                        "suffix_array": round((ref_stats["ms:ref_suffix_array"] or 0) / 1e3, 2)},
+        }
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -29,6 +29,7 @@
 // Every function cites the reference lines it follows.
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -780,6 +781,7 @@ struct run_port {
 	std::vector<std::vector<hom>> filtered; // after sort + filter (+ complete deletion)
 	std::vector<tally> matrix;              // n*n row-major
 	esa_port *esa = nullptr;
+	double t_esa = 0, t_anchor = 0, t_compare = 0; // seconds, for bench.py's cpu_baseline
 	~run_port() { delete esa; }
 };
 
@@ -789,7 +791,11 @@ static void process_port(run_port &r, bool complete_deletion, const int64_t *sa,
 {
 	size_t N = r.n;
 	const std::string &subject = r.seqs[r.ref_idx];
+	auto clk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	double c0 = clk();
 	if (!r.esa) r.esa = new esa_port(subject, sa);
+	double c1 = clk();
+	r.t_esa = c1 - c0;
 	r.gc = gc_content_port(subject.data(), subject.size());
 	r.threshold = min_anchor_length_port(0.025, r.gc, (size_t)r.esa->size);
 	r.raw.assign(N, {});
@@ -802,9 +808,12 @@ static void process_port(run_port &r, bool complete_deletion, const int64_t *sa,
 		sort_and_filter_port(hv);
 		r.filtered[j] = std::move(hv);
 	}
+	double c2 = clk();
+	r.t_anchor = c2 - c1;
 	if (complete_deletion) r.filtered = complete_delete_port(r.filtered);
 	r.matrix.assign(N * N, tally());
 	if (!do_compare) return;
+	double c3 = clk();
 #pragma omp parallel for num_threads(threads) schedule(dynamic)
 	for (size_t i = q_begin; i < q_end; i++) {
 		for (size_t j = i + 1; j < q_end; j++) {
@@ -813,6 +822,7 @@ static void process_port(run_port &r, bool complete_deletion, const int64_t *sa,
 			r.matrix[j * N + i] = t;
 		}
 	}
+	r.t_compare = clk() - c3;
 }
 
 // src/io.cxx:141-163 — PHYLIP text for one matrix.
@@ -1027,6 +1037,13 @@ void orc_run_process(void *rp, int complete_deletion, const int64_t *sa_or_null,
 {
 	process_port(*(run_port *)rp, complete_deletion != 0, sa_or_null, threads < 1 ? 1 : threads,
 				 q_begin, q_end, do_compare != 0);
+}
+void orc_run_times(void *rp, double out[3])
+{
+	run_port *r = (run_port *)rp;
+	out[0] = r->t_esa;
+	out[1] = r->t_anchor;
+	out[2] = r->t_compare;
 }
 size_t orc_run_threshold(void *rp) { return ((run_port *)rp)->threshold; }
 double orc_run_gc(void *rp) { return ((run_port *)rp)->gc; }

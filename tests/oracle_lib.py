@@ -73,6 +73,7 @@ def lib():
     L.orc_run_create.argtypes = [sz, vp, vp, sz]
     L.orc_run_destroy.argtypes = [vp]
     L.orc_run_process.argtypes = [vp, C.c_int, vp, C.c_int, sz, sz, C.c_int]
+    L.orc_run_times.argtypes = [vp, C.POINTER(C.c_double)]
     L.orc_run_threshold.restype = sz
     L.orc_run_threshold.argtypes = [vp]
     L.orc_run_gc.restype = C.c_double
@@ -275,6 +276,12 @@ class Run:
     @property
     def threshold(self):
         return lib().orc_run_threshold(self.h)
+
+    def times(self):
+        """(esa build, anchor phase, compare phase) wall seconds of the last process()."""
+        out = (C.c_double * 3)()
+        lib().orc_run_times(self.h, out)
+        return tuple(out)
 
     @property
     def gc(self):
