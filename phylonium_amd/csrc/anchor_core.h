@@ -35,9 +35,9 @@ namespace phy {
 
 struct RefIndex {
 	const uint8_t *S;    // n bytes of subject + '#' + revcomp, then >= 64 zero bytes
-	const uint32_t *SA;  // n entries
-	const uint32_t *LCP; // n+1 entries; LCP[r] = lcp(suffix SA[r-1], suffix SA[r]); LCP[0]=LCP[n]=0
-	const uint32_t *T;   // 4^k+1 entries; T[c] = #suffixes lexicographically < k-mer c
+	const uint32_t *SA;  // n entries (+4 pad: tables are read 16 bytes at a time)
+	const uint32_t *LCP; // n+1 entries (+4 pad); LCP[r] = lcp(suffix SA[r-1], suffix SA[r]); LCP[0]=LCP[n]=0
+	const uint32_t *T;   // 4^k+1 entries (+4 pad); T[c] = #suffixes lexicographically < k-mer c
 	uint32_t n;          // |S| = 2L+1
 	uint32_t k;          // bucket k-mer length (1..14)
 	uint32_t threshold;  // minimum anchor length
@@ -47,19 +47,23 @@ struct Anchor {
 	uint32_t q, s, len; // this_pos_Q, this_pos_S, this_length of an accepted anchor
 };
 
-PHY_HD uint64_t load8(const uint8_t *p)
+struct U4 { // 16 bytes of sequence or four table entries
+	uint32_t x, y, z, w;
+};
+
+PHY_HD U4 load16(const uint8_t *p)
 {
-	uint64_t v;
-	__builtin_memcpy(&v, p, 8);
+	U4 v;
+	__builtin_memcpy(&v, p, 16);
 	return v;
 }
 
-PHY_HD uint32_t ctz64(uint64_t x)
+PHY_HD uint32_t ctz32(uint32_t x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-	return (uint32_t)__ffsll((unsigned long long)x) - 1u;
+	return (uint32_t)__ffs((int)x) - 1u;
 #else
-	return (uint32_t)__builtin_ctzll(x);
+	return (uint32_t)__builtin_ctz(x);
 #endif
 }
 
@@ -70,97 +74,115 @@ PHY_HD uint32_t nuc_code(uint8_t b)
 	return (((0x54474341u >> (8 * v)) & 0xffu) == b) ? v : 4u;
 }
 
-PHY_HD bool kmer_code(const uint8_t *q, uint32_t k, uint32_t *code)
+PHY_HD uint32_t byte_at(const U4 &v, uint32_t i)
 {
-	uint32_t c = 0;
-	for (uint32_t i = 0; i < k; i++) {
-		uint32_t v = nuc_code(q[i]);
-		if (v > 3) return false;
-		c = (c << 2) | v;
-	}
-	*code = c;
-	return true;
+	uint32_t w = (i < 4) ? v.x : (i < 8) ? v.y : (i < 12) ? v.z : v.w;
+	return (w >> (8 * (i & 3))) & 0xffu;
 }
 
-struct CmpReq {
-	const uint8_t *qp; // query suffix
-	const uint8_t *sp; // subject suffix
-	uint32_t from;     // bytes already known equal
-	uint32_t maxn;     // remaining query length (compare stops there)
-};
+// Four bytes → four 2-bit codes (A0 C1 G2 T3) packed first-byte-first into 8
+// bits; `bad` gets 0x80 in every byte that is not one of A,C,G,T.
+PHY_HD uint32_t code4(uint32_t x, uint32_t *bad)
+{
+	uint32_t c = ((x >> 1) & 0x03030303u) ^ ((x >> 2) & 0x01010101u);
+	uint32_t b0 = c & 0x01010101u, b1 = (c >> 1) & 0x01010101u;
+	uint32_t expect = 0x41414141u + 2u * b0 + 6u * b1 + 11u * (b0 & b1); // 'A','C','G','T' per byte
+	uint32_t diff = expect ^ x;
+	*bad = (((diff & 0x7f7f7f7fu) + 0x7f7f7f7fu) | diff) & 0x80808080u;
+	return (c * 0x40100401u) >> 24;
+}
 
-struct CmpRes {
-	uint32_t len; // common prefix length, <= maxn
-	bool s_less;  // subject byte < query byte at the first difference (false when len==maxn)
-};
+// k-mer code of the first k (<= 14) bytes of a 16-byte window; false if any of
+// them is not A,C,G,T
+PHY_HD bool kmer_code16(const U4 &q, uint32_t k, uint32_t *code)
+{
+	uint32_t b0, b1, b2, b3;
+	uint32_t c = (code4(q.x, &b0) << 24) | (code4(q.y, &b1) << 16) | (code4(q.z, &b2) << 8) | code4(q.w, &b3);
+	uint32_t first_bad = b0 ? (ctz32(b0) >> 3) : b1 ? 4u + (ctz32(b1) >> 3) : b2 ? 8u + (ctz32(b2) >> 3)
+											   : b3 ? 12u + (ctz32(b3) >> 3) : 16u;
+	*code = c >> (2u * (16u - k));
+	return first_bad >= k;
+}
 
-// Compare up to `budget` bytes past `from`. Returns true when decided.
+PHY_HD uint32_t sel4(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t i)
+{
+	return i == 0 ? a0 : i == 1 ? a1 : i == 2 ? a2 : a3;
+}
+
+// index of the first differing byte of two 16-byte windows, 16 if equal
+PHY_HD uint32_t first_diff(const U4 &a, const U4 &b)
+{
+	uint32_t x;
+	if ((x = a.x ^ b.x)) return ctz32(x) >> 3;
+	if ((x = a.y ^ b.y)) return 4u + (ctz32(x) >> 3);
+	if ((x = a.z ^ b.z)) return 8u + (ctz32(x) >> 3);
+	if ((x = a.w ^ b.w)) return 12u + (ctz32(x) >> 3);
+	return 16u;
+}
+
 // The query is followed by zero padding and S by zero padding, and query bytes
-// inside [0,maxn) are never zero, so running past the end of S stops the scan
-// by itself (that is the NUL the reference's loops stop at, esa.cxx:461,
-// process.cxx:179).
-PHY_HD bool cmp_some(const CmpReq &r, uint32_t budget, uint32_t *pos, CmpRes *out)
-{
-	uint32_t i = *pos;
-	uint32_t stop = (r.maxn - i > budget) ? i + budget : r.maxn;
-	while (i < stop) {
-		uint64_t a = load8(r.qp + i), b = load8(r.sp + i);
-		uint64_t x = a ^ b;
-		if (x) {
-			uint32_t byte = ctz64(x) >> 3;
-			i += byte;
-			if (i >= r.maxn) {
-				out->len = r.maxn;
-				out->s_less = false;
-			} else {
-				out->len = i;
-				out->s_less = (uint8_t)(b >> (8 * byte)) < (uint8_t)(a >> (8 * byte));
-			}
-			return true;
-		}
-		i += 8;
-	}
-	if (i >= r.maxn) {
-		out->len = r.maxn;
-		out->s_less = false;
-		return true;
-	}
-	*pos = i;
-	return false;
-}
+// inside [0,n) are never zero, so running past the end of S ends a match by
+// itself (that is the NUL the reference's loops stop at, esa.cxx:461,
+// process.cxx:179); running past the end of the query is cut by `n`.
 
 enum ChainState : uint32_t {
-	ST_STEP = 0, // at a fresh query position
-	ST_LUCKY_R,
-	ST_BS,
+	ST_STEP = 0, // load the query window (and the lucky window)
+	ST_T,        // load T[code], T[code+1]
+	ST_SA,       // load four suffix-array entries around a small bucket
+	ST_CAND,     // load the windows of up to four candidate suffixes
+	ST_EXT,      // extend one comparison by 32 bytes
+	ST_FIN,      // decide; maybe load LCP[best], LCP[best+1]
+	ST_BS,       // generic binary search (large buckets, non-ACGT k-mers) …
 	ST_BS_R,
+	ST_PR_SA,    // … probe: load SA[rank]
+	ST_PR_S,     // … probe: load the suffix window
 	ST_NBP,
 	ST_NBP_R,
 	ST_NBS,
-	ST_NBS_R,
-	ST_FIN
+	ST_NBS_R
 };
 
-enum AdvanceResult : uint32_t { ADV_NEED_CMP = 0, ADV_STEP_DONE = 1 };
+enum ExtKind : uint32_t { EXT_LUCKY = 0, EXT_CAND = 1, EXT_PROBE = 2 };
+
+static const uint32_t EXT_COOP_AT = 16 + 8 * 32; // lanes extend this far alone, then ask the wave
+
+struct Data {
+	U4 w[4];
+};
 
 // One chain = the loop of anchor_homologies (process.cxx:245-282) without the
 // homology bookkeeping (that is a fold over the accepted anchors, done later).
+//
+// A step walks through phases in a fixed order — STEP, T, SA, CAND, GEN, EXT,
+// FIN — and each phase is "issue a batch of independent 16-byte loads, then
+// digest them".  The kernel runs the phases in that order inside one loop trip,
+// every phase executed once for all lanes currently in it: lanes stay roughly in
+// step with each other, each phase's code runs with most lanes active, and a
+// typical step (k-mer bucket of <= 2 suffixes) costs one trip.
 struct Chain {
 	const uint8_t *Q; // query bytes
 	uint32_t qlen;
 	uint32_t q;          // this_pos_Q
 	uint32_t lq, ls, ll; // last_pos_Q, last_pos_S, last_length
 	uint32_t st;
+	bool fin;            // a step has just finished: r_* are valid
 
-	// search state
-	uint32_t lo, hi, mid;
-	uint32_t l_lo, l_hi; // lcp(query, suffix lo-1) / lcp(query, suffix hi) when known
-	uint32_t p_lo, p_hi; // their positions in S
+	U4 qc;               // Q[q .. q+16)
 	uint32_t flags;      // bit0 lo_known, bit1 hi_known, bit2 k-mer bucket valid
-	uint32_t p;          // subject position of the pending comparison
+	uint32_t lo, hi, mid;
+	uint32_t l_lo, l_hi, p_lo, p_hi; // generic search bookkeeping
+	// small-bucket candidates: ranks c_rank0 .. c_rank0+c_n-1
+	uint32_t c_rank0, c_n, c_pending;
+	uint32_t c_pos0, c_pos1, c_pos2, c_pos3, c_len0, c_len1, c_len2, c_len3;
+	uint32_t c_less; // bit i = candidate i < query
+	// extension / probe
+	uint32_t e_kind, e_idx, e_pos, e_p; // which comparison, bytes known equal, subject position
+	uint32_t pr_rank, pr_ret;           // probe rank, state to return to
+	uint32_t pr_pos, pr_len, pr_less;
+	// neighbours of the insertion point
 	uint32_t lp, pp, lsu, psu;
 
-	// result of the step that just finished (valid after ADV_STEP_DONE)
+	// result of the step that just finished (valid while fin)
 	uint32_t r_q, r_s, r_len;
 	bool r_accepted;
 
@@ -174,6 +196,13 @@ struct Chain {
 		ls = a_s;
 		ll = a_len;
 		st = ST_STEP;
+		fin = false;
+	}
+
+	PHY_HD bool lucky_ok(const RefIndex &R) const
+	{
+		uint32_t advance = q - lq;
+		return (ls + advance < R.n) && (advance - ll <= R.threshold); // process.cxx:228-235
 	}
 
 	PHY_HD void finish_step(uint32_t pos, uint32_t len, bool accepted)
@@ -189,71 +218,218 @@ struct Chain {
 		}
 		q += len + 1; // process.cxx:281
 		st = ST_STEP;
+		fin = true;
 	}
 
-	// Runs the machine until it needs a suffix comparison (fills req) or the
-	// current step is complete. `res` is the answer to the previous request.
-	PHY_HD AdvanceResult advance(const RefIndex &R, const CmpRes &res, CmpReq *req)
+	// compare a 16-byte subject window with the query window; true when decided
+	PHY_HD bool window_cmp(const U4 &sw, uint32_t *len, uint32_t *less) const
+	{
+		uint32_t n = qlen - q;
+		uint32_t m = n < 16 ? n : 16;
+		uint32_t d = first_diff(qc, sw);
+		if (d < m) {
+			*len = d;
+			*less = byte_at(sw, d) < byte_at(qc, d) ? 1u : 0u;
+			return true;
+		}
+		if (n <= 16) {
+			*len = n;
+			*less = 0;
+			return true;
+		}
+		return false;
+	}
+
+	PHY_HD void start_ext(uint32_t kind, uint32_t idx, uint32_t p)
+	{
+		e_kind = kind;
+		e_idx = idx;
+		e_pos = 16;
+		e_p = p;
+		st = ST_EXT;
+	}
+
+	PHY_HD void set_len(uint32_t i, uint32_t v)
+	{
+		if (i == 0) c_len0 = v;
+		else if (i == 1) c_len1 = v;
+		else if (i == 2) c_len2 = v;
+		else c_len3 = v;
+	}
+	PHY_HD uint32_t cpos(uint32_t i) const { return sel4(c_pos0, c_pos1, c_pos2, c_pos3, i); }
+	PHY_HD uint32_t clen(uint32_t i) const { return sel4(c_len0, c_len1, c_len2, c_len3, i); }
+
+	PHY_HD void lucky_done(const RefIndex &R, uint32_t len)
+	{
+		if (len >= R.threshold) finish_step(e_p, len, true); // process.cxx:241
+		else begin_search(R);
+	}
+
+	PHY_HD void begin_search(const RefIndex &R)
+	{
+		uint32_t code;
+		flags = 0;
+		l_lo = l_hi = 0;
+		if (qlen - q >= R.k && kmer_code16(qc, R.k, &code)) {
+			lo = code; // phase T reads T[code], T[code+1]
+			flags = 4u;
+			st = ST_T;
+		} else {
+			lo = 0;
+			hi = R.n;
+			st = ST_BS;
+		}
+	}
+
+	// all candidates compared (or one more needs extending)
+	PHY_HD void cand_next(const RefIndex &R)
+	{
+		if (c_pending) {
+			uint32_t i = ctz32(c_pending);
+			start_ext(EXT_CAND, i, cpos(i));
+			return;
+		}
+		// insertion point: bucket members smaller than the query come first
+		uint32_t ins = lo;
+		while (ins < hi && ((c_less >> (ins - c_rank0)) & 1u)) ins++;
+		uint32_t a = 0, b = 0, c = 0, d = 0;
+		if (ins > c_rank0) {
+			a = clen(ins - 1 - c_rank0);
+			b = cpos(ins - 1 - c_rank0);
+		}
+		if (ins < R.n) {
+			c = clen(ins - c_rank0);
+			d = cpos(ins - c_rank0);
+		}
+		lp = a;
+		pp = b;
+		lsu = c;
+		psu = d;
+		lo = hi = ins;
+		st = ST_FIN;
+	}
+
+	// a finished comparison goes back to whoever asked for it
+	PHY_HD void deliver(const RefIndex &R, uint32_t len, uint32_t less)
+	{
+		if (e_kind == EXT_LUCKY) {
+			lucky_done(R, len);
+		} else if (e_kind == EXT_CAND) {
+			set_len(e_idx, len);
+			if (less) c_less |= 1u << e_idx;
+			c_pending &= ~(1u << e_idx);
+			cand_next(R);
+		} else {
+			pr_len = len;
+			pr_less = less;
+			st = pr_ret;
+		}
+	}
+
+	// ── phase STEP: lucky_anchor (process.cxx:227-242), then start the search ──
+	PHY_HD uint32_t issue_step(const RefIndex &R, const uint8_t **a0, const uint8_t **a1) const
+	{
+		*a0 = Q + q;
+		if (lucky_ok(R)) {
+			*a1 = R.S + (ls + (q - lq));
+			return 2;
+		}
+		return 1;
+	}
+	PHY_HD void consume_step(const RefIndex &R, const U4 &qw, const U4 &sw)
+	{
+		qc = qw;
+		if (lucky_ok(R)) {
+			uint32_t len, less;
+			e_p = ls + (q - lq);
+			if (window_cmp(sw, &len, &less)) lucky_done(R, len);
+			else start_ext(EXT_LUCKY, 0, e_p);
+			return;
+		}
+		begin_search(R);
+	}
+
+	// ── phase T ──
+	PHY_HD const uint8_t *issue_T(const RefIndex &R) const { return (const uint8_t *)(R.T + lo); }
+	PHY_HD void consume_T(const U4 &t)
+	{
+		lo = t.x;
+		hi = t.y;
+		if (hi - lo <= 2) {
+			c_rank0 = lo > 0 ? lo - 1 : 0;
+			st = ST_SA;
+		} else {
+			st = ST_BS;
+		}
+	}
+
+	// ── phase SA: predecessor of the bucket, its members, its successor ──
+	PHY_HD const uint8_t *issue_SA(const RefIndex &R) const { return (const uint8_t *)(R.SA + c_rank0); }
+	PHY_HD void consume_SA(const RefIndex &R, const U4 &v)
+	{
+		uint32_t last = hi < R.n ? hi : R.n - 1;
+		c_n = last - c_rank0 + 1;
+		c_pos0 = v.x;
+		c_pos1 = v.y;
+		c_pos2 = v.z;
+		c_pos3 = v.w;
+		st = ST_CAND;
+	}
+
+	// ── phase CAND ──
+	PHY_HD void consume_cand(const RefIndex &R, const Data &d)
+	{
+		c_pending = 0;
+		c_less = 0;
+		uint32_t len, less;
+		if (window_cmp(d.w[0], &len, &less)) c_len0 = len, c_less |= less;
+		else c_pending |= 1u;
+		if (c_n > 1) {
+			if (window_cmp(d.w[1], &len, &less)) c_len1 = len, c_less |= less << 1;
+			else c_pending |= 2u;
+		}
+		if (c_n > 2) {
+			if (window_cmp(d.w[2], &len, &less)) c_len2 = len, c_less |= less << 2;
+			else c_pending |= 4u;
+		}
+		if (c_n > 3) {
+			if (window_cmp(d.w[3], &len, &less)) c_len3 = len, c_less |= less << 3;
+			else c_pending |= 8u;
+		}
+		cand_next(R);
+	}
+
+	// ── phase GEN: generic binary search, one probe per trip ──
+	// part a: run the bookkeeping until a probe needs SA[rank] (returns true)
+	PHY_HD bool gen_advance(const RefIndex &R)
 	{
 		for (;;) {
 			switch (st) {
-				case ST_STEP: {
-					// lucky_anchor, process.cxx:227-242
-					uint32_t advance = q - lq;
-					uint32_t gap = advance - ll;
-					uint32_t try_s = ls + advance;
-					if (try_s < R.n && gap <= R.threshold) {
-						p = try_s;
-						req->qp = Q + q;
-						req->sp = R.S + try_s;
-						req->from = 0;
-						req->maxn = qlen - q;
-						st = ST_LUCKY_R;
-						return ADV_NEED_CMP;
-					}
-					begin_search(R);
-					break;
-				}
-				case ST_LUCKY_R: {
-					if (res.len >= R.threshold) {
-						finish_step(p, res.len, true);
-						return ADV_STEP_DONE;
-					}
-					begin_search(R);
-					break;
-				}
-				case ST_BS: {
+				case ST_BS:
 					if (lo < hi) {
 						mid = lo + ((hi - lo) >> 1);
-						p = R.SA[mid];
-						uint32_t a = (flags & 1u) ? l_lo : 0u, b = (flags & 2u) ? l_hi : 0u;
-						req->qp = Q + q;
-						req->sp = R.S + p;
-						req->from = a < b ? a : b;
-						req->maxn = qlen - q;
-						st = ST_BS_R;
-						return ADV_NEED_CMP;
+						pr_rank = mid;
+						pr_ret = ST_BS_R;
+						st = ST_PR_SA;
+						return true;
 					}
 					st = ST_NBP;
 					break;
-				}
-				case ST_BS_R: {
-					if (res.s_less) {
+				case ST_BS_R:
+					if (pr_less) {
 						lo = mid + 1;
-						l_lo = res.len;
-						p_lo = p;
+						l_lo = pr_len;
+						p_lo = pr_pos;
 						flags |= 1u;
 					} else {
 						hi = mid;
-						l_hi = res.len;
-						p_hi = p;
+						l_hi = pr_len;
+						p_hi = pr_pos;
 						flags |= 2u;
 					}
 					st = ST_BS;
 					break;
-				}
-				case ST_NBP: {
-					// predecessor of the insertion point
+				case ST_NBP: // predecessor of the insertion point
 					if (flags & 1u) {
 						lp = l_lo;
 						pp = p_lo;
@@ -261,24 +437,19 @@ struct Chain {
 						lp = 0; // none, or outside a bucket whose member already shares >= k
 						pp = 0;
 					} else {
-						p = R.SA[lo - 1];
-						req->qp = Q + q;
-						req->sp = R.S + p;
-						req->from = 0;
-						req->maxn = qlen - q;
-						st = ST_NBP_R;
-						return ADV_NEED_CMP;
+						pr_rank = lo - 1;
+						pr_ret = ST_NBP_R;
+						st = ST_PR_SA;
+						return true;
 					}
 					st = ST_NBS;
 					break;
-				}
-				case ST_NBP_R: {
-					lp = res.len;
-					pp = p;
+				case ST_NBP_R:
+					lp = pr_len;
+					pp = pr_pos;
 					st = ST_NBS;
 					break;
-				}
-				case ST_NBS: {
+				case ST_NBS:
 					if (flags & 2u) {
 						lsu = l_hi;
 						psu = p_hi;
@@ -286,64 +457,143 @@ struct Chain {
 						lsu = 0;
 						psu = 0;
 					} else {
-						p = R.SA[hi];
-						req->qp = Q + q;
-						req->sp = R.S + p;
-						req->from = 0;
-						req->maxn = qlen - q;
-						st = ST_NBS_R;
-						return ADV_NEED_CMP;
+						pr_rank = hi;
+						pr_ret = ST_NBS_R;
+						st = ST_PR_SA;
+						return true;
 					}
 					st = ST_FIN;
-					break;
-				}
-				case ST_NBS_R: {
-					lsu = res.len;
-					psu = p;
+					return false;
+				case ST_NBS_R:
+					lsu = pr_len;
+					psu = pr_pos;
 					st = ST_FIN;
-					break;
-				}
-				default: { // ST_FIN — anchor(), process.cxx:219-225
-					uint32_t lmax, pos;
-					bool uniq;
-					if (lp > lsu) {
-						lmax = lp;
-						pos = pp;
-						// rank lo-1 is the best; unique iff rank lo-2 does not share lmax
-						uniq = lmax >= R.threshold && R.LCP[lo - 1] < lmax;
-					} else if (lsu > lp) {
-						lmax = lsu;
-						pos = psu;
-						uniq = lmax >= R.threshold && R.LCP[hi + 1] < lmax;
-					} else {
-						lmax = lp;
-						pos = 0;
-						uniq = false;
-					}
-					finish_step(pos, lmax, uniq && lmax >= R.threshold);
-					return ADV_STEP_DONE;
-				}
+					return false;
+				default: return st == ST_PR_SA;
 			}
 		}
 	}
-
-  private:
-	PHY_HD void begin_search(const RefIndex &R)
+	PHY_HD bool in_gen() const { return st >= ST_BS; }
+	PHY_HD const uint8_t *issue_probe_sa(const RefIndex &R) const { return (const uint8_t *)(R.SA + pr_rank); }
+	PHY_HD void consume_probe_sa(uint32_t pos)
 	{
-		uint32_t code;
-		flags = 0;
-		l_lo = l_hi = 0;
-		if (qlen - q >= R.k && kmer_code(Q + q, R.k, &code)) {
-			lo = R.T[code];
-			hi = R.T[code + 1];
-			flags = 4u;
+		pr_pos = pos;
+		st = ST_PR_S;
+	}
+	PHY_HD const uint8_t *issue_probe_s(const RefIndex &R) const { return R.S + pr_pos; }
+	PHY_HD void consume_probe_s(const U4 &sw)
+	{
+		uint32_t len, less;
+		if (window_cmp(sw, &len, &less)) {
+			pr_len = len;
+			pr_less = less;
+			st = pr_ret;
 		} else {
-			lo = 0;
-			hi = R.n;
+			start_ext(EXT_PROBE, 0, pr_pos);
 		}
-		st = ST_BS;
+	}
+
+	// ── phase EXT: 32 more bytes of one comparison; true = hand over to the wave ──
+	PHY_HD void issue_ext(const RefIndex &R, const uint8_t **a) const
+	{
+		a[0] = Q + q + e_pos;
+		a[1] = Q + q + e_pos + 16;
+		a[2] = R.S + e_p + e_pos;
+		a[3] = R.S + e_p + e_pos + 16;
+	}
+	PHY_HD bool consume_ext(const RefIndex &R, const Data &d)
+	{
+		uint32_t n = qlen - q;
+		uint32_t m = n - e_pos; // > 0
+		uint32_t dd = first_diff(d.w[0], d.w[2]);
+		uint32_t qb = byte_at(d.w[0], dd & 15u), sb = byte_at(d.w[2], dd & 15u);
+		if (dd == 16) {
+			uint32_t d2 = first_diff(d.w[1], d.w[3]);
+			dd = 16 + d2;
+			qb = byte_at(d.w[1], d2 & 15u);
+			sb = byte_at(d.w[3], d2 & 15u);
+		}
+		uint32_t lim = m < 32 ? m : 32;
+		if (dd < lim) {
+			deliver(R, e_pos + dd, sb < qb ? 1u : 0u);
+		} else if (m <= 32) {
+			deliver(R, n, 0);
+		} else {
+			e_pos += 32;
+			return e_pos >= EXT_COOP_AT;
+		}
+		return false;
+	}
+
+	// ── phase FIN: anchor(), process.cxx:219-225 ──
+	// returns true when LCP[best], LCP[best+1] are needed to settle uniqueness
+	PHY_HD bool fin_needs_lcp(const RefIndex &R)
+	{
+		uint32_t lmax = lp > lsu ? lp : lsu;
+		if (lp != lsu && lmax >= R.threshold) return true;
+		finish_step(0, lmax, false);
+		return false;
+	}
+	PHY_HD const uint8_t *issue_lcp(const RefIndex &R) const
+	{
+		// rank lo-1 (lp>lsu) or rank hi (lsu>lp) is the only neighbour attaining lmax
+		return (const uint8_t *)(R.LCP + (lp > lsu ? lo - 1 : hi));
+	}
+	PHY_HD void consume_lcp(const U4 &v)
+	{
+		// unique iff the next suffix outward does not share lmax characters with it
+		uint32_t lmax = lp > lsu ? lp : lsu;
+		uint32_t l = lp > lsu ? v.x : v.y; // LCP[best] / LCP[best+1]
+		finish_step(lp > lsu ? pp : psu, lmax, l < lmax);
 	}
 };
+
+// One trip through the phases for a single chain on the CPU (emulation tests);
+// the GPU kernel runs the same phases in the same order for 64 lanes at once.
+// `tail` finishes a comparison that ran past EXT_COOP_AT (the wave-cooperative
+// part on the GPU).
+template <class Tail> PHY_HD void chain_trip(Chain &ch, const RefIndex &R, Tail tail)
+{
+	Data d;
+	if (ch.st == ST_STEP) {
+		const uint8_t *a0, *a1 = nullptr;
+		uint32_t n = ch.issue_step(R, &a0, &a1);
+		U4 qw = load16(a0), sw = {0, 0, 0, 0};
+		if (n > 1) sw = load16(a1);
+		ch.consume_step(R, qw, sw);
+	}
+	if (ch.st == ST_T) ch.consume_T(load16(ch.issue_T(R)));
+	if (ch.st == ST_SA) ch.consume_SA(R, load16(ch.issue_SA(R)));
+	if (ch.st == ST_CAND) {
+		d.w[0] = load16(R.S + ch.c_pos0);
+		d.w[1] = d.w[2] = d.w[3] = d.w[0];
+		if (ch.c_n > 1) d.w[1] = load16(R.S + ch.c_pos1);
+		if (ch.c_n > 2) d.w[2] = load16(R.S + ch.c_pos2);
+		if (ch.c_n > 3) d.w[3] = load16(R.S + ch.c_pos3);
+		ch.consume_cand(R, d);
+	}
+	if (ch.in_gen()) {
+		if (ch.gen_advance(R)) {
+			U4 v = load16(ch.issue_probe_sa(R));
+			ch.consume_probe_sa(v.x);
+			ch.consume_probe_s(load16(ch.issue_probe_s(R)));
+			if (ch.in_gen()) ch.gen_advance(R); // digest the probe now if it was decided
+		}
+	}
+	if (ch.st == ST_EXT) {
+		const uint8_t *a[4];
+		ch.issue_ext(R, a);
+		for (int i = 0; i < 4; i++) d.w[i] = load16(a[i]);
+		if (ch.consume_ext(R, d)) {
+			uint32_t len, less;
+			tail(ch, &len, &less);
+			ch.deliver(R, len, less);
+		}
+	}
+	if (ch.st == ST_FIN) {
+		if (ch.fin_needs_lcp(R)) ch.consume_lcp(load16(ch.issue_lcp(R)));
+	}
+}
 
 // ───────────────────────── phase-A work layout ─────────────────────────
 //

@@ -23,23 +23,6 @@ static __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src)
 	return (uint64_t)__shfl((unsigned long long)v, src, 64);
 }
 
-// first differing byte of two 16-byte pieces, 16 if equal
-static __device__ __forceinline__ uint32_t first_diff16(const uint4 &a, const uint4 &b)
-{
-	uint32_t x0 = a.x ^ b.x, x1 = a.y ^ b.y, x2 = a.z ^ b.z, x3 = a.w ^ b.w;
-	if (x0) return (uint32_t)(__ffs((int)x0) - 1) >> 3;
-	if (x1) return 4u + ((uint32_t)(__ffs((int)x1) - 1) >> 3);
-	if (x2) return 8u + ((uint32_t)(__ffs((int)x2) - 1) >> 3);
-	if (x3) return 12u + ((uint32_t)(__ffs((int)x3) - 1) >> 3);
-	return 16u;
-}
-
-static __device__ __forceinline__ uint32_t byte_of(const uint4 &v, uint32_t i)
-{
-	uint32_t w = (i < 4) ? v.x : (i < 8) ? v.y : (i < 12) ? v.z : v.w;
-	return (w >> (8 * (i & 3))) & 0xffu;
-}
-
 // All currently active lanes of the wave resolve the leader's comparison
 // together: lane r of the m active lanes takes the 16-byte piece r of each
 // m*16-byte block.  `s_end` is the first byte past S's zero padding.
@@ -57,17 +40,12 @@ static __device__ __forceinline__ void coop_compare(const uint8_t *qp, const uin
 		uint32_t d = 0;
 		uint32_t qb = 1, sb = 0;
 		if (in_q) {
-			uint4 a, b;
-			__builtin_memcpy(&a, qp + off, 16);
-			if (sp + off + 16 <= s_end) {
-				__builtin_memcpy(&b, sp + off, 16);
-			} else {
-				b = make_uint4(0, 0, 0, 0); // past the end of S: the NUL the reference stops at
-			}
-			d = first_diff16(a, b);
+			U4 a = load16(qp + off), b = {0, 0, 0, 0};
+			if (sp + off + 16 <= s_end) b = load16(sp + off); // else past the end of S: the NUL the reference stops at
+			d = first_diff(a, b);
 			if (d < 16) {
-				qb = byte_of(a, d);
-				sb = byte_of(b, d);
+				qb = byte_at(a, d);
+				sb = byte_at(b, d);
 			}
 		}
 		bool hit = !in_q || d < 16;
@@ -95,65 +73,104 @@ struct DevAlloc {
 };
 
 // MODE 0: speculative chunk chains. MODE 1: bridges.
+// Persistent lanes: every lane runs one chain at a time and fetches the next
+// chunk when it finishes.  One loop trip runs the phases of anchor_core.h's
+// Chain in their fixed order; a phase is skipped by the wavefront when none of
+// its lanes is in it.
 template <int MODE> __global__ __launch_bounds__(256) void chain_kernel(PhaseA A, RefIndex R)
 {
 	typename std::conditional<MODE == 0, SpecLane, BridgeLane>::type ln;
+	Chain &ch = ln.ch;
 	const uint8_t *s_end = R.S + R.n + 64;
-	bool active = false, done = false, need = false;
-	CmpRes res = {0, false};
-	CmpReq req = {nullptr, nullptr, 0, 0};
-	uint32_t pos = 0;
+	bool active = false, done = false;
 	DevAlloc alloc = {&A};
+	ch.fin = false;
+	ch.st = ST_STEP;
 
 	for (;;) {
-		if (!need && !done) {
-			for (;;) {
-				if (!active) {
-					uint32_t it = atomicAdd(&A.fetch[MODE], 1u);
-					if (it >= A.nchunks) {
-						done = true;
-						break;
-					}
-					ln.start(A, A.items[it]);
-					active = true;
-				}
-				if (ln.ch.st == ST_STEP) {
-					bool go;
-					if constexpr (MODE == 0) go = ln.begin_step(A);
-					else go = ln.begin_step(A, R);
-					if (!go) {
-						active = false;
-						continue;
-					}
-				}
-				if (ln.ch.advance(R, res, &req) == ADV_NEED_CMP) {
-					need = true;
-					pos = req.from;
-					break;
-				}
+		while (!done) {
+			if (active && ch.fin) {
 				if constexpr (MODE == 0) ln.step_done(A);
 				else ln.step_done(A, alloc);
+				ch.fin = false;
 			}
+			if (!active) {
+				uint32_t it = atomicAdd(&A.fetch[MODE], 1u);
+				if (it >= A.nchunks) {
+					done = true;
+					break;
+				}
+				ln.start(A, A.items[it]);
+				active = true;
+			}
+			if (ch.st == ST_STEP) {
+				bool go;
+				if constexpr (MODE == 0) go = ln.begin_step(A);
+				else go = ln.begin_step(A, R);
+				if (!go) {
+					active = false;
+					continue;
+				}
+			}
+			break;
 		}
 		if (__all(done)) break;
-		// short comparisons stay in the lane …
-		if (need && cmp_some(req, 64, &pos, &res)) need = false;
-		// … long ones are resolved by the whole wave, one at a time
-		uint64_t pending = __ballot(need);
-		while (pending) {
-			int leader = __ffsll((unsigned long long)pending) - 1;
-			const uint8_t *qp = (const uint8_t *)shfl64((uint64_t)req.qp, leader);
-			const uint8_t *sp = (const uint8_t *)shfl64((uint64_t)req.sp, leader);
-			uint32_t p0 = (uint32_t)__shfl((int)pos, leader, 64);
-			uint32_t mx = (uint32_t)__shfl((int)req.maxn, leader, 64);
-			uint32_t len, less;
-			coop_compare(qp, sp, p0, mx, s_end, &len, &less);
-			if ((int)lane_id() == leader) {
-				res.len = len;
-				res.s_less = less != 0;
-				need = false;
+		const bool live = !done;
+
+		if (live && ch.st == ST_STEP) {
+			const uint8_t *a0, *a1 = nullptr;
+			uint32_t n = ch.issue_step(R, &a0, &a1);
+			U4 qw = load16(a0), sw = {0, 0, 0, 0};
+			if (n > 1) sw = load16(a1);
+			ch.consume_step(R, qw, sw);
+		}
+		if (live && ch.st == ST_T) ch.consume_T(load16(ch.issue_T(R)));
+		if (live && ch.st == ST_SA) ch.consume_SA(R, load16(ch.issue_SA(R)));
+		if (live && ch.st == ST_CAND) {
+			Data d;
+			d.w[0] = load16(R.S + ch.c_pos0);
+			d.w[1] = d.w[2] = d.w[3] = d.w[0];
+			if (ch.c_n > 1) d.w[1] = load16(R.S + ch.c_pos1);
+			if (ch.c_n > 2) d.w[2] = load16(R.S + ch.c_pos2);
+			if (ch.c_n > 3) d.w[3] = load16(R.S + ch.c_pos3);
+			ch.consume_cand(R, d);
+		}
+		if (live && ch.in_gen()) {
+			if (ch.gen_advance(R)) {
+				U4 v = load16(ch.issue_probe_sa(R));
+				ch.consume_probe_sa(v.x);
+				ch.consume_probe_s(load16(ch.issue_probe_s(R)));
+				if (ch.in_gen()) ch.gen_advance(R);
 			}
-			pending &= pending - 1;
+		}
+		{
+			bool want = false;
+			if (live && ch.st == ST_EXT) {
+				const uint8_t *a[4];
+				Data d;
+				ch.issue_ext(R, a);
+				d.w[0] = load16(a[0]);
+				d.w[1] = load16(a[1]);
+				d.w[2] = load16(a[2]);
+				d.w[3] = load16(a[3]);
+				want = ch.consume_ext(R, d);
+			}
+			// comparisons that ran past EXT_COOP_AT bytes are finished by the whole wave
+			uint64_t pending = __ballot(want);
+			while (pending) {
+				int leader = __ffsll((unsigned long long)pending) - 1;
+				const uint8_t *qp = (const uint8_t *)shfl64((uint64_t)(ch.Q + ch.q), leader);
+				const uint8_t *sp = (const uint8_t *)shfl64((uint64_t)(R.S + ch.e_p), leader);
+				uint32_t p0 = (uint32_t)__shfl((int)ch.e_pos, leader, 64);
+				uint32_t mx = (uint32_t)__shfl((int)(ch.qlen - ch.q), leader, 64);
+				uint32_t len, less;
+				coop_compare(qp, sp, p0, mx, s_end, &len, &less);
+				if ((int)lane_id() == leader) ch.deliver(R, len, less);
+				pending &= pending - 1;
+			}
+		}
+		if (live && ch.st == ST_FIN) {
+			if (ch.fin_needs_lcp(R)) ch.consume_lcp(load16(ch.issue_lcp(R)));
 		}
 	}
 }
@@ -283,12 +300,26 @@ __global__ __launch_bounds__(64) void fold_kernel(PhaseA A, uint32_t nq, uint32_
 
 // ───────────────────────── launch wrappers ─────────────────────────
 
-void launch_spec(const PhaseA &A, const RefIndex &R, int blocks, hipStream_t st)
+static int resident_blocks(const void *fn, int n_cu)
 {
+	int per_cu = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+	return per_cu * n_cu;
+}
+
+// blocks_cap: never more lanes than chunks
+void launch_spec(const PhaseA &A, const RefIndex &R, int n_cu, hipStream_t st)
+{
+	int blocks = resident_blocks((const void *)chain_kernel<0>, n_cu);
+	int need = (int)((A.nchunks + 255) / 256);
+	if (need < blocks) blocks = need > 0 ? need : 1;
 	hipLaunchKernelGGL(chain_kernel<0>, dim3(blocks), dim3(256), 0, st, A, R);
 }
-void launch_bridge(const PhaseA &A, const RefIndex &R, int blocks, hipStream_t st)
+void launch_bridge(const PhaseA &A, const RefIndex &R, int n_cu, hipStream_t st)
 {
+	int blocks = resident_blocks((const void *)chain_kernel<1>, n_cu);
+	int need = (int)((A.nchunks + 255) / 256);
+	if (need < blocks) blocks = need > 0 ? need : 1;
 	hipLaunchKernelGGL(chain_kernel<1>, dim3(blocks), dim3(256), 0, st, A, R);
 }
 void launch_fold(const PhaseA &A, uint32_t nq, uint32_t border, uint32_t thr, RawHom *out,

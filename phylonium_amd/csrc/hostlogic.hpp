@@ -195,9 +195,11 @@ static inline void kmer_table(const uint8_t *s, uint32_t n, uint32_t k, std::vec
 
 static inline uint32_t choose_k(uint32_t n)
 {
-	// about one suffix per bucket, capped so the table (4^k+1 u32) stays modest
+	// smallest k with 4^k >= n: at most one suffix per bucket on average, so that
+	// nearly every bucket has <= 2 members and takes the four-candidate fast path.
+	// Capped at 14 (the k-mer must fit the 16-byte query window; table = 4^k+1 u32).
 	uint32_t k = 1;
-	while (k < 13 && ((uint64_t)1 << (2 * (k + 1))) <= (uint64_t)n) k++;
+	while (k < 14 && ((uint64_t)1 << (2 * k)) < (uint64_t)n) k++;
 	return k;
 }
 

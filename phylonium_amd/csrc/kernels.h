@@ -9,8 +9,8 @@
 namespace phy {
 
 // anchor_kernels.hip
-void launch_spec(const PhaseA &A, const RefIndex &R, int blocks, hipStream_t st);
-void launch_bridge(const PhaseA &A, const RefIndex &R, int blocks, hipStream_t st);
+void launch_spec(const PhaseA &A, const RefIndex &R, int n_cu, hipStream_t st);
+void launch_bridge(const PhaseA &A, const RefIndex &R, int n_cu, hipStream_t st);
 void launch_fold(const PhaseA &A, uint32_t nq, uint32_t border, uint32_t thr, RawHom *out,
 				 const uint64_t *out_base, const uint32_t *out_cap, uint32_t *out_cnt, hipStream_t st);
 
@@ -38,7 +38,8 @@ struct Pileup {
 	uint32_t L;
 };
 void launch_project(const Pileup &P, const uint8_t *gbase, const uint64_t *goff, const DevHom *homs,
-					const uint32_t *hom_off, uint32_t *bang_flag, hipStream_t st);
+					const uint32_t *hom_off, uint32_t *first, uint32_t *bang_flag, hipStream_t st);
+size_t project_index_entries(const Pileup &P);
 // tiles: list of (ig, jt) pairs packed as ig<<16|jt
 void launch_pairs(const Pileup &P, bool with_bang, const uint32_t *tiles, uint32_t ntiles, uint32_t wchunk,
 				  unsigned long long *subst, unsigned long long *homologs, hipStream_t st);

@@ -106,7 +106,7 @@ struct phylo_ctx {
 	std::vector<std::vector<phylo_homology>> homs;
 
 	// phase B scratch
-	DevBuf<uint32_t> b_planes, b_hom_off, b_tiles, b_flag;
+	DevBuf<uint32_t> b_planes, b_hom_off, b_tiles, b_flag, b_first;
 	DevBuf<DevHom> b_homs;
 	DevBuf<unsigned long long> b_subst, b_homologs;
 	DevBuf<Segment> s_segs;
@@ -290,6 +290,7 @@ void phylo_ctx_destroy(phylo_ctx *c)
 	c->b_hom_off.release();
 	c->b_tiles.release();
 	c->b_flag.release();
+	c->b_first.release();
 	c->b_homs.release();
 	c->b_subst.release();
 	c->b_homologs.release();
@@ -436,7 +437,7 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 	HIPOK(c, hipMemcpy(S.data(), c->d_genomes + c->goff[ref_idx], L, hipMemcpyDeviceToHost));
 	S[L] = '#';
 	revcomp(S.data(), L, S.data() + L + 1);
-	std::vector<uint32_t> SA(ns), LCP((size_t)ns + 1), T;
+	std::vector<uint32_t> SA((size_t)ns + 4, 0), LCP((size_t)ns + 1 + 4, 0), T; // +4: tables are read 16 bytes at a time
 	double t1 = now_ms();
 	if (sa) {
 		for (uint32_t i = 0; i < ns; i++) {
@@ -450,15 +451,16 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 	lcp_kasai(S.data(), ns, SA.data(), LCP.data());
 	uint32_t k = c->opt_kmer ? c->opt_kmer : choose_k(ns);
 	kmer_table(S.data(), ns, k, T);
+	T.resize(T.size() + 4, ns);
 	double t3 = now_ms();
 	if (threshold == 0) threshold = min_anchor_length(0.025, gc_content(S.data(), L), ns);
 	HIPOK(c, c->d_S.ensure(S.size()));
-	HIPOK(c, c->d_SA.ensure(ns));
-	HIPOK(c, c->d_LCP.ensure((size_t)ns + 1));
+	HIPOK(c, c->d_SA.ensure(SA.size()));
+	HIPOK(c, c->d_LCP.ensure(LCP.size()));
 	HIPOK(c, c->d_T.ensure(T.size()));
 	HIPOK(c, hipMemcpy(c->d_S.p, S.data(), S.size(), hipMemcpyHostToDevice));
-	HIPOK(c, hipMemcpy(c->d_SA.p, SA.data(), (size_t)ns * 4, hipMemcpyHostToDevice));
-	HIPOK(c, hipMemcpy(c->d_LCP.p, LCP.data(), ((size_t)ns + 1) * 4, hipMemcpyHostToDevice));
+	HIPOK(c, hipMemcpy(c->d_SA.p, SA.data(), SA.size() * 4, hipMemcpyHostToDevice));
+	HIPOK(c, hipMemcpy(c->d_LCP.p, LCP.data(), LCP.size() * 4, hipMemcpyHostToDevice));
 	HIPOK(c, hipMemcpy(c->d_T.p, T.data(), T.size() * 4, hipMemcpyHostToDevice));
 	c->ref_idx = ref_idx;
 	c->L = (uint32_t)L;
@@ -577,19 +579,15 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	A.error = c->a_misc.p + 3;
 	RefIndex R = {c->d_S.p, c->d_SA.p, c->d_LCP.p, c->d_T.p, c->ns, c->k, c->threshold};
 
-	// persistent lanes: enough waves to cover latency, never more lanes than chunks
-	int blocks = c->n_cu * 8;
-	int need_blocks = (int)((nch + 255) / 256);
-	if (need_blocks < blocks) blocks = need_blocks > 0 ? need_blocks : 1;
 	double t1 = now_ms();
 	if (nch) {
 		{
 			KernelSpan s(c, "anchor_spec");
-			launch_spec(A, R, blocks, st);
+			launch_spec(A, R, c->n_cu, st);
 		}
 		{
 			KernelSpan s(c, "anchor_bridge");
-			launch_bridge(A, R, blocks, st);
+			launch_bridge(A, R, c->n_cu, st);
 		}
 	}
 	{
@@ -791,6 +789,7 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 	HIPOK(c, c->b_hom_off.ensure(N + 1));
 	HIPOK(c, c->b_homs.ensure(tot + 1));
 	HIPOK(c, c->b_flag.ensure(4));
+	HIPOK(c, c->b_first.ensure(project_index_entries(P) + 1));
 	HIPOK(c, c->b_subst.ensure(N * N));
 	HIPOK(c, c->b_homologs.ensure(N * N));
 	HIPOK(c, hipMemcpyAsync(c->b_hom_off.p, hom_off.data(), (N + 1) * 4, hipMemcpyHostToDevice, st));
@@ -800,7 +799,7 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 	HIPOK(c, hipMemsetAsync(c->b_homologs.p, 0, N * N * 8, st));
 	{
 		KernelSpan s(c, "pileup_project");
-		launch_project(P, c->d_genomes, c->d_goff.p, c->b_homs.p, c->b_hom_off.p, c->b_flag.p, st);
+		launch_project(P, c->d_genomes, c->d_goff.p, c->b_homs.p, c->b_hom_off.p, c->b_first.p, c->b_flag.p, st);
 	}
 	HIPOK(c, hipGetLastError());
 	uint32_t flag = 0;

@@ -32,56 +32,136 @@
 
 namespace phy {
 
-// One thread per (word w, genome g), g fastest.
+// movemask of bit `b` of each of the 4 bytes of x → 4 bits
+static __device__ __forceinline__ uint32_t gather4(uint32_t x, uint32_t b)
+{
+	return ((((x >> b) & 0x01010101u) * 0x01020408u) >> 24) & 0xfu;
+}
+
+// bit `b` of each of the 32 bytes of (lo16,hi16) → 32 bits, byte 0 → bit 0
+static __device__ __forceinline__ uint32_t gather32(const uint4 &lo, const uint4 &hi, uint32_t b)
+{
+	return gather4(lo.x, b) | (gather4(lo.y, b) << 4) | (gather4(lo.z, b) << 8) | (gather4(lo.w, b) << 12) |
+		   (gather4(hi.x, b) << 16) | (gather4(hi.y, b) << 20) | (gather4(hi.z, b) << 24) | (gather4(hi.w, b) << 28);
+}
+
+// 1 where the byte equals '!' (0x21): among {A,C,G,T,!} only '!' has bit 5 set and bit 6 clear
+static __device__ __forceinline__ uint32_t bang32(const uint4 &lo, const uint4 &hi)
+{
+	return gather32(lo, hi, 5) & ~gather32(lo, hi, 6);
+}
+
+static const uint32_t PROJ_TW = 64; // words per tile
+static const uint32_t PROJ_TG = 32; // genomes per tile (LDS: 5*64*33*4 = 42 KB → 3 blocks per CU)
+
+// Projection: one block per tile of 64 reference windows × 32 genomes.
+// Reading side: a wavefront takes one genome and its 64 lanes take the 64
+// consecutive windows, so the query bytes of a homology are read as contiguous
+// 32-byte pieces (2 KiB per wave, coalesced).  Writing side: the tile is
+// transposed through LDS so that every plane row [w][g0..g0+31] leaves as one
+// full 128-byte line.
+// first[g*ntw + tw] = first homology of genome g that ends beyond the first
+// position of window tile tw (lists are sorted and disjoint).  One thread per
+// entry, so the binary searches' latencies overlap instead of serialising inside
+// the projection's wavefronts.
+__global__ __launch_bounds__(256) void tile_index_kernel(Pileup P, const DevHom *__restrict__ homs,
+														  const uint32_t *__restrict__ hom_off,
+														  uint32_t *__restrict__ first)
+{
+	const uint32_t ntw = (P.W + PROJ_TW - 1) / PROJ_TW;
+	const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (tid >= (uint64_t)P.N * ntw) return;
+	const uint32_t g = (uint32_t)(tid / ntw), tw = (uint32_t)(tid % ntw);
+	const uint32_t span0 = tw * PROJ_TW * 32u;
+	uint32_t lo = hom_off[g], hi = hom_off[g + 1];
+	while (lo < hi) {
+		uint32_t mid = lo + ((hi - lo) >> 1);
+		if (homs[mid].start + homs[mid].len <= span0) lo = mid + 1;
+		else hi = mid;
+	}
+	first[tid] = lo;
+}
+
 __global__ __launch_bounds__(256) void project_kernel(Pileup P, const uint8_t *__restrict__ gbase,
 													   const uint64_t *__restrict__ goff,
 													   const DevHom *__restrict__ homs,
 													   const uint32_t *__restrict__ hom_off,
+													   const uint32_t *__restrict__ first,
 													   uint32_t *__restrict__ bang_flag)
 {
-	const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	const uint32_t g = (uint32_t)(tid % P.Npad);
-	const uint32_t w = (uint32_t)(tid / P.Npad);
-	if (w >= P.W) return;
-	uint32_t V = 0, N0 = 0, N1 = 0, D = 0, B = 0;
-	if (g < P.N) {
-		const uint32_t h0 = hom_off[g], h1 = hom_off[g + 1];
-		const uint32_t x0 = w * 32u, x1 = x0 + 32u;
-		// first homology whose end is beyond x0 (lists are sorted and disjoint)
-		uint32_t lo = h0, hi = h1;
-		while (lo < hi) {
-			uint32_t mid = lo + ((hi - lo) >> 1);
-			if (homs[mid].start + homs[mid].len <= x0) lo = mid + 1;
-			else hi = mid;
-		}
-		const uint8_t *q = gbase + goff[g];
-		for (uint32_t h = lo; h < h1; h++) {
-			const DevHom hm = homs[h];
-			if (hm.start >= x1) break;
-			uint32_t s = hm.start > x0 ? hm.start : x0;
-			uint32_t e = hm.start + hm.len < x1 ? hm.start + hm.len : x1;
-			for (uint32_t x = s; x < e; x++) {
-				// forward: query index iq + (x - start); reverse: iq + (start + len - 1 - x)
-				uint32_t qi = hm.rev ? hm.iq + (hm.start + hm.len - 1u - x) : hm.iq + (x - hm.start);
-				uint32_t c = q[qi];
-				uint32_t n = (c >> 1) & 3u;
-				if (hm.rev) n ^= 2u;
-				uint32_t bit = 1u << (x - x0);
-				V |= bit;
-				if (n & 1u) N0 |= bit;
-				if (n & 2u) N1 |= bit;
-				if (hm.rev) D |= bit;
-				if (c == '!') B |= bit;
+	__shared__ uint32_t tile[5][PROJ_TW][PROJ_TG + 1];
+	const uint32_t ntw = (P.W + PROJ_TW - 1) / PROJ_TW;
+	const uint32_t tw = blockIdx.x % ntw, tg = blockIdx.x / ntw;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint32_t w = tw * PROJ_TW + lane;
+	const uint32_t x0 = w * 32u, x1 = x0 + 32u;
+	uint32_t any_bang = 0;
+	for (uint32_t gi = wave; gi < PROJ_TG; gi += 4) {
+		const uint32_t g = tg * PROJ_TG + gi;
+		uint32_t V = 0, N0 = 0, N1 = 0, D = 0, B = 0;
+		if (g < P.N && w < P.W) {
+			const uint32_t h1 = hom_off[g + 1];
+			const uint32_t lo = first[(size_t)g * ntw + tw];
+			const uint8_t *q = gbase + goff[g];
+			for (uint32_t h = lo; h < h1; h++) {
+				const DevHom hm = homs[h];
+				if (hm.start >= x1) break;
+				const uint32_t he = hm.start + hm.len;
+				if (he <= x0) continue;
+				if (hm.start <= x0 && he >= x1) {
+					// the window lies inside this homology: 32 query bytes at once
+					uint4 a, b;
+					if (!hm.rev) {
+						const uint8_t *src = q + hm.iq + (x0 - hm.start);
+						__builtin_memcpy(&a, src, 16);
+						__builtin_memcpy(&b, src + 16, 16);
+						N0 = gather32(a, b, 1);
+						N1 = gather32(a, b, 2);
+						B = bang32(a, b);
+					} else {
+						// position x ↔ query index iq + (he-1-x): bytes run backwards
+						const uint8_t *src = q + hm.iq + (he - x1);
+						__builtin_memcpy(&a, src, 16);
+						__builtin_memcpy(&b, src + 16, 16);
+						N0 = __brev(gather32(a, b, 1));
+						N1 = ~__brev(gather32(a, b, 2)); // complement: n ^ 2
+						B = __brev(bang32(a, b));
+						D = 0xffffffffu;
+					}
+					V = 0xffffffffu;
+					break;
+				}
+				uint32_t s = hm.start > x0 ? hm.start : x0;
+				uint32_t e = he < x1 ? he : x1;
+				for (uint32_t x = s; x < e; x++) {
+					uint32_t qi = hm.rev ? hm.iq + (he - 1u - x) : hm.iq + (x - hm.start);
+					uint32_t c = q[qi];
+					uint32_t n = (c >> 1) & 3u;
+					if (hm.rev) n ^= 2u;
+					uint32_t bit = 1u << (x - x0);
+					V |= bit;
+					if (n & 1u) N0 |= bit;
+					if (n & 2u) N1 |= bit;
+					if (hm.rev) D |= bit;
+					if (c == '!') B |= bit;
+				}
 			}
 		}
-		if (B) atomicOr(bang_flag, 1u);
+		any_bang |= B;
+		tile[0][lane][gi] = V;
+		tile[1][lane][gi] = N0;
+		tile[2][lane][gi] = N1;
+		tile[3][lane][gi] = D;
+		tile[4][lane][gi] = B;
 	}
-	const size_t o = (size_t)w * P.Npad + g;
-	P.plane[0][o] = V;
-	P.plane[1][o] = N0;
-	P.plane[2][o] = N1;
-	P.plane[3][o] = D;
-	P.plane[4][o] = B;
+	if (any_bang) atomicOr(bang_flag, 1u);
+	__syncthreads();
+	// rows [w][g0..g0+31] out: 128 contiguous bytes per row
+	for (uint32_t e = threadIdx.x; e < 5 * PROJ_TW * PROJ_TG; e += 256) {
+		const uint32_t gl = e % PROJ_TG, wl = (e / PROJ_TG) % PROJ_TW, p = e / (PROJ_TG * PROJ_TW);
+		const uint32_t ww = tw * PROJ_TW + wl, g = tg * PROJ_TG + gl;
+		if (ww < P.W) P.plane[p][(size_t)ww * P.Npad + g] = tile[p][wl][gl];
+	}
 }
 
 // One wavefront per (tile, window chunk): lane = genome j of the tile's 64,
@@ -139,13 +219,15 @@ __global__ __launch_bounds__(64) void pairs_kernel(Pileup P, const uint32_t *__r
 }
 
 void launch_project(const Pileup &P, const uint8_t *gbase, const uint64_t *goff, const DevHom *homs,
-					const uint32_t *hom_off, uint32_t *bang_flag, hipStream_t st)
+					const uint32_t *hom_off, uint32_t *first, uint32_t *bang_flag, hipStream_t st)
 {
-	uint64_t threads = (uint64_t)P.W * P.Npad;
-	uint32_t blocks = (uint32_t)((threads + 255) / 256);
-	if (!blocks) return;
-	hipLaunchKernelGGL(project_kernel, dim3(blocks), dim3(256), 0, st, P, gbase, goff, homs, hom_off, bang_flag);
+	uint32_t ntw = (P.W + PROJ_TW - 1) / PROJ_TW, ntg = P.Npad / PROJ_TG;
+	if (!ntw || !ntg) return;
+	uint64_t entries = (uint64_t)P.N * ntw;
+	hipLaunchKernelGGL(tile_index_kernel, dim3((uint32_t)((entries + 255) / 256)), dim3(256), 0, st, P, homs, hom_off, first);
+	hipLaunchKernelGGL(project_kernel, dim3(ntw * ntg), dim3(256), 0, st, P, gbase, goff, homs, hom_off, first, bang_flag);
 }
+size_t project_index_entries(const Pileup &P) { return (size_t)P.N * ((P.W + PROJ_TW - 1) / PROJ_TW); }
 
 void launch_pairs(const Pileup &P, bool with_bang, const uint32_t *tiles, uint32_t ntiles, uint32_t wchunk,
 				  unsigned long long *subst, unsigned long long *homologs, hipStream_t st)

@@ -14,18 +14,33 @@ struct EmulOut {
 	std::vector<std::vector<RawHom>> raw;
 	std::vector<std::vector<phylo_homology>> filtered;
 	uint32_t threshold, k, C, nchunks;
-	uint64_t steps_spec = 0, steps_bridge = 0, cmp_calls = 0, pool_used = 0;
+	uint64_t steps_spec = 0, steps_bridge = 0, cmp_calls = 0, pool_used = 0, rounds = 0;
 	int error = 0;
 };
 
-static CmpRes full_cmp(const CmpReq &r, uint64_t *calls)
+template <class Lane, class Begin, class Done>
+static void run_lane(Lane &ln, const RefIndex &R, Begin begin, Done done, uint64_t *steps, uint64_t *trips,
+					 uint64_t *tails)
 {
-	CmpRes out;
-	uint32_t pos = r.from;
-	(*calls)++;
-	while (!cmp_some(r, 64, &pos, &out)) {
+	// stands in for the wave-cooperative tail comparison of the GPU kernel
+	auto tail = [&](const Chain &ch, uint32_t *len, uint32_t *less) {
+		const uint8_t *qp = ch.Q + ch.q, *sp = R.S + ch.e_p;
+		uint32_t n = ch.qlen - ch.q, i = ch.e_pos;
+		(*tails)++;
+		while (i < n && qp[i] == sp[i]) i++;
+		*len = i;
+		*less = (i < n && sp[i] < qp[i]) ? 1u : 0u;
+	};
+	for (;;) {
+		if (ln.ch.fin) {
+			done();
+			(*steps)++;
+			ln.ch.fin = false;
+		}
+		if (ln.ch.st == ST_STEP && !begin()) break;
+		chain_trip(ln.ch, R, tail);
+		(*trips)++;
 	}
-	return out;
 }
 
 extern "C" {
@@ -41,11 +56,12 @@ void *emul_run(size_t n, const char *const *seq, const size_t *len, size_t ref_i
 	memcpy(S.data(), seq[ref_idx], L);
 	S[L] = '#';
 	revcomp((const uint8_t *)seq[ref_idx], L, S.data() + L + 1);
-	std::vector<uint32_t> SA(ns), LCP((size_t)ns + 1), T;
+	std::vector<uint32_t> SA((size_t)ns + 4, 0), LCP((size_t)ns + 1 + 4, 0), T;
 	suffix_array_u32(S.data(), ns, SA.data());
 	lcp_kasai(S.data(), ns, SA.data(), LCP.data());
 	uint32_t k = forced_k ? forced_k : choose_k(ns);
 	kmer_table(S.data(), ns, k, T);
+	T.resize(T.size() + 4, ns);
 	if (threshold == 0) threshold = min_anchor_length(0.025, gc_content((const uint8_t *)seq[ref_idx], L), ns);
 	RefIndex R = {S.data(), SA.data(), LCP.data(), T.data(), ns, k, (uint32_t)threshold};
 	E->threshold = (uint32_t)threshold;
@@ -95,21 +111,12 @@ void *emul_run(size_t n, const char *const *seq, const size_t *len, size_t ref_i
 	A.error = &error;
 	A.fetch = fetch;
 
-	CmpRes res = {0, false};
-	CmpReq req;
 	// K1: speculative chains
 	for (uint32_t it = 0; it < P.nchunks; it++) {
 		SpecLane ln;
 		ln.start(A, P.items[it]);
-		for (;;) {
-			if (ln.ch.st == ST_STEP && !ln.begin_step(A)) break;
-			if (ln.ch.advance(R, res, &req) == ADV_NEED_CMP) {
-				res = full_cmp(req, &E->cmp_calls);
-			} else {
-				ln.step_done(A);
-				E->steps_spec++;
-			}
-		}
+		run_lane(ln, R, [&] { return ln.begin_step(A); }, [&] { ln.step_done(A); }, &E->steps_spec, &E->rounds,
+				 &E->cmp_calls);
 	}
 	// K2: bridges
 	auto alloc = [&]() -> uint32_t {
@@ -119,15 +126,8 @@ void *emul_run(size_t n, const char *const *seq, const size_t *len, size_t ref_i
 	for (uint32_t it = 0; it < P.nchunks; it++) {
 		BridgeLane ln;
 		ln.start(A, P.items[it]);
-		for (;;) {
-			if (ln.ch.st == ST_STEP && !ln.begin_step(A, R)) break;
-			if (ln.ch.advance(R, res, &req) == ADV_NEED_CMP) {
-				res = full_cmp(req, &E->cmp_calls);
-			} else {
-				ln.step_done(A, alloc);
-				E->steps_bridge++;
-			}
-		}
+		run_lane(ln, R, [&] { return ln.begin_step(A, R); }, [&] { ln.step_done(A, alloc); }, &E->steps_bridge,
+				 &E->rounds, &E->cmp_calls);
 	}
 	E->pool_used = pool_next;
 	E->error = (int)error;
@@ -202,7 +202,7 @@ void emul_info(void *e, uint64_t out[8])
 	out[3] = E->nchunks;
 	out[4] = E->steps_spec;
 	out[5] = E->steps_bridge;
-	out[6] = E->cmp_calls;
+	out[6] = E->rounds;
 	out[7] = ((uint64_t)E->error << 32) | E->pool_used;
 }
 

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 CSV output (kernel trace + PMC passes) for the library's
+own kernels (names containing 'phy::'), write small JSON/CSV files, drop the raw
+CSVs.  usage: tools_prof_summary.py <prof_dir>"""
+import csv, glob, json, os, shutil, sys
+from collections import defaultdict
+
+d = sys.argv[1]
+out = {}
+
+def short(name):
+    n = name
+    for key in ("chain_kernel<0>", "chain_kernel<1>", "fold_kernel", "compact_raw_kernel", "project_kernel",
+                "tile_index_kernel", "pairs_kernel<true>", "pairs_kernel<false>", "seqcmp_batch_kernel"):
+        if key in n:
+            return {"chain_kernel<0>": "anchor_spec", "chain_kernel<1>": "anchor_bridge", "fold_kernel": "anchor_fold",
+                    "compact_raw_kernel": "anchor_compact", "project_kernel": "pileup_project",
+                    "tile_index_kernel": "pileup_tile_index", "pairs_kernel<true>": "pileup_pairs_bang",
+                    "pairs_kernel<false>": "pileup_pairs", "seqcmp_batch_kernel": "seqcmp_batch"}[key]
+    return None
+
+# kernel trace
+for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0, None])
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            k = short(r.get("Kernel_Name", ""))
+            if not k:
+                continue
+            dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+            a = agg[k]
+            a[0] += 1; a[1] += dur; a[2] = min(a[2], dur); a[3] = max(a[3], dur)
+            a[4] = {x: r.get(x) for x in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size",
+                                          "Workgroup_Size", "Grid_Size") if x in r}
+    out["kernel_trace"] = {k: {"calls": a[0], "total_ms": round(a[1], 4), "avg_ms": round(a[1] / a[0], 4),
+                               "min_ms": round(a[2], 4), "max_ms": round(a[3], 4), "resources": a[4]} for k, a in agg.items()}
+    tot = sum(a[1] for a in agg.values())
+    for k in out["kernel_trace"]:
+        out["kernel_trace"][k]["pct_of_phy_kernels"] = round(100 * out["kernel_trace"][k]["total_ms"] / tot, 2)
+
+# PMC passes
+pmc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+for f in glob.glob(os.path.join(d, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            k = short(r.get("Kernel_Name", ""))
+            if not k:
+                continue
+            c = r.get("Counter_Name"); v = float(r.get("Counter_Value", 0))
+            pmc[k][c][0] += 1; pmc[k][c][1] += v
+out["pmc_per_dispatch_avg"] = {k: {c: round(v[1] / v[0], 3) for c, v in cs.items()} for k, cs in pmc.items()}
+out["pmc_dispatches"] = {k: {c: v[0] for c, v in cs.items()} for k, cs in pmc.items()}
+for f in glob.glob(os.path.join(d, "*_bench.json")):
+    try:
+        out.setdefault("bench_lines", {})[os.path.basename(f)] = json.load(open(f))
+    except Exception:
+        pass
+json.dump(out, open(os.path.join(d, "summary.json"), "w"), indent=1)
+for sub in glob.glob(os.path.join(d, "*")):
+    if os.path.isdir(sub):
+        shutil.rmtree(sub)
+print(json.dumps({k: v for k, v in out.items() if k != "bench_lines"}, indent=1))
