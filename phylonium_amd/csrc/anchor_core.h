@@ -33,22 +33,25 @@
 
 namespace phy {
 
+struct U4 { // 16 bytes of sequence or four table entries
+	uint32_t x, y, z, w;
+};
+
 struct RefIndex {
 	const uint8_t *S;    // n bytes of subject + '#' + revcomp, then >= 64 zero bytes
-	const uint32_t *SA;  // n entries (+4 pad: tables are read 16 bytes at a time)
+	const U4 *SAX;       // n records (+4 pad), one per rank: see sax_record()
 	const uint32_t *LCP; // n+1 entries (+4 pad); LCP[r] = lcp(suffix SA[r-1], suffix SA[r]); LCP[0]=LCP[n]=0
-	const uint32_t *T;   // 4^k+1 entries (+4 pad); T[c] = #suffixes lexicographically < k-mer c
+	const U4 *SLOT;      // 4^k slots of 8 records (one 128-byte line each): see SLOT_RECS
+	const uint32_t *T;   // host/emulation only: 4^k+1 entries; T[c] = #suffixes lexicographically < k-mer c
 	uint32_t n;          // |S| = 2L+1
 	uint32_t k;          // bucket k-mer length (1..14)
 	uint32_t threshold;  // minimum anchor length
+	uint32_t dbg;        // timing-only ablations (results are wrong when nonzero): 1 slot reads hit one page,
+						 // 2 lucky windows hit one page, 4 extension reads hit one page
 };
 
 struct Anchor {
 	uint32_t q, s, len; // this_pos_Q, this_pos_S, this_length of an accepted anchor
-};
-
-struct U4 { // 16 bytes of sequence or four table entries
-	uint32_t x, y, z, w;
 };
 
 PHY_HD U4 load16(const uint8_t *p)
@@ -92,16 +95,81 @@ PHY_HD uint32_t code4(uint32_t x, uint32_t *bad)
 	return (c * 0x40100401u) >> 24;
 }
 
-// k-mer code of the first k (<= 14) bytes of a 16-byte window; false if any of
-// them is not A,C,G,T
-PHY_HD bool kmer_code16(const U4 &q, uint32_t k, uint32_t *code)
+// 16 bytes → 32-bit code (first byte in bits 31-30) and the number of leading
+// bytes that are A,C,G,T
+PHY_HD uint32_t window_code(const U4 &q, uint32_t *valid)
 {
 	uint32_t b0, b1, b2, b3;
 	uint32_t c = (code4(q.x, &b0) << 24) | (code4(q.y, &b1) << 16) | (code4(q.z, &b2) << 8) | code4(q.w, &b3);
-	uint32_t first_bad = b0 ? (ctz32(b0) >> 3) : b1 ? 4u + (ctz32(b1) >> 3) : b2 ? 8u + (ctz32(b2) >> 3)
-											   : b3 ? 12u + (ctz32(b3) >> 3) : 16u;
-	*code = c >> (2u * (16u - k));
-	return first_bad >= k;
+	*valid = b0 ? (ctz32(b0) >> 3) : b1 ? 4u + (ctz32(b1) >> 3) : b2 ? 8u + (ctz32(b2) >> 3)
+										 : b3 ? 12u + (ctz32(b3) >> 3) : 16u;
+	return c;
+}
+
+PHY_HD uint32_t clz32(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return (uint32_t)__clz((int)x);
+#else
+	return (uint32_t)__builtin_clz(x);
+#endif
+}
+
+// SAX record of rank r: everything a comparison with suffix SA[r] usually needs,
+// in 16 bytes — x: SA[r]; y: 2-bit codes of the suffix's first 16 bytes (bits
+// beyond the valid length are 0); z: number of leading A,C,G,T bytes (<= 16);
+// w: min(LCP[r],0xffff) | min(LCP[r+1],0xffff) << 16.
+PHY_HD U4 sax_record(const uint8_t *S, uint32_t sa, uint32_t lcp_r, uint32_t lcp_r1)
+{
+	U4 w = load16(S + sa);
+	uint32_t valid;
+	uint32_t code = window_code(w, &valid);
+	if (valid < 16) code &= ~(0xffffffffu >> (2 * valid)); // valid == 0 → shift by 0 → mask all
+	if (valid == 0) code = 0;
+	U4 r;
+	r.x = sa;
+	r.y = code;
+	r.z = valid;
+	r.w = (lcp_r < 0xffffu ? lcp_r : 0xffffu) | ((lcp_r1 < 0xffffu ? lcp_r1 : 0xffffu) << 16);
+	return r;
+}
+
+// Slot of k-mer c (one 128-byte line): record 0 = {lo = T[c], hi = T[c+1], 0, 0};
+// records 1..5 = SAX[base .. base+4] with base = lo ? lo-1 : 0, i.e. the bucket's
+// predecessor, up to two members... and its successor for buckets of <= 2 suffixes.
+// A whole small-bucket search is therefore ONE line fetch.
+static const uint32_t SLOT_RECS = 8;
+
+// Compare the query window (code qcode, qv valid bytes, n bytes left in the query)
+// with a suffix prefix (code pre, sv valid bytes).  0: decided (*len,*less);
+// 1: all 16 bytes equal and the query goes on — extend from byte 16;
+// 2: a non-ACGT byte or the end of S is involved — compare the raw bytes.
+PHY_HD uint32_t packed_cmp(uint32_t qcode, uint32_t qv, uint32_t n, uint32_t pre, uint32_t sv, uint32_t *len,
+						   uint32_t *less)
+{
+	uint32_t x = qcode ^ pre;
+	uint32_t d = x ? (clz32(x) >> 1) : 16u;
+	uint32_t m = qv < sv ? qv : sv;
+	if (d < m) {
+		uint32_t sh = 30u - 2u * d;
+		*len = d;
+		*less = ((pre >> sh) & 3u) < ((qcode >> sh) & 3u) ? 1u : 0u;
+		return 0;
+	}
+	if (m == 16) {
+		if (n <= 16) {
+			*len = n;
+			*less = 0;
+			return 0;
+		}
+		return 1;
+	}
+	if (qv == m && n == m) { // the query ends here
+		*len = n;
+		*less = 0;
+		return 0;
+	}
+	return 2;
 }
 
 PHY_HD uint32_t sel4(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t i)
@@ -127,8 +195,8 @@ PHY_HD uint32_t first_diff(const U4 &a, const U4 &b)
 
 enum ChainState : uint32_t {
 	ST_STEP = 0, // load the query window (and the lucky window)
-	ST_T,        // load T[code], T[code+1]
-	ST_SA,       // load four suffix-array entries around a small bucket
+	ST_T,        // load the k-mer's slot: bucket bounds + the records around it
+	ST_SA,       // (unused)
 	ST_CAND,     // load the windows of up to four candidate suffixes
 	ST_EXT,      // extend one comparison by 32 bytes
 	ST_FIN,      // decide; maybe load LCP[best], LCP[best+1]
@@ -168,19 +236,23 @@ struct Chain {
 	bool fin;            // a step has just finished: r_* are valid
 
 	U4 qc;               // Q[q .. q+16)
+	uint32_t qcode, qv;  // its 2-bit code and how many of its bytes are A,C,G,T and inside the query
 	uint32_t flags;      // bit0 lo_known, bit1 hi_known, bit2 k-mer bucket valid
 	uint32_t lo, hi, mid;
 	uint32_t l_lo, l_hi, p_lo, p_hi; // generic search bookkeeping
 	// small-bucket candidates: ranks c_rank0 .. c_rank0+c_n-1
 	uint32_t c_rank0, c_n, c_pending;
 	uint32_t c_pos0, c_pos1, c_pos2, c_pos3, c_len0, c_len1, c_len2, c_len3;
+	uint32_t c_lcp0, c_lcp1, c_lcp2, c_lcp3; // clipped LCP pairs of the candidates' ranks
 	uint32_t c_less; // bit i = candidate i < query
+	uint32_t c_raw;  // candidates that need their raw bytes compared
 	// extension / probe
 	uint32_t e_kind, e_idx, e_pos, e_p; // which comparison, bytes known equal, subject position
 	uint32_t pr_rank, pr_ret;           // probe rank, state to return to
-	uint32_t pr_pos, pr_len, pr_less;
+	uint32_t pr_pos, pr_len, pr_less, pr_lcp;
 	// neighbours of the insertion point
 	uint32_t lp, pp, lsu, psu;
+	uint32_t lcp_p, lcp_s; // clipped LCP pairs of the predecessor's / successor's rank
 
 	// result of the step that just finished (valid while fin)
 	uint32_t r_q, r_s, r_len;
@@ -267,11 +339,10 @@ struct Chain {
 
 	PHY_HD void begin_search(const RefIndex &R)
 	{
-		uint32_t code;
 		flags = 0;
 		l_lo = l_hi = 0;
-		if (qlen - q >= R.k && kmer_code16(qc, R.k, &code)) {
-			lo = code; // phase T reads T[code], T[code+1]
+		if (qv >= R.k) {
+			lo = qcode >> (2u * (16u - R.k)); // phase T reads T[code], T[code+1]
 			flags = 4u;
 			st = ST_T;
 		} else {
@@ -292,19 +363,23 @@ struct Chain {
 		// insertion point: bucket members smaller than the query come first
 		uint32_t ins = lo;
 		while (ins < hi && ((c_less >> (ins - c_rank0)) & 1u)) ins++;
-		uint32_t a = 0, b = 0, c = 0, d = 0;
+		uint32_t a = 0, b = 0, c = 0, d = 0, e = 0, f = 0;
 		if (ins > c_rank0) {
 			a = clen(ins - 1 - c_rank0);
 			b = cpos(ins - 1 - c_rank0);
+			e = sel4(c_lcp0, c_lcp1, c_lcp2, c_lcp3, ins - 1 - c_rank0);
 		}
 		if (ins < R.n) {
 			c = clen(ins - c_rank0);
 			d = cpos(ins - c_rank0);
+			f = sel4(c_lcp0, c_lcp1, c_lcp2, c_lcp3, ins - c_rank0);
 		}
 		lp = a;
 		pp = b;
 		lsu = c;
 		psu = d;
+		lcp_p = e;
+		lcp_s = f;
 		lo = hi = ins;
 		st = ST_FIN;
 	}
@@ -332,6 +407,7 @@ struct Chain {
 		*a0 = Q + q;
 		if (lucky_ok(R)) {
 			*a1 = R.S + (ls + (q - lq));
+			if (R.dbg & 2u) *a1 = R.S + ((ls + (q - lq)) & 4095u);
 			return 2;
 		}
 		return 1;
@@ -339,6 +415,11 @@ struct Chain {
 	PHY_HD void consume_step(const RefIndex &R, const U4 &qw, const U4 &sw)
 	{
 		qc = qw;
+		{
+			uint32_t valid, n = qlen - q;
+			qcode = window_code(qw, &valid);
+			qv = valid < n ? valid : n;
+		}
 		if (lucky_ok(R)) {
 			uint32_t len, less;
 			e_p = ls + (q - lq);
@@ -349,53 +430,82 @@ struct Chain {
 		begin_search(R);
 	}
 
-	// ── phase T ──
-	PHY_HD const uint8_t *issue_T(const RefIndex &R) const { return (const uint8_t *)(R.T + lo); }
-	PHY_HD void consume_T(const U4 &t)
+	// ── phase T: the slot of the query's k-mer ──
+	PHY_HD const uint8_t *issue_T(const RefIndex &R) const
 	{
-		lo = t.x;
-		hi = t.y;
+		size_t code = lo;
+		if (R.dbg & 1u) code &= 31u;
+		return (const uint8_t *)(R.SLOT + code * SLOT_RECS);
+	}
+	// hdr = record 0; d = records 1..4
+	PHY_HD void consume_T(const RefIndex &R, const U4 &hdr, const Data &d)
+	{
+		lo = hdr.x;
+		hi = hdr.y;
 		if (hi - lo <= 2) {
 			c_rank0 = lo > 0 ? lo - 1 : 0;
-			st = ST_SA;
+			consume_SA(R, d);
 		} else {
 			st = ST_BS;
 		}
 	}
 
-	// ── phase SA: predecessor of the bucket, its members, its successor ──
-	PHY_HD const uint8_t *issue_SA(const RefIndex &R) const { return (const uint8_t *)(R.SA + c_rank0); }
-	PHY_HD void consume_SA(const RefIndex &R, const U4 &v)
+	// ── phase SA: the records of the bucket's predecessor, members, successor ──
+	PHY_HD const uint8_t *issue_SA(const RefIndex &R) const { return (const uint8_t *)(R.SAX + c_rank0); }
+	PHY_HD void take_record(uint32_t i, const U4 &r, uint32_t n)
+	{
+		uint32_t len = 0, less = 0;
+		uint32_t k = packed_cmp(qcode, qv, n, r.y, r.z, &len, &less);
+		if (k == 0) {
+			set_len(i, len);
+			c_less |= less << i;
+		} else if (k == 1) {
+			c_pending |= 1u << i;
+		} else {
+			c_raw |= 1u << i;
+		}
+	}
+	PHY_HD void consume_SA(const RefIndex &R, const Data &d)
 	{
 		uint32_t last = hi < R.n ? hi : R.n - 1;
+		uint32_t n = qlen - q;
 		c_n = last - c_rank0 + 1;
-		c_pos0 = v.x;
-		c_pos1 = v.y;
-		c_pos2 = v.z;
-		c_pos3 = v.w;
-		st = ST_CAND;
+		c_pos0 = d.w[0].x;
+		c_pos1 = d.w[1].x;
+		c_pos2 = d.w[2].x;
+		c_pos3 = d.w[3].x;
+		c_lcp0 = d.w[0].w;
+		c_lcp1 = d.w[1].w;
+		c_lcp2 = d.w[2].w;
+		c_lcp3 = d.w[3].w;
+		c_pending = c_less = c_raw = 0;
+		take_record(0, d.w[0], n);
+		if (c_n > 1) take_record(1, d.w[1], n);
+		if (c_n > 2) take_record(2, d.w[2], n);
+		if (c_n > 3) take_record(3, d.w[3], n);
+		if (c_raw) st = ST_CAND; // rare: a '!' / '#' / end of S inside a window
+		else cand_next(R);
 	}
 
-	// ── phase CAND ──
+	// ── phase CAND: raw 16-byte windows for the candidates flagged in c_raw ──
+	PHY_HD void raw_one(uint32_t i, const U4 &sw)
+	{
+		if (!((c_raw >> i) & 1u)) return;
+		uint32_t len, less;
+		if (window_cmp(sw, &len, &less)) {
+			set_len(i, len);
+			c_less |= less << i;
+		} else {
+			c_pending |= 1u << i;
+		}
+	}
 	PHY_HD void consume_cand(const RefIndex &R, const Data &d)
 	{
-		c_pending = 0;
-		c_less = 0;
-		uint32_t len, less;
-		if (window_cmp(d.w[0], &len, &less)) c_len0 = len, c_less |= less;
-		else c_pending |= 1u;
-		if (c_n > 1) {
-			if (window_cmp(d.w[1], &len, &less)) c_len1 = len, c_less |= less << 1;
-			else c_pending |= 2u;
-		}
-		if (c_n > 2) {
-			if (window_cmp(d.w[2], &len, &less)) c_len2 = len, c_less |= less << 2;
-			else c_pending |= 4u;
-		}
-		if (c_n > 3) {
-			if (window_cmp(d.w[3], &len, &less)) c_len3 = len, c_less |= less << 3;
-			else c_pending |= 8u;
-		}
+		raw_one(0, d.w[0]);
+		raw_one(1, d.w[1]);
+		raw_one(2, d.w[2]);
+		raw_one(3, d.w[3]);
+		c_raw = 0;
 		cand_next(R);
 	}
 
@@ -420,11 +530,13 @@ struct Chain {
 						lo = mid + 1;
 						l_lo = pr_len;
 						p_lo = pr_pos;
+						lcp_p = pr_lcp;
 						flags |= 1u;
 					} else {
 						hi = mid;
 						l_hi = pr_len;
 						p_hi = pr_pos;
+						lcp_s = pr_lcp;
 						flags |= 2u;
 					}
 					st = ST_BS;
@@ -447,6 +559,7 @@ struct Chain {
 				case ST_NBP_R:
 					lp = pr_len;
 					pp = pr_pos;
+					lcp_p = pr_lcp;
 					st = ST_NBS;
 					break;
 				case ST_NBS:
@@ -467,6 +580,7 @@ struct Chain {
 				case ST_NBS_R:
 					lsu = pr_len;
 					psu = pr_pos;
+					lcp_s = pr_lcp;
 					st = ST_FIN;
 					return false;
 				default: return st == ST_PR_SA;
@@ -474,11 +588,26 @@ struct Chain {
 		}
 	}
 	PHY_HD bool in_gen() const { return st >= ST_BS; }
-	PHY_HD const uint8_t *issue_probe_sa(const RefIndex &R) const { return (const uint8_t *)(R.SA + pr_rank); }
-	PHY_HD void consume_probe_sa(uint32_t pos)
+	PHY_HD const uint8_t *issue_probe_sa(const RefIndex &R) const { return (const uint8_t *)(R.SAX + pr_rank); }
+	// returns true when the raw suffix window is needed as well
+	PHY_HD bool consume_probe_sa(const U4 &r)
 	{
-		pr_pos = pos;
+		uint32_t len = 0, less = 0;
+		pr_pos = r.x;
+		pr_lcp = r.w;
+		uint32_t k = packed_cmp(qcode, qv, qlen - q, r.y, r.z, &len, &less);
+		if (k == 0) {
+			pr_len = len;
+			pr_less = less;
+			st = pr_ret;
+			return false;
+		}
+		if (k == 1) {
+			start_ext(EXT_PROBE, 0, pr_pos);
+			return false;
+		}
 		st = ST_PR_S;
+		return true;
 	}
 	PHY_HD const uint8_t *issue_probe_s(const RefIndex &R) const { return R.S + pr_pos; }
 	PHY_HD void consume_probe_s(const U4 &sw)
@@ -500,6 +629,10 @@ struct Chain {
 		a[1] = Q + q + e_pos + 16;
 		a[2] = R.S + e_p + e_pos;
 		a[3] = R.S + e_p + e_pos + 16;
+		if (R.dbg & 4u) {
+			a[2] = R.S + ((e_p + e_pos) & 4095u);
+			a[3] = a[2] + 16;
+		}
 	}
 	PHY_HD bool consume_ext(const RefIndex &R, const Data &d)
 	{
@@ -526,22 +659,30 @@ struct Chain {
 	}
 
 	// ── phase FIN: anchor(), process.cxx:219-225 ──
-	// returns true when LCP[best], LCP[best+1] are needed to settle uniqueness
+	// The only neighbour attaining lmax is unique iff the next suffix outward does
+	// not share lmax characters with it: LCP[best] < lmax for the predecessor,
+	// LCP[best+1] < lmax for the successor.  Both values travel with the record,
+	// clipped to 16 bits; returns true when the clipped value cannot decide and
+	// the full LCP array has to be read.
 	PHY_HD bool fin_needs_lcp(const RefIndex &R)
 	{
 		uint32_t lmax = lp > lsu ? lp : lsu;
-		if (lp != lsu && lmax >= R.threshold) return true;
-		finish_step(0, lmax, false);
+		if (lp == lsu || lmax < R.threshold) {
+			finish_step(0, lmax, false);
+			return false;
+		}
+		uint32_t l = lp > lsu ? (lcp_p & 0xffffu) : (lcp_s >> 16);
+		if (l == 0xffffu && lmax >= 0xffffu) return true;
+		finish_step(lp > lsu ? pp : psu, lmax, l < lmax);
 		return false;
 	}
 	PHY_HD const uint8_t *issue_lcp(const RefIndex &R) const
 	{
-		// rank lo-1 (lp>lsu) or rank hi (lsu>lp) is the only neighbour attaining lmax
+		// rank lo-1 (lp>lsu) or rank hi (lsu>lp) is the best neighbour
 		return (const uint8_t *)(R.LCP + (lp > lsu ? lo - 1 : hi));
 	}
 	PHY_HD void consume_lcp(const U4 &v)
 	{
-		// unique iff the next suffix outward does not share lmax characters with it
 		uint32_t lmax = lp > lsu ? lp : lsu;
 		uint32_t l = lp > lsu ? v.x : v.y; // LCP[best] / LCP[best+1]
 		finish_step(lp > lsu ? pp : psu, lmax, l < lmax);
@@ -562,8 +703,12 @@ template <class Tail> PHY_HD void chain_trip(Chain &ch, const RefIndex &R, Tail 
 		if (n > 1) sw = load16(a1);
 		ch.consume_step(R, qw, sw);
 	}
-	if (ch.st == ST_T) ch.consume_T(load16(ch.issue_T(R)));
-	if (ch.st == ST_SA) ch.consume_SA(R, load16(ch.issue_SA(R)));
+	if (ch.st == ST_T) {
+		const uint8_t *a = ch.issue_T(R);
+		U4 hdr = load16(a);
+		for (int i = 0; i < 4; i++) d.w[i] = load16(a + 16 * (i + 1));
+		ch.consume_T(R, hdr, d);
+	}
 	if (ch.st == ST_CAND) {
 		d.w[0] = load16(R.S + ch.c_pos0);
 		d.w[1] = d.w[2] = d.w[3] = d.w[0];
@@ -574,9 +719,7 @@ template <class Tail> PHY_HD void chain_trip(Chain &ch, const RefIndex &R, Tail 
 	}
 	if (ch.in_gen()) {
 		if (ch.gen_advance(R)) {
-			U4 v = load16(ch.issue_probe_sa(R));
-			ch.consume_probe_sa(v.x);
-			ch.consume_probe_s(load16(ch.issue_probe_s(R)));
+			if (ch.consume_probe_sa(load16(ch.issue_probe_sa(R)))) ch.consume_probe_s(load16(ch.issue_probe_s(R)));
 			if (ch.in_gen()) ch.gen_advance(R); // digest the probe now if it was decided
 		}
 	}

@@ -11,6 +11,8 @@
 // Σ|Q| + 26·|S|.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "anchor_core.h"
 #include "kernels.h"
 
@@ -124,8 +126,17 @@ template <int MODE> __global__ __launch_bounds__(256) void chain_kernel(PhaseA A
 			if (n > 1) sw = load16(a1);
 			ch.consume_step(R, qw, sw);
 		}
-		if (live && ch.st == ST_T) ch.consume_T(load16(ch.issue_T(R)));
-		if (live && ch.st == ST_SA) ch.consume_SA(R, load16(ch.issue_SA(R)));
+		if (live && ch.st == ST_T) {
+			// one 128-byte line: bucket bounds + the records of the (<= 4) candidates
+			const uint8_t *a = ch.issue_T(R);
+			U4 hdr = load16(a);
+			Data d;
+			d.w[0] = load16(a + 16);
+			d.w[1] = load16(a + 32);
+			d.w[2] = load16(a + 48);
+			d.w[3] = load16(a + 64);
+			ch.consume_T(R, hdr, d);
+		}
 		if (live && ch.st == ST_CAND) {
 			Data d;
 			d.w[0] = load16(R.S + ch.c_pos0);
@@ -137,9 +148,7 @@ template <int MODE> __global__ __launch_bounds__(256) void chain_kernel(PhaseA A
 		}
 		if (live && ch.in_gen()) {
 			if (ch.gen_advance(R)) {
-				U4 v = load16(ch.issue_probe_sa(R));
-				ch.consume_probe_sa(v.x);
-				ch.consume_probe_s(load16(ch.issue_probe_s(R)));
+				if (ch.consume_probe_sa(load16(ch.issue_probe_sa(R)))) ch.consume_probe_s(load16(ch.issue_probe_s(R)));
 				if (ch.in_gen()) ch.gen_advance(R);
 			}
 		}
@@ -304,6 +313,10 @@ static int resident_blocks(const void *fn, int n_cu)
 {
 	int per_cu = 0;
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+	if (const char *e = getenv("PHYLO_CHAIN_BLOCKS_PER_CU")) { // experiments only
+		int v = atoi(e);
+		if (v >= 1 && v <= per_cu) per_cu = v;
+	}
 	return per_cu * n_cu;
 }
 

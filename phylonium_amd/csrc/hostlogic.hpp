@@ -193,6 +193,30 @@ static inline void kmer_table(const uint8_t *s, uint32_t n, uint32_t k, std::vec
 	}
 }
 
+// One 16-byte record per rank (anchor_core.h: sax_record); +4 zero records of pad.
+static inline void build_sax(const uint8_t *s, uint32_t n, const uint32_t *sa, const uint32_t *lcp,
+							 std::vector<U4> &out)
+{
+	out.assign((size_t)n + 4, U4{0, 0, 0, 0});
+	for (uint32_t r = 0; r < n; r++) out[r] = sax_record(s, sa[r], lcp[r], lcp[r + 1]);
+}
+
+// Slot table for the emulation / small cases on the host (the product builds it
+// on the device, phylo_abi.hip: build_slots_kernel).
+static inline void build_slots(const std::vector<uint32_t> &T, const std::vector<U4> &sax, uint32_t n, uint32_t k,
+							   std::vector<U4> &out)
+{
+	size_t codes = (size_t)1 << (2 * k);
+	out.assign(codes * SLOT_RECS, U4{0, 0, 0, 0});
+	for (size_t c = 0; c < codes; c++) {
+		uint32_t lo = T[c], hi = T[c + 1];
+		uint32_t base = lo ? lo - 1 : 0;
+		out[c * SLOT_RECS] = U4{lo, hi, 0, 0};
+		for (uint32_t i = 0; i < 5; i++)
+			if (base + i < n) out[c * SLOT_RECS + 1 + i] = sax[base + i];
+	}
+}
+
 static inline uint32_t choose_k(uint32_t n)
 {
 	// smallest k with 4^k >= n: at most one suffix per bucket on average, so that

@@ -12,7 +12,12 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
+#include <condition_variable>
+#include <functional>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -61,6 +66,95 @@ struct TimedSpan {
 	hipEvent_t a, b;
 };
 
+// page-locked host staging buffer (grow-only): async copies to/from it do not
+// bounce through the runtime's own staging area
+template <class T> struct PinBuf {
+	T *p = nullptr;
+	size_t cap = 0;
+	hipError_t ensure(size_t n)
+	{
+		if (n <= cap) return hipSuccess;
+		if (p) (void)hipHostFree(p);
+		p = nullptr;
+		cap = 0;
+		size_t want = n + n / 4 + 64;
+		hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
+		if (e == hipSuccess) cap = want;
+		return e;
+	}
+	void release()
+	{
+		if (p) (void)hipHostFree(p);
+		p = nullptr;
+		cap = 0;
+	}
+};
+
+// Persistent worker threads for the per-query host steps (std::sort + chain
+// filter); replaces the reference's `#pragma omp parallel for` at process.cxx:433.
+class WorkerPool
+{
+	std::vector<std::thread> threads;
+	std::mutex m;
+	std::condition_variable cv_work, cv_done;
+	std::function<void(size_t)> job;
+	std::atomic<size_t> next{0};
+	size_t total = 0, generation = 0, running = 0;
+	bool stop = false;
+
+	void loop()
+	{
+		size_t seen = 0;
+		for (;;) {
+			{
+				std::unique_lock<std::mutex> lk(m);
+				cv_work.wait(lk, [&] { return stop || generation != seen; });
+				if (stop) return;
+				seen = generation;
+			}
+			for (;;) {
+				size_t i = next.fetch_add(1);
+				if (i >= total) break;
+				job(i);
+			}
+			std::unique_lock<std::mutex> lk(m);
+			if (--running == 0) cv_done.notify_all();
+		}
+	}
+
+  public:
+	explicit WorkerPool(size_t n)
+	{
+		for (size_t t = 0; t < n; t++) threads.emplace_back([this] { loop(); });
+	}
+	~WorkerPool()
+	{
+		{
+			std::unique_lock<std::mutex> lk(m);
+			stop = true;
+		}
+		cv_work.notify_all();
+		for (auto &t : threads) t.join();
+	}
+	size_t size() const { return threads.size(); }
+	void run(size_t n, std::function<void(size_t)> f)
+	{
+		if (n == 0) return;
+		if (threads.empty() || n == 1) {
+			for (size_t i = 0; i < n; i++) f(i);
+			return;
+		}
+		std::unique_lock<std::mutex> lk(m);
+		job = std::move(f);
+		total = n;
+		next = 0;
+		running = threads.size();
+		generation++;
+		cv_work.notify_all();
+		cv_done.wait(lk, [&] { return running == 0; });
+	}
+};
+
 } // namespace
 
 struct phylo_ctx {
@@ -89,7 +183,8 @@ struct phylo_ctx {
 	size_t ref_idx = 0;
 	uint32_t L = 0, ns = 0, k = 0, threshold = 0;
 	DevBuf<uint8_t> d_S;
-	DevBuf<uint32_t> d_SA, d_LCP, d_T;
+	DevBuf<U4> d_SAX, d_SLOT;
+	DevBuf<uint32_t> d_LCP, d_T;
 
 	// phase A scratch
 	DevBuf<uint64_t> a_qoff;
@@ -111,6 +206,19 @@ struct phylo_ctx {
 	DevBuf<unsigned long long> b_subst, b_homologs;
 	DevBuf<Segment> s_segs;
 	DevBuf<uint64_t> s_out;
+
+	// host staging and workers
+	PinBuf<uint32_t> h_cnt;
+	PinBuf<RawHom> h_raw;
+	PinBuf<DevHom> h_devhom;
+	PinBuf<uint64_t> h_mat;
+	std::unique_ptr<WorkerPool> pool;
+	// cached phase-A plan
+	bool plan_valid = false;
+	size_t plan_qb = 0, plan_qe = 0;
+	ChunkPlan plan;
+	std::vector<uint64_t> plan_out_base;
+	uint64_t plan_raw_total = 0;
 
 	// stats
 	std::map<std::string, double> stats;
@@ -194,31 +302,19 @@ int sync_stream(phylo_ctx *c)
 	return 0;
 }
 
-template <class F> void parallel_for(size_t n, int threads, F f)
+WorkerPool &workers(phylo_ctx *c)
 {
-	if (threads <= 1 || n <= 1) {
-		for (size_t i = 0; i < n; i++) f(i);
-		return;
+	if (!c->pool) {
+		size_t n;
+		if (c->host_threads > 0) {
+			n = (size_t)c->host_threads;
+		} else {
+			unsigned h = std::thread::hardware_concurrency();
+			n = h ? std::min(h, 48u) : 1;
+		}
+		c->pool.reset(new WorkerPool(n <= 1 ? 0 : n));
 	}
-	std::atomic<size_t> next{0};
-	std::vector<std::thread> pool;
-	size_t nt = std::min<size_t>((size_t)threads, n);
-	for (size_t t = 0; t < nt; t++)
-		pool.emplace_back([&]() {
-			for (;;) {
-				size_t i = next.fetch_add(1);
-				if (i >= n) break;
-				f(i);
-			}
-		});
-	for (auto &t : pool) t.join();
-}
-
-int host_threads(const phylo_ctx *c)
-{
-	if (c->host_threads > 0) return c->host_threads;
-	unsigned h = std::thread::hardware_concurrency();
-	return h ? (int)std::min(h, 64u) : 1;
+	return *c->pool;
 }
 
 } // namespace
@@ -261,11 +357,17 @@ void phylo_ctx_destroy(phylo_ctx *c)
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	(void)hipStreamSynchronize(c->stream);
+	c->pool.reset();
+	c->h_cnt.release();
+	c->h_raw.release();
+	c->h_devhom.release();
+	c->h_mat.release();
 	c->genomes_store.release();
 	c->d_goff.release();
 	c->d_glen.release();
 	c->d_S.release();
-	c->d_SA.release();
+	c->d_SAX.release();
+	c->d_SLOT.release();
 	c->d_LCP.release();
 	c->d_T.release();
 	c->a_qoff.release();
@@ -312,6 +414,7 @@ int phylo_set_option(phylo_ctx *c, const char *key, long value)
 	if (k == "chunk") {
 		if (value != 0 && (value < 64 || (value & (value - 1)))) return c->fail("chunk must be 0 or a power of two >= 64");
 		c->opt_chunk = (uint32_t)value;
+		c->plan_valid = false;
 	} else if (k == "kmer") {
 		if (value < 0 || value > 14) return c->fail("kmer must be in 0..14");
 		c->opt_kmer = (uint32_t)value;
@@ -323,6 +426,7 @@ int phylo_set_option(phylo_ctx *c, const char *key, long value)
 		c->backend = (int)value;
 	} else if (k == "host_threads") {
 		c->host_threads = (int)value;
+		c->pool.reset();
 	} else {
 		return c->fail("unknown option '%s'", key);
 	}
@@ -378,6 +482,7 @@ static int install_layout(phylo_ctx *c)
 	HIPOK(c, hipStreamSynchronize(c->stream));
 	c->homs.assign(n, {});
 	c->have_ref = false;
+	c->plan_valid = false;
 	return 0;
 }
 
@@ -423,6 +528,27 @@ int phylo_set_genomes_device(phylo_ctx *c, size_t n, const void *dev_base, const
 
 // ───────────────────────── reference index ─────────────────────────
 
+// One 128-byte slot per k-mer (anchor_core.h: SLOT_RECS): header {T[c], T[c+1]}
+// and the SAX records of ranks base..base+4, base = T[c] ? T[c]-1 : 0.
+__global__ __launch_bounds__(256) void build_slots_kernel(const uint32_t *__restrict__ T, const U4 *__restrict__ sax,
+														   uint32_t n, uint64_t codes, U4 *__restrict__ slot)
+{
+	const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t c = tid >> 3;
+	const uint32_t r = (uint32_t)(tid & 7u);
+	if (c >= codes) return;
+	const uint32_t lo = T[c], hi = T[c + 1];
+	U4 v = {0, 0, 0, 0};
+	if (r == 0) {
+		v.x = lo;
+		v.y = hi;
+	} else if (r <= 5) {
+		uint32_t rank = (lo ? lo - 1 : 0) + (r - 1);
+		if (rank < n) v = sax[rank];
+	}
+	slot[tid] = v;
+}
+
 int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t threshold)
 {
 	if (!c) return 1;
@@ -452,22 +578,34 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 	uint32_t k = c->opt_kmer ? c->opt_kmer : choose_k(ns);
 	kmer_table(S.data(), ns, k, T);
 	T.resize(T.size() + 4, ns);
+	std::vector<U4> SAX;
+	build_sax(S.data(), ns, SA.data(), LCP.data(), SAX);
 	double t3 = now_ms();
 	if (threshold == 0) threshold = min_anchor_length(0.025, gc_content(S.data(), L), ns);
 	HIPOK(c, c->d_S.ensure(S.size()));
-	HIPOK(c, c->d_SA.ensure(SA.size()));
+	HIPOK(c, c->d_SAX.ensure(SAX.size()));
 	HIPOK(c, c->d_LCP.ensure(LCP.size()));
 	HIPOK(c, c->d_T.ensure(T.size()));
 	HIPOK(c, hipMemcpy(c->d_S.p, S.data(), S.size(), hipMemcpyHostToDevice));
-	HIPOK(c, hipMemcpy(c->d_SA.p, SA.data(), SA.size() * 4, hipMemcpyHostToDevice));
+	HIPOK(c, hipMemcpy(c->d_SAX.p, SAX.data(), SAX.size() * sizeof(U4), hipMemcpyHostToDevice));
 	HIPOK(c, hipMemcpy(c->d_LCP.p, LCP.data(), LCP.size() * 4, hipMemcpyHostToDevice));
 	HIPOK(c, hipMemcpy(c->d_T.p, T.data(), T.size() * 4, hipMemcpyHostToDevice));
+	{
+		uint64_t codes = (uint64_t)1 << (2 * k);
+		HIPOK(c, c->d_SLOT.ensure(codes * SLOT_RECS));
+		uint64_t threads = codes * SLOT_RECS;
+		hipLaunchKernelGGL(build_slots_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, c->d_T.p,
+						   c->d_SAX.p, ns, codes, c->d_SLOT.p);
+		HIPOK(c, hipGetLastError());
+		HIPOK(c, hipStreamSynchronize(c->stream));
+	}
 	c->ref_idx = ref_idx;
 	c->L = (uint32_t)L;
 	c->ns = ns;
 	c->k = k;
 	c->threshold = (uint32_t)threshold;
 	c->have_ref = true;
+	c->plan_valid = false;
 	c->stats["ms:ref_fetch"] += t1 - t0;
 	c->stats["ms:ref_suffix_array"] += t2 - t1;
 	c->stats["ms:ref_lcp_table"] += t3 - t2;
@@ -502,57 +640,66 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	if (nq == 0) return 0;
 	double t0 = now_ms();
 
-	std::vector<uint32_t> qlen(nq);
-	std::vector<uint64_t> qoff(nq);
-	uint64_t total = 0;
-	for (size_t j = 0; j < nq; j++) {
-		qlen[j] = (uint32_t)c->glen[q_begin + j];
-		qoff[j] = c->goff[q_begin + j];
-		total += qlen[j];
-	}
-	ChunkPlan P = plan_chunks(qlen, c->threshold, c->opt_chunk);
-	uint32_t nch = P.nchunks;
-
-	// output capacities: an emitted homology spans >= 2*threshold query positions
-	std::vector<uint64_t> out_base(nq + 1);
-	std::vector<uint32_t> out_cap(nq);
-	uint64_t raw_total = 0;
-	for (size_t j = 0; j < nq; j++) {
-		out_base[j] = raw_total;
-		out_cap[j] = qlen[j] / (2 * c->threshold) + 2;
-		raw_total += out_cap[j];
-	}
-	out_base[nq] = raw_total;
-	uint32_t pool_blocks = nch / 4 + 4096;
-
-	HIPOK(c, c->a_qoff.ensure(nq));
-	HIPOK(c, c->a_qlen.ensure(nq));
-	HIPOK(c, c->a_qchunk0.ensure(nq + 1));
-	HIPOK(c, c->a_items.ensure(nch + 1));
-	HIPOK(c, c->a_chunk_query.ensure(nch + 1));
-	HIPOK(c, c->a_spec_cnt.ensure(nch + 1));
-	HIPOK(c, c->a_visited.ensure((size_t)nch * (P.C / 32) + 1));
-	HIPOK(c, c->a_misc.ensure(16));
-	HIPOK(c, c->a_spec_anchors.ensure((size_t)nch * P.cap + 1));
-	HIPOK(c, c->a_spec_exit.ensure(nch + 1));
-	HIPOK(c, c->a_bridge.ensure(nch + 1));
-	HIPOK(c, c->a_pool.ensure(pool_blocks));
-	HIPOK(c, c->a_raw.ensure(raw_total + 1));
-	HIPOK(c, c->a_out_base.ensure(nq + 1));
-	HIPOK(c, c->a_cmp_base.ensure(nq + 1));
-	HIPOK(c, c->a_out_cap.ensure(nq));
-	HIPOK(c, c->a_out_cnt.ensure(nq));
-
 	hipStream_t st = c->stream;
-	HIPOK(c, hipMemcpyAsync(c->a_qoff.p, qoff.data(), nq * 8, hipMemcpyHostToDevice, st));
-	HIPOK(c, hipMemcpyAsync(c->a_qlen.p, qlen.data(), nq * 4, hipMemcpyHostToDevice, st));
-	HIPOK(c, hipMemcpyAsync(c->a_qchunk0.p, P.qchunk0.data(), (nq + 1) * 4, hipMemcpyHostToDevice, st));
-	if (nch) {
-		HIPOK(c, hipMemcpyAsync(c->a_items.p, P.items.data(), (size_t)nch * 4, hipMemcpyHostToDevice, st));
-		HIPOK(c, hipMemcpyAsync(c->a_chunk_query.p, P.chunk_query.data(), (size_t)nch * 4, hipMemcpyHostToDevice, st));
+	if (!c->plan_valid || c->plan_qb != q_begin || c->plan_qe != q_end) {
+		// chunk plan, output capacities and their device copies: rebuilt only when the
+		// query range, the genomes or the reference change
+		std::vector<uint32_t> qlen(nq);
+		std::vector<uint64_t> qoff(nq);
+		for (size_t j = 0; j < nq; j++) {
+			qlen[j] = (uint32_t)c->glen[q_begin + j];
+			qoff[j] = c->goff[q_begin + j];
+		}
+		c->plan = plan_chunks(qlen, c->threshold, c->opt_chunk);
+		const ChunkPlan &P = c->plan;
+		// an emitted homology spans >= 2*threshold query positions
+		c->plan_out_base.assign(nq + 1, 0);
+		std::vector<uint32_t> out_cap(nq);
+		uint64_t raw_total = 0;
+		for (size_t j = 0; j < nq; j++) {
+			c->plan_out_base[j] = raw_total;
+			out_cap[j] = qlen[j] / (2 * c->threshold) + 2;
+			raw_total += out_cap[j];
+		}
+		c->plan_out_base[nq] = raw_total;
+		c->plan_raw_total = raw_total;
+		uint32_t nchp = P.nchunks;
+		HIPOK(c, c->a_qoff.ensure(nq));
+		HIPOK(c, c->a_qlen.ensure(nq));
+		HIPOK(c, c->a_qchunk0.ensure(nq + 1));
+		HIPOK(c, c->a_items.ensure(nchp + 1));
+		HIPOK(c, c->a_chunk_query.ensure(nchp + 1));
+		HIPOK(c, c->a_spec_cnt.ensure(nchp + 1));
+		HIPOK(c, c->a_visited.ensure((size_t)nchp * (P.C / 32) + 1));
+		HIPOK(c, c->a_misc.ensure(16));
+		HIPOK(c, c->a_spec_anchors.ensure((size_t)nchp * P.cap + 1));
+		HIPOK(c, c->a_spec_exit.ensure(nchp + 1));
+		HIPOK(c, c->a_bridge.ensure(nchp + 1));
+		HIPOK(c, c->a_pool.ensure(nchp / 4 + 4096));
+		HIPOK(c, c->a_raw.ensure(raw_total + 1));
+		HIPOK(c, c->a_out_base.ensure(nq + 1));
+		HIPOK(c, c->a_cmp_base.ensure(nq + 1));
+		HIPOK(c, c->a_out_cap.ensure(nq));
+		HIPOK(c, c->a_out_cnt.ensure(nq));
+		HIPOK(c, hipMemcpyAsync(c->a_qoff.p, qoff.data(), nq * 8, hipMemcpyHostToDevice, st));
+		HIPOK(c, hipMemcpyAsync(c->a_qlen.p, qlen.data(), nq * 4, hipMemcpyHostToDevice, st));
+		HIPOK(c, hipMemcpyAsync(c->a_qchunk0.p, P.qchunk0.data(), (nq + 1) * 4, hipMemcpyHostToDevice, st));
+		if (nchp) {
+			HIPOK(c, hipMemcpyAsync(c->a_items.p, P.items.data(), (size_t)nchp * 4, hipMemcpyHostToDevice, st));
+			HIPOK(c, hipMemcpyAsync(c->a_chunk_query.p, P.chunk_query.data(), (size_t)nchp * 4, hipMemcpyHostToDevice, st));
+		}
+		HIPOK(c, hipMemcpyAsync(c->a_out_base.p, c->plan_out_base.data(), (nq + 1) * 8, hipMemcpyHostToDevice, st));
+		HIPOK(c, hipMemcpyAsync(c->a_out_cap.p, out_cap.data(), nq * 4, hipMemcpyHostToDevice, st));
+		HIPOK(c, hipStreamSynchronize(st)); // the host vectors above go out of scope
+		c->plan_qb = q_begin;
+		c->plan_qe = q_end;
+		c->plan_valid = true;
 	}
-	HIPOK(c, hipMemcpyAsync(c->a_out_base.p, out_base.data(), (nq + 1) * 8, hipMemcpyHostToDevice, st));
-	HIPOK(c, hipMemcpyAsync(c->a_out_cap.p, out_cap.data(), nq * 4, hipMemcpyHostToDevice, st));
+	const ChunkPlan &P = c->plan;
+	const uint32_t nch = P.nchunks;
+	const uint32_t pool_blocks = nch / 4 + 4096;
+	uint64_t total = 0;
+	for (size_t j = 0; j < nq; j++) total += c->glen[q_begin + j];
 	HIPOK(c, hipMemsetAsync(c->a_misc.p, 0, 16 * 4, st));
 	if (nch) HIPOK(c, hipMemsetAsync(c->a_visited.p, 0, (size_t)nch * (P.C / 32) * 4, st));
 
@@ -577,7 +724,7 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	A.fetch = c->a_misc.p;          // [0] spec, [1] bridge
 	A.pool_next = c->a_misc.p + 2;
 	A.error = c->a_misc.p + 3;
-	RefIndex R = {c->d_S.p, c->d_SA.p, c->d_LCP.p, c->d_T.p, c->ns, c->k, c->threshold};
+	RefIndex R = {c->d_S.p, c->d_SAX.p, c->d_LCP.p, c->d_SLOT.p, nullptr, c->ns, c->k, c->threshold, getenv("PHYLO_DBG") ? (uint32_t)atoi(getenv("PHYLO_DBG")) : 0u};
 
 	double t1 = now_ms();
 	if (nch) {
@@ -595,9 +742,9 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 		launch_fold(A, (uint32_t)nq, c->L, c->threshold, c->a_raw.p, c->a_out_base.p, c->a_out_cap.p, c->a_out_cnt.p, st);
 	}
 	HIPOK(c, hipGetLastError());
-	std::vector<uint32_t> cnt(nq);
-	uint32_t misc[4];
-	HIPOK(c, hipMemcpyAsync(cnt.data(), c->a_out_cnt.p, nq * 4, hipMemcpyDeviceToHost, st));
+	HIPOK(c, c->h_cnt.ensure(nq + 4));
+	uint32_t *cnt = c->h_cnt.p, *misc = c->h_cnt.p + nq;
+	HIPOK(c, hipMemcpyAsync(cnt, c->a_out_cnt.p, nq * 4, hipMemcpyDeviceToHost, st));
 	HIPOK(c, hipMemcpyAsync(misc, c->a_misc.p, 16, hipMemcpyDeviceToHost, st));
 	if (sync_stream(c)) return 1;
 	double t2 = now_ms();
@@ -610,7 +757,8 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 		ctot += cnt[j];
 	}
 	cbase[nq] = ctot;
-	std::vector<RawHom> raw(ctot);
+	HIPOK(c, c->h_raw.ensure(ctot + 1));
+	const RawHom *raw = c->h_raw.p;
 	if (ctot) {
 		HIPOK(c, c->a_raw_compact.ensure(ctot));
 		HIPOK(c, hipMemcpyAsync(c->a_cmp_base.p, cbase.data(), (nq + 1) * 8, hipMemcpyHostToDevice, st));
@@ -619,13 +767,13 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 			hipLaunchKernelGGL(compact_raw_kernel, dim3((uint32_t)nq), dim3(256), 0, st, c->a_raw.p, c->a_out_base.p,
 							   c->a_out_cnt.p, c->a_cmp_base.p, c->a_raw_compact.p);
 		}
-		HIPOK(c, hipMemcpyAsync(raw.data(), c->a_raw_compact.p, ctot * sizeof(RawHom), hipMemcpyDeviceToHost, st));
+		HIPOK(c, hipMemcpyAsync(c->h_raw.p, c->a_raw_compact.p, ctot * sizeof(RawHom), hipMemcpyDeviceToHost, st));
 		if (sync_stream(c)) return 1;
 	}
 	double t3 = now_ms();
 	// reverseEh + std::sort + filter_overlaps_max on the host cores (process.cxx:438-443)
 	uint64_t border = c->L;
-	parallel_for(nq, host_threads(c), [&](size_t j) {
+	workers(c).run(nq, [&](size_t j) {
 		std::vector<phylo_homology> hv(cnt[j]);
 		for (uint32_t t = 0; t < cnt[j]; t++) hv[t] = project_homology(raw[cbase[j] + t], border);
 		sort_and_filter(hv);
@@ -642,6 +790,7 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	c->stats["count:chunks"] += nch;
 	c->stats["count:raw_homologies"] += (double)ctot;
 	c->stats["count:pool_blocks_used"] += misc[2];
+	(void)pool_blocks;
 	c->stats["anchor:chunk"] = P.C;
 	return 0;
 }
@@ -768,7 +917,8 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 	HIPOK(c, c->b_planes.ensure(plane_words * 5));
 	for (int p = 0; p < 5; p++) P.plane[p] = c->b_planes.p + plane_words * p;
 
-	// filtered homologies → device
+	// filtered homologies → device (built by the worker pool into pinned memory)
+	double t0 = now_ms();
 	std::vector<uint32_t> hom_off(N + 1);
 	size_t tot = 0;
 	for (size_t g = 0; g < N; g++) {
@@ -776,24 +926,27 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		tot += c->homs[g].size();
 	}
 	hom_off[N] = (uint32_t)tot;
-	std::vector<DevHom> dh(tot);
-	for (size_t g = 0; g < N; g++) {
+	HIPOK(c, c->h_devhom.ensure(tot + 1));
+	DevHom *dh = c->h_devhom.p;
+	std::atomic<size_t> bad{(size_t)-1};
+	workers(c).run(N, [&](size_t g) {
 		size_t o = hom_off[g];
 		for (const phylo_homology &h : c->homs[g]) {
-			if (h.index_reference_projected + h.length > c->L)
-				return c->fail("genome %zu: homology reaches beyond the reference", g);
+			if (h.index_reference_projected + h.length > c->L) bad = g;
 			dh[o++] = DevHom{(uint32_t)h.index_reference_projected, (uint32_t)h.index_query, (uint32_t)h.length,
 							 (uint32_t)h.direction};
 		}
-	}
+	});
+	if (bad != (size_t)-1) return c->fail("genome %zu: homology reaches beyond the reference", bad.load());
 	HIPOK(c, c->b_hom_off.ensure(N + 1));
 	HIPOK(c, c->b_homs.ensure(tot + 1));
 	HIPOK(c, c->b_flag.ensure(4));
 	HIPOK(c, c->b_first.ensure(project_index_entries(P) + 1));
 	HIPOK(c, c->b_subst.ensure(N * N));
 	HIPOK(c, c->b_homologs.ensure(N * N));
+	HIPOK(c, c->h_mat.ensure(2 * N * N + 8));
 	HIPOK(c, hipMemcpyAsync(c->b_hom_off.p, hom_off.data(), (N + 1) * 4, hipMemcpyHostToDevice, st));
-	if (tot) HIPOK(c, hipMemcpyAsync(c->b_homs.p, dh.data(), tot * sizeof(DevHom), hipMemcpyHostToDevice, st));
+	if (tot) HIPOK(c, hipMemcpyAsync(c->b_homs.p, dh, tot * sizeof(DevHom), hipMemcpyHostToDevice, st));
 	HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 16, st));
 	HIPOK(c, hipMemsetAsync(c->b_subst.p, 0, N * N * 8, st));
 	HIPOK(c, hipMemsetAsync(c->b_homologs.p, 0, N * N * 8, st));
@@ -802,9 +955,11 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		launch_project(P, c->d_genomes, c->d_goff.p, c->b_homs.p, c->b_hom_off.p, c->b_first.p, c->b_flag.p, st);
 	}
 	HIPOK(c, hipGetLastError());
-	uint32_t flag = 0;
-	HIPOK(c, hipMemcpyAsync(&flag, c->b_flag.p, 4, hipMemcpyDeviceToHost, st));
-	if (sync_stream(c)) return 1;
+	uint32_t *flagp = (uint32_t *)(c->h_mat.p + 2 * N * N);
+	HIPOK(c, hipMemcpyAsync(flagp, c->b_flag.p, 4, hipMemcpyDeviceToHost, st));
+	if (sync_stream(c)) return 1; // hom_off must stay alive until here; the flag picks the pair kernel
+	uint32_t flag = *flagp;
+	double t1 = now_ms();
 
 	// tiles of this part: (ig, jt) with at least one pair i<j, dealt round-robin
 	std::vector<uint32_t> tiles;
@@ -828,10 +983,11 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		}
 		HIPOK(c, hipGetLastError());
 	}
-	std::vector<uint64_t> hs(N * N), hh(N * N);
-	HIPOK(c, hipMemcpyAsync(hs.data(), c->b_subst.p, N * N * 8, hipMemcpyDeviceToHost, st));
-	HIPOK(c, hipMemcpyAsync(hh.data(), c->b_homologs.p, N * N * 8, hipMemcpyDeviceToHost, st));
+	uint64_t *hs = c->h_mat.p, *hh = c->h_mat.p + N * N;
+	HIPOK(c, hipMemcpyAsync(hs, c->b_subst.p, N * N * 8, hipMemcpyDeviceToHost, st));
+	HIPOK(c, hipMemcpyAsync(hh, c->b_homologs.p, N * N * 8, hipMemcpyDeviceToHost, st));
 	if (sync_stream(c)) return 1;
+	double t2 = now_ms();
 	double sites = 0;
 	for (size_t i = 0; i < N; i++)
 		for (size_t j = i + 1; j < N; j++) {
@@ -840,6 +996,9 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 			homologs[a] = homologs[b] = hh[a];
 			sites += (double)hh[a];
 		}
+	c->stats["ms:compare_project_phase"] += t1 - t0;
+	c->stats["ms:compare_pairs_phase"] += t2 - t1;
+	c->stats["ms:compare_symmetrise"] += now_ms() - t2;
 	c->stats["count:compare_sites"] += sites;
 	c->stats["pileup:bang"] = flag;
 	return 0;

@@ -63,7 +63,11 @@ void *emul_run(size_t n, const char *const *seq, const size_t *len, size_t ref_i
 	kmer_table(S.data(), ns, k, T);
 	T.resize(T.size() + 4, ns);
 	if (threshold == 0) threshold = min_anchor_length(0.025, gc_content((const uint8_t *)seq[ref_idx], L), ns);
-	RefIndex R = {S.data(), SA.data(), LCP.data(), T.data(), ns, k, (uint32_t)threshold};
+	std::vector<U4> SAX;
+	build_sax(S.data(), ns, SA.data(), LCP.data(), SAX);
+	std::vector<U4> SLOT;
+	build_slots(T, SAX, ns, k, SLOT);
+	RefIndex R = {S.data(), SAX.data(), LCP.data(), SLOT.data(), T.data(), ns, k, (uint32_t)threshold, 0};
 	E->threshold = (uint32_t)threshold;
 	E->k = k;
 
