@@ -73,9 +73,10 @@ size_t phylo_stat_keys(phylo_ctx *ctx, char *buf, size_t cap);
  * between contigs (src/sequence.cxx:171-199). Copied to the device. */
 int phylo_set_genomes(phylo_ctx *ctx, size_t n, const char *const *seq, const size_t *len);
 /* Same, for genomes already resident in device memory (one allocation;
- * genome j at dev_base+offsets[j], offsets multiples of 64, each genome
- * followed by at least 64 zero bytes). Borrowed until the next set_genomes
- * or destroy. */
+ * genome j at dev_base+offsets[j], offsets multiples of 64 and >= 64, each
+ * genome followed by at least 64 zero bytes — the kernels read whole 16-byte
+ * pieces up to 32 bytes before and 64 bytes after a genome). Borrowed until
+ * the next set_genomes or destroy. */
 int phylo_set_genomes_device(phylo_ctx *ctx, size_t n, const void *dev_base, const uint64_t *offsets,
 							 const uint64_t *lens);
 

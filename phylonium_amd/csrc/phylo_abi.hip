@@ -517,7 +517,8 @@ int phylo_set_genomes_device(phylo_ctx *c, size_t n, const void *dev_base, const
 	if (n && (!dev_base || !offsets || !lens)) return c->fail("null genome arrays");
 	HIPOK(c, hipSetDevice(c->device));
 	for (size_t j = 0; j < n; j++)
-		if (offsets[j] % 64) return c->fail("genome %zu: device offset must be a multiple of 64", j);
+		if (offsets[j] % 64 || offsets[j] < 64)
+			return c->fail("genome %zu: device offset must be a multiple of 64 and >= 64 (kernels read up to 32 bytes before a genome)", j);
 	c->n = n;
 	c->goff.assign(offsets, offsets + n);
 	c->glen.assign(lens, lens + n);

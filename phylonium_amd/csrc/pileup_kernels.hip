@@ -82,6 +82,8 @@ __global__ __launch_bounds__(256) void tile_index_kernel(Pileup P, const DevHom 
 	first[tid] = lo;
 }
 
+static const uint32_t PROJ_HM = 8; // homology descriptors cached per genome and tile
+
 __global__ __launch_bounds__(256) void project_kernel(Pileup P, const uint8_t *__restrict__ gbase,
 													   const uint64_t *__restrict__ goff,
 													   const DevHom *__restrict__ homs,
@@ -90,9 +92,29 @@ __global__ __launch_bounds__(256) void project_kernel(Pileup P, const uint8_t *_
 													   uint32_t *__restrict__ bang_flag)
 {
 	__shared__ uint32_t tile[5][PROJ_TW][PROJ_TG + 1];
+	__shared__ DevHom hcache[PROJ_TG][PROJ_HM];
+	__shared__ uint32_t hlo[PROJ_TG], hend[PROJ_TG];
 	const uint32_t ntw = (P.W + PROJ_TW - 1) / PROJ_TW;
 	const uint32_t tw = blockIdx.x % ntw, tg = blockIdx.x / ntw;
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	// the tile's homology descriptors: two dependent rounds for the whole block
+	{
+		const uint32_t gl = threadIdx.x >> 3, e = threadIdx.x & 7u; // PROJ_TG * PROJ_HM == 256
+		const uint32_t g = tg * PROJ_TG + gl;
+		DevHom hm = {0xffffffffu, 0, 0, 0};
+		uint32_t lo = 0, h1 = 0;
+		if (g < P.N) {
+			lo = first[(size_t)g * ntw + tw];
+			h1 = hom_off[g + 1];
+			if (lo + e < h1) hm = homs[lo + e];
+		}
+		hcache[gl][e] = hm;
+		if (e == 0) {
+			hlo[gl] = lo;
+			hend[gl] = h1;
+		}
+	}
+	__syncthreads();
 	const uint32_t w = tw * PROJ_TW + lane;
 	const uint32_t x0 = w * 32u, x1 = x0 + 32u;
 	uint32_t any_bang = 0;
@@ -100,51 +122,42 @@ __global__ __launch_bounds__(256) void project_kernel(Pileup P, const uint8_t *_
 		const uint32_t g = tg * PROJ_TG + gi;
 		uint32_t V = 0, N0 = 0, N1 = 0, D = 0, B = 0;
 		if (g < P.N && w < P.W) {
-			const uint32_t h1 = hom_off[g + 1];
-			const uint32_t lo = first[(size_t)g * ntw + tw];
+			const uint32_t lo = hlo[gi], h1 = hend[gi];
 			const uint8_t *q = gbase + goff[g];
 			for (uint32_t h = lo; h < h1; h++) {
-				const DevHom hm = homs[h];
+				const DevHom hm = (h - lo < PROJ_HM) ? hcache[gi][h - lo] : homs[h];
 				if (hm.start >= x1) break;
 				const uint32_t he = hm.start + hm.len;
 				if (he <= x0) continue;
-				if (hm.start <= x0 && he >= x1) {
-					// the window lies inside this homology: 32 query bytes at once
-					uint4 a, b;
-					if (!hm.rev) {
-						const uint8_t *src = q + hm.iq + (x0 - hm.start);
-						__builtin_memcpy(&a, src, 16);
-						__builtin_memcpy(&b, src + 16, 16);
-						N0 = gather32(a, b, 1);
-						N1 = gather32(a, b, 2);
-						B = bang32(a, b);
-					} else {
-						// position x ↔ query index iq + (he-1-x): bytes run backwards
-						const uint8_t *src = q + hm.iq + (he - x1);
-						__builtin_memcpy(&a, src, 16);
-						__builtin_memcpy(&b, src + 16, 16);
-						N0 = __brev(gather32(a, b, 1));
-						N1 = ~__brev(gather32(a, b, 2)); // complement: n ^ 2
-						B = __brev(bang32(a, b));
-						D = 0xffffffffu;
-					}
-					V = 0xffffffffu;
-					break;
+				// covered part of this window; the 32 bytes are fetched whole (genomes are
+				// padded on both sides) and the bits outside the homology masked off
+				const uint32_t s = hm.start > x0 ? hm.start - x0 : 0u;
+				const uint32_t e = he < x1 ? he - x0 : 32u;
+				const uint32_t mask = (e >= 32u ? 0xffffffffu : ((1u << e) - 1u)) & ~((1u << s) - 1u);
+				uint4 a, b;
+				uint32_t n0, n1, bg;
+				if (!hm.rev) {
+					// position x ↔ query index iq + (x - start)
+					const uint8_t *src = q + ((int64_t)hm.iq + (int64_t)x0 - (int64_t)hm.start);
+					__builtin_memcpy(&a, src, 16);
+					__builtin_memcpy(&b, src + 16, 16);
+					n0 = gather32(a, b, 1);
+					n1 = gather32(a, b, 2);
+					bg = bang32(a, b);
+				} else {
+					// position x ↔ query index iq + (he-1-x): bytes run backwards, complemented
+					const uint8_t *src = q + ((int64_t)hm.iq + (int64_t)he - (int64_t)x1);
+					__builtin_memcpy(&a, src, 16);
+					__builtin_memcpy(&b, src + 16, 16);
+					n0 = __brev(gather32(a, b, 1));
+					n1 = ~__brev(gather32(a, b, 2)); // complement: n ^ 2
+					bg = __brev(bang32(a, b));
+					D |= mask;
 				}
-				uint32_t s = hm.start > x0 ? hm.start : x0;
-				uint32_t e = he < x1 ? he : x1;
-				for (uint32_t x = s; x < e; x++) {
-					uint32_t qi = hm.rev ? hm.iq + (he - 1u - x) : hm.iq + (x - hm.start);
-					uint32_t c = q[qi];
-					uint32_t n = (c >> 1) & 3u;
-					if (hm.rev) n ^= 2u;
-					uint32_t bit = 1u << (x - x0);
-					V |= bit;
-					if (n & 1u) N0 |= bit;
-					if (n & 2u) N1 |= bit;
-					if (hm.rev) D |= bit;
-					if (c == '!') B |= bit;
-				}
+				V |= mask;
+				N0 |= n0 & mask;
+				N1 |= n1 & mask;
+				B |= bg & mask;
 			}
 		}
 		any_bang |= B;
