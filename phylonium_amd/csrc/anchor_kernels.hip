@@ -184,119 +184,216 @@ template <int MODE> __global__ __launch_bounds__(256) void chain_kernel(PhaseA A
 	}
 }
 
-// One wavefront per query: walk the true chain (speculative log, bridge,
-// target log from the merge index, …) and fold the accepted anchors into
-// homologies (process.cxx:246-292), 64 anchors per step with ballots.
-struct FoldCarry {
-	uint32_t lq, ls, ll; // last anchor
-	uint32_t lr;         // last_was_right_anchor
-	uint32_t cs, cq;     // start of the homology being grown
+// ───────────────────────── fold: anchors → homologies ─────────────────────────
+// One 256-thread block per query.
+//  (1) The chunk metadata of a window of FOLD_WCH chunks (bridge target, merge
+//      index, bridge size, log size) is copied into LDS with coalesced loads.
+//  (2) One thread walks the true chain inside LDS — chunk 0's log, its bridge,
+//      the target chunk's log from the merge index, … — and writes the list of
+//      anchor segments (address, count) with running offsets.  No global
+//      pointer chasing except through bridge overflow blocks (rare).
+//  (3) All threads fold the window's anchors, 256 per iteration, exactly as
+//      process.cxx:246-292 does one at a time: the right-anchor test needs only
+//      the previous anchor (neighbour lane / LDS across waves), a homology ends at
+//      every non-right anchor, its start is the latest non-right anchor before it
+//      (ballot + LDS), and the output position is a prefix count, so emission
+//      stays in query order (the host's std::sort depends on the input order).
+
+static const uint32_t FOLD_WCH = 1024;  // chunks of metadata per window
+static const uint32_t FOLD_SEGS = 3072; // anchor segments per window
+
+struct FoldShared {
+	uint32_t tgt[FOLD_WCH], idxm[FOLD_WCH], bn[FOLD_WCH], blk[FOLD_WCH], scnt[FOLD_WCH];
+	const Anchor *seg_ptr[FOLD_SEGS];
+	uint32_t seg_off[FOLD_SEGS + 1];
+	uint32_t nseg, next_gc, next_idx, finished;
+	// per-iteration exchange between the four waves
+	uint32_t wl_q[4], wl_s[4], wl_len[4], wl_r[4]; // last anchor of each wave and its right flag
+	uint32_t st_has[4], st_s[4], st_q[4];          // latest non-right anchor of each wave
+	uint32_t ecnt[4];
 };
 
-static __device__ __forceinline__ void fold_batch(const Anchor *src, uint32_t m, FoldCarry &c, uint32_t border,
-												  uint32_t thr, RawHom *out, uint32_t &cnt, uint32_t cap,
-												  uint32_t *error)
+__global__ __launch_bounds__(256) void fold_kernel(PhaseA A, uint32_t nq, uint32_t border, uint32_t thr,
+												   RawHom *out, const uint64_t *out_base, const uint32_t *out_cap,
+												   uint32_t *out_cnt)
 {
-	const uint32_t lane = lane_id();
-	Anchor a = {0, 0, 0};
-	if (lane < m) a = src[lane];
-	int up = (int)lane - 1;
-	uint32_t pq = (uint32_t)__shfl_up((int)a.q, 1, 64);
-	uint32_t ps = (uint32_t)__shfl_up((int)a.s, 1, 64);
-	uint32_t pl = (uint32_t)__shfl_up((int)a.len, 1, 64);
-	if (up < 0) {
-		pq = c.lq;
-		ps = c.ls;
-		pl = c.ll;
-	}
-	Anchor prev = {pq, ps, pl};
-	uint32_t right = (lane < m && is_right_anchor(prev, a, border)) ? 1u : 0u;
-	uint32_t prev_right = (uint32_t)__shfl_up((int)right, 1, 64);
-	if (up < 0) prev_right = c.lr;
-	bool start = lane < m && !right;
-	bool emit = start && (prev_right || pl / 2 >= thr);
-	uint64_t sm = __ballot(start);
-	uint64_t below = sm & ((1ull << lane) - 1ull);
-	int js = below ? 63 - __clzll((long long)below) : 0;
-	uint32_t rs = (uint32_t)__shfl((int)a.s, js, 64);
-	uint32_t rq = (uint32_t)__shfl((int)a.q, js, 64);
-	if (!below) {
-		rs = c.cs;
-		rq = c.cq;
-	}
-	uint64_t em = __ballot(emit);
-	if (emit) {
-		uint32_t slot = cnt + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
-		if (slot < cap) {
-			RawHom h = {rs, rq, pq + pl - rq};
-			out[slot] = h;
-		} else {
-			*error = 3;
-		}
-	}
-	cnt += (uint32_t)__popcll(em);
-	// carry out
-	int lastl = (int)m - 1;
-	c.lq = (uint32_t)__shfl((int)a.q, lastl, 64);
-	c.ls = (uint32_t)__shfl((int)a.s, lastl, 64);
-	c.ll = (uint32_t)__shfl((int)a.len, lastl, 64);
-	c.lr = (uint32_t)__shfl((int)right, lastl, 64);
-	if (sm) {
-		int jl = 63 - __clzll((long long)sm);
-		c.cs = (uint32_t)__shfl((int)a.s, jl, 64);
-		c.cq = (uint32_t)__shfl((int)a.q, jl, 64);
-	}
-}
-
-__global__ __launch_bounds__(64) void fold_kernel(PhaseA A, uint32_t nq, uint32_t border, uint32_t thr,
-												  RawHom *out, const uint64_t *out_base, const uint32_t *out_cap,
-												  uint32_t *out_cnt)
-{
+	__shared__ FoldShared sh;
 	const uint32_t j = blockIdx.x;
 	if (j >= nq) return;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	RawHom *dst = out + out_base[j];
 	const uint32_t cap = out_cap[j];
-	uint32_t cnt = 0;
-	FoldCarry c = {0, 0, 0, 0, 0, 0};
 	const uint32_t qlen = A.qlen[j];
-	if (A.qchunk0[j] < A.qchunk0[j + 1]) {
-		uint32_t gc = A.qchunk0[j], idx = 0;
-		for (;;) {
-			const uint32_t n_spec = A.spec_cnt[gc];
-			const Anchor *log = A.spec_anchors + (size_t)gc * A.cap;
-			for (uint32_t t = idx; t < n_spec; t += 64) {
-				uint32_t m = n_spec - t;
-				fold_batch(log + t, m < 64 ? m : 64, c, border, thr, dst, cnt, cap, A.error);
+	const uint32_t c_begin = A.qchunk0[j], c_end = A.qchunk0[j + 1];
+	// carry (identical in every thread)
+	uint32_t lq = 0, ls = 0, ll = 0, lr = 0, cs = 0, cq = 0, cnt = 0;
+	uint32_t gc = c_begin, idx = 0;
+	bool more = c_begin < c_end;
+
+	while (more) {
+		// (1) metadata window [gc, gc + FOLD_WCH)
+		const uint32_t wbeg = gc;
+		const uint32_t wn = (c_end - wbeg < FOLD_WCH) ? c_end - wbeg : FOLD_WCH;
+		for (uint32_t t = tid; t < wn; t += 256) {
+			const BridgeRec *b = &A.bridge[wbeg + t];
+			sh.tgt[t] = b->target;
+			sh.idxm[t] = b->idx_m;
+			sh.bn[t] = b->n;
+			sh.blk[t] = b->block;
+			sh.scnt[t] = A.spec_cnt[wbeg + t];
+		}
+		__syncthreads();
+		// (2) walk
+		if (tid == 0) {
+			uint32_t ns = 0, off = 0, g = gc, ix = idx, fin = 0;
+			for (;;) {
+				if (g - wbeg >= wn || ns + 8 > FOLD_SEGS) break; // next window
+				const uint32_t t = g - wbeg;
+				const uint32_t n_spec = sh.scnt[t];
+				if (n_spec > ix) {
+					sh.seg_ptr[ns] = A.spec_anchors + (size_t)g * A.cap + ix;
+					sh.seg_off[ns++] = off;
+					off += n_spec - ix;
+				}
+				uint32_t b_n = sh.bn[t];
+				if (b_n) {
+					uint32_t m = b_n < BRIDGE_INLINE ? b_n : BRIDGE_INLINE;
+					sh.seg_ptr[ns] = A.bridge[g].a;
+					sh.seg_off[ns++] = off;
+					off += m;
+					uint32_t left = b_n - m, bk = sh.blk[t];
+					while (left && bk != NO_BLOCK && ns + 2 <= FOLD_SEGS) {
+						uint32_t mm = left < POOL_BLOCK ? left : POOL_BLOCK;
+						sh.seg_ptr[ns] = A.pool[bk].a;
+						sh.seg_off[ns++] = off;
+						off += mm;
+						left -= mm;
+						bk = A.pool[bk].next;
+					}
+					if (left) *A.error = 4; // a bridge longer than a window's segment list
+				}
+				if (sh.tgt[t] == BRIDGE_END) {
+					fin = 1;
+					break;
+				}
+				ix = sh.idxm[t];
+				g = sh.tgt[t];
 			}
-			const BridgeRec *b = &A.bridge[gc];
-			const uint32_t bn = b->n, target = b->target, idx_m = b->idx_m;
-			if (bn) {
-				fold_batch(b->a, bn < BRIDGE_INLINE ? bn : BRIDGE_INLINE, c, border, thr, dst, cnt, cap, A.error);
-				uint32_t left = bn > BRIDGE_INLINE ? bn - BRIDGE_INLINE : 0;
-				uint32_t blk = b->block;
-				while (left && blk != NO_BLOCK) {
-					uint32_t m = left < POOL_BLOCK ? left : POOL_BLOCK;
-					fold_batch(A.pool[blk].a, m, c, border, thr, dst, cnt, cap, A.error);
-					left -= m;
-					blk = A.pool[blk].next;
+			sh.seg_off[ns] = off;
+			sh.nseg = ns;
+			sh.next_gc = g;
+			sh.next_idx = ix;
+			sh.finished = fin;
+		}
+		__syncthreads();
+		const uint32_t nseg = sh.nseg, total = sh.seg_off[nseg];
+		// (3) block-parallel fold over the window's `total` anchors
+		uint32_t cur = 0; // segment cursor of this thread (anchor indices only grow)
+		for (uint32_t base = 0; base < total; base += 256) {
+			const uint32_t k = base + tid;
+			const bool valid = k < total;
+			Anchor a = {0, 0, 0};
+			if (valid) {
+				while (sh.seg_off[cur + 1] <= k) cur++;
+				a = sh.seg_ptr[cur][k - sh.seg_off[cur]];
+			}
+			const uint32_t m = total - base < 256 ? total - base : 256; // valid anchors this iteration
+			// last valid anchor of every wave → LDS
+			const bool wave_last = valid && (lane == 63 || k + 1 == total);
+			if (wave_last) {
+				sh.wl_q[wave] = a.q;
+				sh.wl_s[wave] = a.s;
+				sh.wl_len[wave] = a.len;
+			}
+			__syncthreads();
+			Anchor prev;
+			prev.q = (uint32_t)__shfl_up((int)a.q, 1, 64);
+			prev.s = (uint32_t)__shfl_up((int)a.s, 1, 64);
+			prev.len = (uint32_t)__shfl_up((int)a.len, 1, 64);
+			if (lane == 0) {
+				if (wave == 0) {
+					prev.q = lq;
+					prev.s = ls;
+					prev.len = ll;
+				} else {
+					prev.q = sh.wl_q[wave - 1];
+					prev.s = sh.wl_s[wave - 1];
+					prev.len = sh.wl_len[wave - 1];
 				}
 			}
-			if (target == BRIDGE_END) break;
-			gc = target;
-			idx = idx_m;
+			const uint32_t right = (valid && is_right_anchor(prev, a, border)) ? 1u : 0u;
+			const bool start = valid && !right;
+			const uint64_t sm = __ballot(start);
+			if (wave_last) sh.wl_r[wave] = right;
+			if (lane == 0) sh.st_has[wave] = sm ? 1u : 0u;
+			if (sm && (int)lane == 63 - __clzll((long long)sm)) {
+				sh.st_s[wave] = a.s;
+				sh.st_q[wave] = a.q;
+			}
+			__syncthreads();
+			uint32_t prev_right = (uint32_t)__shfl_up((int)right, 1, 64);
+			if (lane == 0) prev_right = wave == 0 ? lr : sh.wl_r[wave - 1];
+			const bool emit = start && (prev_right || prev.len / 2 >= thr);
+			const uint64_t em = __ballot(emit);
+			if (lane == 0) sh.ecnt[wave] = (uint32_t)__popcll(em);
+			// start of the homology that ends here: latest non-right anchor before this one
+			const uint64_t below = sm & ((1ull << lane) - 1ull);
+			const int js = below ? 63 - __clzll((long long)below) : 0;
+			uint32_t rs = (uint32_t)__shfl((int)a.s, js, 64);
+			uint32_t rq = (uint32_t)__shfl((int)a.q, js, 64);
+			if (!below) {
+				rs = cs;
+				rq = cq;
+				for (int w2 = (int)wave - 1; w2 >= 0; w2--)
+					if (sh.st_has[w2]) {
+						rs = sh.st_s[w2];
+						rq = sh.st_q[w2];
+						break;
+					}
+			}
+			__syncthreads();
+			uint32_t ebase = cnt;
+			for (uint32_t w2 = 0; w2 < wave; w2++) ebase += sh.ecnt[w2];
+			if (emit) {
+				uint32_t slot = ebase + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
+				if (slot < cap) {
+					RawHom h = {rs, rq, prev.q + prev.len - rq};
+					dst[slot] = h;
+				} else {
+					*A.error = 3;
+				}
+			}
+			// carry out (same values in every thread)
+			const uint32_t lw = (m - 1) >> 6;
+			cnt += sh.ecnt[0] + sh.ecnt[1] + sh.ecnt[2] + sh.ecnt[3];
+			lq = sh.wl_q[lw];
+			ls = sh.wl_s[lw];
+			ll = sh.wl_len[lw];
+			lr = sh.wl_r[lw];
+			for (int w2 = 3; w2 >= 0; w2--)
+				if (sh.st_has[w2]) {
+					cs = sh.st_s[w2];
+					cq = sh.st_q[w2];
+					break;
+				}
+			__syncthreads(); // the exchange arrays are rewritten next iteration
 		}
+		more = !sh.finished;
+		gc = sh.next_gc;
+		idx = sh.next_idx;
+		__syncthreads();
 	}
-	// fold_finish (process.cxx:285-292); every lane holds the same carry
-	if (lane_id() == 0) {
-		uint32_t cs = c.cs, cq = c.cq, clen = c.lq + c.ll - c.cq;
-		if (c.ll >= qlen) {
-			cs = c.ls;
-			cq = 0;
-			clen = qlen;
+	// fold_finish (process.cxx:285-292)
+	if (tid == 0) {
+		uint32_t fs = cs, fq = cq, flen = lq + ll - cq;
+		if (ll >= qlen) {
+			fs = ls;
+			fq = 0;
+			flen = qlen;
 		}
-		if (c.lr || c.ll / 2 >= thr) {
+		if (lr || ll / 2 >= thr) {
 			if (cnt < cap) {
-				RawHom h = {cs, cq, clen};
+				RawHom h = {fs, fq, flen};
 				dst[cnt] = h;
 			} else {
 				*A.error = 3;
@@ -338,7 +435,7 @@ void launch_bridge(const PhaseA &A, const RefIndex &R, int n_cu, hipStream_t st)
 void launch_fold(const PhaseA &A, uint32_t nq, uint32_t border, uint32_t thr, RawHom *out,
 				 const uint64_t *out_base, const uint32_t *out_cap, uint32_t *out_cnt, hipStream_t st)
 {
-	hipLaunchKernelGGL(fold_kernel, dim3(nq), dim3(64), 0, st, A, nq, border, thr, out, out_base, out_cap, out_cnt);
+	hipLaunchKernelGGL(fold_kernel, dim3(nq), dim3(256), 0, st, A, nq, border, thr, out, out_base, out_cap, out_cnt);
 }
 
 } // namespace phy
