@@ -84,7 +84,7 @@ def make_genomes_gpu(torch, n, length, seed, device, d_range, indel_per_mbp, inv
     for l in lens:
         offs.append(tot)
         tot += (l + 63) // 64 * 64 + 64
-    buf = torch.zeros(tot, dtype=torch.uint8, device=device)
+    buf = torch.zeros(tot + 256, dtype=torch.uint8, device=device)  # +256: kernels prefetch 128-byte query windows
     for c, o, l in zip(codes, offs, lens):
         buf[o:o + l] = lut[c.long()]
     del codes

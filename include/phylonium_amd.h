@@ -75,8 +75,9 @@ int phylo_set_genomes(phylo_ctx *ctx, size_t n, const char *const *seq, const si
 /* Same, for genomes already resident in device memory (one allocation;
  * genome j at dev_base+offsets[j], offsets multiples of 64 and >= 64, each
  * genome followed by at least 64 zero bytes — the kernels read whole 16-byte
- * pieces up to 32 bytes before and 64 bytes after a genome). Borrowed until
- * the next set_genomes or destroy. */
+ * pieces up to 32 bytes before and 64 bytes after a genome, and prefetch
+ * 128-byte windows: 256 readable bytes must follow the last genome's padding).
+ * Borrowed until the next set_genomes or destroy. */
 int phylo_set_genomes_device(phylo_ctx *ctx, size_t n, const void *dev_base, const uint64_t *offsets,
 							 const uint64_t *lens);
 

@@ -407,19 +407,21 @@ struct Chain {
 		*a0 = Q + q;
 		if (lucky_ok(R)) {
 			*a1 = R.S + (ls + (q - lq));
-			if (R.dbg & 2u) *a1 = R.S + ((ls + (q - lq)) & 4095u);
 			return 2;
 		}
 		return 1;
 	}
-	PHY_HD void consume_step(const RefIndex &R, const U4 &qw, const U4 &sw)
+	// pre_step: take the query window; post_step: lucky_anchor, then start the search.
+	// (Split so the kernel can fetch the k-mer's slot together with the lucky window.)
+	PHY_HD void pre_step(const U4 &qw)
 	{
 		qc = qw;
-		{
-			uint32_t valid, n = qlen - q;
-			qcode = window_code(qw, &valid);
-			qv = valid < n ? valid : n;
-		}
+		uint32_t valid, n = qlen - q;
+		qcode = window_code(qw, &valid);
+		qv = valid < n ? valid : n;
+	}
+	PHY_HD void post_step(const RefIndex &R, const U4 &sw)
+	{
 		if (lucky_ok(R)) {
 			uint32_t len, less;
 			e_p = ls + (q - lq);
@@ -429,13 +431,22 @@ struct Chain {
 		}
 		begin_search(R);
 	}
+	PHY_HD void consume_step(const RefIndex &R, const U4 &qw, const U4 &sw)
+	{
+		pre_step(qw);
+		post_step(R, sw);
+	}
+	// slot of the current window's k-mer, or nullptr when the k-mer is not pure ACGT
+	PHY_HD const uint8_t *slot_of_window(const RefIndex &R) const
+	{
+		if (qv < R.k) return nullptr;
+		return (const uint8_t *)(R.SLOT + (size_t)(qcode >> (2u * (16u - R.k))) * SLOT_RECS);
+	}
 
 	// ── phase T: the slot of the query's k-mer ──
 	PHY_HD const uint8_t *issue_T(const RefIndex &R) const
 	{
-		size_t code = lo;
-		if (R.dbg & 1u) code &= 31u;
-		return (const uint8_t *)(R.SLOT + code * SLOT_RECS);
+		return (const uint8_t *)(R.SLOT + (size_t)lo * SLOT_RECS);
 	}
 	// hdr = record 0; d = records 1..4
 	PHY_HD void consume_T(const RefIndex &R, const U4 &hdr, const Data &d)
@@ -629,10 +640,6 @@ struct Chain {
 		a[1] = Q + q + e_pos + 16;
 		a[2] = R.S + e_p + e_pos;
 		a[3] = R.S + e_p + e_pos + 16;
-		if (R.dbg & 4u) {
-			a[2] = R.S + ((e_p + e_pos) & 4095u);
-			a[3] = a[2] + 16;
-		}
 	}
 	PHY_HD bool consume_ext(const RefIndex &R, const Data &d)
 	{

@@ -65,6 +65,8 @@ static __device__ __forceinline__ void coop_compare(const uint8_t *qp, const uin
 	}
 }
 
+static const uint32_t QRING_BYTES = 128;
+
 struct DevAlloc {
 	const PhaseA *A;
 	__device__ uint32_t operator()() const
@@ -88,6 +90,10 @@ template <int MODE> __global__ __launch_bounds__(256) void chain_kernel(PhaseA A
 	DevAlloc alloc = {&A};
 	ch.fin = false;
 	ch.st = ST_STEP;
+	// per-lane window of the query, [wbase, wbase + QRING_BYTES); row-major by dword so
+	// that lane l always hits LDS bank l whatever offset it reads
+	__shared__ uint32_t qring[QRING_BYTES / 4 + 1][256];
+	uint32_t wbase = 0;
 
 	for (;;) {
 		while (!done) {
@@ -104,6 +110,7 @@ template <int MODE> __global__ __launch_bounds__(256) void chain_kernel(PhaseA A
 				}
 				ln.start(A, A.items[it]);
 				active = true;
+				wbase = 0xffffff00u; // force a refill
 			}
 			if (ch.st == ST_STEP) {
 				bool go;
@@ -119,23 +126,50 @@ template <int MODE> __global__ __launch_bounds__(256) void chain_kernel(PhaseA A
 		if (__all(done)) break;
 		const bool live = !done;
 
-		if (live && ch.st == ST_STEP) {
-			const uint8_t *a0, *a1 = nullptr;
-			uint32_t n = ch.issue_step(R, &a0, &a1);
-			U4 qw = load16(a0), sw = {0, 0, 0, 0};
-			if (n > 1) sw = load16(a1);
-			ch.consume_step(R, qw, sw);
-		}
-		if (live && ch.st == ST_T) {
-			// one 128-byte line: bucket bounds + the records of the (<= 4) candidates
-			const uint8_t *a = ch.issue_T(R);
-			U4 hdr = load16(a);
-			Data d;
-			d.w[0] = load16(a + 16);
-			d.w[1] = load16(a + 32);
-			d.w[2] = load16(a + 48);
-			d.w[3] = load16(a + 64);
-			ch.consume_T(R, hdr, d);
+		// ── STEP + T: query window from the lane's LDS ring; the lucky window and the
+		//    k-mer's slot line are fetched together, one memory hop for both ──
+		{
+			const bool stp = live && ch.st == ST_STEP;
+			if (stp && (ch.q < wbase || ch.q + 16u > wbase + QRING_BYTES)) {
+				wbase = ch.q & ~15u;
+				const uint8_t *src = ch.Q + wbase;
+#pragma unroll
+				for (uint32_t sl = 0; sl < QRING_BYTES / 16; sl++) {
+					U4 v = load16(src + 16 * sl);
+					qring[4 * sl + 0][threadIdx.x] = v.x;
+					qring[4 * sl + 1][threadIdx.x] = v.y;
+					qring[4 * sl + 2][threadIdx.x] = v.z;
+					qring[4 * sl + 3][threadIdx.x] = v.w;
+				}
+			}
+			if (stp) {
+				const uint32_t p = ch.q - wbase, i0 = p >> 2, sh = p & 3u;
+				const uint32_t d0 = qring[i0][threadIdx.x], d1 = qring[i0 + 1][threadIdx.x],
+							   d2 = qring[i0 + 2][threadIdx.x], d3 = qring[i0 + 3][threadIdx.x],
+							   d4 = qring[i0 + 4][threadIdx.x];
+				U4 qw;
+				qw.x = __builtin_amdgcn_alignbyte(d1, d0, sh);
+				qw.y = __builtin_amdgcn_alignbyte(d2, d1, sh);
+				qw.z = __builtin_amdgcn_alignbyte(d3, d2, sh);
+				qw.w = __builtin_amdgcn_alignbyte(d4, d3, sh);
+				ch.pre_step(qw);
+				const uint8_t *a0, *a1 = nullptr;
+				const uint32_t nl = ch.issue_step(R, &a0, &a1);
+				const uint8_t *sa = ch.slot_of_window(R);
+				U4 sw = {0, 0, 0, 0}, hdr = {0, 0, 0, 0};
+				Data d;
+				d.w[0] = d.w[1] = d.w[2] = d.w[3] = sw;
+				if (nl > 1) sw = load16(a1);
+				if (sa) {
+					hdr = load16(sa);
+					d.w[0] = load16(sa + 16);
+					d.w[1] = load16(sa + 32);
+					d.w[2] = load16(sa + 48);
+					d.w[3] = load16(sa + 64);
+				}
+				ch.post_step(R, sw);
+				if (ch.st == ST_T) ch.consume_T(R, hdr, d); // st == ST_T implies the k-mer was valid, so sa != nullptr
+			}
 		}
 		if (live && ch.st == ST_CAND) {
 			Data d;

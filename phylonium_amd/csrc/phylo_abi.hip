@@ -500,6 +500,7 @@ int phylo_set_genomes(phylo_ctx *c, size_t n, const char *const *seq, const size
 		c->glen[j] = len[j];
 		tot += ((len[j] + 63) / 64) * 64 + 64;
 	}
+	tot += 256; // kernels prefetch whole 128-byte query windows
 	HIPOK(c, c->genomes_store.ensure(tot));
 	HIPOK(c, hipMemsetAsync(c->genomes_store.p, 0, tot, c->stream));
 	for (size_t j = 0; j < n; j++)
