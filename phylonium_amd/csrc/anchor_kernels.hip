@@ -277,47 +277,98 @@ __global__ __launch_bounds__(256) void fold_kernel(PhaseA A, uint32_t nq, uint32
 			sh.scnt[t] = A.spec_cnt[wbeg + t];
 		}
 		__syncthreads();
-		// (2) walk
-		if (tid == 0) {
+		// (2) walk, by wave 0.  Runs of chunks whose bridge merges into the very next
+		// chunk (the common case) are taken 64 at a time: a ballot gives the run
+		// length, wave prefix sums give every chunk its segment slots and anchor
+		// offsets.  A chunk with an irregular link (skip, end) or an overflow bridge
+		// is then stepped alone.  All lanes keep the same (g, ix, ns, off).
+		if (wave == 0) {
 			uint32_t ns = 0, off = 0, g = gc, ix = idx, fin = 0;
 			for (;;) {
-				if (g - wbeg >= wn || ns + 8 > FOLD_SEGS) break; // next window
-				const uint32_t t = g - wbeg;
-				const uint32_t n_spec = sh.scnt[t];
-				if (n_spec > ix) {
-					sh.seg_ptr[ns] = A.spec_anchors + (size_t)g * A.cap + ix;
-					sh.seg_off[ns++] = off;
-					off += n_spec - ix;
-				}
-				uint32_t b_n = sh.bn[t];
-				if (b_n) {
-					uint32_t m = b_n < BRIDGE_INLINE ? b_n : BRIDGE_INLINE;
-					sh.seg_ptr[ns] = A.bridge[g].a;
-					sh.seg_off[ns++] = off;
-					off += m;
-					uint32_t left = b_n - m, bk = sh.blk[t];
-					while (left && bk != NO_BLOCK && ns + 2 <= FOLD_SEGS) {
-						uint32_t mm = left < POOL_BLOCK ? left : POOL_BLOCK;
-						sh.seg_ptr[ns] = A.pool[bk].a;
-						sh.seg_off[ns++] = off;
-						off += mm;
-						left -= mm;
-						bk = A.pool[bk].next;
+				if (g - wbeg >= wn || ns + 140 > FOLD_SEGS) break; // next window
+				// ── parallel part ──
+				const uint32_t t = g - wbeg + lane;
+				const bool inw = t < wn;
+				const uint32_t my_tgt = inw ? sh.tgt[t] : 0u, my_idxm = inw ? sh.idxm[t] : 0u;
+				const uint32_t my_bn = inw ? sh.bn[t] : 0u, my_scnt = inw ? sh.scnt[t] : 0u;
+				const bool ok = inw && my_tgt == wbeg + t + 1 && my_bn <= BRIDGE_INLINE;
+				const uint64_t okm = __ballot(ok);
+				const uint32_t r = ~okm ? (uint32_t)__ffsll((unsigned long long)~okm) - 1u : 64u; // leading ok lanes
+				if (r) {
+					uint32_t idx_in = (uint32_t)__shfl_up((int)my_idxm, 1, 64);
+					if (lane == 0) idx_in = ix;
+					const bool mine = lane < r;
+					const uint32_t spec_n = (mine && my_scnt > idx_in) ? my_scnt - idx_in : 0u;
+					const uint32_t br_n = mine ? my_bn : 0u;
+					uint32_t segs = (spec_n ? 1u : 0u) + (br_n ? 1u : 0u), anch = spec_n + br_n;
+					uint32_t ps = segs, pa = anch; // inclusive wave scans
+#pragma unroll
+					for (int d = 1; d < 64; d <<= 1) {
+						uint32_t a1 = (uint32_t)__shfl_up((int)ps, d, 64), a2 = (uint32_t)__shfl_up((int)pa, d, 64);
+						if ((int)lane >= d) {
+							ps += a1;
+							pa += a2;
+						}
 					}
-					if (left) *A.error = 4; // a bridge longer than a window's segment list
+					uint32_t slot = ns + ps - segs, o = off + pa - anch;
+					if (spec_n) {
+						sh.seg_ptr[slot] = A.spec_anchors + (size_t)(wbeg + t) * A.cap + idx_in;
+						sh.seg_off[slot] = o;
+						slot++;
+						o += spec_n;
+					}
+					if (br_n) {
+						sh.seg_ptr[slot] = A.bridge[wbeg + t].a;
+						sh.seg_off[slot] = o;
+					}
+					ns += (uint32_t)__shfl((int)ps, 63, 64);
+					off += (uint32_t)__shfl((int)pa, 63, 64);
+					ix = (uint32_t)__shfl((int)my_idxm, (int)r - 1, 64);
+					g += r;
+					if (g - wbeg >= wn) break;
 				}
-				if (sh.tgt[t] == BRIDGE_END) {
-					fin = 1;
-					break;
+				if (r == 64) continue;
+				// ── one chunk with an irregular link or an overflow bridge (uniform code) ──
+				{
+					const uint32_t tt = g - wbeg;
+					const uint32_t n_spec = sh.scnt[tt];
+					if (n_spec > ix) {
+						sh.seg_ptr[ns] = A.spec_anchors + (size_t)g * A.cap + ix;
+						sh.seg_off[ns++] = off;
+						off += n_spec - ix;
+					}
+					uint32_t b_n = sh.bn[tt];
+					if (b_n) {
+						uint32_t m = b_n < BRIDGE_INLINE ? b_n : BRIDGE_INLINE;
+						sh.seg_ptr[ns] = A.bridge[g].a;
+						sh.seg_off[ns++] = off;
+						off += m;
+						uint32_t left = b_n - m, bk = sh.blk[tt];
+						while (left && bk != NO_BLOCK && ns + 2 <= FOLD_SEGS) {
+							uint32_t mm = left < POOL_BLOCK ? left : POOL_BLOCK;
+							sh.seg_ptr[ns] = A.pool[bk].a;
+							sh.seg_off[ns++] = off;
+							off += mm;
+							left -= mm;
+							bk = A.pool[bk].next;
+						}
+						if (left) *A.error = 4; // a bridge longer than a window's segment list
+					}
+					if (sh.tgt[tt] == BRIDGE_END) {
+						fin = 1;
+						break;
+					}
+					ix = sh.idxm[tt];
+					g = sh.tgt[tt];
 				}
-				ix = sh.idxm[t];
-				g = sh.tgt[t];
 			}
-			sh.seg_off[ns] = off;
-			sh.nseg = ns;
-			sh.next_gc = g;
-			sh.next_idx = ix;
-			sh.finished = fin;
+			if (lane == 0) {
+				sh.seg_off[ns] = off;
+				sh.nseg = ns;
+				sh.next_gc = g;
+				sh.next_idx = ix;
+				sh.finished = fin;
+			}
 		}
 		__syncthreads();
 		const uint32_t nseg = sh.nseg, total = sh.seg_off[nseg];

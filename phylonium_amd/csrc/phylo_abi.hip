@@ -651,6 +651,11 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 		for (size_t j = 0; j < nq; j++) {
 			qlen[j] = (uint32_t)c->glen[q_begin + j];
 			qoff[j] = c->goff[q_begin + j];
+			// The subject is one of the queries (src/phylonium.cxx:287).  Against itself the
+			// chain is one lucky anchor of the whole length (process.cxx:227-242 at q = 0), so
+			// its list is written directly below; as a GPU query it would make every
+			// speculative chunk compare to the end of the genome.
+			if (q_begin + j == c->ref_idx) qlen[j] = 0;
 		}
 		c->plan = plan_chunks(qlen, c->threshold, c->opt_chunk);
 		const ChunkPlan &P = c->plan;
@@ -778,6 +783,12 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	workers(c).run(nq, [&](size_t j) {
 		std::vector<phylo_homology> hv(cnt[j]);
 		for (uint32_t t = 0; t < cnt[j]; t++) hv[t] = project_homology(raw[cbase[j] + t], border);
+		if (q_begin + j == c->ref_idx) {
+			// anchor_homologies(ref, threshold, subject): homology(0, 0, L), pushed iff
+			// last_length / 2 >= threshold (process.cxx:285-292)
+			hv.clear();
+			if (border / 2 >= c->threshold) hv.push_back(project_homology(RawHom{0, 0, (uint32_t)border}, border));
+		}
 		sort_and_filter(hv);
 		c->homs[q_begin + j] = std::move(hv);
 	});
