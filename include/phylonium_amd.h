@@ -96,14 +96,23 @@ int phylo_anchor(phylo_ctx *ctx, size_t q_begin, size_t q_end);
 int phylo_get_homologies(phylo_ctx *ctx, size_t j, const phylo_homology **h, size_t *n);
 /* Install lists computed elsewhere (another rank). */
 int phylo_set_homologies(phylo_ctx *ctx, size_t j, const phylo_homology *h, size_t n);
+/* Bulk forms for the exchange between ranks: counts[j - q_begin] and the lists
+ * of genomes [q_begin, q_end) back to back in buf. Export returns the number
+ * of entries via *total and copies them when cap suffices (call with cap = 0
+ * to size the buffer). */
+int phylo_export_homologies(phylo_ctx *ctx, size_t q_begin, size_t q_end, uint64_t *counts,
+							phylo_homology *buf, size_t cap, size_t *total);
+int phylo_import_homologies(phylo_ctx *ctx, size_t q_begin, size_t q_end, const uint64_t *counts,
+							const phylo_homology *buf);
 /* complete_delete over all genomes' lists, src/process.cxx:467-469,725-776 (host). */
 int phylo_complete_delete(phylo_ctx *ctx);
 
 /* ── phase B: the pair grid, src/process.cxx:517-549 ──
- * subst / homologs: caller-owned N*N row-major; every pair (i<j) of this part
- * is written at [i*N+j] and [j*N+i]; everything else is set to 0. Parts
- * partition the pair grid (part in [0,nparts)); summing the outputs of all
- * parts gives the full matrix. */
+ * subst / homologs: caller-owned N*N row-major, symmetric, diagonal 0.
+ * Parts (part in [0,nparts)) partition the work — the pileup backend by range
+ * of reference windows, the segment backend by pair — and each call writes the
+ * tallies of its part; summing the outputs of all parts gives the full matrix
+ * (one all-reduce across ranks). */
 int phylo_compare(phylo_ctx *ctx, size_t part, size_t nparts, uint64_t *subst, uint64_t *homologs);
 int phylo_compare_all(phylo_ctx *ctx, uint64_t *subst, uint64_t *homologs);
 

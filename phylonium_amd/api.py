@@ -23,6 +23,7 @@ SYMBOLS = [
     "phylo_ctx_create", "phylo_ctx_destroy", "phylo_last_error", "phylo_set_option", "phylo_get_stat",
     "phylo_reset_stats", "phylo_stat_keys", "phylo_set_genomes", "phylo_set_genomes_device",
     "phylo_set_reference", "phylo_threshold", "phylo_anchor", "phylo_get_homologies", "phylo_set_homologies",
+    "phylo_export_homologies", "phylo_import_homologies",
     "phylo_complete_delete", "phylo_compare", "phylo_compare_all", "phylo_process", "phylo_seqcmp",
     "phylo_revseqcmp", "phylo_seqcmp_batch", "phylo_host_suffix_array", "phylo_host_min_anchor_length",
     "phylo_host_sort_filter", "phylo_estimate", "phylo_format_phylip", "phylo_version",
@@ -62,6 +63,8 @@ def load():
     L.phylo_anchor.argtypes = [vp, sz, sz]
     L.phylo_get_homologies.argtypes = [vp, sz, C.POINTER(vp), C.POINTER(sz)]
     L.phylo_set_homologies.argtypes = [vp, sz, vp, sz]
+    L.phylo_export_homologies.argtypes = [vp, sz, sz, vp, vp, sz, C.POINTER(sz)]
+    L.phylo_import_homologies.argtypes = [vp, sz, sz, vp, vp]
     L.phylo_complete_delete.argtypes = [vp]
     L.phylo_compare.argtypes = [vp, sz, sz, vp, vp]
     L.phylo_compare_all.argtypes = [vp, vp, vp]
@@ -191,6 +194,24 @@ class Context:
     def set_homologies(self, j, h):
         h = np.ascontiguousarray(h, dtype=PHOM)
         self._chk(self.L.phylo_set_homologies(self.h, j, h.ctypes.data_as(C.c_void_p), h.size))
+
+    def export_homologies(self, q_begin, q_end):
+        """(counts[q_end-q_begin], flat PHOM array) of genomes [q_begin, q_end)."""
+        counts = np.zeros(q_end - q_begin, np.uint64)
+        tot = C.c_size_t()
+        self._chk(self.L.phylo_export_homologies(self.h, q_begin, q_end, counts.ctypes.data_as(C.c_void_p), None, 0,
+                                                 C.byref(tot)))
+        flat = np.zeros(tot.value, PHOM)
+        self._chk(self.L.phylo_export_homologies(self.h, q_begin, q_end, counts.ctypes.data_as(C.c_void_p),
+                                                 flat.ctypes.data_as(C.c_void_p), flat.size, C.byref(tot)))
+        return counts, flat
+
+    def import_homologies(self, q_begin, q_end, counts, flat):
+        counts = np.ascontiguousarray(counts, np.uint64)
+        flat = np.ascontiguousarray(flat, PHOM)
+        assert int(counts.sum()) == flat.size
+        self._chk(self.L.phylo_import_homologies(self.h, q_begin, q_end, counts.ctypes.data_as(C.c_void_p),
+                                                 flat.ctypes.data_as(C.c_void_p)))
 
     def complete_delete(self):
         self._chk(self.L.phylo_complete_delete(self.h))

@@ -32,8 +32,9 @@ struct DevHom {
 	uint32_t rev;
 };
 struct Pileup {
-	uint32_t *plane[5]; // V, N0, N1, D (reverse), B ('!'); each [W][Npad]
-	uint32_t W;         // words of 32 reference positions
+	uint32_t *plane[5]; // V, N0, N1, D (reverse), B ('!'); each [W][Npad] for this part's windows
+	uint32_t W;         // words (32 reference positions each) held by this part
+	uint32_t w0;        // first word of this part on the reference (multiple of 64)
 	uint32_t N, Npad;
 	uint32_t L;
 };

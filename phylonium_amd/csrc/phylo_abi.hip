@@ -140,7 +140,7 @@ class WorkerPool
 	void run(size_t n, std::function<void(size_t)> f)
 	{
 		if (n == 0) return;
-		if (threads.empty() || n == 1) {
+		if (threads.empty() || n < 8) { // waking the pool costs more than a handful of lists
 			for (size_t i = 0; i < n; i++) f(i);
 			return;
 		}
@@ -826,6 +826,41 @@ int phylo_set_homologies(phylo_ctx *c, size_t j, const phylo_homology *h, size_t
 	return 0;
 }
 
+int phylo_export_homologies(phylo_ctx *c, size_t q_begin, size_t q_end, uint64_t *counts, phylo_homology *buf,
+							size_t cap, size_t *total)
+{
+	if (!c) return 1;
+	if (q_begin > q_end || q_end > c->n || !counts || !total) return c->fail("phylo_export_homologies: bad arguments");
+	size_t tot = 0;
+	for (size_t j = q_begin; j < q_end; j++) {
+		counts[j - q_begin] = c->homs[j].size();
+		tot += c->homs[j].size();
+	}
+	*total = tot;
+	if (buf && cap >= tot) {
+		size_t o = 0;
+		for (size_t j = q_begin; j < q_end; j++) {
+			std::copy(c->homs[j].begin(), c->homs[j].end(), buf + o);
+			o += c->homs[j].size();
+		}
+	}
+	return 0;
+}
+
+int phylo_import_homologies(phylo_ctx *c, size_t q_begin, size_t q_end, const uint64_t *counts,
+							const phylo_homology *buf)
+{
+	if (!c) return 1;
+	if (q_begin > q_end || q_end > c->n || !counts) return c->fail("phylo_import_homologies: bad arguments");
+	size_t o = 0;
+	for (size_t j = q_begin; j < q_end; j++) {
+		if (counts[j - q_begin] && !buf) return c->fail("phylo_import_homologies: null buffer");
+		c->homs[j].assign(buf + o, buf + o + counts[j - q_begin]);
+		o += counts[j - q_begin];
+	}
+	return 0;
+}
+
 int phylo_complete_delete(phylo_ctx *c)
 {
 	if (!c) return 1;
@@ -925,7 +960,17 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 	P.N = (uint32_t)N;
 	P.Npad = (uint32_t)((N + 63) / 64 * 64);
 	P.L = c->L;
-	P.W = (c->L + 31) / 32;
+	// this part's share of the reference: a range of 64-window tiles.  Every part
+	// projects and compares ALL genomes over its own range, so both kernels
+	// shrink with the number of parts and the partial tallies simply add up.
+	{
+		uint32_t Wall = (c->L + 31) / 32;
+		uint32_t ntile = (Wall + 63) / 64;
+		uint32_t t0 = (uint32_t)((uint64_t)ntile * part / nparts), t1 = (uint32_t)((uint64_t)ntile * (part + 1) / nparts);
+		P.w0 = t0 * 64;
+		uint32_t wend = std::min<uint32_t>(Wall, t1 * 64);
+		P.W = wend > P.w0 ? wend - P.w0 : 0;
+	}
 	size_t plane_words = (size_t)P.W * P.Npad;
 	HIPOK(c, c->b_planes.ensure(plane_words * 5));
 	for (int p = 0; p < 5; p++) P.plane[p] = c->b_planes.p + plane_words * p;
@@ -974,16 +1019,15 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 	uint32_t flag = *flagp;
 	double t1 = now_ms();
 
-	// tiles of this part: (ig, jt) with at least one pair i<j, dealt round-robin
+	// pair tiles (ig, jt) holding at least one pair i<j
 	std::vector<uint32_t> tiles;
 	uint32_t nig = (uint32_t)((N + PAIR_IG - 1) / PAIR_IG), njt = (uint32_t)((N + PAIR_JT - 1) / PAIR_JT);
-	size_t tid = 0;
 	for (uint32_t ig = 0; ig < nig; ig++)
 		for (uint32_t jt = 0; jt < njt; jt++) {
 			if ((uint64_t)ig * PAIR_IG >= (uint64_t)jt * PAIR_JT + PAIR_JT - 1) continue; // no i<j inside
-			if (tid++ % nparts == part) tiles.push_back((ig << 16) | jt);
+			tiles.push_back((ig << 16) | jt);
 		}
-	if (!tiles.empty()) {
+	if (!tiles.empty() && P.W) {
 		HIPOK(c, c->b_tiles.ensure(tiles.size()));
 		HIPOK(c, hipMemcpyAsync(c->b_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, st));
 		// enough blocks to fill the chip several times over, chunks of >= 64 windows

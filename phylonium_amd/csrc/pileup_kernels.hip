@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void tile_index_kernel(Pileup P, const DevHom 
 	const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (tid >= (uint64_t)P.N * ntw) return;
 	const uint32_t g = (uint32_t)(tid / ntw), tw = (uint32_t)(tid % ntw);
-	const uint32_t span0 = tw * PROJ_TW * 32u;
+	const uint32_t span0 = (P.w0 + tw * PROJ_TW) * 32u;
 	uint32_t lo = hom_off[g], hi = hom_off[g + 1];
 	while (lo < hi) {
 		uint32_t mid = lo + ((hi - lo) >> 1);
@@ -115,8 +115,8 @@ __global__ __launch_bounds__(256) void project_kernel(Pileup P, const uint8_t *_
 		}
 	}
 	__syncthreads();
-	const uint32_t w = tw * PROJ_TW + lane;
-	const uint32_t x0 = w * 32u, x1 = x0 + 32u;
+	const uint32_t w = tw * PROJ_TW + lane; // row of this part; reference window P.w0 + w
+	const uint32_t x0 = (P.w0 + w) * 32u, x1 = x0 + 32u;
 	uint32_t any_bang = 0;
 	for (uint32_t gi = wave; gi < PROJ_TG; gi += 4) {
 		const uint32_t g = tg * PROJ_TG + gi;

@@ -35,44 +35,33 @@ def _dev(backend_device):
     return backend_device if backend_device is not None else torch.device("cpu")
 
 
-def allgather_homologies(local, n, device=None):
-    """local: {genome index: PHOM array} for this rank's queries → list of n arrays."""
-    world = td.get_world_size()
+def exchange_homologies(ctx, n, rank, world, bounds, device=None):
+    """After phase A every rank holds the lists of its own query block; afterwards
+    every rank holds all of them.  Two collectives: the per-genome counts
+    (all-reduce of a vector that is zero outside the own block) and the flat
+    lists (all-gather of byte tensors padded to the longest block)."""
     dev = _dev(device)
-    idx = sorted(local)
-    counts = np.zeros(n, np.int64)
-    for j in idx:
-        counts[j] = len(local[j])
-    ct = torch.from_numpy(counts).to(dev)
+    qb, qe = bounds[rank], bounds[rank + 1]
+    counts, flat = ctx.export_homologies(qb, qe)
+    call = np.zeros(n, np.int64)
+    call[qb:qe] = counts.astype(np.int64)
+    ct = torch.from_numpy(call).to(dev)
     td.all_reduce(ct, op=td.ReduceOp.SUM)
-    counts_all = ct.cpu().numpy()
-    flat = np.concatenate([np.ascontiguousarray(local[j], PHOM) for j in idx]) if idx else np.zeros(0, PHOM)
-    mine = torch.from_numpy(flat.view(np.uint8).copy()).to(dev)
-    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
-    sizes[td.get_rank()] = mine.numel()
-    td.all_reduce(sizes, op=td.ReduceOp.SUM)
-    sizes = sizes.cpu().numpy()
-    cap = int(sizes.max())
-    pad = torch.zeros(max(cap, 1), dtype=torch.uint8, device=dev)
-    pad[:mine.numel()] = mine
-    parts = [torch.zeros_like(pad) for _ in range(world)]
-    td.all_gather(parts, pad)
-    owner = torch.full((n,), -1, dtype=torch.int64, device=dev)
-    for j in idx:
-        owner[j] = td.get_rank()
-    td.all_reduce(owner, op=td.ReduceOp.MAX)
-    owner = owner.cpu().numpy()
-    out = [np.zeros(0, PHOM)] * n
-    cursor = [0] * world
-    for j in range(n):
-        r = int(owner[j])
-        if r < 0:
+    call = ct.cpu().numpy()
+    item = PHOM.itemsize
+    sizes = [int(call[bounds[r]:bounds[r + 1]].sum()) * item for r in range(world)]
+    cap = max(max(sizes), 1)
+    mine = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    if flat.size:
+        mine[:flat.size * item] = torch.from_numpy(flat.view(np.uint8)).to(dev)
+    gathered = torch.zeros(world * cap, dtype=torch.uint8, device=dev)
+    td.all_gather_into_tensor(gathered, mine)
+    g = gathered.cpu().numpy()
+    for r in range(world):
+        if r == rank or bounds[r] == bounds[r + 1]:
             continue
-        nb = int(counts_all[j]) * PHOM.itemsize
-        buf = parts[r][cursor[r]:cursor[r] + nb].cpu().numpy()
-        cursor[r] += nb
-        out[j] = buf.view(PHOM).copy()
-    return out
+        part = g[r * cap:r * cap + sizes[r]].view(PHOM)
+        ctx.import_homologies(bounds[r], bounds[r + 1], call[bounds[r]:bounds[r + 1]].astype(np.uint64), part)
 
 
 def allreduce_matrix(subst, homologs, device=None):
@@ -89,14 +78,12 @@ def process_sharded(ctx, ref_idx, rank, world, device=None, lengths=None, set_re
     ctx: an api.Context (or any object with the same methods) holding all genomes."""
     if set_reference:
         ctx.set_reference(ref_idx)
-    qb, qe = query_shard(ctx.n, rank, world, lengths or getattr(ctx, "lengths", None))
+    lens = lengths or getattr(ctx, "lengths", None)
+    bounds = [query_shard(ctx.n, r, world, lens)[0] for r in range(world)] + [ctx.n]
+    qb, qe = bounds[rank], bounds[rank + 1]
     ctx.anchor(qb, qe)
     if world > 1:
-        local = {j: ctx.homologies(j) for j in range(qb, qe)}
-        allh = allgather_homologies(local, ctx.n, device)
-        for j in range(ctx.n):
-            if not (qb <= j < qe):
-                ctx.set_homologies(j, allh[j])
+        exchange_homologies(ctx, ctx.n, rank, world, bounds, device)
     s, h = ctx.compare(rank, world)
     if world > 1:
         s, h = allreduce_matrix(s, h, device)

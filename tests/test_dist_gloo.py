@@ -54,6 +54,19 @@ class OracleCtx:
     def set_homologies(self, j, h):
         self.h[j] = np.array(h)
 
+    def export_homologies(self, qb, qe):
+        from phylonium_amd.api import PHOM
+        counts = np.array([len(self.h[j]) for j in range(qb, qe)], np.uint64)
+        flat = np.concatenate([self.h[j] for j in range(qb, qe)]) if qe > qb else np.zeros(0, PHOM)
+        return counts, flat
+
+    def import_homologies(self, qb, qe, counts, flat):
+        o = 0
+        for k, j in enumerate(range(qb, qe)):
+            c = int(counts[k])
+            self.h[j] = np.array(flat[o:o + c])
+            o += c
+
     def compare(self, part, nparts):
         O = self.O
         s = np.zeros((self.n, self.n), np.uint64)

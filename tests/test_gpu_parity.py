@@ -231,3 +231,52 @@ def test_medium_scale_parity_and_properties(ctx):
     assert (s == so).all() and (h == ho).all()
     assert (s == s.T).all() and (h == h.T).all() and (s <= h).all()
     assert (np.diag(h) == 0).all()
+
+
+def test_export_import_roundtrip(ctx):
+    gs = synth.make_genomes(9, 15000, seed=61, d_range=(0.01, 0.2), inv_frac=0.05)
+    ctx.set_genomes(gs)
+    ctx.set_reference(4)
+    ctx.anchor()
+    s, h = ctx.compare()
+    counts, flat = ctx.export_homologies(2, 7)
+    assert [int(c) for c in counts] == [len(ctx.homologies(j)) for j in range(2, 7)]
+    for j in range(2, 7):
+        ctx.set_homologies(j, np.zeros(0, api.PHOM))
+    ctx.import_homologies(2, 7, counts, flat)
+    s2, h2 = ctx.compare()
+    assert (s == s2).all() and (h == h2).all()
+
+
+def _two_rank_worker(rank, world, port, out):
+    import torch.distributed as td
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from phylonium_amd import dist
+    gs = synth.make_genomes(11, 30000, seed=71, d_range=(0.01, 0.25), indel_per_mbp=300, inv_frac=0.06)
+    c = api.Context(0)  # both ranks share the one GPU of the test box; collectives go over gloo
+    c.set_genomes(gs)
+    s, h = dist.process_sharded(c, 3, rank, world, device=None)
+    if rank == 0:
+        np.save(out + ".s.npy", s)
+        np.save(out + ".h.npy", h)
+    c.close()
+    td.destroy_process_group()
+
+
+def test_two_process_sharded_run_on_gpu(tmp_path):
+    """The real multi-rank path (query shard → phase A → bulk exchange → window-range
+    shard of phase B → matrix sum) with two processes; RCCL is replaced by gloo because
+    the test box has a single GPU."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "res")
+    mp.spawn(_two_rank_worker, args=(2, port, out), nprocs=2, join=True)
+    gs = synth.make_genomes(11, 30000, seed=71, d_range=(0.01, 0.25), indel_per_mbp=300, inv_frac=0.06)
+    so, ho = O.Run(gs, 3).process().matrix()
+    assert (np.load(out + ".s.npy") == so).all()
+    assert (np.load(out + ".h.npy") == ho).all()
