@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--genomes", type=int, default=0, help="override genome count")
     ap.add_argument("--length", type=int, default=0, help="override genome length")
     ap.add_argument("--seed", type=int, default=20260101)
-    ap.add_argument("--cpu-sample", type=int, default=7, help="queries in the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=63, help="queries in the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernels with HIP events")
     ap.add_argument("--check", action="store_true", help="verify a sample of the result against the oracle")
     args = ap.parse_args()
@@ -210,8 +210,10 @@ def main():
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "alg_bytes_per_launch": alg.get(dom, 0.0), "avg_launch_ms": round(avg_ms, 4),
-                    "note": "anchor_* kernels are latency/random-access bound (gathers over SA/LCP/T/S), not HBM-streaming; "
-                            "pileup_pairs moves far fewer HBM bytes than the reference layout's algorithmic 2 B/site"}
+                    "note": "anchor_* kernels gather random 128-B lines (k-mer slots, subject windows): dependent-access "
+                            "latency bound, not HBM-streaming; `traffic` = HBM-side bytes per launch from rocprofv3 PMC "
+                            "(profiles/pmc_traffic.json); pileup_pairs moves far fewer HBM bytes than the reference "
+                            "layout's algorithmic 2 B/site"}
         cpu = None
         if world == 1 and args.cpu_sample > 0:
             try:
@@ -222,7 +224,7 @@ def main():
                 refb = buf[offs[ref_idx]:offs[ref_idx] + lens[ref_idx]].cpu().numpy().tobytes()
                 S = refb + b"#" + O.revcomp(refb)
                 sa_ref = api.host_suffix_array(S)  # the suffix array is unique; saves the oracle's slow sorter
-                threads = min(os.cpu_count() or 1, 1 + min(args.cpu_sample, n - 1))
+                threads = min(os.cpu_count() or 1, 64, 1 + min(args.cpu_sample, n - 1))
                 cpu = cpu_baseline(torch, buf, offs, lens, ref_idx, sa_ref, min(args.cpu_sample, n - 1), threads)
             except Exception as e:  # the baseline is a report, never a reason to lose the bench line
                 cpu = {"value": None, "unit": "Gbp/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}

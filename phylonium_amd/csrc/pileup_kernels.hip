@@ -182,11 +182,18 @@ __global__ __launch_bounds__(256) void project_kernel(Pileup P, const uint8_t *_
 // chunk and leave with one 64-bit atomic per pair.
 template <bool BANG>
 __global__ __launch_bounds__(64) void pairs_kernel(Pileup P, const uint32_t *__restrict__ tiles, uint32_t ntiles,
-													uint32_t wchunk, unsigned long long *__restrict__ subst,
+													uint32_t wchunk, uint32_t nwc, unsigned long long *__restrict__ subst,
 													unsigned long long *__restrict__ homologs)
 {
-	const uint32_t tile = blockIdx.x % ntiles;
-	const uint32_t wc = blockIdx.x / ntiles;
+	// XCD-aware order: blocks are dealt round-robin over the 8 XCDs (b and b+8
+	// share one), so give every XCD its own window chunks and run all the pair
+	// tiles of a chunk back to back there — the chunk's plane rows (sized to fit
+	// the XCD's 4 MiB L2) are then fetched from HBM once, not once per tile.
+	// Placement only affects speed, never the result.
+	const uint32_t xcd = blockIdx.x & 7u, local = blockIdx.x >> 3;
+	const uint32_t tile = local % ntiles;
+	const uint32_t wc = (local / ntiles) * 8u + xcd;
+	if (wc >= nwc) return;
 	const uint32_t ig = tiles[tile] >> 16, jt = tiles[tile] & 0xffffu;
 	const uint32_t i0 = ig * PAIR_IG;
 	const uint32_t j = jt * PAIR_JT + (threadIdx.x & 63u);
@@ -247,11 +254,11 @@ void launch_pairs(const Pileup &P, bool with_bang, const uint32_t *tiles, uint32
 {
 	if (!ntiles || !P.W) return;
 	uint32_t nwc = (P.W + wchunk - 1) / wchunk;
-	dim3 grid(ntiles * nwc);
+	dim3 grid(((nwc + 7) / 8) * 8 * ntiles);
 	if (with_bang)
-		hipLaunchKernelGGL(pairs_kernel<true>, grid, dim3(64), 0, st, P, tiles, ntiles, wchunk, subst, homologs);
+		hipLaunchKernelGGL(pairs_kernel<true>, grid, dim3(64), 0, st, P, tiles, ntiles, wchunk, nwc, subst, homologs);
 	else
-		hipLaunchKernelGGL(pairs_kernel<false>, grid, dim3(64), 0, st, P, tiles, ntiles, wchunk, subst, homologs);
+		hipLaunchKernelGGL(pairs_kernel<false>, grid, dim3(64), 0, st, P, tiles, ntiles, wchunk, nwc, subst, homologs);
 }
 
 } // namespace phy

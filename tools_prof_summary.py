@@ -56,7 +56,11 @@ for f in glob.glob(os.path.join(d, "*_bench.json")):
     except Exception:
         pass
 json.dump(out, open(os.path.join(d, "summary.json"), "w"), indent=1)
+ks = os.path.join(d, "kernel_stats.csv")
+if os.path.exists(ks):
+    out["rocprof_kernel_stats_csv"] = open(ks).read()
+    json.dump(out, open(os.path.join(d, "summary.json"), "w"), indent=1)
 for sub in glob.glob(os.path.join(d, "*")):
     if os.path.isdir(sub):
         shutil.rmtree(sub)
-print(json.dumps({k: v for k, v in out.items() if k != "bench_lines"}, indent=1))
+print(json.dumps({k: v for k, v in out.items() if k not in ("bench_lines", "rocprof_kernel_stats_csv")}, indent=1))
