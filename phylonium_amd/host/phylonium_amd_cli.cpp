@@ -1,0 +1,437 @@
+// phylonium_amd_cli.cpp — host driver over the C ABI with phylonium's command
+// line: FASTA files in, PHYLIP distance matrix out.
+//
+// Mirrors /root/reference/src/phylonium.cxx:89-299 (option parsing, reference
+// choice, one or two passes), src/io.cxx:36-233 (genome names, FASTA → joined
+// sequence, warnings, matrix output) and the flag-gated consumers of the
+// tallies in src/process.cxx:467-513 (-p) and src/evo_model.cxx:136-147
+// (bootstrap).  The hot path itself — process() — is libphylonium_amd.so.
+// Written from the behaviour, not from the reference's text.
+#include <algorithm>
+#include <cerrno>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <getopt.h>
+#include <iostream>
+#include <limits>
+#include <numeric>
+#include <random>
+#include <string>
+#include <strings.h>
+#include <unistd.h>
+#include <vector>
+
+#include "../../include/phylonium_amd.h"
+
+namespace {
+
+const char *PROG = "phylonium-amd";
+int RETURN_CODE = EXIT_SUCCESS;
+
+enum Flags { F_VERBOSE = 1, F_EXTRA_VERBOSE = 2, F_COMPLETE_DELETION = 4, F_PROGRESS = 8, F_POSITIONS = 16, F_ANI = 32, F_RAW = 64 };
+
+struct Genome {
+	std::string name; // file name without directory and .fa/.fas/.fasta (io.cxx:36-59)
+	std::string nucl; // contigs joined by '!' (sequence.cxx:171-199)
+};
+
+[[noreturn]] void die(const std::string &msg)
+{
+	fprintf(stderr, "%s: %s\n", PROG, msg.c_str());
+	exit(1);
+}
+void soft_err(const std::string &msg)
+{
+	RETURN_CODE |= EXIT_FAILURE;
+	fprintf(stderr, "%s: %s\n", PROG, msg.c_str());
+}
+
+std::string genome_name(const std::string &path)
+{
+	size_t left = path.rfind('/');
+	left = (left == std::string::npos) ? 0 : left + 1;
+	size_t right = path.rfind('.');
+	if (right != std::string::npos) {
+		std::string ext = path.substr(right);
+		if (!(ext == ".fa" || ext == ".fas" || ext == ".fasta")) right = path.size();
+	} else {
+		right = path.size();
+	}
+	return path.substr(left, right - left);
+}
+
+// FASTA records of one file → nucleotides filtered to ACGT (upper-cased,
+// sequence.cxx:109-146), contigs joined by '!'
+Genome read_genome(const std::string &path)
+{
+	std::ifstream in(path, std::ios::binary);
+	if (!in) die(path + ": " + strerror(errno));
+	Genome g;
+	g.name = genome_name(path);
+	std::string line;
+	bool in_record = false, any = false;
+	std::string contig;
+	auto flush = [&]() {
+		if (!in_record) return;
+		if (any) g.nucl += '!';
+		g.nucl += contig;
+		contig.clear();
+		any = true;
+	};
+	while (std::getline(in, line)) {
+		if (!line.empty() && line[0] == '>') {
+			flush();
+			in_record = true;
+			continue;
+		}
+		if (!in_record) {
+			bool blank = true;
+			for (char c : line)
+				if (!isspace((unsigned char)c)) blank = false;
+			if (blank) continue;
+			die(path + ": File is not in FASTA format.");
+		}
+		for (unsigned char c : line) {
+			switch (c) {
+				case 'A': case 'a': contig += 'A'; break;
+				case 'C': case 'c': contig += 'C'; break;
+				case 'G': case 'g': contig += 'G'; break;
+				case 'T': case 't': contig += 'T'; break;
+				default: break;
+			}
+		}
+	}
+	flush();
+	if (!any) die(path + ": Empty file.");
+	return g;
+}
+
+struct Tally {
+	uint64_t subst = 0, homologs = 0;
+};
+using Matrix = std::vector<Tally>;
+
+double dist_of(const Tally &t, int flags, bool zero_on_error = false)
+{
+	int kind = (flags & F_RAW) ? 1 : (flags & F_ANI) ? 2 : 0;
+	return phylo_estimate(kind, t.subst, t.homologs, zero_on_error);
+}
+
+// just_print, io.cxx:141-163
+void print_phylip(const std::vector<Genome> &q, const std::vector<double> &d, int flags)
+{
+	size_t N = q.size();
+	std::cout << N << std::endl;
+	std::cout.precision(4);
+	std::cout << ((flags & F_ANI) ? std::dec : std::scientific);
+	for (size_t i = 0; i < N; i++) {
+		std::cout << q[i].name;
+		for (size_t j = 0; j < N; j++) std::cout << "  " << (i == j ? 0.0 : d[i * N + j]);
+		std::cout << std::endl;
+	}
+}
+
+// print_matrix, io.cxx:165-233
+void print_matrix(const std::vector<Genome> &q, const Matrix &m, int flags, unsigned long bootstrap, size_t ref_idx,
+				  std::mt19937 &prng)
+{
+	size_t N = q.size();
+	std::vector<double> d(N * N);
+	for (size_t k = 0; k < N * N; k++) d[k] = dist_of(m[k], flags);
+	// warnings first (io.cxx:106-139)
+	for (size_t i = 0; i < N; i++)
+		for (size_t j = 0; j < i; j++) {
+			double v = d[i * N + j];
+			char buf[1024];
+			if (std::isnan(v)) {
+				snprintf(buf, sizeof buf,
+						 "For the two sequences '%s' and '%s' the distance computation failed and is reported as nan.",
+						 q[i].name.c_str(), q[j].name.c_str());
+				soft_err(buf);
+			} else {
+				double c1 = (double)m[i * N + j].homologs / q[i].nucl.size();
+				double c2 = (double)m[i * N + j].homologs / q[j].nucl.size();
+				if (c1 < 0.2 || c2 < 0.2) {
+					snprintf(buf, sizeof buf,
+							 "For the two sequences '%s' and '%s' less than 20%% homology were found (%f and %f, "
+							 "respectively).",
+							 q[i].name.c_str(), q[j].name.c_str(), c1, c2);
+					soft_err(buf);
+				}
+			}
+		}
+	print_phylip(q, d, flags);
+	for (unsigned long k = 0; k < bootstrap; k++) { // evo_model::bootstrap, evo_model.cxx:136-147
+		std::vector<double> b(N * N);
+		for (size_t t = 0; t < N * N; t++) {
+			Tally r = m[t];
+			double rate = r.subst / (double)r.homologs;
+			std::binomial_distribution<> dist((int)r.homologs, rate);
+			r.subst = (uint64_t)dist(prng);
+			b[t] = dist_of(r, flags);
+		}
+		print_phylip(q, b, flags);
+	}
+	if (flags & F_VERBOSE) {
+		double sum = 0;
+		size_t counter = 0;
+		for (size_t i = 0; i < N; i++)
+			for (size_t j = 0; j < i; j++) {
+				if (std::isnan(d[i * N + j])) continue;
+				sum += (double)m[i * N + j].homologs / q[i].nucl.size() + (double)m[i * N + j].homologs / q[j].nucl.size();
+				counter += 2;
+			}
+		size_t aligned = 0, total = 0;
+		for (size_t i = 0; i < N; i++) {
+			if (i == ref_idx) continue;
+			aligned += m[ref_idx * N + i].homologs;
+			total += q[i].nucl.size();
+		}
+		std::cerr << "avg coverage:\t" << sum / counter << std::endl;
+		std::cerr << "alignment:\t" << aligned << "\t" << total << "\t" << aligned / (double)total << std::endl;
+	}
+}
+
+// pick_first_pass, phylonium.cxx:360-382 — median length by nth_element, then
+// the first genome equal to it
+size_t pick_first_pass(const std::vector<Genome> &q, int flags)
+{
+	std::vector<size_t> idx(q.size());
+	std::iota(idx.begin(), idx.end(), 0);
+	std::nth_element(idx.begin(), idx.begin() + idx.size() / 2, idx.end(),
+					 [&](size_t a, size_t b) { return q[a].nucl.size() < q[b].nucl.size(); });
+	size_t chosen = idx[idx.size() / 2];
+	size_t ref = chosen;
+	for (size_t i = 0; i < q.size(); i++)
+		if (q[i].name == q[chosen].name && q[i].nucl == q[chosen].nucl) {
+			ref = i;
+			break;
+		}
+	if (flags & F_VERBOSE) std::cerr << "chosen reference: " << q[ref].name << std::endl;
+	return ref;
+}
+
+// pick_second_pass, phylonium.cxx:317-344 — the row with the smallest sum of JC distances
+size_t pick_second_pass(size_t N, const Matrix &m)
+{
+	double best = std::numeric_limits<double>::max();
+	size_t arg = 0;
+	for (size_t i = 0; i < N; i++) {
+		double sum = 0.0;
+		for (size_t j = 0; j < N; j++) sum += phylo_estimate(0, m[i * N + j].subst, m[i * N + j].homologs, 1);
+		if (sum < best) {
+			best = sum;
+			arg = i;
+		}
+	}
+	return arg;
+}
+
+struct Run {
+	phylo_ctx *ctx = nullptr;
+	std::vector<Genome> *q = nullptr;
+	int flags = 0;
+	std::string refpos_file;
+};
+
+void ok(Run &r, int rc)
+{
+	if (rc) die(phylo_last_error(r.ctx));
+}
+
+// -p FILE: reference positions of the core alignment with the segregating
+// sites of every block (process.cxx:471-513, 665-723)
+void write_positions(Run &r, size_t ref_idx)
+{
+	auto &q = *r.q;
+	size_t N = q.size();
+	std::vector<const phylo_homology *> H(N);
+	std::vector<size_t> n(N);
+	for (size_t g = 0; g < N; g++) ok(r, phylo_get_homologies(r.ctx, g, &H[g], &n[g]));
+	std::ofstream out(r.refpos_file);
+	size_t counter = 1;
+	const std::string &subject = q[ref_idx].nucl;
+	for (size_t i = 0; i < n[0]; i++) {
+		const phylo_homology &h0 = H[0][i];
+		std::vector<char> seg(h0.length, 0);
+		for (size_t m = 0; m < N; m++) {
+			const phylo_homology &hm = H[m][i];
+			// after complete deletion all blocks share start and length
+			uint64_t len = h0.length;
+			const char *a = q[0].nucl.data() + h0.index_query, *b = q[m].nucl.data() + hm.index_query;
+			std::vector<char> f(len, 0);
+			if (h0.direction == hm.direction) {
+				for (uint64_t t = 0; t < len; t++) f[t] = a[t] != b[t];
+				if (h0.direction == 1) std::reverse(f.begin(), f.end());
+			} else if (hm.direction == 1) {
+				for (uint64_t t = 0; t < len; t++) f[t] = (((a[t] ^ b[len - t - 1]) & 6) != 4);
+			} else {
+				for (uint64_t t = 0; t < len; t++) f[t] = (((b[t] ^ a[len - t - 1]) & 6) != 4);
+			}
+			for (uint64_t t = 0; t < len; t++) seg[t] |= f[t];
+		}
+		std::vector<size_t> pos;
+		for (size_t t = 0; t < seg.size(); t++)
+			if (seg[t]) pos.push_back(t);
+		uint64_t start = h0.index_reference_projected, end = start + h0.length;
+		out << ">part" << counter++ << "\t(" << (start + 1) << ".." << (end + 1) << ")  " << pos.size();
+		for (size_t p : pos) out << "  " << (p + 1);
+		out << std::endl;
+		out << subject.substr(start, end - start) << std::endl;
+	}
+}
+
+// process(), process.cxx:408-556, over the C ABI
+Matrix process(Run &r, size_t ref_idx)
+{
+	auto &q = *r.q;
+	size_t N = q.size();
+	ok(r, phylo_set_reference(r.ctx, ref_idx, nullptr, 0));
+	if (r.flags & F_VERBOSE) std::cerr << "ref: " << q[ref_idx].name << std::endl;
+	ok(r, phylo_anchor(r.ctx, 0, N));
+	if (r.flags & F_COMPLETE_DELETION) ok(r, phylo_complete_delete(r.ctx));
+	if (r.flags & F_POSITIONS) write_positions(r, ref_idx);
+	std::vector<uint64_t> s(N * N), h(N * N);
+	ok(r, phylo_compare_all(r.ctx, s.data(), h.data()));
+	Matrix m(N * N);
+	for (size_t k = 0; k < N * N; k++) m[k] = Tally{s[k], h[k]};
+	return m;
+}
+
+[[noreturn]] void usage(int status)
+{
+	const char str[] = {
+		"Usage: phylonium-amd [OPTIONS] FILES...\n"
+		"\tFILES... can be any sequence of FASTA files, each file representing one genome.\n\n"
+		"Options:\n"
+		"  -2, --2pass          Enable two-pass algorithm\n"
+		"  -b, --bootstrap=N    Print additional bootstrap matrices\n"
+		"  --complete-deletion  Delete the whole aligned column in case of gaps\n"
+		"  -p FILE              Print reference positions to FILE (implies complete deletion)\n"
+		"    --progress=WHEN    Accepted for compatibility; no progress bar is drawn\n"
+		"  -r FILE              Set the reference genome\n"
+		"  -t, --threads=N      Host threads for the per-genome sort/filter step\n"
+		"  -d, --device=N       GPU ordinal (default 0)\n"
+		"  -v, --verbose        Print additional information\n"
+		"      --distance=OPT   Choose between raw, jc corrected and ANI\n"
+		"  -h, --help           Display this help and exit\n"
+		"      --version        Output version information\n"};
+	fprintf(status == EXIT_SUCCESS ? stdout : stderr, "%s", str);
+	exit(status);
+}
+
+} // namespace
+
+int main(int argc, char *argv[])
+{
+	std::random_device rd;
+	std::mt19937 prng(rd());
+	int version_flag = 0, flags = 0, device = 0;
+	long threads = 0;
+	bool two_pass = false;
+	unsigned long bootstrap = 0;
+	std::string reference_name, refpos_file;
+
+	static struct option long_options[] = {{"2pass", no_argument, NULL, '2'},
+										   {"bootstrap", required_argument, NULL, 'b'},
+										   {"complete-deletion", no_argument, NULL, 0},
+										   {"distance", required_argument, NULL, 0},
+										   {"help", no_argument, NULL, 'h'},
+										   {"progress", optional_argument, NULL, 0},
+										   {"threads", required_argument, NULL, 't'},
+										   {"device", required_argument, NULL, 'd'},
+										   {"verbose", no_argument, NULL, 'v'},
+										   {"version", no_argument, &version_flag, 1},
+										   {0, 0, 0, 0}};
+	for (;;) {
+		int option_index = 0;
+		int c = getopt_long(argc, argv, "2b:d:hp:r:t:v", long_options, &option_index);
+		if (c == -1) break;
+		switch (c) {
+			case 0: {
+				std::string name = long_options[option_index].name;
+				if (name == "complete-deletion") flags |= F_COMPLETE_DELETION;
+				if (name == "distance") {
+					if (strcasecmp(optarg, "raw") == 0) flags |= F_RAW;
+					else if (strcasecmp(optarg, "jc") == 0) {
+					} else if (strcasecmp(optarg, "ani") == 0) flags |= F_ANI;
+					else
+						soft_err(std::string("ignoring argument for --distance '") + optarg +
+								 "' expected one of 'raw', 'jc', or 'ani'");
+				}
+				break;
+			}
+			case '2': two_pass = true; break;
+			case 'b': {
+				errno = 0;
+				char *end;
+				unsigned long b = strtoul(optarg, &end, 10);
+				if (errno || end == optarg || *end != '\0' || b == 0) {
+					soft_err(std::string("Expected a positive number for -b argument, but '") + optarg +
+							 "' was given. Ignoring -b argument.");
+					break;
+				}
+				bootstrap = b - 1;
+				break;
+			}
+			case 'd': device = atoi(optarg); break;
+			case 'h': usage(EXIT_SUCCESS);
+			case 'p':
+				flags |= F_POSITIONS | F_COMPLETE_DELETION;
+				refpos_file = optarg;
+				break;
+			case 'r': reference_name = optarg; break;
+			case 't': threads = strtol(optarg, nullptr, 10); break;
+			case 'v': flags |= (flags & F_VERBOSE) ? F_EXTRA_VERBOSE : F_VERBOSE; break;
+			default: usage(EXIT_FAILURE);
+		}
+	}
+	if (flags & F_POSITIONS) {
+		std::ifstream probe(refpos_file);
+		if (probe.good()) die("output file '" + refpos_file + "' already exists");
+	}
+	if (version_flag) {
+		printf("%s\n", phylo_version());
+		return 0;
+	}
+	std::vector<std::string> files(argv + optind, argv + argc);
+	if (!reference_name.empty()) { // cleanup_names, phylonium.cxx:384-391
+		files.push_back(reference_name);
+		std::sort(files.begin(), files.end());
+		files.erase(std::unique(files.begin(), files.end()), files.end());
+	}
+	if (files.size() < 2) usage(EXIT_FAILURE);
+
+	std::vector<Genome> q(files.size());
+	for (size_t i = 0; i < files.size(); i++) q[i] = read_genome(files[i]);
+
+	size_t ref_idx;
+	if (reference_name.empty()) ref_idx = pick_first_pass(q, flags);
+	else ref_idx = std::find(files.begin(), files.end(), reference_name) - files.begin();
+
+	Run r;
+	r.q = &q;
+	r.flags = flags;
+	r.refpos_file = refpos_file;
+	if (phylo_ctx_create(&r.ctx, device)) die(phylo_last_error(nullptr));
+	if (threads > 0) ok(r, phylo_set_option(r.ctx, "host_threads", threads));
+	std::vector<const char *> seq(q.size());
+	std::vector<size_t> len(q.size());
+	for (size_t i = 0; i < q.size(); i++) {
+		seq[i] = q[i].nucl.data();
+		len[i] = q[i].nucl.size();
+	}
+	ok(r, phylo_set_genomes(r.ctx, q.size(), seq.data(), len.data()));
+
+	Matrix m = process(r, ref_idx);
+	if (two_pass) {
+		ref_idx = pick_second_pass(q.size(), m);
+		m = process(r, ref_idx);
+	}
+	print_matrix(q, m, flags, bootstrap, ref_idx, prng);
+	phylo_ctx_destroy(r.ctx);
+	return RETURN_CODE;
+}
