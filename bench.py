@@ -29,12 +29,15 @@ WORKLOADS = {
     "c2like": (29, 5_000_000, (0.0002, 0.03), 20, 0.005, "configs[1] stand-in (eco29 data absent): 29 x 5 Mbp, d in [0.0002,0.03]"),
     "c3": (256, 5_000_000, (0.01, 0.3), 100, 0.02, "configs[2]: 256 x 5 Mbp, d in [0.01,0.3] from the reference, 100 indels/Mbp, 2% inverted"),
     "c4": (1024, 5_000_000, (0.01, 0.3), 100, 0.02, "configs[3]: 1024 x 5 Mbp, same distribution as c3"),
+    "c5s": (16, 20_000_000, (0.005, 0.1), 100, 0.10, "configs[4] scaled down: 16 x 20 Mbp, 50 contigs each, 10% inverted"),
+    "c5": (64, 100_000_000, (0.005, 0.1), 100, 0.10, "configs[4]: 64 x 100 Mbp, 100 contigs each, 10% inverted"),
     "small": (32, 1_000_000, (0.01, 0.3), 100, 0.02, "dev: 32 x 1 Mbp"),
 }
+CONTIGS = {"c5s": 50, "c5": 100}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 
 
-def make_genomes_gpu(torch, n, length, seed, device, d_range, indel_per_mbp, inv_frac, inv_len=(1000, 5000)):
+def make_genomes_gpu(torch, n, length, seed, device, d_range, indel_per_mbp, inv_frac, inv_len=(1000, 5000), contigs=1):
     """Synthetic genome set on the GPU. Genome 0 is the unmutated base (the reference,
     like simf's S0, test/simf.cxx:32); genome g>0 = base at JC distance d_g ~ U(d_range),
     plus indel events and inverted blocks. Returns (buffer, offsets, lengths)."""
@@ -87,6 +90,9 @@ def make_genomes_gpu(torch, n, length, seed, device, d_range, indel_per_mbp, inv
     buf = torch.zeros(tot + 256, dtype=torch.uint8, device=device)  # +256: kernels prefetch 128-byte query windows
     for c, o, l in zip(codes, offs, lens):
         buf[o:o + l] = lut[c.long()]
+        if contigs > 1:  # contig breaks: '!' replaces a base (src/sequence.cxx:171-199 joins contigs with '!')
+            cuts = torch.from_numpy(np.sort(rng.choice(np.arange(1000, l - 1000), size=contigs - 1, replace=False))).to(device)
+            buf[o + cuts] = ord("!")
     del codes
     return buf, offs, lens
 
@@ -142,7 +148,8 @@ def main():
     n = args.genomes or n
     length = args.length or length
     t_gen = time.time()
-    buf, offs, lens = make_genomes_gpu(torch, n, length, args.seed, device, d_range, indel, inv)
+    buf, offs, lens = make_genomes_gpu(torch, n, length, args.seed, device, d_range, indel, inv,
+                                       contigs=CONTIGS.get(args.workload, 1))
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
     ref_idx = 0

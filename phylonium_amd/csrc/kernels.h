@@ -45,6 +45,8 @@ size_t project_index_entries(const Pileup &P);
 void launch_pairs(const Pileup &P, bool with_bang, const uint32_t *tiles, uint32_t ntiles, uint32_t wchunk,
 				  unsigned long long *subst, unsigned long long *homologs, hipStream_t st);
 
+void launch_symmetrise(uint32_t N, unsigned long long *a, unsigned long long *b, hipStream_t st);
+
 static const uint32_t PAIR_IG = 16; // i-genomes per block (scalar side)
 static const uint32_t PAIR_JT = 64; // j-genomes per block (one per lane)
 

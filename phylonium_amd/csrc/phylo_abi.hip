@@ -1041,19 +1041,17 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		}
 		HIPOK(c, hipGetLastError());
 	}
+	launch_symmetrise((uint32_t)N, c->b_subst.p, c->b_homologs.p, st);
 	uint64_t *hs = c->h_mat.p, *hh = c->h_mat.p + N * N;
 	HIPOK(c, hipMemcpyAsync(hs, c->b_subst.p, N * N * 8, hipMemcpyDeviceToHost, st));
 	HIPOK(c, hipMemcpyAsync(hh, c->b_homologs.p, N * N * 8, hipMemcpyDeviceToHost, st));
 	if (sync_stream(c)) return 1;
 	double t2 = now_ms();
+	memcpy(subst, hs, N * N * 8);
+	memcpy(homologs, hh, N * N * 8);
 	double sites = 0;
-	for (size_t i = 0; i < N; i++)
-		for (size_t j = i + 1; j < N; j++) {
-			size_t a = i * N + j, b = j * N + i;
-			subst[a] = subst[b] = hs[a];
-			homologs[a] = homologs[b] = hh[a];
-			sites += (double)hh[a];
-		}
+	for (size_t k = 0; k < N * N; k++) sites += (double)hh[k];
+	sites *= 0.5;
 	c->stats["ms:compare_project_phase"] += t1 - t0;
 	c->stats["ms:compare_pairs_phase"] += t2 - t1;
 	c->stats["ms:compare_symmetrise"] += now_ms() - t2;

@@ -208,7 +208,8 @@ __global__ __launch_bounds__(64) void pairs_kernel(Pileup P, const uint32_t *__r
 #pragma unroll
 	for (uint32_t t = 0; t < PAIR_IG; t++) acc_h[t] = acc_s[t] = 0;
 
-	for (uint32_t w = w0; w < w1; w++) {
+	uint32_t w = w0;
+	for (; w < w1; w++) {
 		const size_t row = (size_t)w * P.Npad;
 		const uint32_t vj = pV[row + j], aj = p0[row + j], bj = p1[row + j];
 		uint32_t dj = 0, gj = 0;
@@ -236,6 +237,24 @@ __global__ __launch_bounds__(64) void pairs_kernel(Pileup P, const uint32_t *__r
 			}
 		}
 	}
+}
+
+// tallies are accumulated for i<j only; mirror them so the matrices leave symmetric
+__global__ __launch_bounds__(256) void symmetrise_kernel(uint32_t N, unsigned long long *__restrict__ a,
+														  unsigned long long *__restrict__ b)
+{
+	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= (uint64_t)N * N) return;
+	const uint32_t i = (uint32_t)(t / N), j = (uint32_t)(t % N);
+	if (i > j) {
+		a[t] = a[(size_t)j * N + i];
+		b[t] = b[(size_t)j * N + i];
+	}
+}
+void launch_symmetrise(uint32_t N, unsigned long long *a, unsigned long long *b, hipStream_t st)
+{
+	uint64_t n = (uint64_t)N * N;
+	if (n) hipLaunchKernelGGL(symmetrise_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, N, a, b);
 }
 
 void launch_project(const Pileup &P, const uint8_t *gbase, const uint64_t *goff, const DevHom *homs,
