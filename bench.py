@@ -127,6 +127,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=63, help="queries in the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernels with HIP events")
     ap.add_argument("--check", action="store_true", help="verify a sample of the result against the oracle")
+    ap.add_argument("--chunk", type=int, default=0, help="dev: force the phase-A chunk length")
+    ap.add_argument("--emulate-rank", default="", help="dev: R/N — time rank R of N's share of the work on this one GPU "
+                    "(no collectives; the printed value is NOT a bench result)")
     args = ap.parse_args()
 
     import torch
@@ -156,6 +159,8 @@ def main():
 
     ctx = api.Context(local)
     ctx.set_option("profile", 0 if args.no_profile else 1)
+    if args.chunk:
+        ctx.set_option("chunk", args.chunk)
     ctx.set_genomes_device(buf.data_ptr(), offs, lens)
     t_ref = time.time()
     ctx.set_reference(ref_idx)  # host suffix array + tables: outside the metric
@@ -163,8 +168,20 @@ def main():
     ref_stats = {k: ctx.stat(k) for k in ("ms:ref_suffix_array", "ms:ref_lcp_table", "ms:ref_total")}
     total_bases = float(sum(lens))
 
+    emu = None
+    if args.emulate_rank:
+        er, en = (int(x) for x in args.emulate_rank.split("/"))
+        emu = (er, en)
+
     def step():
+        if emu:
+            bounds = [dist.query_shard(n, r, emu[1], lens)[0] for r in range(emu[1])] + [n]
+            ctx.anchor(bounds[emu[0]], bounds[emu[0] + 1])
+            return ctx.compare(emu[0], emu[1])
         return dist.process_sharded(ctx, ref_idx, rank, world, device=device, lengths=lens, set_reference=False)
+
+    if emu:  # the other ranks' lists must exist for the projection: compute them once, untimed
+        ctx.anchor(0, n)
 
     for _ in range(args.warmup):
         s, h = step()

@@ -241,6 +241,12 @@ struct FoldShared {
 	const Anchor *seg_ptr[FOLD_SEGS];
 	uint32_t seg_off[FOLD_SEGS + 1];
 	uint32_t nseg, next_gc, next_idx, finished;
+	// chain walk by pointer doubling: node FOLD_WCH.. = "left the window"
+	uint16_t jump[11][FOLD_WCH + 1]; // jump[k][t] = node reached from t after 2^k links
+	uint16_t dist[FOLD_WCH + 1];     // links from t until the window is left
+	uint16_t path[FOLD_WCH];         // live chunks in chain order
+	uint8_t live[FOLD_WCH + 1];
+	uint32_t scan_s[4], scan_a[4];
 	// per-iteration exchange between the four waves
 	uint32_t wl_q[4], wl_s[4], wl_len[4], wl_r[4]; // last anchor of each wave and its right flag
 	uint32_t st_has[4], st_s[4], st_q[4];          // latest non-right anchor of each wave
@@ -277,97 +283,140 @@ __global__ __launch_bounds__(256) void fold_kernel(PhaseA A, uint32_t nq, uint32
 			sh.scnt[t] = A.spec_cnt[wbeg + t];
 		}
 		__syncthreads();
-		// (2) walk, by wave 0.  Runs of chunks whose bridge merges into the very next
-		// chunk (the common case) are taken 64 at a time: a ballot gives the run
-		// length, wave prefix sums give every chunk its segment slots and anchor
-		// offsets.  A chunk with an irregular link (skip, end) or an overflow bridge
-		// is then stepped alone.  All lanes keep the same (g, ix, ns, off).
-		if (wave == 0) {
-			uint32_t ns = 0, off = 0, g = gc, ix = idx, fin = 0;
-			for (;;) {
-				if (g - wbeg >= wn || ns + 140 > FOLD_SEGS) break; // next window
-				// ── parallel part ──
-				const uint32_t t = g - wbeg + lane;
-				const bool inw = t < wn;
-				const uint32_t my_tgt = inw ? sh.tgt[t] : 0u, my_idxm = inw ? sh.idxm[t] : 0u;
-				const uint32_t my_bn = inw ? sh.bn[t] : 0u, my_scnt = inw ? sh.scnt[t] : 0u;
-				const bool ok = inw && my_tgt == wbeg + t + 1 && my_bn <= BRIDGE_INLINE;
-				const uint64_t okm = __ballot(ok);
-				const uint32_t r = ~okm ? (uint32_t)__ffsll((unsigned long long)~okm) - 1u : 64u; // leading ok lanes
-				if (r) {
-					uint32_t idx_in = (uint32_t)__shfl_up((int)my_idxm, 1, 64);
-					if (lane == 0) idx_in = ix;
-					const bool mine = lane < r;
-					const uint32_t spec_n = (mine && my_scnt > idx_in) ? my_scnt - idx_in : 0u;
-					const uint32_t br_n = mine ? my_bn : 0u;
-					uint32_t segs = (spec_n ? 1u : 0u) + (br_n ? 1u : 0u), anch = spec_n + br_n;
-					uint32_t ps = segs, pa = anch; // inclusive wave scans
-#pragma unroll
-					for (int d = 1; d < 64; d <<= 1) {
-						uint32_t a1 = (uint32_t)__shfl_up((int)ps, d, 64), a2 = (uint32_t)__shfl_up((int)pa, d, 64);
-						if ((int)lane >= d) {
-							ps += a1;
-							pa += a2;
-						}
-					}
-					uint32_t slot = ns + ps - segs, o = off + pa - anch;
-					if (spec_n) {
-						sh.seg_ptr[slot] = A.spec_anchors + (size_t)(wbeg + t) * A.cap + idx_in;
-						sh.seg_off[slot] = o;
-						slot++;
-						o += spec_n;
-					}
-					if (br_n) {
-						sh.seg_ptr[slot] = A.bridge[wbeg + t].a;
-						sh.seg_off[slot] = o;
-					}
-					ns += (uint32_t)__shfl((int)ps, 63, 64);
-					off += (uint32_t)__shfl((int)pa, 63, 64);
-					ix = (uint32_t)__shfl((int)my_idxm, (int)r - 1, 64);
-					g += r;
-					if (g - wbeg >= wn) break;
+		// (2) walk.  Every chunk has one outgoing link (its bridge's merge target), so the
+		// true chain inside the window is found without following it link by link:
+		//   jump[k][t]  by doubling;  dist[t] = number of links until the window is left;
+		//   a chunk is live iff it is reached from the entry chunk — marked level by
+		//   level (live ∪= jump[k](live), k = 10..0);  its position in the chain is
+		//   dist[entry] - dist[t].
+		// Then block-wide prefix sums over the chain give every live chunk its segment
+		// slots and anchor offsets.
+		const uint32_t SINK = wn; // any node >= wn means "outside the window"
+		for (uint32_t t = tid; t <= wn; t += 256) {
+			uint32_t nx = SINK;
+			if (t < wn) {
+				uint32_t tg = sh.tgt[t];
+				if (tg != BRIDGE_END && tg - wbeg < wn) nx = tg - wbeg;
+			}
+			sh.jump[0][t] = (uint16_t)nx;
+			sh.dist[t] = t < wn ? 1 : 0;
+			sh.live[t] = 0;
+		}
+		__syncthreads();
+		for (uint32_t k = 0; k < 10; k++) {
+			uint32_t nd[5], nj[5], c = 0;
+			for (uint32_t t = tid; t <= wn; t += 256, c++) {
+				uint32_t jt = sh.jump[k][t];
+				nd[c] = (uint32_t)sh.dist[t] + (uint32_t)sh.dist[jt];
+				nj[c] = sh.jump[k][jt];
+			}
+			__syncthreads();
+			c = 0;
+			for (uint32_t t = tid; t <= wn; t += 256, c++) {
+				sh.dist[t] = (uint16_t)nd[c];
+				sh.jump[k + 1][t] = (uint16_t)nj[c];
+			}
+			__syncthreads();
+		}
+		const uint32_t entry = gc - wbeg;
+		if (tid == 0) sh.live[entry] = 1;
+		__syncthreads();
+		for (int k = 10; k >= 0; k--) {
+			for (uint32_t t = tid; t < wn; t += 256)
+				if (sh.live[t]) {
+					uint32_t jt = sh.jump[k][t];
+					if (jt < wn) sh.live[jt] = 1;
 				}
-				if (r == 64) continue;
-				// ── one chunk with an irregular link or an overflow bridge (uniform code) ──
-				{
-					const uint32_t tt = g - wbeg;
-					const uint32_t n_spec = sh.scnt[tt];
-					if (n_spec > ix) {
-						sh.seg_ptr[ns] = A.spec_anchors + (size_t)g * A.cap + ix;
-						sh.seg_off[ns++] = off;
-						off += n_spec - ix;
+			__syncthreads();
+		}
+		const uint32_t npath = sh.dist[entry]; // live chunks in this window
+		for (uint32_t t = tid; t < wn; t += 256)
+			if (sh.live[t]) sh.path[npath - sh.dist[t]] = (uint16_t)t;
+		__syncthreads();
+		// segments: every thread takes 4 consecutive chain positions
+		{
+			uint32_t my_seg[4], my_an[4], my_spec[4], my_idx[4];
+			uint32_t ssum = 0, asum = 0;
+#pragma unroll
+			for (uint32_t e = 0; e < 4; e++) {
+				const uint32_t pz = tid * 4 + e;
+				my_seg[e] = my_an[e] = my_spec[e] = my_idx[e] = 0;
+				if (pz < npath) {
+					const uint32_t t = sh.path[pz];
+					const uint32_t idx_in = pz == 0 ? idx : sh.idxm[sh.path[pz - 1]];
+					const uint32_t sc = sh.scnt[t], b_n = sh.bn[t];
+					const uint32_t spec_n = sc > idx_in ? sc - idx_in : 0u;
+					const uint32_t nblk = b_n > BRIDGE_INLINE ? (b_n - BRIDGE_INLINE + POOL_BLOCK - 1) / POOL_BLOCK : 0u;
+					my_idx[e] = idx_in;
+					my_spec[e] = spec_n;
+					my_seg[e] = (spec_n ? 1u : 0u) + (b_n ? 1u : 0u) + nblk;
+					my_an[e] = spec_n + b_n;
+				}
+				ssum += my_seg[e];
+				asum += my_an[e];
+			}
+			// exclusive block scan of (ssum, asum)
+			uint32_t ps = ssum, pa = asum;
+#pragma unroll
+			for (int dd = 1; dd < 64; dd <<= 1) {
+				uint32_t a1 = (uint32_t)__shfl_up((int)ps, dd, 64), a2 = (uint32_t)__shfl_up((int)pa, dd, 64);
+				if ((int)lane >= dd) {
+					ps += a1;
+					pa += a2;
+				}
+			}
+			if (lane == 63) {
+				sh.scan_s[wave] = ps;
+				sh.scan_a[wave] = pa;
+			}
+			__syncthreads();
+			uint32_t bs = 0, ba = 0;
+			for (uint32_t w2 = 0; w2 < wave; w2++) {
+				bs += sh.scan_s[w2];
+				ba += sh.scan_a[w2];
+			}
+			const uint32_t tot_s = sh.scan_s[0] + sh.scan_s[1] + sh.scan_s[2] + sh.scan_s[3];
+			const uint32_t tot_a = sh.scan_a[0] + sh.scan_a[1] + sh.scan_a[2] + sh.scan_a[3];
+			uint32_t slot = bs + ps - ssum, off = ba + pa - asum;
+			if (tot_s > FOLD_SEGS) {
+				if (tid == 0) *A.error = 4; // more anchor segments than a window's list holds
+			} else {
+#pragma unroll
+				for (uint32_t e = 0; e < 4; e++) {
+					const uint32_t pz = tid * 4 + e;
+					if (pz >= npath) break;
+					const uint32_t t = sh.path[pz], g = wbeg + t;
+					if (my_spec[e]) {
+						sh.seg_ptr[slot] = A.spec_anchors + (size_t)g * A.cap + my_idx[e];
+						sh.seg_off[slot++] = off;
+						off += my_spec[e];
 					}
-					uint32_t b_n = sh.bn[tt];
+					uint32_t b_n = sh.bn[t];
 					if (b_n) {
 						uint32_t m = b_n < BRIDGE_INLINE ? b_n : BRIDGE_INLINE;
-						sh.seg_ptr[ns] = A.bridge[g].a;
-						sh.seg_off[ns++] = off;
+						sh.seg_ptr[slot] = A.bridge[g].a;
+						sh.seg_off[slot++] = off;
 						off += m;
-						uint32_t left = b_n - m, bk = sh.blk[tt];
-						while (left && bk != NO_BLOCK && ns + 2 <= FOLD_SEGS) {
+						uint32_t left = b_n - m, bk = sh.blk[t];
+						while (left && bk != NO_BLOCK) {
 							uint32_t mm = left < POOL_BLOCK ? left : POOL_BLOCK;
-							sh.seg_ptr[ns] = A.pool[bk].a;
-							sh.seg_off[ns++] = off;
+							sh.seg_ptr[slot] = A.pool[bk].a;
+							sh.seg_off[slot++] = off;
 							off += mm;
 							left -= mm;
 							bk = A.pool[bk].next;
 						}
-						if (left) *A.error = 4; // a bridge longer than a window's segment list
 					}
-					if (sh.tgt[tt] == BRIDGE_END) {
-						fin = 1;
-						break;
-					}
-					ix = sh.idxm[tt];
-					g = sh.tgt[tt];
 				}
 			}
-			if (lane == 0) {
-				sh.seg_off[ns] = off;
-				sh.nseg = ns;
-				sh.next_gc = g;
-				sh.next_idx = ix;
-				sh.finished = fin;
+			if (tid == 0) {
+				const uint32_t last = sh.path[npath - 1];
+				const uint32_t tg = sh.tgt[last];
+				sh.nseg = tot_s > FOLD_SEGS ? 0 : tot_s;
+				sh.seg_off[sh.nseg] = tot_s > FOLD_SEGS ? 0 : tot_a;
+				sh.finished = (tg == BRIDGE_END || tot_s > FOLD_SEGS) ? 1u : 0u;
+				sh.next_gc = tg;
+				sh.next_idx = sh.idxm[last];
 			}
 		}
 		__syncthreads();

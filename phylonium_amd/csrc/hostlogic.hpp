@@ -449,9 +449,11 @@ static inline ChunkPlan plan_chunks(const std::vector<uint32_t> &qlen, uint32_t 
 	for (uint32_t l : qlen) total += l;
 	uint32_t C = forced_C;
 	if (C == 0) {
-		// aim for ~512k chains, 512 <= C <= 8192
-		C = 512;
-		while (C < 8192 && total / C > 512 * 1024) C <<= 1;
+		// ~one chunk per resident lane (256 CUs x 16 waves x 64): fewer leaves lanes idle,
+		// more only adds bridge and fold work.  Measured on C3 and on 1/8 of it: 4096 and
+		// 1024 are the respective optima, 512 never is.
+		C = 1024;
+		while (C < 8192 && total / C > 320 * 1024) C <<= 1;
 	}
 	while (C <= 2 * threshold + 32) C <<= 1; // chunk starts must be lucky-ineligible from (0,0,0)
 	P.C = C;

@@ -1030,11 +1030,14 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 	if (!tiles.empty() && P.W) {
 		HIPOK(c, c->b_tiles.ensure(tiles.size()));
 		HIPOK(c, hipMemcpyAsync(c->b_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, st));
-		// window chunks whose plane rows (3 or 5 planes x Npad x 4 B per window) fit an
-		// XCD's 4 MiB L2 with room to spare, but at least 64 windows
+		// window chunks: small enough that a chunk's plane rows (3 or 5 planes x Npad x 4 B
+		// per window) fit an XCD's 4 MiB L2 with room to spare, and small enough that
+		// tiles x chunks fills the chip several times over; at least 64 windows
 		uint32_t row_bytes = (flag ? 5u : 3u) * P.Npad * 4u;
-		uint32_t wchunk = std::max<uint32_t>(64, (3u << 20) / row_bytes);
-		wchunk = std::min<uint32_t>(wchunk, std::max<uint32_t>(64, P.W));
+		uint32_t l2_fit = std::max<uint32_t>(64, (3u << 20) / row_bytes);
+		uint32_t want_chunks = std::max<uint32_t>(1, ((uint32_t)c->n_cu * 32u) / (uint32_t)tiles.size());
+		uint32_t wchunk = std::max<uint32_t>(64, (P.W + want_chunks - 1) / want_chunks);
+		wchunk = std::min(wchunk, l2_fit);
 		{
 			KernelSpan s(c, flag ? "pileup_pairs_bang" : "pileup_pairs");
 			launch_pairs(P, flag != 0, c->b_tiles.p, (uint32_t)tiles.size(), wchunk, c->b_subst.p, c->b_homologs.p, st);
