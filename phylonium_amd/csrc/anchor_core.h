@@ -42,12 +42,9 @@ struct RefIndex {
 	const U4 *SAX;       // n records (+4 pad), one per rank: see sax_record()
 	const uint32_t *LCP; // n+1 entries (+4 pad); LCP[r] = lcp(suffix SA[r-1], suffix SA[r]); LCP[0]=LCP[n]=0
 	const U4 *SLOT;      // 4^k slots of 8 records (one 128-byte line each): see SLOT_RECS
-	const uint32_t *T;   // host/emulation only: 4^k+1 entries; T[c] = #suffixes lexicographically < k-mer c
 	uint32_t n;          // |S| = 2L+1
 	uint32_t k;          // bucket k-mer length (1..14)
 	uint32_t threshold;  // minimum anchor length
-	uint32_t dbg;        // timing-only ablations (results are wrong when nonzero): 1 slot reads hit one page,
-						 // 2 lucky windows hit one page, 4 extension reads hit one page
 };
 
 struct Anchor {
@@ -147,29 +144,18 @@ static const uint32_t SLOT_RECS = 8;
 PHY_HD uint32_t packed_cmp(uint32_t qcode, uint32_t qv, uint32_t n, uint32_t pre, uint32_t sv, uint32_t *len,
 						   uint32_t *less)
 {
-	uint32_t x = qcode ^ pre;
-	uint32_t d = x ? (clz32(x) >> 1) : 16u;
-	uint32_t m = qv < sv ? qv : sv;
-	if (d < m) {
-		uint32_t sh = 30u - 2u * d;
-		*len = d;
-		*less = ((pre >> sh) & 3u) < ((qcode >> sh) & 3u) ? 1u : 0u;
-		return 0;
-	}
-	if (m == 16) {
-		if (n <= 16) {
-			*len = n;
-			*less = 0;
-			return 0;
-		}
-		return 1;
-	}
-	if (qv == m && n == m) { // the query ends here
-		*len = n;
-		*less = 0;
-		return 0;
-	}
-	return 2;
+	// written with selects, not branches: on the GPU every divergent `if` costs
+	// scalar exec-mask instructions, and the CU has one scalar unit for all its waves
+	const uint32_t x = qcode ^ pre;
+	const uint32_t d = x ? (clz32(x) >> 1) : 16u;
+	const uint32_t m = qv < sv ? qv : sv;
+	const uint32_t sh = 30u - 2u * (d < 15u ? d : 15u);
+	const bool mism = d < m;
+	const bool full = !mism && m == 16u;                        // 16 bytes equal
+	const bool qend = !mism && n == m && (m == 16u || qv == m); // the query ends inside the window
+	*len = mism ? d : n;
+	*less = (mism && ((pre >> sh) & 3u) < ((qcode >> sh) & 3u)) ? 1u : 0u;
+	return (mism || qend) ? 0u : (full ? 1u : 2u);
 }
 
 PHY_HD uint32_t sel4(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t i)
@@ -180,12 +166,9 @@ PHY_HD uint32_t sel4(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_
 // index of the first differing byte of two 16-byte windows, 16 if equal
 PHY_HD uint32_t first_diff(const U4 &a, const U4 &b)
 {
-	uint32_t x;
-	if ((x = a.x ^ b.x)) return ctz32(x) >> 3;
-	if ((x = a.y ^ b.y)) return 4u + (ctz32(x) >> 3);
-	if ((x = a.z ^ b.z)) return 8u + (ctz32(x) >> 3);
-	if ((x = a.w ^ b.w)) return 12u + (ctz32(x) >> 3);
-	return 16u;
+	const uint32_t x0 = a.x ^ b.x, x1 = a.y ^ b.y, x2 = a.z ^ b.z, x3 = a.w ^ b.w;
+	return x0 ? (ctz32(x0) >> 3)
+			  : x1 ? 4u + (ctz32(x1) >> 3) : x2 ? 8u + (ctz32(x2) >> 3) : x3 ? 12u + (ctz32(x3) >> 3) : 16u;
 }
 
 // The query is followed by zero padding and S by zero padding, and query bytes
@@ -196,7 +179,6 @@ PHY_HD uint32_t first_diff(const U4 &a, const U4 &b)
 enum ChainState : uint32_t {
 	ST_STEP = 0, // load the query window (and the lucky window)
 	ST_T,        // load the k-mer's slot: bucket bounds + the records around it
-	ST_SA,       // (unused)
 	ST_CAND,     // load the windows of up to four candidate suffixes
 	ST_EXT,      // extend one comparison by 32 bytes
 	ST_FIN,      // decide; maybe load LCP[best], LCP[best+1]
@@ -283,11 +265,9 @@ struct Chain {
 		r_s = pos;
 		r_len = len;
 		r_accepted = accepted;
-		if (accepted) { // process.cxx:275-277
-			lq = q;
-			ls = pos;
-			ll = len;
-		}
+		lq = accepted ? q : lq; // process.cxx:275-277
+		ls = accepted ? pos : ls;
+		ll = accepted ? len : ll;
 		q += len + 1; // process.cxx:281
 		st = ST_STEP;
 		fin = true;
@@ -296,20 +276,14 @@ struct Chain {
 	// compare a 16-byte subject window with the query window; true when decided
 	PHY_HD bool window_cmp(const U4 &sw, uint32_t *len, uint32_t *less) const
 	{
-		uint32_t n = qlen - q;
-		uint32_t m = n < 16 ? n : 16;
-		uint32_t d = first_diff(qc, sw);
-		if (d < m) {
-			*len = d;
-			*less = byte_at(sw, d) < byte_at(qc, d) ? 1u : 0u;
-			return true;
-		}
-		if (n <= 16) {
-			*len = n;
-			*less = 0;
-			return true;
-		}
-		return false;
+		const uint32_t n = qlen - q;
+		const uint32_t m = n < 16 ? n : 16;
+		const uint32_t d = first_diff(qc, sw);
+		const uint32_t di = d < 15u ? d : 15u;
+		const bool mism = d < m;
+		*len = mism ? d : n;
+		*less = (mism && byte_at(sw, di) < byte_at(qc, di)) ? 1u : 0u;
+		return mism || n <= 16;
 	}
 
 	PHY_HD void start_ext(uint32_t kind, uint32_t idx, uint32_t p)
@@ -339,17 +313,12 @@ struct Chain {
 
 	PHY_HD void begin_search(const RefIndex &R)
 	{
-		flags = 0;
+		const bool kv = qv >= R.k;
+		flags = kv ? 4u : 0u;
 		l_lo = l_hi = 0;
-		if (qv >= R.k) {
-			lo = qcode >> (2u * (16u - R.k)); // phase T reads T[code], T[code+1]
-			flags = 4u;
-			st = ST_T;
-		} else {
-			lo = 0;
-			hi = R.n;
-			st = ST_BS;
-		}
+		lo = kv ? (qcode >> (2u * (16u - R.k))) : 0u; // phase T reads the slot of this code
+		hi = R.n;
+		st = kv ? ST_T : ST_BS;
 	}
 
 	// all candidates compared (or one more needs extending)
@@ -360,26 +329,20 @@ struct Chain {
 			start_ext(EXT_CAND, i, cpos(i));
 			return;
 		}
-		// insertion point: bucket members smaller than the query come first
-		uint32_t ins = lo;
-		while (ins < hi && ((c_less >> (ins - c_rank0)) & 1u)) ins++;
-		uint32_t a = 0, b = 0, c = 0, d = 0, e = 0, f = 0;
-		if (ins > c_rank0) {
-			a = clen(ins - 1 - c_rank0);
-			b = cpos(ins - 1 - c_rank0);
-			e = sel4(c_lcp0, c_lcp1, c_lcp2, c_lcp3, ins - 1 - c_rank0);
-		}
-		if (ins < R.n) {
-			c = clen(ins - c_rank0);
-			d = cpos(ins - c_rank0);
-			f = sel4(c_lcp0, c_lcp1, c_lcp2, c_lcp3, ins - c_rank0);
-		}
-		lp = a;
-		pp = b;
-		lsu = c;
-		psu = d;
-		lcp_p = e;
-		lcp_s = f;
+		// insertion point: bucket members (at most two on this path) smaller than the
+		// query come first
+		const uint32_t o = lo - c_rank0;
+		const uint32_t s0 = (lo < hi) ? ((c_less >> o) & 1u) : 0u;
+		const uint32_t s1 = (lo + 1 < hi) ? (s0 & (c_less >> (o + 1)) & 1u) : 0u;
+		const uint32_t ins = lo + s0 + s1;
+		const bool hasp = ins > c_rank0, hass = ins < R.n;
+		const uint32_t ip = hasp ? ins - 1 - c_rank0 : 0u, is = hass ? ins - c_rank0 : 0u;
+		lp = hasp ? clen(ip) : 0u;
+		pp = hasp ? cpos(ip) : 0u;
+		lcp_p = hasp ? sel4(c_lcp0, c_lcp1, c_lcp2, c_lcp3, ip) : 0u;
+		lsu = hass ? clen(is) : 0u;
+		psu = hass ? cpos(is) : 0u;
+		lcp_s = hass ? sel4(c_lcp0, c_lcp1, c_lcp2, c_lcp3, is) : 0u;
 		lo = hi = ins;
 		st = ST_FIN;
 	}
@@ -422,14 +385,14 @@ struct Chain {
 	}
 	PHY_HD void post_step(const RefIndex &R, const U4 &sw)
 	{
-		if (lucky_ok(R)) {
-			uint32_t len, less;
-			e_p = ls + (q - lq);
-			if (window_cmp(sw, &len, &less)) lucky_done(R, len);
-			else start_ext(EXT_LUCKY, 0, e_p);
-			return;
-		}
-		begin_search(R);
+		const bool lucky = lucky_ok(R);
+		uint32_t len, less;
+		const bool decided = window_cmp(sw, &len, &less);
+		const uint32_t try_s = ls + (q - lq);
+		begin_search(R); // the default outcome; overridden below
+		if (lucky && !decided) start_ext(EXT_LUCKY, 0, try_s);
+		e_p = lucky ? try_s : e_p;
+		if (lucky && decided && len >= R.threshold) finish_step(try_s, len, true); // process.cxx:241
 	}
 	PHY_HD void consume_step(const RefIndex &R, const U4 &qw, const U4 &sw)
 	{
@@ -462,24 +425,20 @@ struct Chain {
 	}
 
 	// ── phase SA: the records of the bucket's predecessor, members, successor ──
-	PHY_HD const uint8_t *issue_SA(const RefIndex &R) const { return (const uint8_t *)(R.SAX + c_rank0); }
-	PHY_HD void take_record(uint32_t i, const U4 &r, uint32_t n)
+	// one candidate record against the query window; `on` = the candidate exists
+	PHY_HD void take_record(uint32_t i, const U4 &r, uint32_t n, bool on, uint32_t *clen_i)
 	{
 		uint32_t len = 0, less = 0;
-		uint32_t k = packed_cmp(qcode, qv, n, r.y, r.z, &len, &less);
-		if (k == 0) {
-			set_len(i, len);
-			c_less |= less << i;
-		} else if (k == 1) {
-			c_pending |= 1u << i;
-		} else {
-			c_raw |= 1u << i;
-		}
+		const uint32_t k = packed_cmp(qcode, qv, n, r.y, r.z, &len, &less);
+		*clen_i = len;
+		c_less |= ((on && k == 0u) ? less : 0u) << i;
+		c_pending |= ((on && k == 1u) ? 1u : 0u) << i;
+		c_raw |= ((on && k == 2u) ? 1u : 0u) << i;
 	}
 	PHY_HD void consume_SA(const RefIndex &R, const Data &d)
 	{
-		uint32_t last = hi < R.n ? hi : R.n - 1;
-		uint32_t n = qlen - q;
+		const uint32_t last = hi < R.n ? hi : R.n - 1;
+		const uint32_t n = qlen - q;
 		c_n = last - c_rank0 + 1;
 		c_pos0 = d.w[0].x;
 		c_pos1 = d.w[1].x;
@@ -490,10 +449,10 @@ struct Chain {
 		c_lcp2 = d.w[2].w;
 		c_lcp3 = d.w[3].w;
 		c_pending = c_less = c_raw = 0;
-		take_record(0, d.w[0], n);
-		if (c_n > 1) take_record(1, d.w[1], n);
-		if (c_n > 2) take_record(2, d.w[2], n);
-		if (c_n > 3) take_record(3, d.w[3], n);
+		take_record(0, d.w[0], n, true, &c_len0);
+		take_record(1, d.w[1], n, c_n > 1, &c_len1);
+		take_record(2, d.w[2], n, c_n > 2, &c_len2);
+		take_record(3, d.w[3], n, c_n > 3, &c_len3);
 		if (c_raw) st = ST_CAND; // rare: a '!' / '#' / end of S inside a window
 		else cand_next(R);
 	}
@@ -673,14 +632,12 @@ struct Chain {
 	// the full LCP array has to be read.
 	PHY_HD bool fin_needs_lcp(const RefIndex &R)
 	{
-		uint32_t lmax = lp > lsu ? lp : lsu;
-		if (lp == lsu || lmax < R.threshold) {
-			finish_step(0, lmax, false);
-			return false;
-		}
-		uint32_t l = lp > lsu ? (lcp_p & 0xffffu) : (lcp_s >> 16);
-		if (l == 0xffffu && lmax >= 0xffffu) return true;
-		finish_step(lp > lsu ? pp : psu, lmax, l < lmax);
+		const uint32_t lmax = lp > lsu ? lp : lsu;
+		const bool pbest = lp > lsu;
+		const uint32_t l = pbest ? (lcp_p & 0xffffu) : (lcp_s >> 16);
+		const bool cand = lp != lsu && lmax >= R.threshold;
+		if (cand && l == 0xffffu && lmax >= 0xffffu) return true; // clipped: read the full LCP array
+		finish_step(pbest ? pp : psu, lmax, cand && l < lmax);
 		return false;
 	}
 	PHY_HD const uint8_t *issue_lcp(const RefIndex &R) const
@@ -835,14 +792,14 @@ struct SpecLane {
 		ch.reset(A.qbase + A.qoff[j], ql, q0, 0, 0, 0);
 		cnt = 0;
 		vis_word = 0;
-		vis_idx = NO_BLOCK;
+		vis_idx = chunk * (A.C >> 5); // the chunk's first bitmap word
 	}
 
 	// Called when ch.st == ST_STEP. Returns false when the chunk is finished.
 	PHY_HD bool begin_step(const PhaseA &A)
 	{
 		if (ch.q >= q_end) {
-			if (vis_idx != NO_BLOCK) A.visited[vis_idx] = vis_word;
+			A.visited[vis_idx] = vis_word;
 			A.spec_cnt[gc] = cnt;
 			SpecExit x = {ch.q, ch.lq, ch.ls, ch.ll};
 			A.spec_exit[gc] = x;
@@ -850,8 +807,8 @@ struct SpecLane {
 		}
 		uint32_t local = ch.q & (A.C - 1);
 		uint32_t w = gc * (A.C >> 5) + (local >> 5);
-		if (w != vis_idx) {
-			if (vis_idx != NO_BLOCK) A.visited[vis_idx] = vis_word;
+		if (w != vis_idx) { // positions only grow: the previous word is complete
+			A.visited[vis_idx] = vis_word;
 			vis_idx = w;
 			vis_word = 0;
 		}

@@ -11,8 +11,6 @@
 // Σ|Q| + 26·|S|.
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-
 #include "anchor_core.h"
 #include "kernels.h"
 
@@ -66,6 +64,7 @@ static __device__ __forceinline__ void coop_compare(const uint8_t *qp, const uin
 }
 
 static const uint32_t QRING_BYTES = 128;
+static const int CHAIN_SUBTRIPS = 2;
 
 struct DevAlloc {
 	const PhaseA *A;
@@ -96,81 +95,88 @@ template <int MODE> __global__ __launch_bounds__(256) void chain_kernel(PhaseA A
 	uint32_t wbase = 0;
 
 	for (;;) {
-		while (!done) {
+		// Two sub-trips of the common path (finish the previous step, start the next:
+		// STEP + T + FIN) per loop trip, so the rarer phases below (CAND, GEN, EXT) and
+		// their divergence cost are paid once per two steps.
+#pragma nounroll
+		for (int sub = 0; sub < CHAIN_SUBTRIPS; sub++) {
+			// finish the previous step, start the next one or the next chunk — straight-line
+			// code (no loop): a finished lane picks up its next chunk now and steps it below
 			if (active && ch.fin) {
 				if constexpr (MODE == 0) ln.step_done(A);
 				else ln.step_done(A, alloc);
 				ch.fin = false;
 			}
-			if (!active) {
-				uint32_t it = atomicAdd(&A.fetch[MODE], 1u);
-				if (it >= A.nchunks) {
-					done = true;
-					break;
-				}
-				ln.start(A, A.items[it]);
-				active = true;
-				wbase = 0xffffff00u; // force a refill
-			}
-			if (ch.st == ST_STEP) {
+			if (active && ch.st == ST_STEP) {
 				bool go;
 				if constexpr (MODE == 0) go = ln.begin_step(A);
 				else go = ln.begin_step(A, R);
-				if (!go) {
-					active = false;
-					continue;
+				active = go;
+			}
+			if (!active && !done) {
+				uint32_t it = atomicAdd(&A.fetch[MODE], 1u);
+				done = it >= A.nchunks;
+				if (!done) {
+					ln.start(A, A.items[it]);
+					wbase = 0xffffff00u; // force a refill of the query ring
+					bool go;
+					if constexpr (MODE == 0) go = ln.begin_step(A);
+					else go = ln.begin_step(A, R);
+					active = go;
 				}
 			}
-			break;
+			const bool live = active;
+			// ── STEP + T: query window from the lane's LDS ring; the lucky window and the
+			//    k-mer's slot line are fetched together, one memory hop for both ──
+			{
+				const bool stp = live && ch.st == ST_STEP;
+				if (stp && (ch.q < wbase || ch.q + 16u > wbase + QRING_BYTES)) {
+					wbase = ch.q & ~15u;
+					const uint8_t *src = ch.Q + wbase;
+	#pragma unroll
+					for (uint32_t sl = 0; sl < QRING_BYTES / 16; sl++) {
+						U4 v = load16(src + 16 * sl);
+						qring[4 * sl + 0][threadIdx.x] = v.x;
+						qring[4 * sl + 1][threadIdx.x] = v.y;
+						qring[4 * sl + 2][threadIdx.x] = v.z;
+						qring[4 * sl + 3][threadIdx.x] = v.w;
+					}
+				}
+				if (stp) {
+					const uint32_t p = ch.q - wbase, i0 = p >> 2, sh = p & 3u;
+					const uint32_t d0 = qring[i0][threadIdx.x], d1 = qring[i0 + 1][threadIdx.x],
+								   d2 = qring[i0 + 2][threadIdx.x], d3 = qring[i0 + 3][threadIdx.x],
+								   d4 = qring[i0 + 4][threadIdx.x];
+					U4 qw;
+					qw.x = __builtin_amdgcn_alignbyte(d1, d0, sh);
+					qw.y = __builtin_amdgcn_alignbyte(d2, d1, sh);
+					qw.z = __builtin_amdgcn_alignbyte(d3, d2, sh);
+					qw.w = __builtin_amdgcn_alignbyte(d4, d3, sh);
+					ch.pre_step(qw);
+					const uint8_t *a0, *a1 = nullptr;
+					const uint32_t nl = ch.issue_step(R, &a0, &a1);
+					const uint8_t *sa = ch.slot_of_window(R);
+					U4 sw = {0, 0, 0, 0}, hdr = {0, 0, 0, 0};
+					Data d;
+					d.w[0] = d.w[1] = d.w[2] = d.w[3] = sw;
+					if (nl > 1) sw = load16(a1);
+					if (sa) {
+						hdr = load16(sa);
+						d.w[0] = load16(sa + 16);
+						d.w[1] = load16(sa + 32);
+						d.w[2] = load16(sa + 48);
+						d.w[3] = load16(sa + 64);
+					}
+					ch.post_step(R, sw);
+					if (ch.st == ST_T) ch.consume_T(R, hdr, d); // st == ST_T implies the k-mer was valid, so sa != nullptr
+				}
+			}
+			if (live && ch.st == ST_FIN) {
+				if (ch.fin_needs_lcp(R)) ch.consume_lcp(load16(ch.issue_lcp(R)));
+			}
 		}
-		if (__all(done)) break;
-		const bool live = !done;
-
-		// ── STEP + T: query window from the lane's LDS ring; the lucky window and the
-		//    k-mer's slot line are fetched together, one memory hop for both ──
-		{
-			const bool stp = live && ch.st == ST_STEP;
-			if (stp && (ch.q < wbase || ch.q + 16u > wbase + QRING_BYTES)) {
-				wbase = ch.q & ~15u;
-				const uint8_t *src = ch.Q + wbase;
-#pragma unroll
-				for (uint32_t sl = 0; sl < QRING_BYTES / 16; sl++) {
-					U4 v = load16(src + 16 * sl);
-					qring[4 * sl + 0][threadIdx.x] = v.x;
-					qring[4 * sl + 1][threadIdx.x] = v.y;
-					qring[4 * sl + 2][threadIdx.x] = v.z;
-					qring[4 * sl + 3][threadIdx.x] = v.w;
-				}
-			}
-			if (stp) {
-				const uint32_t p = ch.q - wbase, i0 = p >> 2, sh = p & 3u;
-				const uint32_t d0 = qring[i0][threadIdx.x], d1 = qring[i0 + 1][threadIdx.x],
-							   d2 = qring[i0 + 2][threadIdx.x], d3 = qring[i0 + 3][threadIdx.x],
-							   d4 = qring[i0 + 4][threadIdx.x];
-				U4 qw;
-				qw.x = __builtin_amdgcn_alignbyte(d1, d0, sh);
-				qw.y = __builtin_amdgcn_alignbyte(d2, d1, sh);
-				qw.z = __builtin_amdgcn_alignbyte(d3, d2, sh);
-				qw.w = __builtin_amdgcn_alignbyte(d4, d3, sh);
-				ch.pre_step(qw);
-				const uint8_t *a0, *a1 = nullptr;
-				const uint32_t nl = ch.issue_step(R, &a0, &a1);
-				const uint8_t *sa = ch.slot_of_window(R);
-				U4 sw = {0, 0, 0, 0}, hdr = {0, 0, 0, 0};
-				Data d;
-				d.w[0] = d.w[1] = d.w[2] = d.w[3] = sw;
-				if (nl > 1) sw = load16(a1);
-				if (sa) {
-					hdr = load16(sa);
-					d.w[0] = load16(sa + 16);
-					d.w[1] = load16(sa + 32);
-					d.w[2] = load16(sa + 48);
-					d.w[3] = load16(sa + 64);
-				}
-				ch.post_step(R, sw);
-				if (ch.st == ST_T) ch.consume_T(R, hdr, d); // st == ST_T implies the k-mer was valid, so sa != nullptr
-			}
-		}
+		if (__all(done && !active)) break;
+		const bool live = active;
 		if (live && ch.st == ST_CAND) {
 			Data d;
 			d.w[0] = load16(R.S + ch.c_pos0);
@@ -544,10 +550,6 @@ static int resident_blocks(const void *fn, int n_cu)
 {
 	int per_cu = 0;
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-	if (const char *e = getenv("PHYLO_CHAIN_BLOCKS_PER_CU")) { // experiments only
-		int v = atoi(e);
-		if (v >= 1 && v <= per_cu) per_cu = v;
-	}
 	return per_cu * n_cu;
 }
 

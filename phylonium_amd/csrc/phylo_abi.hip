@@ -731,7 +731,7 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	A.fetch = c->a_misc.p;          // [0] spec, [1] bridge
 	A.pool_next = c->a_misc.p + 2;
 	A.error = c->a_misc.p + 3;
-	RefIndex R = {c->d_S.p, c->d_SAX.p, c->d_LCP.p, c->d_SLOT.p, nullptr, c->ns, c->k, c->threshold, getenv("PHYLO_DBG") ? (uint32_t)atoi(getenv("PHYLO_DBG")) : 0u};
+	RefIndex R = {c->d_S.p, c->d_SAX.p, c->d_LCP.p, c->d_SLOT.p, c->ns, c->k, c->threshold};
 
 	double t1 = now_ms();
 	if (nch) {

@@ -67,7 +67,7 @@ void *emul_run(size_t n, const char *const *seq, const size_t *len, size_t ref_i
 	build_sax(S.data(), ns, SA.data(), LCP.data(), SAX);
 	std::vector<U4> SLOT;
 	build_slots(T, SAX, ns, k, SLOT);
-	RefIndex R = {S.data(), SAX.data(), LCP.data(), SLOT.data(), T.data(), ns, k, (uint32_t)threshold, 0};
+	RefIndex R = {S.data(), SAX.data(), LCP.data(), SLOT.data(), ns, k, (uint32_t)threshold};
 	E->threshold = (uint32_t)threshold;
 	E->k = k;
 

@@ -11,4 +11,4 @@ for set in "$@"; do
   i=$((i+1))
   timeout 240 rocprofv3 --kernel-include-regex "phy::" --pmc $set -d $OUT/pmc_$i --output-format csv -- python3 $ROOT/bench.py --workload $WL --steps 1 --warmup 0 --cpu-sample 0 --no-profile > $OUT/p${i}_bench.json 2> $OUT/p$i.err
 done
-python3 $ROOT/tools_prof_summary.py $OUT > $OUT/summary.txt 2>&1
+python3 $ROOT/tools/tools_prof_summary.py $OUT > $OUT/summary.txt 2>&1

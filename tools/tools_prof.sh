@@ -21,4 +21,4 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
   i=$((i+1))
   timeout 240 rocprofv3 $F --pmc $set -d $OUT/pmc_$i --output-format csv -- python3 $ROOT/bench.py --workload $WL --steps 1 --warmup 0 --cpu-sample 0 --no-profile "$@" > $OUT/pmc${i}_bench.json 2> $OUT/pmc$i.err
 done
-python3 $ROOT/tools_prof_summary.py $OUT > $OUT/summary.txt 2>&1; du -sh $OUT
+python3 $ROOT/tools/tools_prof_summary.py $OUT > $OUT/summary.txt 2>&1; du -sh $OUT
