@@ -14,6 +14,13 @@ void launch_bridge(const PhaseA &A, const RefIndex &R, int n_cu, hipStream_t st)
 void launch_fold(const PhaseA &A, uint32_t nq, uint32_t border, uint32_t thr, RawHom *out,
 				 const uint64_t *out_base, const uint32_t *out_cap, uint32_t *out_cnt, hipStream_t st);
 
+// index_kernels.hip
+void launch_lcp(const uint8_t *S, const uint32_t *SA, uint32_t n, uint32_t cap, uint32_t *LCP, uint32_t *capped,
+				hipStream_t st);
+void launch_kmer_table(const uint8_t *S, uint32_t n, uint32_t k, uint32_t *T, uint32_t *scratch_sums, hipStream_t st);
+size_t kmer_table_scratch(uint32_t k);
+void launch_sax(const uint8_t *S, const uint32_t *SA, const uint32_t *LCP, uint32_t n, U4 *SAX, hipStream_t st);
+
 // seqcmp_kernels.hip
 struct Segment {
 	uint64_t a;   // byte offset of the first string in the genome buffer

@@ -184,6 +184,7 @@ struct phylo_ctx {
 	uint32_t L = 0, ns = 0, k = 0, threshold = 0;
 	DevBuf<uint8_t> d_S;
 	DevBuf<U4> d_SAX, d_SLOT;
+	DevBuf<uint32_t> d_SA;
 	DevBuf<uint32_t> d_LCP, d_T;
 
 	// phase A scratch
@@ -368,6 +369,7 @@ void phylo_ctx_destroy(phylo_ctx *c)
 	c->d_S.release();
 	c->d_SAX.release();
 	c->d_SLOT.release();
+	c->d_SA.release();
 	c->d_LCP.release();
 	c->d_T.release();
 	c->a_qoff.release();
@@ -565,7 +567,7 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 	HIPOK(c, hipMemcpy(S.data(), c->d_genomes + c->goff[ref_idx], L, hipMemcpyDeviceToHost));
 	S[L] = '#';
 	revcomp(S.data(), L, S.data() + L + 1);
-	std::vector<uint32_t> SA((size_t)ns + 4, 0), LCP((size_t)ns + 1 + 4, 0), T; // +4: tables are read 16 bytes at a time
+	std::vector<uint32_t> SA((size_t)ns + 4, 0); // +4: tables are read 16 bytes at a time
 	double t1 = now_ms();
 	if (sa) {
 		for (uint32_t i = 0; i < ns; i++) {
@@ -573,34 +575,47 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 			SA[i] = (uint32_t)sa[i];
 		}
 	} else {
-		suffix_array_u32(S.data(), ns, SA.data());
+		suffix_array_u32(S.data(), ns, SA.data()); // host cores (north star); everything below is on the device
 	}
 	double t2 = now_ms();
-	lcp_kasai(S.data(), ns, SA.data(), LCP.data());
 	uint32_t k = c->opt_kmer ? c->opt_kmer : choose_k(ns);
-	kmer_table(S.data(), ns, k, T);
-	T.resize(T.size() + 4, ns);
-	std::vector<U4> SAX;
-	build_sax(S.data(), ns, SA.data(), LCP.data(), SAX);
-	double t3 = now_ms();
 	if (threshold == 0) threshold = min_anchor_length(0.025, gc_content(S.data(), L), ns);
+	const uint64_t codes = (uint64_t)1 << (2 * k);
+	hipStream_t st = c->stream;
 	HIPOK(c, c->d_S.ensure(S.size()));
-	HIPOK(c, c->d_SAX.ensure(SAX.size()));
-	HIPOK(c, c->d_LCP.ensure(LCP.size()));
-	HIPOK(c, c->d_T.ensure(T.size()));
-	HIPOK(c, hipMemcpy(c->d_S.p, S.data(), S.size(), hipMemcpyHostToDevice));
-	HIPOK(c, hipMemcpy(c->d_SAX.p, SAX.data(), SAX.size() * sizeof(U4), hipMemcpyHostToDevice));
-	HIPOK(c, hipMemcpy(c->d_LCP.p, LCP.data(), LCP.size() * 4, hipMemcpyHostToDevice));
-	HIPOK(c, hipMemcpy(c->d_T.p, T.data(), T.size() * 4, hipMemcpyHostToDevice));
-	{
-		uint64_t codes = (uint64_t)1 << (2 * k);
-		HIPOK(c, c->d_SLOT.ensure(codes * SLOT_RECS));
-		uint64_t threads = codes * SLOT_RECS;
-		hipLaunchKernelGGL(build_slots_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, c->d_T.p,
-						   c->d_SAX.p, ns, codes, c->d_SLOT.p);
-		HIPOK(c, hipGetLastError());
-		HIPOK(c, hipStreamSynchronize(c->stream));
+	HIPOK(c, c->d_SA.ensure(SA.size()));
+	HIPOK(c, c->d_SAX.ensure((size_t)ns + 4));
+	HIPOK(c, c->d_LCP.ensure((size_t)ns + 1 + 4));
+	HIPOK(c, c->d_T.ensure(codes + 1 + 4 + kmer_table_scratch(k)));
+	HIPOK(c, c->d_SLOT.ensure(codes * SLOT_RECS));
+	HIPOK(c, c->a_misc.ensure(16));
+	HIPOK(c, hipMemcpyAsync(c->d_S.p, S.data(), S.size(), hipMemcpyHostToDevice, st));
+	HIPOK(c, hipMemcpyAsync(c->d_SA.p, SA.data(), SA.size() * 4, hipMemcpyHostToDevice, st));
+	HIPOK(c, hipMemsetAsync(c->a_misc.p, 0, 64, st));
+	HIPOK(c, hipMemsetAsync(c->d_LCP.p, 0, ((size_t)ns + 1 + 4) * 4, st));
+	// LCP by direct comparison of neighbouring suffixes, capped at the 16-bit clip of the
+	// SAX records; only a repeat of >= 64 kbp needs the exact values (host, Kasai)
+	launch_lcp(c->d_S.p, c->d_SA.p, ns, 0xffffu, c->d_LCP.p, c->a_misc.p, st);
+	uint32_t capped = 0;
+	HIPOK(c, hipMemcpyAsync(&capped, c->a_misc.p, 4, hipMemcpyDeviceToHost, st));
+	HIPOK(c, hipStreamSynchronize(st));
+	if (capped) {
+		std::vector<uint32_t> LCP((size_t)ns + 1 + 4, 0);
+		lcp_kasai(S.data(), ns, SA.data(), LCP.data());
+		HIPOK(c, hipMemcpyAsync(c->d_LCP.p, LCP.data(), LCP.size() * 4, hipMemcpyHostToDevice, st));
+		HIPOK(c, hipStreamSynchronize(st));
+		c->stats["ref:lcp_from_host"] = 1;
 	}
+	launch_kmer_table(c->d_S.p, ns, k, c->d_T.p, c->d_T.p + codes + 1 + 4, st);
+	launch_sax(c->d_S.p, c->d_SA.p, c->d_LCP.p, ns, c->d_SAX.p, st);
+	{
+		uint64_t threads = codes * SLOT_RECS;
+		hipLaunchKernelGGL(build_slots_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, st, c->d_T.p,
+						   c->d_SAX.p, ns, codes, c->d_SLOT.p);
+	}
+	HIPOK(c, hipGetLastError());
+	HIPOK(c, hipStreamSynchronize(st));
+	double t3 = now_ms();
 	c->ref_idx = ref_idx;
 	c->L = (uint32_t)L;
 	c->ns = ns;
