@@ -14,6 +14,10 @@ import torch.distributed as td
 from .api import PHOM
 
 
+# tests: run the collectives even in a one-rank group (exercises the RCCL code path on a single GPU)
+_FORCE_COLLECTIVES = False
+
+
 def query_shard(n, rank, world, lengths=None):
     """Contiguous block of queries for this rank, balanced by total length."""
     if lengths is None:
@@ -82,9 +86,9 @@ def process_sharded(ctx, ref_idx, rank, world, device=None, lengths=None, set_re
     bounds = [query_shard(ctx.n, r, world, lens)[0] for r in range(world)] + [ctx.n]
     qb, qe = bounds[rank], bounds[rank + 1]
     ctx.anchor(qb, qe)
-    if world > 1:
+    if world > 1 or _FORCE_COLLECTIVES:
         exchange_homologies(ctx, ctx.n, rank, world, bounds, device)
     s, h = ctx.compare(rank, world)
-    if world > 1:
+    if world > 1 or _FORCE_COLLECTIVES:
         s, h = allreduce_matrix(s, h, device)
     return s, h

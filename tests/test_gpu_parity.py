@@ -304,3 +304,40 @@ def test_fuzz_small_random_sets(ctx, seed):
     kmer = int(rng.choice([0, 0, 2, 5]))
     backend = int(rng.integers(0, 2))
     check_process(ctx, gs, ref, chunk=chunk, kmer=kmer, backend=backend)
+
+
+def _nccl_one_rank_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as td
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    td.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from phylonium_amd import dist
+    dist._FORCE_COLLECTIVES = True
+    gs = synth.make_genomes(6, 20000, seed=91, d_range=(0.01, 0.2), inv_frac=0.05)
+    c = api.Context(0)
+    c.set_genomes(gs)
+    s, h = dist.process_sharded(c, 1, rank, world, device=dev)
+    np.save(out + ".s.npy", s)
+    np.save(out + ".h.npy", h)
+    c.close()
+    td.destroy_process_group()
+
+
+def test_rccl_collectives_in_a_one_rank_group(tmp_path):
+    """bench.py's N>1 path uses torch.distributed with backend nccl (= RCCL). The test
+    box has one GPU, so run the same exchange code in a one-rank RCCL group: the
+    all_reduce / all_gather_into_tensor calls on CUDA tensors must work and leave the
+    result unchanged."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "res")
+    mp.spawn(_nccl_one_rank_worker, args=(1, port, out), nprocs=1, join=True)
+    gs = synth.make_genomes(6, 20000, seed=91, d_range=(0.01, 0.2), inv_frac=0.05)
+    so, ho = O.Run(gs, 1).process().matrix()
+    assert (np.load(out + ".s.npy") == so).all() and (np.load(out + ".h.npy") == ho).all()
