@@ -427,60 +427,93 @@ __global__ __launch_bounds__(256) void fold_kernel(PhaseA A, uint32_t nq, uint32
 		}
 		__syncthreads();
 		const uint32_t nseg = sh.nseg, total = sh.seg_off[nseg];
-		// (3) block-parallel fold over the window's `total` anchors
+		// (3) block-parallel fold over the window's `total` anchors, 1024 per iteration
+		// (four consecutive anchors per thread)
 		uint32_t cur = 0; // segment cursor of this thread (anchor indices only grow)
-		for (uint32_t base = 0; base < total; base += 256) {
-			const uint32_t k = base + tid;
-			const bool valid = k < total;
-			Anchor a = {0, 0, 0};
-			if (valid) {
-				while (sh.seg_off[cur + 1] <= k) cur++;
-				a = sh.seg_ptr[cur][k - sh.seg_off[cur]];
-			}
-			const uint32_t m = total - base < 256 ? total - base : 256; // valid anchors this iteration
-			// last valid anchor of every wave → LDS
-			const bool wave_last = valid && (lane == 63 || k + 1 == total);
-			if (wave_last) {
-				sh.wl_q[wave] = a.q;
-				sh.wl_s[wave] = a.s;
-				sh.wl_len[wave] = a.len;
-			}
-			__syncthreads();
-			Anchor prev;
-			prev.q = (uint32_t)__shfl_up((int)a.q, 1, 64);
-			prev.s = (uint32_t)__shfl_up((int)a.s, 1, 64);
-			prev.len = (uint32_t)__shfl_up((int)a.len, 1, 64);
-			if (lane == 0) {
-				if (wave == 0) {
-					prev.q = lq;
-					prev.s = ls;
-					prev.len = ll;
-				} else {
-					prev.q = sh.wl_q[wave - 1];
-					prev.s = sh.wl_s[wave - 1];
-					prev.len = sh.wl_len[wave - 1];
+		for (uint32_t base = 0; base < total; base += 1024) {
+			const uint32_t k0 = base + tid * 4;
+			Anchor a[4];
+			uint32_t ev = 0; // valid anchors of this thread (the invalid ones are at the very end)
+#pragma unroll
+			for (uint32_t e = 0; e < 4; e++) {
+				a[e].q = a[e].s = a[e].len = 0;
+				if (k0 + e < total) {
+					while (sh.seg_off[cur + 1] <= k0 + e) cur++;
+					a[e] = sh.seg_ptr[cur][k0 + e - sh.seg_off[cur]];
+					ev = e + 1;
 				}
 			}
-			const uint32_t right = (valid && is_right_anchor(prev, a, border)) ? 1u : 0u;
-			const bool start = valid && !right;
-			const uint64_t sm = __ballot(start);
-			if (wave_last) sh.wl_r[wave] = right;
-			if (lane == 0) sh.st_has[wave] = sm ? 1u : 0u;
-			if (sm && (int)lane == 63 - __clzll((long long)sm)) {
-				sh.st_s[wave] = a.s;
-				sh.st_q[wave] = a.q;
+			const uint32_t m = total - base < 1024 ? total - base : 1024; // valid anchors this iteration
+			const Anchor tl = ev == 4 ? a[3] : ev == 3 ? a[2] : ev == 2 ? a[1] : a[0]; // this thread's last
+			const bool wave_last = ev > 0 && (lane == 63 || k0 + ev == total);
+			if (wave_last) {
+				sh.wl_q[wave] = tl.q;
+				sh.wl_s[wave] = tl.s;
+				sh.wl_len[wave] = tl.len;
 			}
 			__syncthreads();
-			uint32_t prev_right = (uint32_t)__shfl_up((int)right, 1, 64);
-			if (lane == 0) prev_right = wave == 0 ? lr : sh.wl_r[wave - 1];
-			const bool emit = start && (prev_right || prev.len / 2 >= thr);
-			const uint64_t em = __ballot(emit);
-			if (lane == 0) sh.ecnt[wave] = (uint32_t)__popcll(em);
-			// start of the homology that ends here: latest non-right anchor before this one
+			Anchor prev0;
+			prev0.q = (uint32_t)__shfl_up((int)tl.q, 1, 64);
+			prev0.s = (uint32_t)__shfl_up((int)tl.s, 1, 64);
+			prev0.len = (uint32_t)__shfl_up((int)tl.len, 1, 64);
+			if (lane == 0) {
+				if (wave == 0) {
+					prev0.q = lq;
+					prev0.s = ls;
+					prev0.len = ll;
+				} else {
+					prev0.q = sh.wl_q[wave - 1];
+					prev0.s = sh.wl_s[wave - 1];
+					prev0.len = sh.wl_len[wave - 1];
+				}
+			}
+			uint32_t r[4];
+			r[0] = (ev > 0 && is_right_anchor(prev0, a[0], border)) ? 1u : 0u;
+			r[1] = (ev > 1 && is_right_anchor(a[0], a[1], border)) ? 1u : 0u;
+			r[2] = (ev > 2 && is_right_anchor(a[1], a[2], border)) ? 1u : 0u;
+			r[3] = (ev > 3 && is_right_anchor(a[2], a[3], border)) ? 1u : 0u;
+			const uint32_t rl = ev == 4 ? r[3] : ev == 3 ? r[2] : ev == 2 ? r[1] : r[0];
+			// this thread's latest non-right anchor
+			bool has_t = false;
+			uint32_t ts = 0, tq = 0;
+#pragma unroll
+			for (uint32_t e = 0; e < 4; e++)
+				if (e < ev && !r[e]) {
+					has_t = true;
+					ts = a[e].s;
+					tq = a[e].q;
+				}
+			const uint64_t sm = __ballot(has_t);
+			if (wave_last) sh.wl_r[wave] = rl;
+			if (lane == 0) sh.st_has[wave] = sm ? 1u : 0u;
+			if (sm && (int)lane == 63 - __clzll((long long)sm)) {
+				sh.st_s[wave] = ts;
+				sh.st_q[wave] = tq;
+			}
+			__syncthreads();
+			uint32_t prev_right0 = (uint32_t)__shfl_up((int)rl, 1, 64);
+			if (lane == 0) prev_right0 = wave == 0 ? lr : sh.wl_r[wave - 1];
+			// a homology ends at every non-right anchor; it is emitted iff the anchor before it
+			// was a right anchor or long enough (process.cxx:261)
+			bool em[4];
+			em[0] = ev > 0 && !r[0] && (prev_right0 || prev0.len / 2 >= thr);
+			em[1] = ev > 1 && !r[1] && (r[0] || a[0].len / 2 >= thr);
+			em[2] = ev > 2 && !r[2] && (r[1] || a[1].len / 2 >= thr);
+			em[3] = ev > 3 && !r[3] && (r[2] || a[2].len / 2 >= thr);
+			const uint32_t ne = (em[0] ? 1u : 0u) + (em[1] ? 1u : 0u) + (em[2] ? 1u : 0u) + (em[3] ? 1u : 0u);
+			uint32_t pe = ne; // inclusive wave scan of the emit counts
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) {
+				uint32_t t1 = (uint32_t)__shfl_up((int)pe, d, 64);
+				if ((int)lane >= d) pe += t1;
+			}
+			if (lane == 63) sh.ecnt[wave] = pe;
+			// the run that is open when this thread's first anchor arrives started at the latest
+			// non-right anchor of an earlier thread / wave / iteration
 			const uint64_t below = sm & ((1ull << lane) - 1ull);
 			const int js = below ? 63 - __clzll((long long)below) : 0;
-			uint32_t rs = (uint32_t)__shfl((int)a.s, js, 64);
-			uint32_t rq = (uint32_t)__shfl((int)a.q, js, 64);
+			uint32_t rs = (uint32_t)__shfl((int)ts, js, 64);
+			uint32_t rq = (uint32_t)__shfl((int)tq, js, 64);
 			if (!below) {
 				rs = cs;
 				rq = cq;
@@ -492,19 +525,27 @@ __global__ __launch_bounds__(256) void fold_kernel(PhaseA A, uint32_t nq, uint32
 					}
 			}
 			__syncthreads();
-			uint32_t ebase = cnt;
-			for (uint32_t w2 = 0; w2 < wave; w2++) ebase += sh.ecnt[w2];
-			if (emit) {
-				uint32_t slot = ebase + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
-				if (slot < cap) {
-					RawHom h = {rs, rq, prev.q + prev.len - rq};
-					dst[slot] = h;
-				} else {
-					*A.error = 3;
+			uint32_t slot = cnt + pe - ne;
+			for (uint32_t w2 = 0; w2 < wave; w2++) slot += sh.ecnt[w2];
+#pragma unroll
+			for (uint32_t e = 0; e < 4; e++) {
+				if (em[e]) {
+					const Anchor &pv = e == 0 ? prev0 : a[e - 1];
+					if (slot < cap) {
+						RawHom h = {rs, rq, pv.q + pv.len - rq};
+						dst[slot] = h;
+					} else {
+						*A.error = 3;
+					}
+					slot++;
+				}
+				if (e < ev && !r[e]) {
+					rs = a[e].s;
+					rq = a[e].q;
 				}
 			}
 			// carry out (same values in every thread)
-			const uint32_t lw = (m - 1) >> 6;
+			const uint32_t lw = ((m - 1) >> 2) >> 6;
 			cnt += sh.ecnt[0] + sh.ecnt[1] + sh.ecnt[2] + sh.ecnt[3];
 			lq = sh.wl_q[lw];
 			ls = sh.wl_s[lw];
