@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="dev: force the phase-A chunk length")
     ap.add_argument("--emulate-rank", default="", help="dev: R/N — time rank R of N's share of the work on this one GPU "
                     "(no collectives; the printed value is NOT a bench result)")
+    ap.add_argument("--emulate-exchange", action="store_true", help="dev, with --emulate-rank: also pay the host side of "
+                    "the two exchanges (export, one-rank RCCL collectives, import of the other ranks' lists, matrix all-reduce)")
     args = ap.parse_args()
 
     import torch
@@ -143,9 +145,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or args.emulate_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group(backend="nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29577")
+        td.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
 
     n, length, d_range, indel, inv, desc = WORKLOADS[args.workload]
     n = args.genomes or n
@@ -173,15 +176,28 @@ def main():
         er, en = (int(x) for x in args.emulate_rank.split("/"))
         emu = (er, en)
 
+    others = []
+
     def step():
         if emu:
             bounds = [dist.query_shard(n, r, emu[1], lens)[0] for r in range(emu[1])] + [n]
             ctx.anchor(bounds[emu[0]], bounds[emu[0] + 1])
+            if args.emulate_exchange:
+                dist.exchange_homologies(ctx, n, 0, 1, [bounds[emu[0]], bounds[emu[0] + 1]], device, _n_pad=emu[1])
+                for (qb, qe, c, f) in others:
+                    ctx.import_packed(qb, qe, c, f)
+                sh = ctx.compare(emu[0], emu[1])
+                return dist.allreduce_matrix(sh[0], sh[1], device)
             return ctx.compare(emu[0], emu[1])
         return dist.process_sharded(ctx, ref_idx, rank, world, device=device, lengths=lens, set_reference=False)
 
     if emu:  # the other ranks' lists must exist for the projection: compute them once, untimed
         ctx.anchor(0, n)
+        if args.emulate_exchange:
+            bounds = [dist.query_shard(n, r, emu[1], lens)[0] for r in range(emu[1])] + [n]
+            for r in range(emu[1]):
+                if r != emu[0]:
+                    others.append((bounds[r], bounds[r + 1]) + ctx.export_packed(bounds[r], bounds[r + 1]))
 
     for _ in range(args.warmup):
         s, h = step()

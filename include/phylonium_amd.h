@@ -96,6 +96,16 @@ int phylo_anchor(phylo_ctx *ctx, size_t q_begin, size_t q_end);
 int phylo_get_homologies(phylo_ctx *ctx, size_t j, const phylo_homology **h, size_t *n);
 /* Install lists computed elsewhere (another rank). */
 int phylo_set_homologies(phylo_ctx *ctx, size_t j, const phylo_homology *h, size_t n);
+/* 16-byte wire form of a homology for the exchange between ranks (lossless:
+ * index_reference follows from the projected start, the length and the
+ * direction, src/process.h:72-80). */
+typedef struct phylo_packed_homology {
+	uint32_t start; /* index_reference_projected */
+	uint32_t index_query;
+	uint32_t length;
+	uint32_t direction;
+} phylo_packed_homology;
+
 /* Bulk forms for the exchange between ranks: counts[j - q_begin] and the lists
  * of genomes [q_begin, q_end) back to back in buf. Export returns the number
  * of entries via *total and copies them when cap suffices (call with cap = 0
@@ -104,6 +114,11 @@ int phylo_export_homologies(phylo_ctx *ctx, size_t q_begin, size_t q_end, uint64
 							phylo_homology *buf, size_t cap, size_t *total);
 int phylo_import_homologies(phylo_ctx *ctx, size_t q_begin, size_t q_end, const uint64_t *counts,
 							const phylo_homology *buf);
+/* The same with 16-byte records (needs a reference to be set: the conversion uses L). */
+int phylo_export_packed(phylo_ctx *ctx, size_t q_begin, size_t q_end, uint64_t *counts,
+						phylo_packed_homology *buf, size_t cap, size_t *total);
+int phylo_import_packed(phylo_ctx *ctx, size_t q_begin, size_t q_end, const uint64_t *counts,
+						const phylo_packed_homology *buf);
 /* complete_delete over all genomes' lists, src/process.cxx:467-469,725-776 (host). */
 int phylo_complete_delete(phylo_ctx *ctx);
 

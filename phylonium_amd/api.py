@@ -15,6 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libphylonium_amd.so")
 
+PACKED = np.dtype([("start", "<u4"), ("index_query", "<u4"), ("length", "<u4"), ("direction", "<u4")])
 PHOM = np.dtype([("index_reference", "<u8"), ("index_reference_projected", "<u8"), ("index_query", "<u8"),
                  ("length", "<u8"), ("direction", "<i4"), ("_pad", "<i4")])
 
@@ -23,7 +24,7 @@ SYMBOLS = [
     "phylo_ctx_create", "phylo_ctx_destroy", "phylo_last_error", "phylo_set_option", "phylo_get_stat",
     "phylo_reset_stats", "phylo_stat_keys", "phylo_set_genomes", "phylo_set_genomes_device",
     "phylo_set_reference", "phylo_threshold", "phylo_anchor", "phylo_get_homologies", "phylo_set_homologies",
-    "phylo_export_homologies", "phylo_import_homologies",
+    "phylo_export_homologies", "phylo_import_homologies", "phylo_export_packed", "phylo_import_packed",
     "phylo_complete_delete", "phylo_compare", "phylo_compare_all", "phylo_process", "phylo_seqcmp",
     "phylo_revseqcmp", "phylo_seqcmp_batch", "phylo_host_suffix_array", "phylo_host_min_anchor_length",
     "phylo_host_sort_filter", "phylo_estimate", "phylo_format_phylip", "phylo_version",
@@ -65,6 +66,8 @@ def load():
     L.phylo_set_homologies.argtypes = [vp, sz, vp, sz]
     L.phylo_export_homologies.argtypes = [vp, sz, sz, vp, vp, sz, C.POINTER(sz)]
     L.phylo_import_homologies.argtypes = [vp, sz, sz, vp, vp]
+    L.phylo_export_packed.argtypes = [vp, sz, sz, vp, vp, sz, C.POINTER(sz)]
+    L.phylo_import_packed.argtypes = [vp, sz, sz, vp, vp]
     L.phylo_complete_delete.argtypes = [vp]
     L.phylo_compare.argtypes = [vp, sz, sz, vp, vp]
     L.phylo_compare_all.argtypes = [vp, vp, vp]
@@ -205,6 +208,23 @@ class Context:
         self._chk(self.L.phylo_export_homologies(self.h, q_begin, q_end, counts.ctypes.data_as(C.c_void_p),
                                                  flat.ctypes.data_as(C.c_void_p), flat.size, C.byref(tot)))
         return counts, flat
+
+    def export_packed(self, q_begin, q_end):
+        """(counts, flat PACKED array): 16-byte wire records of genomes [q_begin, q_end)."""
+        counts = np.zeros(q_end - q_begin, np.uint64)
+        tot = C.c_size_t()
+        self._chk(self.L.phylo_export_packed(self.h, q_begin, q_end, counts.ctypes.data_as(C.c_void_p), None, 0, C.byref(tot)))
+        flat = np.zeros(tot.value, PACKED)
+        self._chk(self.L.phylo_export_packed(self.h, q_begin, q_end, counts.ctypes.data_as(C.c_void_p),
+                                             flat.ctypes.data_as(C.c_void_p), flat.size, C.byref(tot)))
+        return counts, flat
+
+    def import_packed(self, q_begin, q_end, counts, flat):
+        counts = np.ascontiguousarray(counts, np.uint64)
+        flat = np.ascontiguousarray(flat, PACKED)
+        assert int(counts.sum()) == flat.size
+        self._chk(self.L.phylo_import_packed(self.h, q_begin, q_end, counts.ctypes.data_as(C.c_void_p),
+                                             flat.ctypes.data_as(C.c_void_p)))
 
     def import_homologies(self, q_begin, q_end, counts, flat):
         counts = np.ascontiguousarray(counts, np.uint64)

@@ -26,6 +26,23 @@ static __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src)
 // All currently active lanes of the wave resolve the leader's comparison
 // together: lane r of the m active lanes takes the 16-byte piece r of each
 // m*16-byte block.  `s_end` is the first byte past S's zero padding.
+// A pointer that went through LDS or a lane shuffle comes back generic, and a generic
+// load is a FLAT instruction that also counts against LDS waits.  These restate that the
+// address is in global memory.
+typedef const uint8_t __attribute__((address_space(1))) *global_bytes;
+static __device__ __forceinline__ U4 gload16(const uint8_t *p)
+{
+	U4 v;
+	__builtin_memcpy(&v, (global_bytes)(uintptr_t)p, 16);
+	return v;
+}
+static __device__ __forceinline__ Anchor gload_anchor(const Anchor *p)
+{
+	Anchor v;
+	__builtin_memcpy(&v, (global_bytes)(uintptr_t)p, sizeof(Anchor));
+	return v;
+}
+
 static __device__ __forceinline__ void coop_compare(const uint8_t *qp, const uint8_t *sp, uint32_t pos,
 													uint32_t maxn, const uint8_t *s_end, uint32_t *out_len,
 													uint32_t *out_less)
@@ -40,8 +57,8 @@ static __device__ __forceinline__ void coop_compare(const uint8_t *qp, const uin
 		uint32_t d = 0;
 		uint32_t qb = 1, sb = 0;
 		if (in_q) {
-			U4 a = load16(qp + off), b = {0, 0, 0, 0};
-			if (sp + off + 16 <= s_end) b = load16(sp + off); // else past the end of S: the NUL the reference stops at
+			U4 a = gload16(qp + off), b = {0, 0, 0, 0};
+			if (sp + off + 16 <= s_end) b = gload16(sp + off); // else past the end of S: the NUL the reference stops at
 			d = first_diff(a, b);
 			if (d < 16) {
 				qb = byte_at(a, d);
@@ -241,6 +258,17 @@ template <int MODE> __global__ __launch_bounds__(256) void chain_kernel(PhaseA A
 
 static const uint32_t FOLD_WCH = 1024;  // chunks of metadata per window
 static const uint32_t FOLD_SEGS = 3072; // anchor segments per window
+static const uint32_t FOLD_APT = 8;     // anchors per thread and iteration
+static const uint32_t FOLD_ITER = 256 * FOLD_APT;
+
+// Workgroup barrier that orders LDS traffic only: global loads issued before it may
+// still be in flight afterwards (__syncthreads would wait for them).
+__device__ __forceinline__ void lds_barrier()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+	__builtin_amdgcn_s_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 
 struct FoldShared {
 	uint32_t tgt[FOLD_WCH], idxm[FOLD_WCH], bn[FOLD_WCH], blk[FOLD_WCH], scnt[FOLD_WCH];
@@ -427,31 +455,66 @@ __global__ __launch_bounds__(256) void fold_kernel(PhaseA A, uint32_t nq, uint32
 		}
 		__syncthreads();
 		const uint32_t nseg = sh.nseg, total = sh.seg_off[nseg];
-		// (3) block-parallel fold over the window's `total` anchors, 1024 per iteration
-		// (four consecutive anchors per thread)
+		// (3) block-parallel fold over the window's `total` anchors, FOLD_ITER per iteration
+		// (FOLD_APT consecutive anchors per thread: the shuffles, scans and barriers of an
+		// iteration are a fixed latency chain, so it pays to put many anchors behind each).
+		// The next iteration's anchors are requested before this one's are folded: the
+		// barriers below wait for LDS only (lds_barrier), so the loads stay in flight.
 		uint32_t cur = 0; // segment cursor of this thread (anchor indices only grow)
-		for (uint32_t base = 0; base < total; base += 1024) {
-			const uint32_t k0 = base + tid * 4;
-			Anchor a[4];
-			uint32_t ev = 0; // valid anchors of this thread (the invalid ones are at the very end)
+		Anchor an[FOLD_APT];
+		uint32_t evn = 0;
+		auto fetch = [&](uint32_t base) {
+			const uint32_t k0 = base + tid * FOLD_APT;
+			evn = 0;
 #pragma unroll
-			for (uint32_t e = 0; e < 4; e++) {
-				a[e].q = a[e].s = a[e].len = 0;
-				if (k0 + e < total) {
-					while (sh.seg_off[cur + 1] <= k0 + e) cur++;
-					a[e] = sh.seg_ptr[cur][k0 + e - sh.seg_off[cur]];
-					ev = e + 1;
+			for (uint32_t e = 0; e < FOLD_APT; e++) an[e].q = an[e].s = an[e].len = 0;
+			if (k0 < total) {
+				// the segment holding anchor k0: last s in [cur, nseg) with seg_off[s] <= k0
+				uint32_t lo = cur, hi = nseg;
+				while (hi - lo > 1) {
+					const uint32_t mid = (lo + hi) >> 1;
+					if (sh.seg_off[mid] <= k0)
+						lo = mid;
+					else
+						hi = mid;
 				}
+				cur = lo;
+				uint32_t s_beg = sh.seg_off[cur], s_end = sh.seg_off[cur + 1];
+				const Anchor *s_ptr = sh.seg_ptr[cur];
+#pragma unroll
+				for (uint32_t e = 0; e < FOLD_APT; e++)
+					if (k0 + e < total) {
+						if (k0 + e >= s_end) {
+							do s_end = sh.seg_off[++cur + 1];
+							while (k0 + e >= s_end);
+							s_beg = sh.seg_off[cur];
+							s_ptr = sh.seg_ptr[cur];
+						}
+						an[e] = gload_anchor(s_ptr + (k0 + e - s_beg));
+						evn = e + 1;
+					}
 			}
-			const uint32_t m = total - base < 1024 ? total - base : 1024; // valid anchors this iteration
-			const Anchor tl = ev == 4 ? a[3] : ev == 3 ? a[2] : ev == 2 ? a[1] : a[0]; // this thread's last
+		};
+		if (total) fetch(0);
+		for (uint32_t base = 0; base < total; base += FOLD_ITER) {
+			const uint32_t k0 = base + tid * FOLD_APT;
+			Anchor a[FOLD_APT];
+#pragma unroll
+			for (uint32_t e = 0; e < FOLD_APT; e++) a[e] = an[e];
+			const uint32_t ev = evn; // valid anchors of this thread (the invalid ones are at the very end)
+			if (base + FOLD_ITER < total) fetch(base + FOLD_ITER);
+			const uint32_t m = total - base < FOLD_ITER ? total - base : FOLD_ITER; // valid anchors this iteration
+			Anchor tl = a[0]; // this thread's last valid anchor
+#pragma unroll
+			for (uint32_t e = 1; e < FOLD_APT; e++)
+				if (e < ev) tl = a[e];
 			const bool wave_last = ev > 0 && (lane == 63 || k0 + ev == total);
 			if (wave_last) {
 				sh.wl_q[wave] = tl.q;
 				sh.wl_s[wave] = tl.s;
 				sh.wl_len[wave] = tl.len;
 			}
-			__syncthreads();
+			lds_barrier();
 			Anchor prev0;
 			prev0.q = (uint32_t)__shfl_up((int)tl.q, 1, 64);
 			prev0.s = (uint32_t)__shfl_up((int)tl.s, 1, 64);
@@ -467,18 +530,18 @@ __global__ __launch_bounds__(256) void fold_kernel(PhaseA A, uint32_t nq, uint32
 					prev0.len = sh.wl_len[wave - 1];
 				}
 			}
-			uint32_t r[4];
-			r[0] = (ev > 0 && is_right_anchor(prev0, a[0], border)) ? 1u : 0u;
-			r[1] = (ev > 1 && is_right_anchor(a[0], a[1], border)) ? 1u : 0u;
-			r[2] = (ev > 2 && is_right_anchor(a[1], a[2], border)) ? 1u : 0u;
-			r[3] = (ev > 3 && is_right_anchor(a[2], a[3], border)) ? 1u : 0u;
-			const uint32_t rl = ev == 4 ? r[3] : ev == 3 ? r[2] : ev == 2 ? r[1] : r[0];
+			// r: bit e = anchor e is a right anchor of its predecessor
+			uint32_t r = (ev > 0 && is_right_anchor(prev0, a[0], border)) ? 1u : 0u;
+#pragma unroll
+			for (uint32_t e = 1; e < FOLD_APT; e++)
+				if (e < ev && is_right_anchor(a[e - 1], a[e], border)) r |= 1u << e;
+			const uint32_t rl = ev ? (r >> (ev - 1)) & 1u : 0u;
 			// this thread's latest non-right anchor
 			bool has_t = false;
 			uint32_t ts = 0, tq = 0;
 #pragma unroll
-			for (uint32_t e = 0; e < 4; e++)
-				if (e < ev && !r[e]) {
+			for (uint32_t e = 0; e < FOLD_APT; e++)
+				if (e < ev && !((r >> e) & 1u)) {
 					has_t = true;
 					ts = a[e].s;
 					tq = a[e].q;
@@ -490,17 +553,16 @@ __global__ __launch_bounds__(256) void fold_kernel(PhaseA A, uint32_t nq, uint32
 				sh.st_s[wave] = ts;
 				sh.st_q[wave] = tq;
 			}
-			__syncthreads();
+			lds_barrier();
 			uint32_t prev_right0 = (uint32_t)__shfl_up((int)rl, 1, 64);
 			if (lane == 0) prev_right0 = wave == 0 ? lr : sh.wl_r[wave - 1];
 			// a homology ends at every non-right anchor; it is emitted iff the anchor before it
 			// was a right anchor or long enough (process.cxx:261)
-			bool em[4];
-			em[0] = ev > 0 && !r[0] && (prev_right0 || prev0.len / 2 >= thr);
-			em[1] = ev > 1 && !r[1] && (r[0] || a[0].len / 2 >= thr);
-			em[2] = ev > 2 && !r[2] && (r[1] || a[1].len / 2 >= thr);
-			em[3] = ev > 3 && !r[3] && (r[2] || a[2].len / 2 >= thr);
-			const uint32_t ne = (em[0] ? 1u : 0u) + (em[1] ? 1u : 0u) + (em[2] ? 1u : 0u) + (em[3] ? 1u : 0u);
+			uint32_t em = (ev > 0 && !(r & 1u) && (prev_right0 || prev0.len / 2 >= thr)) ? 1u : 0u;
+#pragma unroll
+			for (uint32_t e = 1; e < FOLD_APT; e++)
+				if (e < ev && !((r >> e) & 1u) && (((r >> (e - 1)) & 1u) || a[e - 1].len / 2 >= thr)) em |= 1u << e;
+			const uint32_t ne = (uint32_t)__popc(em);
 			uint32_t pe = ne; // inclusive wave scan of the emit counts
 #pragma unroll
 			for (int d = 1; d < 64; d <<= 1) {
@@ -524,13 +586,13 @@ __global__ __launch_bounds__(256) void fold_kernel(PhaseA A, uint32_t nq, uint32
 						break;
 					}
 			}
-			__syncthreads();
+			lds_barrier();
 			uint32_t slot = cnt + pe - ne;
 			for (uint32_t w2 = 0; w2 < wave; w2++) slot += sh.ecnt[w2];
 #pragma unroll
-			for (uint32_t e = 0; e < 4; e++) {
-				if (em[e]) {
-					const Anchor &pv = e == 0 ? prev0 : a[e - 1];
+			for (uint32_t e = 0; e < FOLD_APT; e++) {
+				if ((em >> e) & 1u) {
+					const Anchor &pv = e == 0 ? prev0 : a[e ? e - 1 : 0];
 					if (slot < cap) {
 						RawHom h = {rs, rq, pv.q + pv.len - rq};
 						dst[slot] = h;
@@ -539,13 +601,13 @@ __global__ __launch_bounds__(256) void fold_kernel(PhaseA A, uint32_t nq, uint32
 					}
 					slot++;
 				}
-				if (e < ev && !r[e]) {
+				if (e < ev && !((r >> e) & 1u)) {
 					rs = a[e].s;
 					rq = a[e].q;
 				}
 			}
 			// carry out (same values in every thread)
-			const uint32_t lw = ((m - 1) >> 2) >> 6;
+			const uint32_t lw = ((m - 1) / FOLD_APT) >> 6;
 			cnt += sh.ecnt[0] + sh.ecnt[1] + sh.ecnt[2] + sh.ecnt[3];
 			lq = sh.wl_q[lw];
 			ls = sh.wl_s[lw];
@@ -557,7 +619,7 @@ __global__ __launch_bounds__(256) void fold_kernel(PhaseA A, uint32_t nq, uint32
 					cq = sh.st_q[w2];
 					break;
 				}
-			__syncthreads(); // the exchange arrays are rewritten next iteration
+			lds_barrier(); // the exchange arrays are rewritten next iteration
 		}
 		more = !sh.finished;
 		gc = sh.next_gc;

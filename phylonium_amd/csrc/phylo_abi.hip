@@ -876,6 +876,54 @@ int phylo_import_homologies(phylo_ctx *c, size_t q_begin, size_t q_end, const ui
 	return 0;
 }
 
+int phylo_export_packed(phylo_ctx *c, size_t q_begin, size_t q_end, uint64_t *counts, phylo_packed_homology *buf,
+						size_t cap, size_t *total)
+{
+	if (!c) return 1;
+	if (q_begin > q_end || q_end > c->n || !counts || !total) return c->fail("phylo_export_packed: bad arguments");
+	size_t tot = 0;
+	for (size_t j = q_begin; j < q_end; j++) {
+		counts[j - q_begin] = c->homs[j].size();
+		tot += c->homs[j].size();
+	}
+	*total = tot;
+	if (buf && cap >= tot) {
+		size_t o = 0;
+		for (size_t j = q_begin; j < q_end; j++)
+			for (const phylo_homology &h : c->homs[j])
+				buf[o++] = phylo_packed_homology{(uint32_t)h.index_reference_projected, (uint32_t)h.index_query,
+												 (uint32_t)h.length, (uint32_t)h.direction};
+	}
+	return 0;
+}
+
+int phylo_import_packed(phylo_ctx *c, size_t q_begin, size_t q_end, const uint64_t *counts,
+						const phylo_packed_homology *buf)
+{
+	if (!c) return 1;
+	if (q_begin > q_end || q_end > c->n || !counts) return c->fail("phylo_import_packed: bad arguments");
+	if (!c->have_ref) return c->fail("phylo_import_packed: no reference set");
+	const uint64_t L = c->L;
+	size_t o = 0;
+	for (size_t j = q_begin; j < q_end; j++) {
+		size_t m = counts[j - q_begin];
+		if (m && !buf) return c->fail("phylo_import_packed: null buffer");
+		c->homs[j].resize(m);
+		for (size_t t = 0; t < m; t++, o++) {
+			phylo_homology h;
+			h.index_reference_projected = buf[o].start;
+			h.index_query = buf[o].index_query;
+			h.length = buf[o].length;
+			h.direction = (int32_t)buf[o].direction;
+			h._pad = 0;
+			// inverse of homology::reverseEh (src/process.h:72-80)
+			h.index_reference = h.direction ? 2 * L + 1 - h.length - h.index_reference_projected : h.index_reference_projected;
+			c->homs[j][t] = h;
+		}
+	}
+	return 0;
+}
+
 int phylo_complete_delete(phylo_ctx *c)
 {
 	if (!c) return 1;

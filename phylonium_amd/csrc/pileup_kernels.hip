@@ -125,7 +125,11 @@ __global__ __launch_bounds__(256) void project_kernel(Pileup P, const uint8_t *_
 			const uint32_t lo = hlo[gi], h1 = hend[gi];
 			const uint8_t *q = gbase + goff[g];
 			for (uint32_t h = lo; h < h1; h++) {
-				const DevHom hm = (h - lo < PROJ_HM) ? hcache[gi][h - lo] : homs[h];
+				DevHom hm; // two loads: one through a selected pointer would be a FLAT load
+				if (h - lo < PROJ_HM)
+					hm = hcache[gi][h - lo];
+				else
+					__builtin_memcpy(&hm, (const uint8_t __attribute__((address_space(1))) *)(uintptr_t)(homs + h), sizeof(DevHom));
 				if (hm.start >= x1) break;
 				const uint32_t he = hm.start + hm.len;
 				if (he <= x0) continue;

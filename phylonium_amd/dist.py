@@ -11,7 +11,7 @@ import numpy as np
 import torch
 import torch.distributed as td
 
-from .api import PHOM
+from .api import PACKED
 
 
 # tests: run the collectives even in a one-rank group (exercises the RCCL code path on a single GPU)
@@ -39,33 +39,33 @@ def _dev(backend_device):
     return backend_device if backend_device is not None else torch.device("cpu")
 
 
-def exchange_homologies(ctx, n, rank, world, bounds, device=None):
+def exchange_homologies(ctx, n, rank, world, bounds, device=None, _n_pad=1):
     """After phase A every rank holds the lists of its own query block; afterwards
     every rank holds all of them.  Two collectives: the per-genome counts
     (all-reduce of a vector that is zero outside the own block) and the flat
     lists (all-gather of byte tensors padded to the longest block)."""
     dev = _dev(device)
     qb, qe = bounds[rank], bounds[rank + 1]
-    counts, flat = ctx.export_homologies(qb, qe)
+    counts, flat = ctx.export_packed(qb, qe)  # 16-byte wire records
     call = np.zeros(n, np.int64)
     call[qb:qe] = counts.astype(np.int64)
     ct = torch.from_numpy(call).to(dev)
     td.all_reduce(ct, op=td.ReduceOp.SUM)
     call = ct.cpu().numpy()
-    item = PHOM.itemsize
+    item = PACKED.itemsize
     sizes = [int(call[bounds[r]:bounds[r + 1]].sum()) * item for r in range(world)]
     cap = max(max(sizes), 1)
     mine = torch.zeros(cap, dtype=torch.uint8, device=dev)
     if flat.size:
         mine[:flat.size * item] = torch.from_numpy(flat.view(np.uint8)).to(dev)
-    gathered = torch.zeros(world * cap, dtype=torch.uint8, device=dev)
-    td.all_gather_into_tensor(gathered, mine)
+    gathered = torch.empty(world * cap * _n_pad, dtype=torch.uint8, device=dev)  # _n_pad: bench emulation of a wider gather
+    td.all_gather_into_tensor(gathered[:world * cap], mine)
     g = gathered.cpu().numpy()
     for r in range(world):
         if r == rank or bounds[r] == bounds[r + 1]:
             continue
-        part = g[r * cap:r * cap + sizes[r]].view(PHOM)
-        ctx.import_homologies(bounds[r], bounds[r + 1], call[bounds[r]:bounds[r + 1]].astype(np.uint64), part)
+        part = g[r * cap:r * cap + sizes[r]].view(PACKED)
+        ctx.import_packed(bounds[r], bounds[r + 1], call[bounds[r]:bounds[r + 1]].astype(np.uint64), part)
 
 
 def allreduce_matrix(subst, homologs, device=None):

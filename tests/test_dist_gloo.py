@@ -54,17 +54,27 @@ class OracleCtx:
     def set_homologies(self, j, h):
         self.h[j] = np.array(h)
 
-    def export_homologies(self, qb, qe):
-        from phylonium_amd.api import PHOM
+    def export_packed(self, qb, qe):
+        from phylonium_amd.api import PACKED, PHOM
         counts = np.array([len(self.h[j]) for j in range(qb, qe)], np.uint64)
-        flat = np.concatenate([self.h[j] for j in range(qb, qe)]) if qe > qb else np.zeros(0, PHOM)
+        full = np.concatenate([self.h[j] for j in range(qb, qe)]) if qe > qb else np.zeros(0, PHOM)
+        flat = np.zeros(len(full), PACKED)
+        flat["start"], flat["index_query"] = full["index_reference_projected"], full["index_query"]
+        flat["length"], flat["direction"] = full["length"], full["direction"]
         return counts, flat
 
-    def import_homologies(self, qb, qe, counts, flat):
+    def import_packed(self, qb, qe, counts, flat):
+        from phylonium_amd.api import PHOM
+        L = self.lengths[self.ref_idx]
         o = 0
         for k, j in enumerate(range(qb, qe)):
             c = int(counts[k])
-            self.h[j] = np.array(flat[o:o + c])
+            p = flat[o:o + c]
+            h = np.zeros(c, PHOM)
+            h["index_reference_projected"], h["index_query"] = p["start"], p["index_query"]
+            h["length"], h["direction"] = p["length"], p["direction"]
+            h["index_reference"] = np.where(p["direction"] == 1, 2 * L + 1 - p["length"].astype(np.int64) - p["start"], p["start"])
+            self.h[j] = h
             o += c
 
     def compare(self, part, nparts):

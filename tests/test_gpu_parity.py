@@ -248,6 +248,24 @@ def test_export_import_roundtrip(ctx):
     assert (s == s2).all() and (h == h2).all()
 
 
+def test_packed_export_import_is_lossless(ctx):
+    gs = synth.make_genomes(9, 15000, seed=62, d_range=(0.01, 0.2), inv_frac=0.1)
+    ctx.set_genomes(gs)
+    ctx.set_reference(3)
+    ctx.anchor()
+    before = [np.array(ctx.homologies(j)) for j in range(9)]
+    assert any((b["direction"] == 1).any() for b in before)
+    counts, flat = ctx.export_packed(0, 9)
+    assert flat.dtype.itemsize == 16
+    for j in range(9):
+        ctx.set_homologies(j, np.zeros(0, api.PHOM))
+    ctx.import_packed(0, 9, counts, flat)
+    for j in range(9):
+        after = np.array(ctx.homologies(j))
+        for f in ("index_reference", "index_reference_projected", "index_query", "length", "direction"):
+            assert (after[f] == before[j][f]).all(), (j, f)
+
+
 def _two_rank_worker(rank, world, port, out):
     import torch.distributed as td
     os.environ["MASTER_ADDR"] = "127.0.0.1"
