@@ -362,6 +362,77 @@ static inline void sort_and_filter(std::vector<phylo_homology> &hv)
 	filter_overlaps_max(hv);
 }
 
+// The same sort + filter on packed keys, for the per-query lists of phase A.
+// get(i, &start, &len) describes entry i.  The order by projected start is unique
+// unless two entries share a start; std::sort is not stable, so with such a tie the
+// reference's order is whatever libstdc++'s introsort leaves — the function then
+// returns false and the caller runs sort_and_filter on the structs.  Otherwise
+// `kept` receives the surviving entries (indices into the input) in pile order.
+struct SortFilterScratch {
+	std::vector<uint64_t> by_start, by_end;
+	std::vector<uint32_t> st, len;
+	std::vector<int64_t> score;
+	std::vector<int32_t> pred;
+};
+
+template <class Get>
+static inline bool sort_filter_order(size_t n, Get get, SortFilterScratch &w, std::vector<uint32_t> &kept)
+{
+	kept.clear();
+	if (n >= 0x7fffffffu) return false;
+	w.by_start.resize(n);
+	for (size_t i = 0; i < n; i++) {
+		uint64_t s, l;
+		get(i, &s, &l);
+		if ((s + l) >> 32) return false;
+		w.by_start[i] = s << 32 | (uint64_t)i;
+	}
+	std::sort(w.by_start.begin(), w.by_start.end());
+	for (size_t p = 1; p < n; p++)
+		if ((w.by_start[p] >> 32) == (w.by_start[p - 1] >> 32)) return false;
+	// pile order p: entry by_start[p] & 0xffffffff
+	w.st.resize(n);
+	w.len.resize(n);
+	w.by_end.resize(n);
+	for (size_t p = 0; p < n; p++) {
+		uint64_t s, l;
+		get((size_t)(w.by_start[p] & 0xffffffffu), &s, &l);
+		w.st[p] = (uint32_t)s;
+		w.len[p] = (uint32_t)l;
+		w.by_end[p] = (s + l) << 32 | (uint64_t)p; // ties by pile index = stable
+	}
+	std::sort(w.by_end.begin(), w.by_end.end());
+	w.score.resize(n);
+	w.pred.resize(n);
+	int64_t best = 0;
+	int32_t best_k = -1;
+	size_t q = 0;
+	for (size_t i = 0; i < n; i++) {
+		const uint64_t start_i = w.st[i];
+		while (q < n && (w.by_end[q] >> 32) <= start_i) {
+			const int32_t k = (int32_t)(w.by_end[q] & 0xffffffffu);
+			if (w.score[(size_t)k] > best || (w.score[(size_t)k] == best && k < best_k)) {
+				best = w.score[(size_t)k];
+				best_k = k;
+			}
+			q++;
+		}
+		w.pred[i] = best_k;
+		w.score[i] = (best_k >= 0 ? w.score[(size_t)best_k] : 0) + (int64_t)w.len[i];
+	}
+	int64_t top = 0;
+	int32_t idx = -1;
+	for (size_t i = 0; i < n; i++)
+		if (w.score[i] > top) {
+			top = w.score[i];
+			idx = (int32_t)i;
+		}
+	if (n == 1) idx = 0; // a pile of one is returned as it is (process.cxx:358)
+	for (; idx >= 0; idx = w.pred[(size_t)idx]) kept.push_back((uint32_t)(w.by_start[(size_t)idx] & 0xffffffffu));
+	std::reverse(kept.begin(), kept.end());
+	return true;
+}
+
 // homology::trim, src/process.h:119-143
 static inline phylo_homology trim_homology(const phylo_homology &h, uint64_t s, uint64_t e)
 {

@@ -795,17 +795,34 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	double t3 = now_ms();
 	// reverseEh + std::sort + filter_overlaps_max on the host cores (process.cxx:438-443)
 	uint64_t border = c->L;
+	std::atomic<uint32_t> tie_lists{0};
 	workers(c).run(nq, [&](size_t j) {
-		std::vector<phylo_homology> hv(cnt[j]);
-		for (uint32_t t = 0; t < cnt[j]; t++) hv[t] = project_homology(raw[cbase[j] + t], border);
+		std::vector<phylo_homology> &dst = c->homs[q_begin + j];
 		if (q_begin + j == c->ref_idx) {
 			// anchor_homologies(ref, threshold, subject): homology(0, 0, L), pushed iff
 			// last_length / 2 >= threshold (process.cxx:285-292)
-			hv.clear();
-			if (border / 2 >= c->threshold) hv.push_back(project_homology(RawHom{0, 0, (uint32_t)border}, border));
+			dst.clear();
+			if (border / 2 >= c->threshold) dst.push_back(project_homology(RawHom{0, 0, (uint32_t)border}, border));
+			return;
 		}
-		sort_and_filter(hv);
-		c->homs[q_begin + j] = std::move(hv);
+		static thread_local SortFilterScratch scratch;
+		static thread_local std::vector<uint32_t> kept;
+		const RawHom *r = raw + cbase[j];
+		const size_t m = cnt[j];
+		auto get = [&](size_t i, uint64_t *start, uint64_t *len) {
+			*len = r[i].len;
+			*start = r[i].iref >= border ? 2 * border + 1 - r[i].len - r[i].iref : r[i].iref;
+		};
+		if (sort_filter_order(m, get, scratch, kept)) {
+			dst.resize(kept.size());
+			for (size_t t = 0; t < kept.size(); t++) dst[t] = project_homology(r[kept[t]], border);
+		} else { // equal starts: only std::sort on the structs reproduces the reference's order
+			std::vector<phylo_homology> hv(m);
+			for (size_t t = 0; t < m; t++) hv[t] = project_homology(r[t], border);
+			sort_and_filter(hv);
+			dst = std::move(hv);
+			tie_lists.fetch_add(1, std::memory_order_relaxed);
+		}
 	});
 	double t4 = now_ms();
 	c->stats["ms:anchor_setup"] += t1 - t0;
@@ -817,6 +834,7 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	c->stats["count:query_bases"] += (double)total;
 	c->stats["count:chunks"] += nch;
 	c->stats["count:raw_homologies"] += (double)ctot;
+	c->stats["count:lists_with_equal_starts"] += (double)tie_lists.load();
 	c->stats["count:pool_blocks_used"] += misc[2];
 	(void)pool_blocks;
 	c->stats["anchor:chunk"] = P.C;
@@ -1252,8 +1270,22 @@ size_t phylo_host_min_anchor_length(double p, double gc, size_t l) { return min_
 size_t phylo_host_sort_filter(phylo_homology *h, size_t n, int do_sort)
 {
 	std::vector<phylo_homology> v(h, h + n);
-	if (do_sort) sort_and_filter(v);
-	else filter_overlaps_max(v);
+	if (do_sort) {
+		// the path phase A takes: packed keys, structs only when two entries share a start
+		SortFilterScratch scratch;
+		std::vector<uint32_t> kept;
+		auto get = [&](size_t i, uint64_t *start, uint64_t *len) {
+			*start = v[i].index_reference_projected;
+			*len = v[i].length;
+		};
+		if (sort_filter_order(n, get, scratch, kept)) {
+			for (size_t t = 0; t < kept.size(); t++) h[t] = v[kept[t]];
+			return kept.size();
+		}
+		sort_and_filter(v);
+	} else {
+		filter_overlaps_max(v);
+	}
 	std::copy(v.begin(), v.end(), h);
 	return v.size();
 }

@@ -71,6 +71,26 @@ def test_host_sort_filter_matches_reference_dp(lib):
                [(int(a["iproj"]), int(a["iq"]), int(a["len"])) for a in want]
 
 
+def test_host_sort_filter_packed_path_distinct_starts(lib):
+    """Distinct starts take the packed-key path (no std::sort on structs): equal ends and
+    equal scores must still pick the reference's predecessor."""
+    rng = np.random.default_rng(5)
+    for trial in range(400):
+        n = int(rng.integers(0, 70))
+        start = rng.choice(120, n, replace=False)
+        ln = rng.integers(1, 30, n)
+        iq = rng.integers(0, 1000, n)
+        h = np.zeros(n, api.PHOM)
+        o = np.zeros(n, O.HOM_DTYPE)
+        for t in range(n):
+            h[t] = (start[t], start[t], iq[t], ln[t], 0, 0)
+            o[t] = (0, start[t], start[t], iq[t], ln[t])
+        got = api.host_sort_filter(h)
+        want = O.sort_filter(o)
+        assert [(int(a["index_reference_projected"]), int(a["index_query"]), int(a["length"])) for a in got] == \
+               [(int(a["iproj"]), int(a["iq"]), int(a["len"])) for a in want]
+
+
 def test_estimates_and_phylip(lib):
     for s, h in ((0, 0), (0, 10), (5, 100), (89758, 972512), (75, 100), (80, 100)):
         for kind in ("jc", "raw", "ani"):
