@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not time kernels with HIP events")
     ap.add_argument("--check", action="store_true", help="verify a sample of the result against the oracle")
     ap.add_argument("--chunk", type=int, default=0, help="dev: force the phase-A chunk length")
+    ap.add_argument("--d-range", default="", help="dev: lo,hi — override the workload's divergence range")
     ap.add_argument("--emulate-rank", default="", help="dev: R/N — time rank R of N's share of the work on this one GPU "
                     "(no collectives; the printed value is NOT a bench result)")
     ap.add_argument("--emulate-exchange", action="store_true", help="dev, with --emulate-rank: also pay the host side of "
@@ -153,6 +154,8 @@ def main():
     n, length, d_range, indel, inv, desc = WORKLOADS[args.workload]
     n = args.genomes or n
     length = args.length or length
+    if args.d_range:
+        d_range = tuple(float(x) for x in args.d_range.split(","))
     t_gen = time.time()
     buf, offs, lens = make_genomes_gpu(torch, n, length, args.seed, device, d_range, indel, inv,
                                        contigs=CONTIGS.get(args.workload, 1))

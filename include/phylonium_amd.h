@@ -55,7 +55,7 @@ int phylo_ctx_create(phylo_ctx **out, int device);
 void phylo_ctx_destroy(phylo_ctx *ctx);
 /* ctx may be NULL: last error of a failed phylo_ctx_create on this thread. */
 const char *phylo_last_error(const phylo_ctx *ctx);
-/* Tunables, mostly for tests: "chunk" (phase-A chunk length, power of two),
+/* Tunables, mostly for tests: "chunk" (phase-A chunk length, a multiple of 64),
  * "kmer" (bucket k), "profile" (1: time every kernel with HIP events),
  * "compare_backend" (0 pileup, 1 segment list). */
 int phylo_set_option(phylo_ctx *ctx, const char *key, long value);

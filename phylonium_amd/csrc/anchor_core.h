@@ -747,8 +747,7 @@ struct PhaseA {
 	const uint32_t *items;     // [nchunks] work order: global chunk ids, round-robin over queries
 	const uint32_t *chunk_query; // [nchunks] query id of each global chunk
 	uint32_t nchunks;
-	uint32_t C;                // chunk length (power of two)
-	uint32_t logC;
+	uint32_t C;                // chunk length (a multiple of 64)
 	uint32_t cap;              // anchor slots per chunk
 	// speculative logs
 	Anchor *spec_anchors;      // [nchunks*cap]
@@ -775,7 +774,7 @@ PHY_HD bool lucky_eligible(uint32_t q, uint32_t aq, uint32_t as, uint32_t al, co
 struct SpecLane {
 	Chain ch;
 	uint32_t gc;        // global chunk id; BRIDGE_END when out of work
-	uint32_t q_end;     // chunk end (clipped to query length)
+	uint32_t q0;        // chunk start; the chunk ends at min(q0 + C, query length)
 	uint32_t cnt;       // anchors logged
 	uint32_t vis_word;  // visited bits being accumulated
 	uint32_t vis_idx;   // word index (global) of vis_word, or NO_BLOCK
@@ -785,11 +784,8 @@ struct SpecLane {
 		gc = chunk;
 		uint32_t j = A.chunk_query[chunk];
 		uint32_t c = chunk - A.qchunk0[j];
-		uint32_t q0 = c << A.logC;
-		uint32_t ql = A.qlen[j];
-		uint32_t e = q0 + A.C;
-		q_end = e < ql ? e : ql;
-		ch.reset(A.qbase + A.qoff[j], ql, q0, 0, 0, 0);
+		q0 = c * A.C;
+		ch.reset(A.qbase + A.qoff[j], A.qlen[j], q0, 0, 0, 0);
 		cnt = 0;
 		vis_word = 0;
 		vis_idx = chunk * (A.C >> 5); // the chunk's first bitmap word
@@ -798,14 +794,15 @@ struct SpecLane {
 	// Called when ch.st == ST_STEP. Returns false when the chunk is finished.
 	PHY_HD bool begin_step(const PhaseA &A)
 	{
-		if (ch.q >= q_end) {
+		const uint32_t e = q0 + A.C;
+		if (ch.q >= (e < ch.qlen ? e : ch.qlen)) {
 			A.visited[vis_idx] = vis_word;
 			A.spec_cnt[gc] = cnt;
 			SpecExit x = {ch.q, ch.lq, ch.ls, ch.ll};
 			A.spec_exit[gc] = x;
 			return false;
 		}
-		uint32_t local = ch.q & (A.C - 1);
+		uint32_t local = ch.q - q0;
 		uint32_t w = gc * (A.C >> 5) + (local >> 5);
 		if (w != vis_idx) { // positions only grow: the previous word is complete
 			A.visited[vis_idx] = vis_word;
@@ -836,6 +833,7 @@ struct BridgeLane {
 	uint32_t src;      // chunk whose exit state is being continued; BRIDGE_END when idle
 	uint32_t qc0;      // first global chunk of the query
 	uint32_t cur_gc;   // chunk of the speculative log being compared against
+	uint32_t cur_q0;   // its first position
 	uint32_t sp_cnt, sp_idx;
 	Anchor Ls;         // last anchor the speculative chain had accepted before ch.q
 	uint32_t n;        // anchors accepted by this bridge
@@ -849,6 +847,7 @@ struct BridgeLane {
 		SpecExit x = A.spec_exit[chunk];
 		ch.reset(A.qbase + A.qoff[j], A.qlen[j], x.q, x.lq, x.ls, x.ll);
 		cur_gc = BRIDGE_END;
+		cur_q0 = 0;
 		sp_cnt = sp_idx = 0;
 		Ls.q = Ls.s = Ls.len = 0;
 		n = 0;
@@ -871,19 +870,21 @@ struct BridgeLane {
 			finish(A, BRIDGE_END, 0);
 			return false;
 		}
-		uint32_t gc = qc0 + (ch.q >> A.logC);
-		if (gc != cur_gc) {
-			cur_gc = gc;
-			sp_cnt = A.spec_cnt[gc];
+		if (cur_gc == BRIDGE_END || ch.q - cur_q0 >= A.C) { // entered another chunk (C need not be a power of two)
+			uint32_t lc = ch.q / A.C;
+			cur_gc = qc0 + lc;
+			cur_q0 = lc * A.C;
+			sp_cnt = A.spec_cnt[cur_gc];
 			sp_idx = 0;
 			Ls.q = Ls.s = Ls.len = 0;
 		}
+		const uint32_t gc = cur_gc;
 		const Anchor *log = A.spec_anchors + (size_t)gc * A.cap;
 		while (sp_idx < sp_cnt && log[sp_idx].q < ch.q) {
 			Ls = log[sp_idx];
 			sp_idx++;
 		}
-		uint32_t local = ch.q & (A.C - 1);
+		uint32_t local = ch.q - cur_q0;
 		uint32_t w = A.visited[gc * (A.C >> 5) + (local >> 5)];
 		if ((w >> (local & 31)) & 1u) {
 			bool eb = lucky_eligible(ch.q, ch.lq, ch.ls, ch.ll, R);

@@ -656,10 +656,20 @@ static int resident_blocks(const void *fn, int n_cu)
 	return per_cu * n_cu;
 }
 
+int spec_resident_blocks(int n_cu)
+{
+	static int cached_cu = 0, cached = 0;
+	if (cached_cu != n_cu) {
+		cached = resident_blocks((const void *)chain_kernel<0>, n_cu);
+		cached_cu = n_cu;
+	}
+	return cached;
+}
+
 // blocks_cap: never more lanes than chunks
 void launch_spec(const PhaseA &A, const RefIndex &R, int n_cu, hipStream_t st)
 {
-	int blocks = resident_blocks((const void *)chain_kernel<0>, n_cu);
+	int blocks = spec_resident_blocks(n_cu);
 	int need = (int)((A.nchunks + 255) / 256);
 	if (need < blocks) blocks = need > 0 ? need : 1;
 	hipLaunchKernelGGL(chain_kernel<0>, dim3(blocks), dim3(256), 0, st, A, R);

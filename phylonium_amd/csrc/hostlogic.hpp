@@ -504,32 +504,50 @@ static inline double estimate_jc(uint64_t s, uint64_t h, bool zero_on_error)
 // ───────────────────────── phase-A work layout ─────────────────────────
 
 struct ChunkPlan {
-	uint32_t C = 0, logC = 0, cap = 0, nchunks = 0;
+	uint32_t C = 0, cap = 0, nchunks = 0;
 	std::vector<uint32_t> qchunk0;     // [nq+1]
 	std::vector<uint32_t> chunk_query; // [nchunks]
 	std::vector<uint32_t> items;       // [nchunks] round-robin over queries
 };
 
+static const uint32_t CHUNK_MIN = 1536, CHUNK_MAX = 10240;
+
 // Chunks of C positions per query; the work order interleaves queries so the 64
 // lanes of a wavefront hold chunks of different genomes (a near-identical
 // genome's long matches are then spread over many wavefronts).
-static inline ChunkPlan plan_chunks(const std::vector<uint32_t> &qlen, uint32_t threshold, uint32_t forced_C)
+// `lanes` = chains the device keeps resident (CUs x blocks per CU x 256).  A chain
+// is a dependent sequence, so a chunk's latency is proportional to C whatever
+// the load, and when the work queue runs dry the device idles while the last
+// chunks finish.  Measured on MI355X (C3, C4, 29 x 5 Mbp, 1/8 of C3): one chunk
+// per lane beats two or three shorter ones (5056 vs 2496 on C3: 5.4 vs 6.0 ms),
+// many rounds of long chunks are as good as one (C4: 4096..20096 within 4 %), and
+// below one chunk per lane 1536 is the best length (shorter ones only add bridge
+// and fold work).  So: the fewest rounds with C <= CHUNK_MAX, the chunk count 3 %
+// under a whole number of rounds (every query also ends in a partial chunk),
+// and never below CHUNK_MIN.
+static inline ChunkPlan plan_chunks(const std::vector<uint32_t> &qlen, uint32_t threshold, uint32_t forced_C,
+									uint32_t lanes = 256u * 4u * 256u)
 {
 	ChunkPlan P;
 	uint64_t total = 0;
 	for (uint32_t l : qlen) total += l;
 	uint32_t C = forced_C;
 	if (C == 0) {
-		// ~one chunk per resident lane (256 CUs x 16 waves x 64): fewer leaves lanes idle,
-		// more only adds bridge and fold work.  Measured on C3 and on 1/8 of it: 4096 and
-		// 1024 are the respective optima, 512 never is.
-		C = 1024;
-		while (C < 8192 && total / C > 320 * 1024) C <<= 1;
+		const uint64_t L = lanes ? lanes : 1;
+		if (total <= L * CHUNK_MIN) {
+			C = CHUNK_MIN;
+		} else {
+			const uint64_t rounds = (total + L * CHUNK_MAX - 1) / (L * CHUNK_MAX);
+			// every query also ends in a partial chunk: aim 3 % under the whole number
+			const uint64_t want = (uint64_t)((double)(rounds * L) * 0.97);
+			uint64_t c = (total + want - 1) / want;
+			c = (c + 63) / 64 * 64;
+			C = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(c, CHUNK_MIN), CHUNK_MAX);
+		}
 	}
-	while (C <= 2 * threshold + 32) C <<= 1; // chunk starts must be lucky-ineligible from (0,0,0)
+	C = (C + 63) / 64 * 64;
+	while (C <= 2 * threshold + 32) C += 64; // chunk starts must be lucky-ineligible from (0,0,0)
 	P.C = C;
-	P.logC = 0;
-	while ((1u << P.logC) < C) P.logC++;
 	P.cap = C / (threshold + 1) + 2;
 	size_t nq = qlen.size();
 	P.qchunk0.resize(nq + 1);

@@ -9,6 +9,7 @@
 namespace phy {
 
 // anchor_kernels.hip
+int spec_resident_blocks(int n_cu); // blocks of the speculative-chain kernel the device holds at once
 void launch_spec(const PhaseA &A, const RefIndex &R, int n_cu, hipStream_t st);
 void launch_bridge(const PhaseA &A, const RefIndex &R, int n_cu, hipStream_t st);
 void launch_fold(const PhaseA &A, uint32_t nq, uint32_t border, uint32_t thr, RawHom *out,

@@ -414,7 +414,7 @@ int phylo_set_option(phylo_ctx *c, const char *key, long value)
 	if (!c || !key) return 1;
 	std::string k = key;
 	if (k == "chunk") {
-		if (value != 0 && (value < 64 || (value & (value - 1)))) return c->fail("chunk must be 0 or a power of two >= 64");
+		if (value != 0 && (value < 64 || value % 64 || value > 65536)) return c->fail("chunk must be 0 or a multiple of 64 in 64..65536");
 		c->opt_chunk = (uint32_t)value;
 		c->plan_valid = false;
 	} else if (k == "kmer") {
@@ -672,7 +672,7 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 			// speculative chunk compare to the end of the genome.
 			if (q_begin + j == c->ref_idx) qlen[j] = 0;
 		}
-		c->plan = plan_chunks(qlen, c->threshold, c->opt_chunk);
+		c->plan = plan_chunks(qlen, c->threshold, c->opt_chunk, (uint32_t)spec_resident_blocks(c->n_cu) * 256u);
 		const ChunkPlan &P = c->plan;
 		// an emitted homology spans >= 2*threshold query positions
 		c->plan_out_base.assign(nq + 1, 0);
@@ -734,7 +734,6 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	A.chunk_query = c->a_chunk_query.p;
 	A.nchunks = nch;
 	A.C = P.C;
-	A.logC = P.logC;
 	A.cap = P.cap;
 	A.spec_anchors = c->a_spec_anchors.p;
 	A.spec_cnt = c->a_spec_cnt.p;

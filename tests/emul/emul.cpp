@@ -102,7 +102,6 @@ void *emul_run(size_t n, const char *const *seq, const size_t *len, size_t ref_i
 	A.chunk_query = P.chunk_query.data();
 	A.nchunks = P.nchunks;
 	A.C = P.C;
-	A.logC = P.logC;
 	A.cap = P.cap;
 	A.spec_anchors = spec_anchors.data();
 	A.spec_cnt = spec_cnt.data();

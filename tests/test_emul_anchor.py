@@ -32,7 +32,7 @@ def assert_same(gs, ref, chunk=0, kmer=0, allow_quirk=False):
     return r, e
 
 
-@pytest.mark.parametrize("chunk", [0, 64, 128, 1024])
+@pytest.mark.parametrize("chunk", [0, 64, 128, 192, 1024, 1088])
 def test_star_substitutions(chunk):
     gs = synth.make_genomes(5, 20000, seed=3, d_range=(0.01, 0.25))
     assert_same(gs, 0, chunk=chunk)
@@ -44,7 +44,7 @@ def test_indels_inversions_contigs(seed):
     gs = synth.make_genomes(6, 30000, seed=seed, d_range=(0.01, 0.3), indel_per_mbp=500, inv_frac=0.1,
                             contigs=3, inv_len=(100, 1500))
     for ref in (0, 4):
-        for chunk, k in ((256, 0), (64, 3), (64, 1)):
+        for chunk, k in ((256, 0), (320, 0), (64, 3), (64, 1)):
             r = O.Run(gs, ref).process(compare=False)
             esa_quirks = O.Esa(gs[ref]).cache_quirks()
             if esa_quirks:

@@ -91,7 +91,7 @@ def test_b0_reference_signatures(ctx):
 
 
 # ── the path ──
-@pytest.mark.parametrize("chunk", [0, 64, 256])
+@pytest.mark.parametrize("chunk", [0, 64, 192, 256, 320])
 def test_process_star(ctx, chunk):
     gs = synth.make_genomes(6, 30000, seed=3, d_range=(0.01, 0.25))
     check_process(ctx, gs, 0, chunk=chunk)
@@ -318,7 +318,7 @@ def test_fuzz_small_random_sets(ctx, seed):
     ref = int(rng.integers(0, len(gs)))
     if O.Esa(gs[ref]).cache_quirks():
         pytest.skip("reference 6-mer cache quirk present (esa.cxx:174-199)")
-    chunk = int(rng.choice([0, 64, 128, 512]))
+    chunk = int(rng.choice([0, 64, 128, 192, 448, 512]))
     kmer = int(rng.choice([0, 0, 2, 5]))
     backend = int(rng.integers(0, 2))
     check_process(ctx, gs, ref, chunk=chunk, kmer=kmer, backend=backend)
