@@ -234,7 +234,7 @@ def main():
         kernels = {}
         if kern:
             alg = {"anchor_spec": bytes_a / world, "anchor_bridge": 0.0, "anchor_fold": 0.0, "anchor_compact": 0.0,
-                   "pileup_project": total_bases, "pileup_pairs": bytes_b / world, "pileup_pairs_bang": bytes_b / world,
+                   "pileup_project": total_bases, "pileup_project5": total_bases, "pileup_pairs": bytes_b / world, "pileup_pairs_bang": bytes_b / world,
                    "seqcmp_batch": bytes_b / world}
             for k in kern:
                 avg_ms = kern[k] / launches[k]

@@ -203,6 +203,7 @@ struct phylo_ctx {
 
 	// phase B scratch
 	DevBuf<uint32_t> b_planes, b_hom_off, b_tiles, b_flag, b_first;
+	bool pileup_five = false; // the last projection met '!': start with five planes next time
 	DevBuf<DevHom> b_homs;
 	DevBuf<unsigned long long> b_subst, b_homologs;
 	DevBuf<Segment> s_segs;
@@ -1088,15 +1089,24 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 	HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 16, st));
 	HIPOK(c, hipMemsetAsync(c->b_subst.p, 0, N * N * 8, st));
 	HIPOK(c, hipMemsetAsync(c->b_homologs.p, 0, N * N * 8, st));
-	{
-		KernelSpan s(c, "pileup_project");
-		launch_project(P, c->d_genomes, c->d_goff.p, c->b_homs.p, c->b_hom_off.p, c->b_first.p, c->b_flag.p, st);
-	}
-	HIPOK(c, hipGetLastError());
+	launch_tile_index(P, c->b_homs.p, c->b_hom_off.p, c->b_first.p, st);
+	// Three planes unless '!' turns up among the projected bytes (the flag says so);
+	// then all five are made.  A context remembers the outcome for its next call.
 	uint32_t *flagp = (uint32_t *)(c->h_mat.p + 2 * N * N);
-	HIPOK(c, hipMemcpyAsync(flagp, c->b_flag.p, 4, hipMemcpyDeviceToHost, st));
-	if (sync_stream(c)) return 1; // hom_off must stay alive until here; the flag picks the pair kernel
-	uint32_t flag = *flagp;
+	uint32_t flag = 0;
+	for (int pass = 0; pass < 2; pass++) {
+		const bool five = pass == 1 || c->pileup_five;
+		{
+			KernelSpan s(c, five ? "pileup_project5" : "pileup_project");
+			launch_project(P, five, c->d_genomes, c->d_goff.p, c->b_homs.p, c->b_hom_off.p, c->b_first.p, c->b_flag.p, st);
+		}
+		HIPOK(c, hipGetLastError());
+		HIPOK(c, hipMemcpyAsync(flagp, c->b_flag.p, 4, hipMemcpyDeviceToHost, st));
+		if (sync_stream(c)) return 1; // hom_off must stay alive until here; the flag picks the pair kernel
+		flag = *flagp;
+		if (five || !flag) break;
+	}
+	c->pileup_five = flag != 0;
 	double t1 = now_ms();
 
 	// pair tiles (ig, jt) holding at least one pair i<j

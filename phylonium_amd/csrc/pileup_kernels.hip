@@ -32,27 +32,37 @@
 
 namespace phy {
 
-// movemask of bit `b` of each of the 4 bytes of x → 4 bits
-static __device__ __forceinline__ uint32_t gather4(uint32_t x, uint32_t b)
+// Bit order inside a plane word.  A window is 32 reference positions; position
+// p = 4*i + k (byte k of dword i of the 32 query bytes behind it) is kept at bit
+// 8*k + i.  Every plane of every genome uses the same order and the pair kernel
+// only ANDs, XORs and counts bits, so the order is free to choose — and this one
+// is what eight shift+and_or steps produce straight from the loaded dwords, with no
+// multiplies (v_mul_lo_u32 is quarter rate) and no per-dword movemask.
+static __device__ __forceinline__ uint32_t plane_bit(uint32_t p) { return 8u * (p & 3u) + (p >> 2); }
+
+// bit `B` of each of the 32 bytes d[0..7] → one word in plane order
+template <int B> static __device__ __forceinline__ uint32_t gather_plane(const uint32_t (&d)[8])
 {
-	return ((((x >> b) & 0x01010101u) * 0x01020408u) >> 24) & 0xfu;
+	uint32_t acc = 0;
+#pragma unroll
+	for (int i = 0; i < 8; i++) {
+		const uint32_t t = (B >= i) ? d[i] >> (B - i) : d[i] << (i - B);
+		acc |= t & (0x01010101u << i);
+	}
+	return acc;
 }
 
-// bit `b` of each of the 32 bytes of (lo16,hi16) → 32 bits, byte 0 → bit 0
-static __device__ __forceinline__ uint32_t gather32(const uint4 &lo, const uint4 &hi, uint32_t b)
+// an explicitly global load (a pointer selected between LDS and global memory would be FLAT)
+static __device__ __forceinline__ DevHom gload_hom(const DevHom *p)
 {
-	return gather4(lo.x, b) | (gather4(lo.y, b) << 4) | (gather4(lo.z, b) << 8) | (gather4(lo.w, b) << 12) |
-		   (gather4(hi.x, b) << 16) | (gather4(hi.y, b) << 20) | (gather4(hi.z, b) << 24) | (gather4(hi.w, b) << 28);
-}
-
-// 1 where the byte equals '!' (0x21): among {A,C,G,T,!} only '!' has bit 5 set and bit 6 clear
-static __device__ __forceinline__ uint32_t bang32(const uint4 &lo, const uint4 &hi)
-{
-	return gather32(lo, hi, 5) & ~gather32(lo, hi, 6);
+	DevHom hm;
+	__builtin_memcpy(&hm, (const uint8_t __attribute__((address_space(1))) *)(uintptr_t)p, sizeof(DevHom));
+	return hm;
 }
 
 static const uint32_t PROJ_TW = 64; // words per tile
 static const uint32_t PROJ_TG = 32; // genomes per tile (LDS: 5*64*33*4 = 42 KB → 3 blocks per CU)
+static const uint32_t PROJ_GPW = PROJ_TG / 4; // genomes per wavefront
 
 // Projection: one block per tile of 64 reference windows × 32 genomes.
 // Reading side: a wavefront takes one genome and its 64 lanes take the 64
@@ -84,6 +94,9 @@ __global__ __launch_bounds__(256) void tile_index_kernel(Pileup P, const DevHom 
 
 static const uint32_t PROJ_HM = 8; // homology descriptors cached per genome and tile
 
+// FIVE = false writes V, N0, N1 only (and still raises bang_flag when a projected
+// position holds '!'): the host then repeats the projection with all five planes.
+template <bool FIVE>
 __global__ __launch_bounds__(256) void project_kernel(Pileup P, const uint8_t *__restrict__ gbase,
 													   const uint64_t *__restrict__ goff,
 													   const DevHom *__restrict__ homs,
@@ -91,12 +104,19 @@ __global__ __launch_bounds__(256) void project_kernel(Pileup P, const uint8_t *_
 													   const uint32_t *__restrict__ first,
 													   uint32_t *__restrict__ bang_flag)
 {
-	__shared__ uint32_t tile[5][PROJ_TW][PROJ_TG + 1];
+	constexpr uint32_t NP = FIVE ? 5u : 3u;
+	__shared__ uint32_t tile[NP][PROJ_TW][PROJ_TG + 1];
 	__shared__ DevHom hcache[PROJ_TG][PROJ_HM];
 	__shared__ uint32_t hlo[PROJ_TG], hend[PROJ_TG];
+	__shared__ uint32_t below[33]; // below[t] = plane-order mask of the positions < t
 	const uint32_t ntw = (P.W + PROJ_TW - 1) / PROJ_TW;
 	const uint32_t tw = blockIdx.x % ntw, tg = blockIdx.x / ntw;
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	if (threadIdx.x < 33) {
+		uint32_t m = 0;
+		for (uint32_t pp = 0; pp < threadIdx.x; pp++) m |= 1u << plane_bit(pp);
+		below[threadIdx.x] = m;
+	}
 	// the tile's homology descriptors: two dependent rounds for the whole block
 	{
 		const uint32_t gl = threadIdx.x >> 3, e = threadIdx.x & 7u; // PROJ_TG * PROJ_HM == 256
@@ -118,66 +138,125 @@ __global__ __launch_bounds__(256) void project_kernel(Pileup P, const uint8_t *_
 	const uint32_t w = tw * PROJ_TW + lane; // row of this part; reference window P.w0 + w
 	const uint32_t x0 = (P.w0 + w) * 32u, x1 = x0 + 32u;
 	uint32_t any_bang = 0;
-	for (uint32_t gi = wave; gi < PROJ_TG; gi += 4) {
-		const uint32_t g = tg * PROJ_TG + gi;
-		uint32_t V = 0, N0 = 0, N1 = 0, D = 0, B = 0;
-		if (g < P.N && w < P.W) {
-			const uint32_t lo = hlo[gi], h1 = hend[gi];
-			const uint8_t *q = gbase + goff[g];
-			for (uint32_t h = lo; h < h1; h++) {
-				DevHom hm; // two loads: one through a selected pointer would be a FLAT load
-				if (h - lo < PROJ_HM)
-					hm = hcache[gi][h - lo];
-				else
-					__builtin_memcpy(&hm, (const uint8_t __attribute__((address_space(1))) *)(uintptr_t)(homs + h), sizeof(DevHom));
-				if (hm.start >= x1) break;
-				const uint32_t he = hm.start + hm.len;
-				if (he <= x0) continue;
-				// covered part of this window; the 32 bytes are fetched whole (genomes are
-				// padded on both sides) and the bits outside the homology masked off
+	// A wavefront owns PROJ_GPW genomes of the tile.  The covering homology of each is
+	// looked up first (LDS only), then the PROJ_GPW 32-byte reads are issued together
+	// — one read per genome in flight at a time left the kernel waiting on HBM latency
+	// three quarters of its cycles — then the planes are formed.  A window that a
+	// second homology also touches (list boundaries) is finished by the loop below.
+	struct Piece {
+		const uint8_t *src;
+		uint32_t mask, rev, next;
+	};
+	auto load_hom = [&](uint32_t gi, uint32_t h, uint32_t lo) {
+		DevHom hm; // two loads: one through a selected pointer would be a FLAT load
+		if (h - lo < PROJ_HM)
+			hm = hcache[gi][h - lo];
+		else
+			hm = gload_hom(homs + h);
+		return hm;
+	};
+	// first homology of genome gi at or after h that overlaps the window; next = h1 if none
+	auto find_piece = [&](uint32_t gi, const uint8_t *q, uint32_t h, uint32_t lo, uint32_t h1) {
+		Piece pc = {q, 0u, 0u, h1};
+		for (; h < h1; h++) {
+			const DevHom hm = load_hom(gi, h, lo);
+			if (hm.start >= x1) break;
+			const uint32_t he = hm.start + hm.len;
+			if (he <= x0) continue;
+			// covered part of this window; the 32 bytes are fetched whole (genomes are
+			// padded on both sides) and the bits outside the homology masked off
+			pc.mask = 0xffffffffu;
+			if (hm.start > x0 || he < x1) {
 				const uint32_t s = hm.start > x0 ? hm.start - x0 : 0u;
 				const uint32_t e = he < x1 ? he - x0 : 32u;
-				const uint32_t mask = (e >= 32u ? 0xffffffffu : ((1u << e) - 1u)) & ~((1u << s) - 1u);
+				pc.mask = below[e] & ~below[s];
+			}
+			// forward: position x ↔ query index iq + (x - start)
+			// reverse: position x ↔ query index iq + (he-1-x): bytes run backwards, complemented
+			pc.src = hm.rev ? q + ((int64_t)hm.iq + (int64_t)he - (int64_t)x1)
+							: q + ((int64_t)hm.iq + (int64_t)x0 - (int64_t)hm.start);
+			pc.rev = hm.rev;
+			pc.next = he < x1 ? h + 1 : h1; // lists are sorted and disjoint: nothing else if this one reaches the end
+			break;
+		}
+		return pc;
+	};
+	auto add_piece = [&](const Piece &pc, uint4 a, uint4 b, uint32_t &V, uint32_t &N0, uint32_t &N1, uint32_t &D,
+						 uint32_t &B) {
+		uint32_t d[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+		uint32_t flip = 0;
+		if (pc.rev) {
+			const uint32_t r[8] = {__builtin_bswap32(d[7]), __builtin_bswap32(d[6]), __builtin_bswap32(d[5]),
+								   __builtin_bswap32(d[4]), __builtin_bswap32(d[3]), __builtin_bswap32(d[2]),
+								   __builtin_bswap32(d[1]), __builtin_bswap32(d[0])};
+#pragma unroll
+			for (int i = 0; i < 8; i++) d[i] = r[i];
+			flip = 0xffffffffu; // complement: n ^ 2
+			if (FIVE) D |= pc.mask;
+		}
+		V |= pc.mask;
+		N0 |= gather_plane<1>(d) & pc.mask;
+		N1 |= (gather_plane<2>(d) ^ flip) & pc.mask;
+		// '!' (0x21) is the only byte with bit 6 clear (zero padding aside): look closer
+		// only when some byte of the 32 has it clear
+		const uint32_t all = d[0] & d[1] & d[2] & d[3] & d[4] & d[5] & d[6] & d[7];
+		if ((all & 0x40404040u) != 0x40404040u) B |= gather_plane<5>(d) & ~gather_plane<6>(d) & pc.mask;
+	};
+	Piece pc[PROJ_GPW];
+	uint4 da[PROJ_GPW], db[PROJ_GPW];
+#pragma unroll
+	for (uint32_t u = 0; u < PROJ_GPW; u++) {
+		const uint32_t gi = wave + 4 * u, g = tg * PROJ_TG + gi;
+		pc[u] = Piece{gbase, 0u, 0u, 0u};
+		if (g < P.N && w < P.W) pc[u] = find_piece(gi, gbase + goff[g], hlo[gi], hlo[gi], hend[gi]);
+	}
+#pragma unroll
+	for (uint32_t u = 0; u < PROJ_GPW; u++) { // mask == 0: src is a valid address all the same, the data is ignored
+		__builtin_memcpy(&da[u], pc[u].src, 16);
+		__builtin_memcpy(&db[u], pc[u].src + 16, 16);
+	}
+#pragma unroll
+	for (uint32_t u = 0; u < PROJ_GPW; u++) {
+		const uint32_t gi = wave + 4 * u, g = tg * PROJ_TG + gi;
+		uint32_t V = 0, N0 = 0, N1 = 0, D = 0, B = 0;
+		if (pc[u].mask) {
+			add_piece(pc[u], da[u], db[u], V, N0, N1, D, B);
+			const uint32_t lo = hlo[gi], h1 = hend[gi];
+			const uint8_t *q = gbase + goff[g];
+			uint32_t h = pc[u].next;
+			while (h < h1) {
+				const Piece more = find_piece(gi, q, h, lo, h1);
+				if (!more.mask) break;
 				uint4 a, b;
-				uint32_t n0, n1, bg;
-				if (!hm.rev) {
-					// position x ↔ query index iq + (x - start)
-					const uint8_t *src = q + ((int64_t)hm.iq + (int64_t)x0 - (int64_t)hm.start);
-					__builtin_memcpy(&a, src, 16);
-					__builtin_memcpy(&b, src + 16, 16);
-					n0 = gather32(a, b, 1);
-					n1 = gather32(a, b, 2);
-					bg = bang32(a, b);
-				} else {
-					// position x ↔ query index iq + (he-1-x): bytes run backwards, complemented
-					const uint8_t *src = q + ((int64_t)hm.iq + (int64_t)he - (int64_t)x1);
-					__builtin_memcpy(&a, src, 16);
-					__builtin_memcpy(&b, src + 16, 16);
-					n0 = __brev(gather32(a, b, 1));
-					n1 = ~__brev(gather32(a, b, 2)); // complement: n ^ 2
-					bg = __brev(bang32(a, b));
-					D |= mask;
-				}
-				V |= mask;
-				N0 |= n0 & mask;
-				N1 |= n1 & mask;
-				B |= bg & mask;
+				__builtin_memcpy(&a, more.src, 16);
+				__builtin_memcpy(&b, more.src + 16, 16);
+				add_piece(more, a, b, V, N0, N1, D, B);
+				h = more.next;
 			}
 		}
 		any_bang |= B;
 		tile[0][lane][gi] = V;
 		tile[1][lane][gi] = N0;
 		tile[2][lane][gi] = N1;
-		tile[3][lane][gi] = D;
-		tile[4][lane][gi] = B;
+		if (FIVE) {
+			tile[NP - 2][lane][gi] = D;
+			tile[NP - 1][lane][gi] = B;
+		}
 	}
 	if (any_bang) atomicOr(bang_flag, 1u);
 	__syncthreads();
-	// rows [w][g0..g0+31] out: 128 contiguous bytes per row
-	for (uint32_t e = threadIdx.x; e < 5 * PROJ_TW * PROJ_TG; e += 256) {
-		const uint32_t gl = e % PROJ_TG, wl = (e / PROJ_TG) % PROJ_TW, p = e / (PROJ_TG * PROJ_TW);
-		const uint32_t ww = tw * PROJ_TW + wl, g = tg * PROJ_TG + gl;
-		if (ww < P.W) P.plane[p][(size_t)ww * P.Npad + g] = tile[p][wl][gl];
+	// rows [w][g0..g0+31] out: 128 contiguous bytes per row; a thread keeps its genome
+	// column and walks down the rows
+	{
+		const uint32_t gl = threadIdx.x & 31u, wl0 = threadIdx.x >> 5;
+		const uint32_t g = tg * PROJ_TG + gl;
+#pragma unroll
+		for (uint32_t p = 0; p < NP; p++) {
+			uint32_t *dst = P.plane[p] + (size_t)(tw * PROJ_TW + wl0) * P.Npad + g;
+#pragma unroll
+			for (uint32_t k = 0; k < PROJ_TW / 8; k++)
+				if (tw * PROJ_TW + wl0 + 8 * k < P.W) dst[(size_t)(8 * k) * P.Npad] = tile[p][wl0 + 8 * k][gl];
+		}
 	}
 }
 
@@ -261,14 +340,22 @@ void launch_symmetrise(uint32_t N, unsigned long long *a, unsigned long long *b,
 	if (n) hipLaunchKernelGGL(symmetrise_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, N, a, b);
 }
 
-void launch_project(const Pileup &P, const uint8_t *gbase, const uint64_t *goff, const DevHom *homs,
-					const uint32_t *hom_off, uint32_t *first, uint32_t *bang_flag, hipStream_t st)
+void launch_tile_index(const Pileup &P, const DevHom *homs, const uint32_t *hom_off, uint32_t *first, hipStream_t st)
+{
+	uint32_t ntw = (P.W + PROJ_TW - 1) / PROJ_TW;
+	if (!ntw || !P.N) return;
+	uint64_t entries = (uint64_t)P.N * ntw;
+	hipLaunchKernelGGL(tile_index_kernel, dim3((uint32_t)((entries + 255) / 256)), dim3(256), 0, st, P, homs, hom_off, first);
+}
+void launch_project(const Pileup &P, bool five_planes, const uint8_t *gbase, const uint64_t *goff, const DevHom *homs,
+					const uint32_t *hom_off, const uint32_t *first, uint32_t *bang_flag, hipStream_t st)
 {
 	uint32_t ntw = (P.W + PROJ_TW - 1) / PROJ_TW, ntg = P.Npad / PROJ_TG;
 	if (!ntw || !ntg) return;
-	uint64_t entries = (uint64_t)P.N * ntw;
-	hipLaunchKernelGGL(tile_index_kernel, dim3((uint32_t)((entries + 255) / 256)), dim3(256), 0, st, P, homs, hom_off, first);
-	hipLaunchKernelGGL(project_kernel, dim3(ntw * ntg), dim3(256), 0, st, P, gbase, goff, homs, hom_off, first, bang_flag);
+	if (five_planes)
+		hipLaunchKernelGGL(project_kernel<true>, dim3(ntw * ntg), dim3(256), 0, st, P, gbase, goff, homs, hom_off, first, bang_flag);
+	else
+		hipLaunchKernelGGL(project_kernel<false>, dim3(ntw * ntg), dim3(256), 0, st, P, gbase, goff, homs, hom_off, first, bang_flag);
 }
 size_t project_index_entries(const Pileup &P) { return (size_t)P.N * ((P.W + PROJ_TW - 1) / PROJ_TW); }
 
