@@ -294,7 +294,8 @@ def main():
                                    if k in ("ms:anchor_total", "ms:anchor_gpu", "ms:anchor_setup", "ms:anchor_copyback",
                                             "ms:host_sort_filter", "ms:compare_total")},
             "extra_ms": {k[3:]: round(v / K, 3) for k, v in stats.items()
-                         if k in ("ms:compare_project_phase", "ms:compare_pairs_phase", "ms:compare_symmetrise")},
+                         if k in ("ms:compare_project_phase", "ms:compare_pairs_phase", "ms:compare_symmetrise",
+                                  "ms:compare_hom_flatten", "ms:compare_hom_upload")},
             "kernels": kernels,
             "compared_sites": sites, "alg_bytes": {"anchor": bytes_a, "compare": bytes_b},
             "path_alg_GBps": round((bytes_a + bytes_b) * K / dt / 1e9, 2),

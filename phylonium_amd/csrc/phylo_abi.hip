@@ -202,7 +202,10 @@ struct phylo_ctx {
 	std::vector<std::vector<phylo_homology>> homs;
 
 	// phase B scratch
-	DevBuf<uint32_t> b_planes, b_hom_off, b_tiles, b_flag, b_first;
+	DevBuf<uint32_t> b_planes, b_hom_rng, b_tiles, b_flag, b_first;
+	// phase A over all genomes leaves the filtered lists on the device already (see phylo_anchor)
+	bool homs_staged = false;
+	PinBuf<uint32_t> h_rng;
 	bool pileup_five = false; // the last projection met '!': start with five planes next time
 	DevBuf<DevHom> b_homs;
 	DevBuf<unsigned long long> b_subst, b_homologs;
@@ -361,6 +364,7 @@ void phylo_ctx_destroy(phylo_ctx *c)
 	(void)hipStreamSynchronize(c->stream);
 	c->pool.reset();
 	c->h_cnt.release();
+	c->h_rng.release();
 	c->h_raw.release();
 	c->h_devhom.release();
 	c->h_mat.release();
@@ -392,7 +396,7 @@ void phylo_ctx_destroy(phylo_ctx *c)
 	c->a_out_cap.release();
 	c->a_out_cnt.release();
 	c->b_planes.release();
-	c->b_hom_off.release();
+	c->b_hom_rng.release();
 	c->b_tiles.release();
 	c->b_flag.release();
 	c->b_first.release();
@@ -418,6 +422,8 @@ int phylo_set_option(phylo_ctx *c, const char *key, long value)
 		if (value != 0 && (value < 64 || value % 64 || value > 65536)) return c->fail("chunk must be 0 or a multiple of 64 in 64..65536");
 		c->opt_chunk = (uint32_t)value;
 		c->plan_valid = false;
+		c->homs_staged = false;
+	c->homs_staged = false;
 	} else if (k == "kmer") {
 		if (value < 0 || value > 14) return c->fail("kmer must be in 0..14");
 		c->opt_kmer = (uint32_t)value;
@@ -486,6 +492,7 @@ static int install_layout(phylo_ctx *c)
 	c->homs.assign(n, {});
 	c->have_ref = false;
 	c->plan_valid = false;
+	c->homs_staged = false;
 	return 0;
 }
 
@@ -624,6 +631,7 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 	c->threshold = (uint32_t)threshold;
 	c->have_ref = true;
 	c->plan_valid = false;
+	c->homs_staged = false;
 	c->stats["ms:ref_fetch"] += t1 - t0;
 	c->stats["ms:ref_suffix_array"] += t2 - t1;
 	c->stats["ms:ref_lcp_table"] += t3 - t2;
@@ -796,6 +804,45 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	// reverseEh + std::sort + filter_overlaps_max on the host cores (process.cxx:438-443)
 	uint64_t border = c->L;
 	std::atomic<uint32_t> tie_lists{0};
+	// When this call makes every genome's list, phase B's device copy of them is staged
+	// here as well: a worker writes its list in the 16-byte device form into pinned
+	// memory (slot cbase[j] + j: the raw count bounds the filtered one, and the self
+	// query keeps one entry of zero raw ones), and the last worker of each group of
+	// queries sends the group's slots off, so the upload runs under the sorting.
+	const bool stage = q_begin == 0 && q_end == c->n && nq > 0;
+	c->homs_staged = false;
+	const size_t ngroups = stage ? std::min<size_t>(16, nq) : 0;
+	std::vector<std::atomic<uint32_t>> group_left(ngroups);
+	std::atomic<int> stage_err{0};
+	uint32_t *rng = nullptr;
+	DevHom *dh = nullptr;
+	if (stage) {
+		HIPOK(c, c->h_devhom.ensure(ctot + nq + 1));
+		HIPOK(c, c->h_rng.ensure(2 * nq));
+		HIPOK(c, c->b_homs.ensure(ctot + nq + 1));
+		HIPOK(c, c->b_hom_rng.ensure(2 * nq));
+		rng = c->h_rng.p;
+		dh = c->h_devhom.p;
+		for (size_t g = 0; g < ngroups; g++)
+			group_left[g] = (uint32_t)((g + 1) * nq / ngroups - g * nq / ngroups);
+	}
+	auto stage_list = [&](size_t j, const std::vector<phylo_homology> &list) {
+		const size_t o = cbase[j] + j;
+		for (size_t t = 0; t < list.size(); t++)
+			dh[o + t] = DevHom{(uint32_t)list[t].index_reference_projected, (uint32_t)list[t].index_query,
+							   (uint32_t)list[t].length, (uint32_t)list[t].direction};
+		rng[2 * j] = (uint32_t)o;
+		rng[2 * j + 1] = (uint32_t)(o + list.size());
+		size_t g = 0; // the group whose range [g*nq/G, (g+1)*nq/G) holds j
+		while ((g + 1) * nq / ngroups <= j) g++;
+		if (group_left[g].fetch_sub(1, std::memory_order_acq_rel) == 1) {
+			const size_t j0 = g * nq / ngroups, j1 = (g + 1) * nq / ngroups;
+			const size_t o0 = cbase[j0] + j0, o1 = cbase[j1] + j1;
+			if (hipSetDevice(c->device) != hipSuccess ||
+				hipMemcpyAsync(c->b_homs.p + o0, dh + o0, (o1 - o0) * sizeof(DevHom), hipMemcpyHostToDevice, st) != hipSuccess)
+				stage_err = 1;
+		}
+	};
 	workers(c).run(nq, [&](size_t j) {
 		std::vector<phylo_homology> &dst = c->homs[q_begin + j];
 		if (q_begin + j == c->ref_idx) {
@@ -803,6 +850,7 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 			// last_length / 2 >= threshold (process.cxx:285-292)
 			dst.clear();
 			if (border / 2 >= c->threshold) dst.push_back(project_homology(RawHom{0, 0, (uint32_t)border}, border));
+			if (stage) stage_list(j, dst);
 			return;
 		}
 		static thread_local SortFilterScratch scratch;
@@ -823,7 +871,13 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 			dst = std::move(hv);
 			tie_lists.fetch_add(1, std::memory_order_relaxed);
 		}
+		if (stage) stage_list(j, dst);
 	});
+	if (stage) {
+		if (stage_err) return c->fail("staging the homology lists on the device failed");
+		HIPOK(c, hipMemcpyAsync(c->b_hom_rng.p, rng, 2 * nq * 4, hipMemcpyHostToDevice, st));
+		c->homs_staged = true;
+	}
 	double t4 = now_ms();
 	c->stats["ms:anchor_setup"] += t1 - t0;
 	c->stats["ms:anchor_gpu"] += t2 - t1;
@@ -856,6 +910,7 @@ int phylo_set_homologies(phylo_ctx *c, size_t j, const phylo_homology *h, size_t
 	if (j >= c->n) return c->fail("genome index out of range");
 	if (n && !h) return c->fail("null homology list");
 	c->homs[j].assign(h, h + n);
+	c->homs_staged = false;
 	return 0;
 }
 
@@ -885,6 +940,7 @@ int phylo_import_homologies(phylo_ctx *c, size_t q_begin, size_t q_end, const ui
 {
 	if (!c) return 1;
 	if (q_begin > q_end || q_end > c->n || !counts) return c->fail("phylo_import_homologies: bad arguments");
+	c->homs_staged = false;
 	size_t o = 0;
 	for (size_t j = q_begin; j < q_end; j++) {
 		if (counts[j - q_begin] && !buf) return c->fail("phylo_import_homologies: null buffer");
@@ -920,6 +976,7 @@ int phylo_import_packed(phylo_ctx *c, size_t q_begin, size_t q_end, const uint64
 {
 	if (!c) return 1;
 	if (q_begin > q_end || q_end > c->n || !counts) return c->fail("phylo_import_packed: bad arguments");
+	c->homs_staged = false;
 	if (!c->have_ref) return c->fail("phylo_import_packed: no reference set");
 	const uint64_t L = c->L;
 	size_t o = 0;
@@ -946,6 +1003,7 @@ int phylo_complete_delete(phylo_ctx *c)
 {
 	if (!c) return 1;
 	c->homs = complete_delete(c->homs);
+	c->homs_staged = false;
 	return 0;
 }
 
@@ -1056,40 +1114,44 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 	HIPOK(c, c->b_planes.ensure(plane_words * 5));
 	for (int p = 0; p < 5; p++) P.plane[p] = c->b_planes.p + plane_words * p;
 
-	// filtered homologies → device (built by the worker pool into pinned memory)
+	// filtered homologies → device, unless phase A staged them there already
 	double t0 = now_ms();
-	std::vector<uint32_t> hom_off(N + 1);
-	size_t tot = 0;
-	for (size_t g = 0; g < N; g++) {
-		hom_off[g] = (uint32_t)tot;
-		tot += c->homs[g].size();
-	}
-	hom_off[N] = (uint32_t)tot;
-	HIPOK(c, c->h_devhom.ensure(tot + 1));
-	DevHom *dh = c->h_devhom.p;
-	std::atomic<size_t> bad{(size_t)-1};
-	workers(c).run(N, [&](size_t g) {
-		size_t o = hom_off[g];
-		for (const phylo_homology &h : c->homs[g]) {
-			if (h.index_reference_projected + h.length > c->L) bad = g;
-			dh[o++] = DevHom{(uint32_t)h.index_reference_projected, (uint32_t)h.index_query, (uint32_t)h.length,
-							 (uint32_t)h.direction};
+	if (!c->homs_staged) {
+		std::vector<uint32_t> hom_rng(2 * N);
+		size_t tot = 0;
+		for (size_t g = 0; g < N; g++) {
+			hom_rng[2 * g] = (uint32_t)tot;
+			tot += c->homs[g].size();
+			hom_rng[2 * g + 1] = (uint32_t)tot;
 		}
-	});
-	if (bad != (size_t)-1) return c->fail("genome %zu: homology reaches beyond the reference", bad.load());
-	HIPOK(c, c->b_hom_off.ensure(N + 1));
-	HIPOK(c, c->b_homs.ensure(tot + 1));
+		HIPOK(c, c->h_devhom.ensure(tot + 1));
+		DevHom *dh = c->h_devhom.p;
+		std::atomic<size_t> bad{(size_t)-1};
+		workers(c).run(N, [&](size_t g) {
+			size_t o = hom_rng[2 * g];
+			for (const phylo_homology &h : c->homs[g]) {
+				if (h.index_reference_projected + h.length > c->L) bad = g;
+				dh[o++] = DevHom{(uint32_t)h.index_reference_projected, (uint32_t)h.index_query, (uint32_t)h.length,
+								 (uint32_t)h.direction};
+			}
+		});
+		if (bad != (size_t)-1) return c->fail("genome %zu: homology reaches beyond the reference", bad.load());
+		HIPOK(c, c->b_hom_rng.ensure(2 * N));
+		HIPOK(c, c->b_homs.ensure(tot + 1));
+		HIPOK(c, hipMemcpyAsync(c->b_hom_rng.p, hom_rng.data(), 2 * N * 4, hipMemcpyHostToDevice, st));
+		if (tot) HIPOK(c, hipMemcpyAsync(c->b_homs.p, dh, tot * sizeof(DevHom), hipMemcpyHostToDevice, st));
+		if (sync_stream(c)) return 1; // hom_rng goes out of scope
+		c->stats["ms:compare_hom_upload"] += now_ms() - t0;
+	}
 	HIPOK(c, c->b_flag.ensure(4));
 	HIPOK(c, c->b_first.ensure(project_index_entries(P) + 1));
 	HIPOK(c, c->b_subst.ensure(N * N));
 	HIPOK(c, c->b_homologs.ensure(N * N));
 	HIPOK(c, c->h_mat.ensure(2 * N * N + 8));
-	HIPOK(c, hipMemcpyAsync(c->b_hom_off.p, hom_off.data(), (N + 1) * 4, hipMemcpyHostToDevice, st));
-	if (tot) HIPOK(c, hipMemcpyAsync(c->b_homs.p, dh, tot * sizeof(DevHom), hipMemcpyHostToDevice, st));
 	HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 16, st));
 	HIPOK(c, hipMemsetAsync(c->b_subst.p, 0, N * N * 8, st));
 	HIPOK(c, hipMemsetAsync(c->b_homologs.p, 0, N * N * 8, st));
-	launch_tile_index(P, c->b_homs.p, c->b_hom_off.p, c->b_first.p, st);
+	launch_tile_index(P, c->b_homs.p, c->b_hom_rng.p, c->b_first.p, st);
 	// Three planes unless '!' turns up among the projected bytes (the flag says so);
 	// then all five are made.  A context remembers the outcome for its next call.
 	uint32_t *flagp = (uint32_t *)(c->h_mat.p + 2 * N * N);
@@ -1098,11 +1160,11 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		const bool five = pass == 1 || c->pileup_five;
 		{
 			KernelSpan s(c, five ? "pileup_project5" : "pileup_project");
-			launch_project(P, five, c->d_genomes, c->d_goff.p, c->b_homs.p, c->b_hom_off.p, c->b_first.p, c->b_flag.p, st);
+			launch_project(P, five, c->d_genomes, c->d_goff.p, c->b_homs.p, c->b_hom_rng.p, c->b_first.p, c->b_flag.p, st);
 		}
 		HIPOK(c, hipGetLastError());
 		HIPOK(c, hipMemcpyAsync(flagp, c->b_flag.p, 4, hipMemcpyDeviceToHost, st));
-		if (sync_stream(c)) return 1; // hom_off must stay alive until here; the flag picks the pair kernel
+		if (sync_stream(c)) return 1; // the flag picks the pair kernel
 		flag = *flagp;
 		if (five || !flag) break;
 	}

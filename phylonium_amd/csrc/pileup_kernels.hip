@@ -75,7 +75,7 @@ static const uint32_t PROJ_GPW = PROJ_TG / 4; // genomes per wavefront
 // entry, so the binary searches' latencies overlap instead of serialising inside
 // the projection's wavefronts.
 __global__ __launch_bounds__(256) void tile_index_kernel(Pileup P, const DevHom *__restrict__ homs,
-														  const uint32_t *__restrict__ hom_off,
+														  const uint32_t *__restrict__ hom_rng,
 														  uint32_t *__restrict__ first)
 {
 	const uint32_t ntw = (P.W + PROJ_TW - 1) / PROJ_TW;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void tile_index_kernel(Pileup P, const DevHom 
 	if (tid >= (uint64_t)P.N * ntw) return;
 	const uint32_t g = (uint32_t)(tid / ntw), tw = (uint32_t)(tid % ntw);
 	const uint32_t span0 = (P.w0 + tw * PROJ_TW) * 32u;
-	uint32_t lo = hom_off[g], hi = hom_off[g + 1];
+	uint32_t lo = hom_rng[2 * g], hi = hom_rng[2 * g + 1]; // genome g's list is homs[lo, hi)
 	while (lo < hi) {
 		uint32_t mid = lo + ((hi - lo) >> 1);
 		if (homs[mid].start + homs[mid].len <= span0) lo = mid + 1;
@@ -100,7 +100,7 @@ template <bool FIVE>
 __global__ __launch_bounds__(256) void project_kernel(Pileup P, const uint8_t *__restrict__ gbase,
 													   const uint64_t *__restrict__ goff,
 													   const DevHom *__restrict__ homs,
-													   const uint32_t *__restrict__ hom_off,
+													   const uint32_t *__restrict__ hom_rng,
 													   const uint32_t *__restrict__ first,
 													   uint32_t *__restrict__ bang_flag)
 {
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void project_kernel(Pileup P, const uint8_t *_
 		uint32_t lo = 0, h1 = 0;
 		if (g < P.N) {
 			lo = first[(size_t)g * ntw + tw];
-			h1 = hom_off[g + 1];
+			h1 = hom_rng[2 * g + 1];
 			if (lo + e < h1) hm = homs[lo + e];
 		}
 		hcache[gl][e] = hm;
@@ -340,22 +340,22 @@ void launch_symmetrise(uint32_t N, unsigned long long *a, unsigned long long *b,
 	if (n) hipLaunchKernelGGL(symmetrise_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, N, a, b);
 }
 
-void launch_tile_index(const Pileup &P, const DevHom *homs, const uint32_t *hom_off, uint32_t *first, hipStream_t st)
+void launch_tile_index(const Pileup &P, const DevHom *homs, const uint32_t *hom_rng, uint32_t *first, hipStream_t st)
 {
 	uint32_t ntw = (P.W + PROJ_TW - 1) / PROJ_TW;
 	if (!ntw || !P.N) return;
 	uint64_t entries = (uint64_t)P.N * ntw;
-	hipLaunchKernelGGL(tile_index_kernel, dim3((uint32_t)((entries + 255) / 256)), dim3(256), 0, st, P, homs, hom_off, first);
+	hipLaunchKernelGGL(tile_index_kernel, dim3((uint32_t)((entries + 255) / 256)), dim3(256), 0, st, P, homs, hom_rng, first);
 }
 void launch_project(const Pileup &P, bool five_planes, const uint8_t *gbase, const uint64_t *goff, const DevHom *homs,
-					const uint32_t *hom_off, const uint32_t *first, uint32_t *bang_flag, hipStream_t st)
+					const uint32_t *hom_rng, const uint32_t *first, uint32_t *bang_flag, hipStream_t st)
 {
 	uint32_t ntw = (P.W + PROJ_TW - 1) / PROJ_TW, ntg = P.Npad / PROJ_TG;
 	if (!ntw || !ntg) return;
 	if (five_planes)
-		hipLaunchKernelGGL(project_kernel<true>, dim3(ntw * ntg), dim3(256), 0, st, P, gbase, goff, homs, hom_off, first, bang_flag);
+		hipLaunchKernelGGL(project_kernel<true>, dim3(ntw * ntg), dim3(256), 0, st, P, gbase, goff, homs, hom_rng, first, bang_flag);
 	else
-		hipLaunchKernelGGL(project_kernel<false>, dim3(ntw * ntg), dim3(256), 0, st, P, gbase, goff, homs, hom_off, first, bang_flag);
+		hipLaunchKernelGGL(project_kernel<false>, dim3(ntw * ntg), dim3(256), 0, st, P, gbase, goff, homs, hom_rng, first, bang_flag);
 }
 size_t project_index_entries(const Pileup &P) { return (size_t)P.N * ((P.W + PROJ_TW - 1) / PROJ_TW); }
 
