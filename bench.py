@@ -135,6 +135,13 @@ def main():
                     "the two exchanges (export, one-rank RCCL collectives, import of the other ranks' lists, matrix all-reduce)")
     args = ap.parse_args()
 
+    # stdout carries exactly one JSON line.  Libraries below (RCCL prints a version banner
+    # through C stdio) write to fd 1 whenever they like: lend them stderr until the result
+    # is ready, then flush C stdio and take fd 1 back.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as td
     from phylonium_amd import api, dist
@@ -179,28 +186,61 @@ def main():
         er, en = (int(x) for x in args.emulate_rank.split("/"))
         emu = (er, en)
 
-    others = []
+    emu_state = {}
 
     def step():
         if emu:
             bounds = [dist.query_shard(n, r, emu[1], lens)[0] for r in range(emu[1])] + [n]
-            ctx.anchor(bounds[emu[0]], bounds[emu[0] + 1])
+            qb, qe = bounds[emu[0]], bounds[emu[0] + 1]
+            ctx.anchor(qb, qe)
             if args.emulate_exchange:
-                dist.exchange_homologies(ctx, n, 0, 1, [bounds[emu[0]], bounds[emu[0] + 1]], device, _n_pad=emu[1])
-                for (qb, qe, c, f) in others:
-                    ctx.import_packed(qb, qe, c, f)
-                sh = ctx.compare(emu[0], emu[1])
-                return dist.allreduce_matrix(sh[0], sh[1], device)
+                # what rank emu[0] of emu[1] does around its kernels, with a one-rank RCCL group standing
+                # in for the collectives and the other ranks' records copied in from a prepared buffer
+                W, item = emu[1], 16
+                call = np.zeros(n, np.int64)
+                call[qb:qe] = ctx.hom_counts(qb, qe).astype(np.int64)
+                ct = torch.from_numpy(call).to(device)
+                td.all_reduce(ct)
+                ct.cpu()
+                call = emu_state["counts"]
+                sizes = [int(call[bounds[r]:bounds[r + 1]].sum()) for r in range(W)]
+                cap = max(max(sizes), 1)
+                mine = torch.empty(cap * item, dtype=torch.uint8, device=device)
+                gathered = torch.empty(W * cap * item, dtype=torch.uint8, device=device)
+                torch.cuda.current_stream(device).synchronize()
+                ctx.export_packed_device(qb, qe, mine.data_ptr(), cap)
+                td.all_gather_into_tensor(gathered[emu[0] * cap * item:(emu[0] + 1) * cap * item], mine)
+                begin = np.zeros(n, np.uint64)
+                src_off = np.concatenate(([0], np.cumsum(call)))
+                for r in range(W):
+                    b0, b1 = bounds[r], bounds[r + 1]
+                    if b1 > b0:
+                        begin[b0:b1] = r * cap + (src_off[b0:b1] - src_off[b0])
+                        if r != emu[0]:
+                            gathered[r * cap * item:r * cap * item + sizes[r] * item] = \
+                                emu_state["all"][int(src_off[b0]) * item:int(src_off[b1]) * item]
+                torch.cuda.current_stream(device).synchronize()
+                ctx.attach_packed_device(gathered.data_ptr(), begin, call.astype(np.uint64), qb, qe)
+                t = torch.empty(2 * n * n, dtype=torch.int64, device=device)
+                torch.cuda.current_stream(device).synchronize()
+                ctx.compare_device(emu[0], W, t.data_ptr(), t.data_ptr() + n * n * 8)
+                ctx._attached_records = gathered
+                td.all_reduce(t)
+                m = t.cpu().numpy().view(np.uint64).reshape(2, n, n)
+                return m[0], m[1]
             return ctx.compare(emu[0], emu[1])
         return dist.process_sharded(ctx, ref_idx, rank, world, device=device, lengths=lens, set_reference=False)
 
     if emu:  # the other ranks' lists must exist for the projection: compute them once, untimed
         ctx.anchor(0, n)
         if args.emulate_exchange:
-            bounds = [dist.query_shard(n, r, emu[1], lens)[0] for r in range(emu[1])] + [n]
-            for r in range(emu[1]):
-                if r != emu[0]:
-                    others.append((bounds[r], bounds[r + 1]) + ctx.export_packed(bounds[r], bounds[r + 1]))
+            cnt_all = ctx.hom_counts(0, n).astype(np.int64)
+            tot = int(cnt_all.sum())
+            allrec = torch.empty(max(tot, 1) * 16, dtype=torch.uint8, device=device)
+            torch.cuda.synchronize()
+            ctx.export_packed_device(0, n, allrec.data_ptr(), max(tot, 1))
+            emu_state["counts"] = cnt_all
+            emu_state["all"] = allrec
 
     for _ in range(args.warmup):
         s, h = step()
@@ -302,10 +342,18 @@ def main():
             "setup_s": {"generate": round(t_gen, 2), "reference_index": round(t_ref, 2),
                         "suffix_array": round((ref_stats["ms:ref_suffix_array"] or 0) / 1e3, 2)},
         }
-        print(json.dumps(out))
+    else:
+        out = None
     ctx.close()
-    if world > 1:
+    if world > 1 or args.emulate_exchange:
         td.destroy_process_group()
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    os.dup2(real_stdout, 1)
+    os.close(real_stdout)
+    if out is not None:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -119,6 +119,19 @@ int phylo_export_packed(phylo_ctx *ctx, size_t q_begin, size_t q_end, uint64_t *
 						phylo_packed_homology *buf, size_t cap, size_t *total);
 int phylo_import_packed(phylo_ctx *ctx, size_t q_begin, size_t q_end, const uint64_t *counts,
 						const phylo_packed_homology *buf);
+/* Device-resident forms for one process per GPU (the records never visit the host
+ * between ranks).  Export: the lists of genomes [q_begin, q_end) back to back into
+ * device memory dev_dst (cap records; call with dev_dst = NULL to size it).
+ * Attach: from now on genome g's filtered list is dev_records[begin[g] ..
+ * begin[g] + count[g]) in device memory, for all g — e.g. the output of an
+ * all-gather of every rank's export.  The buffer is borrowed until the next
+ * phylo_anchor / phylo_set_* call.  Host-side lists of genomes in
+ * [keep_begin, keep_end) are kept as they are (the caller computed them here);
+ * the others are read back from the buffer only if somebody asks for them. */
+int phylo_export_packed_device(phylo_ctx *ctx, size_t q_begin, size_t q_end, void *dev_dst, size_t cap,
+							   uint64_t *counts, size_t *total);
+int phylo_attach_packed_device(phylo_ctx *ctx, const void *dev_records, const uint64_t *begin,
+							   const uint64_t *count, size_t keep_begin, size_t keep_end);
 /* complete_delete over all genomes' lists, src/process.cxx:467-469,725-776 (host). */
 int phylo_complete_delete(phylo_ctx *ctx);
 
@@ -130,6 +143,8 @@ int phylo_complete_delete(phylo_ctx *ctx);
  * (one all-reduce across ranks). */
 int phylo_compare(phylo_ctx *ctx, size_t part, size_t nparts, uint64_t *subst, uint64_t *homologs);
 int phylo_compare_all(phylo_ctx *ctx, uint64_t *subst, uint64_t *homologs);
+/* phylo_compare with the two N*N tallies left in device memory (for a device-side all-reduce). */
+int phylo_compare_device(phylo_ctx *ctx, size_t part, size_t nparts, uint64_t *dev_subst, uint64_t *dev_homologs);
 
 /* ── B2 in one call ── */
 int phylo_process(phylo_ctx *ctx, size_t ref_idx, int flags, uint64_t *subst, uint64_t *homologs);

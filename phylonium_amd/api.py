@@ -25,6 +25,7 @@ SYMBOLS = [
     "phylo_reset_stats", "phylo_stat_keys", "phylo_set_genomes", "phylo_set_genomes_device",
     "phylo_set_reference", "phylo_threshold", "phylo_anchor", "phylo_get_homologies", "phylo_set_homologies",
     "phylo_export_homologies", "phylo_import_homologies", "phylo_export_packed", "phylo_import_packed",
+    "phylo_export_packed_device", "phylo_attach_packed_device", "phylo_compare_device",
     "phylo_complete_delete", "phylo_compare", "phylo_compare_all", "phylo_process", "phylo_seqcmp",
     "phylo_revseqcmp", "phylo_seqcmp_batch", "phylo_host_suffix_array", "phylo_host_min_anchor_length",
     "phylo_host_sort_filter", "phylo_estimate", "phylo_format_phylip", "phylo_version",
@@ -71,6 +72,9 @@ def load():
     L.phylo_complete_delete.argtypes = [vp]
     L.phylo_compare.argtypes = [vp, sz, sz, vp, vp]
     L.phylo_compare_all.argtypes = [vp, vp, vp]
+    L.phylo_compare_device.argtypes = [vp, sz, sz, vp, vp]
+    L.phylo_export_packed_device.argtypes = [vp, sz, sz, vp, sz, vp, C.POINTER(sz)]
+    L.phylo_attach_packed_device.argtypes = [vp, vp, vp, vp, sz, sz]
     L.phylo_process.argtypes = [vp, sz, C.c_int, vp, vp]
     L.phylo_seqcmp.restype = sz
     L.phylo_seqcmp.argtypes = [vp, vp, sz]
@@ -218,6 +222,36 @@ class Context:
         self._chk(self.L.phylo_export_packed(self.h, q_begin, q_end, counts.ctypes.data_as(C.c_void_p),
                                              flat.ctypes.data_as(C.c_void_p), flat.size, C.byref(tot)))
         return counts, flat
+
+    def hom_counts(self, q_begin, q_end):
+        """Filtered-list lengths of genomes [q_begin, q_end) (uint64)."""
+        counts = np.zeros(q_end - q_begin, np.uint64)
+        tot = C.c_size_t()
+        self._chk(self.L.phylo_export_packed_device(self.h, q_begin, q_end, None, 0,
+                                                    counts.ctypes.data_as(C.c_void_p), C.byref(tot)))
+        return counts
+
+    def export_packed_device(self, q_begin, q_end, dev_ptr, cap):
+        """The lists of genomes [q_begin, q_end) as 16-byte records into device memory at dev_ptr."""
+        counts = np.zeros(q_end - q_begin, np.uint64)
+        tot = C.c_size_t()
+        self._chk(self.L.phylo_export_packed_device(self.h, q_begin, q_end, C.c_void_p(dev_ptr), cap,
+                                                    counts.ctypes.data_as(C.c_void_p), C.byref(tot)))
+        if tot.value > cap:
+            raise RuntimeError("export_packed_device: buffer too small")
+        return counts
+
+    def attach_packed_device(self, dev_ptr, begin, count, keep_begin, keep_end):
+        """Every genome's list lives at dev_ptr[begin[g] : begin[g] + count[g]] (records) from now on."""
+        begin = np.ascontiguousarray(begin, np.uint64)
+        count = np.ascontiguousarray(count, np.uint64)
+        assert begin.size == self.n and count.size == self.n
+        self._chk(self.L.phylo_attach_packed_device(self.h, C.c_void_p(dev_ptr), begin.ctypes.data_as(C.c_void_p),
+                                                    count.ctypes.data_as(C.c_void_p), keep_begin, keep_end))
+
+    def compare_device(self, part, nparts, dev_subst_ptr, dev_homologs_ptr):
+        """compare() with the two N*N uint64 tallies written to device memory."""
+        self._chk(self.L.phylo_compare_device(self.h, part, nparts, C.c_void_p(dev_subst_ptr), C.c_void_p(dev_homologs_ptr)))
 
     def import_packed(self, q_begin, q_end, counts, flat):
         counts = np.ascontiguousarray(counts, np.uint64)

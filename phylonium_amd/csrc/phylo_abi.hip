@@ -206,6 +206,10 @@ struct phylo_ctx {
 	// phase A over all genomes leaves the filtered lists on the device already (see phylo_anchor)
 	bool homs_staged = false;
 	PinBuf<uint32_t> h_rng;
+	// lists attached by phylo_attach_packed_device: borrowed device records + per-genome ranges
+	const DevHom *att_homs = nullptr;
+	std::vector<uint64_t> att_begin, att_count;
+	std::vector<uint8_t> host_stale; // [n] 1: the host list of this genome must be fetched from att_homs first
 	bool pileup_five = false; // the last projection met '!': start with five planes next time
 	DevBuf<DevHom> b_homs;
 	DevBuf<unsigned long long> b_subst, b_homologs;
@@ -493,6 +497,8 @@ static int install_layout(phylo_ctx *c)
 	c->have_ref = false;
 	c->plan_valid = false;
 	c->homs_staged = false;
+	c->att_homs = nullptr; // lists that only lived in an attached buffer are gone
+	c->host_stale.clear();
 	return 0;
 }
 
@@ -632,6 +638,8 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 	c->have_ref = true;
 	c->plan_valid = false;
 	c->homs_staged = false;
+	c->att_homs = nullptr; // lists that only lived in an attached buffer are gone
+	c->host_stale.clear();
 	c->stats["ms:ref_fetch"] += t1 - t0;
 	c->stats["ms:ref_suffix_array"] += t2 - t1;
 	c->stats["ms:ref_lcp_table"] += t3 - t2;
@@ -811,6 +819,8 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	// queries sends the group's slots off, so the upload runs under the sorting.
 	const bool stage = q_begin == 0 && q_end == c->n && nq > 0;
 	c->homs_staged = false;
+	c->att_homs = nullptr; // an attached buffer is only borrowed until the next phase A
+	c->host_stale.clear();
 	const size_t ngroups = stage ? std::min<size_t>(16, nq) : 0;
 	std::vector<std::atomic<uint32_t>> group_left(ngroups);
 	std::atomic<int> stage_err{0};
@@ -895,10 +905,33 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	return 0;
 }
 
+static int unpack_lists(phylo_ctx *c, size_t q_begin, size_t q_end, const uint64_t *counts,
+						const phylo_packed_homology *buf);
+
+// Host lists of genomes [g0, g1) that only exist as attached device records: fetch them.
+static int ensure_host_lists(phylo_ctx *c, size_t g0, size_t g1)
+{
+	if (c->host_stale.empty()) return 0;
+	for (size_t g = g0; g < g1; g++) {
+		if (!c->host_stale[g]) continue;
+		const size_t m = c->att_count[g];
+		std::vector<phylo_packed_homology> tmp(m);
+		if (m) {
+			HIPOK(c, hipSetDevice(c->device));
+			HIPOK(c, hipMemcpy(tmp.data(), c->att_homs + c->att_begin[g], m * sizeof(DevHom), hipMemcpyDeviceToHost));
+		}
+		uint64_t one = m;
+		c->host_stale[g] = 0;
+		if (unpack_lists(c, g, g + 1, &one, tmp.data())) return 1;
+	}
+	return 0;
+}
+
 int phylo_get_homologies(phylo_ctx *c, size_t j, const phylo_homology **h, size_t *n)
 {
 	if (!c || !h || !n) return 1;
 	if (j >= c->n) return c->fail("genome index out of range");
+	if (ensure_host_lists(c, j, j + 1)) return 1;
 	*h = c->homs[j].data();
 	*n = c->homs[j].size();
 	return 0;
@@ -911,6 +944,10 @@ int phylo_set_homologies(phylo_ctx *c, size_t j, const phylo_homology *h, size_t
 	if (n && !h) return c->fail("null homology list");
 	c->homs[j].assign(h, h + n);
 	c->homs_staged = false;
+	if (!c->host_stale.empty()) {
+		if (ensure_host_lists(c, 0, j) || ensure_host_lists(c, j + 1, c->n)) return 1;
+		c->host_stale.clear();
+	}
 	return 0;
 }
 
@@ -919,6 +956,7 @@ int phylo_export_homologies(phylo_ctx *c, size_t q_begin, size_t q_end, uint64_t
 {
 	if (!c) return 1;
 	if (q_begin > q_end || q_end > c->n || !counts || !total) return c->fail("phylo_export_homologies: bad arguments");
+	if (ensure_host_lists(c, q_begin, q_end)) return 1;
 	size_t tot = 0;
 	for (size_t j = q_begin; j < q_end; j++) {
 		counts[j - q_begin] = c->homs[j].size();
@@ -940,6 +978,10 @@ int phylo_import_homologies(phylo_ctx *c, size_t q_begin, size_t q_end, const ui
 {
 	if (!c) return 1;
 	if (q_begin > q_end || q_end > c->n || !counts) return c->fail("phylo_import_homologies: bad arguments");
+	if (!c->host_stale.empty()) {
+		if (ensure_host_lists(c, 0, q_begin) || ensure_host_lists(c, q_end, c->n)) return 1;
+		c->host_stale.clear();
+	}
 	c->homs_staged = false;
 	size_t o = 0;
 	for (size_t j = q_begin; j < q_end; j++) {
@@ -955,6 +997,7 @@ int phylo_export_packed(phylo_ctx *c, size_t q_begin, size_t q_end, uint64_t *co
 {
 	if (!c) return 1;
 	if (q_begin > q_end || q_end > c->n || !counts || !total) return c->fail("phylo_export_packed: bad arguments");
+	if (ensure_host_lists(c, q_begin, q_end)) return 1;
 	size_t tot = 0;
 	for (size_t j = q_begin; j < q_end; j++) {
 		counts[j - q_begin] = c->homs[j].size();
@@ -971,13 +1014,10 @@ int phylo_export_packed(phylo_ctx *c, size_t q_begin, size_t q_end, uint64_t *co
 	return 0;
 }
 
-int phylo_import_packed(phylo_ctx *c, size_t q_begin, size_t q_end, const uint64_t *counts,
+// packed records → host lists of genomes [q_begin, q_end)
+static int unpack_lists(phylo_ctx *c, size_t q_begin, size_t q_end, const uint64_t *counts,
 						const phylo_packed_homology *buf)
 {
-	if (!c) return 1;
-	if (q_begin > q_end || q_end > c->n || !counts) return c->fail("phylo_import_packed: bad arguments");
-	c->homs_staged = false;
-	if (!c->have_ref) return c->fail("phylo_import_packed: no reference set");
 	const uint64_t L = c->L;
 	size_t o = 0;
 	for (size_t j = q_begin; j < q_end; j++) {
@@ -999,9 +1039,86 @@ int phylo_import_packed(phylo_ctx *c, size_t q_begin, size_t q_end, const uint64
 	return 0;
 }
 
+int phylo_import_packed(phylo_ctx *c, size_t q_begin, size_t q_end, const uint64_t *counts,
+						const phylo_packed_homology *buf)
+{
+	if (!c) return 1;
+	if (q_begin > q_end || q_end > c->n || !counts) return c->fail("phylo_import_packed: bad arguments");
+	if (!c->have_ref) return c->fail("phylo_import_packed: no reference set");
+	if (!c->host_stale.empty()) {
+		for (size_t g = q_begin; g < q_end; g++) c->host_stale[g] = 0; // replaced below
+		if (ensure_host_lists(c, 0, q_begin) || ensure_host_lists(c, q_end, c->n)) return 1;
+		c->host_stale.clear();
+	}
+	c->homs_staged = false;
+	return unpack_lists(c, q_begin, q_end, counts, buf);
+}
+
+static_assert(sizeof(DevHom) == sizeof(phylo_packed_homology), "the wire record is the device record");
+
+int phylo_export_packed_device(phylo_ctx *c, size_t q_begin, size_t q_end, void *dev_dst, size_t cap, uint64_t *counts,
+							   size_t *total)
+{
+	if (!c) return 1;
+	if (q_begin > q_end || q_end > c->n || !counts || !total) return c->fail("phylo_export_packed_device: bad arguments");
+	if (ensure_host_lists(c, q_begin, q_end)) return 1;
+	HIPOK(c, hipSetDevice(c->device));
+	size_t tot = 0;
+	for (size_t j = q_begin; j < q_end; j++) {
+		counts[j - q_begin] = c->homs[j].size();
+		tot += c->homs[j].size();
+	}
+	*total = tot;
+	if (!dev_dst || cap < tot) return 0; // sizing call
+	if (!tot) return 0;
+	HIPOK(c, c->h_devhom.ensure(tot + 1));
+	DevHom *dh = c->h_devhom.p;
+	std::vector<size_t> off(q_end - q_begin + 1, 0);
+	for (size_t j = q_begin; j < q_end; j++) off[j - q_begin + 1] = off[j - q_begin] + c->homs[j].size();
+	workers(c).run(q_end - q_begin, [&](size_t t) {
+		size_t o = off[t];
+		for (const phylo_homology &h : c->homs[q_begin + t])
+			dh[o++] = DevHom{(uint32_t)h.index_reference_projected, (uint32_t)h.index_query, (uint32_t)h.length,
+							 (uint32_t)h.direction};
+	});
+	HIPOK(c, hipMemcpyAsync(dev_dst, dh, tot * sizeof(DevHom), hipMemcpyHostToDevice, c->stream));
+	return sync_stream(c);
+}
+
+int phylo_attach_packed_device(phylo_ctx *c, const void *dev_records, const uint64_t *begin, const uint64_t *count,
+							   size_t keep_begin, size_t keep_end)
+{
+	if (!c) return 1;
+	if (!begin || !count || keep_begin > keep_end || keep_end > c->n) return c->fail("phylo_attach_packed_device: bad arguments");
+	if (!c->have_ref) return c->fail("phylo_attach_packed_device: no reference set");
+	HIPOK(c, hipSetDevice(c->device));
+	const size_t N = c->n;
+	HIPOK(c, c->h_rng.ensure(2 * N));
+	HIPOK(c, c->b_hom_rng.ensure(2 * N));
+	uint64_t total = 0;
+	for (size_t g = 0; g < N; g++) {
+		if (begin[g] + count[g] > 0xffffffffull) return c->fail("phylo_attach_packed_device: more than 2^32 records");
+		c->h_rng.p[2 * g] = (uint32_t)begin[g];
+		c->h_rng.p[2 * g + 1] = (uint32_t)(begin[g] + count[g]);
+		total += count[g];
+	}
+	if (total && !dev_records) return c->fail("phylo_attach_packed_device: null records");
+	HIPOK(c, hipMemcpyAsync(c->b_hom_rng.p, c->h_rng.p, 2 * N * 4, hipMemcpyHostToDevice, c->stream));
+	if (sync_stream(c)) return 1;
+	c->att_homs = (const DevHom *)dev_records;
+	c->att_begin.assign(begin, begin + N);
+	c->att_count.assign(count, count + N);
+	c->host_stale.assign(N, 1);
+	for (size_t g = keep_begin; g < keep_end; g++) c->host_stale[g] = 0;
+	c->homs_staged = true;
+	return 0;
+}
+
 int phylo_complete_delete(phylo_ctx *c)
 {
 	if (!c) return 1;
+	if (ensure_host_lists(c, 0, c->n)) return 1;
+	c->host_stale.clear();
 	c->homs = complete_delete(c->homs);
 	c->homs_staged = false;
 	return 0;
@@ -1048,6 +1165,7 @@ static void pair_segments(const phylo_ctx *c, size_t i, size_t j, std::vector<Se
 
 static int compare_segments(phylo_ctx *c, size_t part, size_t nparts, uint64_t *subst, uint64_t *homologs)
 {
+	if (ensure_host_lists(c, 0, c->n)) return 1;
 	size_t N = c->n;
 	std::vector<Segment> segs;
 	std::vector<uint32_t> seg_pair; // pair index of each segment
@@ -1091,7 +1209,8 @@ static int compare_segments(phylo_ctx *c, size_t part, size_t nparts, uint64_t *
 	return 0;
 }
 
-static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *subst, uint64_t *homologs)
+// dev_out: leave the tallies in the caller's device buffers (subst / homologs are device pointers)
+static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *subst, uint64_t *homologs, bool dev_out = false)
 {
 	size_t N = c->n;
 	hipStream_t st = c->stream;
@@ -1117,6 +1236,9 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 	// filtered homologies → device, unless phase A staged them there already
 	double t0 = now_ms();
 	if (!c->homs_staged) {
+		if (ensure_host_lists(c, 0, N)) return 1;
+		c->host_stale.clear();
+		c->att_homs = nullptr;
 		std::vector<uint32_t> hom_rng(2 * N);
 		size_t tot = 0;
 		for (size_t g = 0; g < N; g++) {
@@ -1145,13 +1267,22 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 	}
 	HIPOK(c, c->b_flag.ensure(4));
 	HIPOK(c, c->b_first.ensure(project_index_entries(P) + 1));
-	HIPOK(c, c->b_subst.ensure(N * N));
-	HIPOK(c, c->b_homologs.ensure(N * N));
+	unsigned long long *acc_s, *acc_h; // where the pair kernel accumulates
+	if (dev_out) {
+		acc_s = (unsigned long long *)subst;
+		acc_h = (unsigned long long *)homologs;
+	} else {
+		HIPOK(c, c->b_subst.ensure(N * N));
+		HIPOK(c, c->b_homologs.ensure(N * N));
+		acc_s = c->b_subst.p;
+		acc_h = c->b_homologs.p;
+	}
 	HIPOK(c, c->h_mat.ensure(2 * N * N + 8));
 	HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 16, st));
-	HIPOK(c, hipMemsetAsync(c->b_subst.p, 0, N * N * 8, st));
-	HIPOK(c, hipMemsetAsync(c->b_homologs.p, 0, N * N * 8, st));
-	launch_tile_index(P, c->b_homs.p, c->b_hom_rng.p, c->b_first.p, st);
+	HIPOK(c, hipMemsetAsync(acc_s, 0, N * N * 8, st));
+	HIPOK(c, hipMemsetAsync(acc_h, 0, N * N * 8, st));
+	const DevHom *dev_homs = c->att_homs ? c->att_homs : c->b_homs.p;
+	launch_tile_index(P, dev_homs, c->b_hom_rng.p, c->b_first.p, st);
 	// Three planes unless '!' turns up among the projected bytes (the flag says so);
 	// then all five are made.  A context remembers the outcome for its next call.
 	uint32_t *flagp = (uint32_t *)(c->h_mat.p + 2 * N * N);
@@ -1160,7 +1291,7 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		const bool five = pass == 1 || c->pileup_five;
 		{
 			KernelSpan s(c, five ? "pileup_project5" : "pileup_project");
-			launch_project(P, five, c->d_genomes, c->d_goff.p, c->b_homs.p, c->b_hom_rng.p, c->b_first.p, c->b_flag.p, st);
+			launch_project(P, five, c->d_genomes, c->d_goff.p, dev_homs, c->b_hom_rng.p, c->b_first.p, c->b_flag.p, st);
 		}
 		HIPOK(c, hipGetLastError());
 		HIPOK(c, hipMemcpyAsync(flagp, c->b_flag.p, 4, hipMemcpyDeviceToHost, st));
@@ -1192,14 +1323,21 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		wchunk = std::min(wchunk, l2_fit);
 		{
 			KernelSpan s(c, flag ? "pileup_pairs_bang" : "pileup_pairs");
-			launch_pairs(P, flag != 0, c->b_tiles.p, (uint32_t)tiles.size(), wchunk, c->b_subst.p, c->b_homologs.p, st);
+			launch_pairs(P, flag != 0, c->b_tiles.p, (uint32_t)tiles.size(), wchunk, acc_s, acc_h, st);
 		}
 		HIPOK(c, hipGetLastError());
 	}
-	launch_symmetrise((uint32_t)N, c->b_subst.p, c->b_homologs.p, st);
+	launch_symmetrise((uint32_t)N, acc_s, acc_h, st);
+	if (dev_out) {
+		if (sync_stream(c)) return 1;
+		c->stats["ms:compare_project_phase"] += t1 - t0;
+		c->stats["ms:compare_pairs_phase"] += now_ms() - t1;
+		c->stats["pileup:bang"] = flag;
+		return 0;
+	}
 	uint64_t *hs = c->h_mat.p, *hh = c->h_mat.p + N * N;
-	HIPOK(c, hipMemcpyAsync(hs, c->b_subst.p, N * N * 8, hipMemcpyDeviceToHost, st));
-	HIPOK(c, hipMemcpyAsync(hh, c->b_homologs.p, N * N * 8, hipMemcpyDeviceToHost, st));
+	HIPOK(c, hipMemcpyAsync(hs, acc_s, N * N * 8, hipMemcpyDeviceToHost, st));
+	HIPOK(c, hipMemcpyAsync(hh, acc_h, N * N * 8, hipMemcpyDeviceToHost, st));
 	if (sync_stream(c)) return 1;
 	double t2 = now_ms();
 	memcpy(subst, hs, N * N * 8);
@@ -1228,6 +1366,31 @@ int phylo_compare(phylo_ctx *c, size_t part, size_t nparts, uint64_t *subst, uin
 	std::fill(homologs, homologs + N * N, 0);
 	int rc = c->backend == 1 ? compare_segments(c, part, nparts, subst, homologs)
 							 : compare_pileup(c, part, nparts, subst, homologs);
+	c->stats["ms:compare_total"] += now_ms() - t0;
+	c->stats["n:compare_calls"] += 1;
+	return rc;
+}
+
+int phylo_compare_device(phylo_ctx *c, size_t part, size_t nparts, uint64_t *dev_subst, uint64_t *dev_homologs)
+{
+	if (!c) return 1;
+	if (!dev_subst || !dev_homologs) return c->fail("null output matrix");
+	if (nparts == 0 || part >= nparts) return c->fail("bad part %zu of %zu", part, nparts);
+	if (!c->have_ref) return c->fail("phylo_compare_device: no reference set");
+	HIPOK(c, hipSetDevice(c->device));
+	double t0 = now_ms();
+	int rc;
+	if (c->backend == 1) { // the segment backend tallies on the host: copy its result over
+		size_t N = c->n;
+		std::vector<uint64_t> s(N * N, 0), h(N * N, 0);
+		rc = compare_segments(c, part, nparts, s.data(), h.data());
+		if (!rc) {
+			HIPOK(c, hipMemcpy(dev_subst, s.data(), N * N * 8, hipMemcpyHostToDevice));
+			HIPOK(c, hipMemcpy(dev_homologs, h.data(), N * N * 8, hipMemcpyHostToDevice));
+		}
+	} else {
+		rc = compare_pileup(c, part, nparts, dev_subst, dev_homologs, true);
+	}
 	c->stats["ms:compare_total"] += now_ms() - t0;
 	c->stats["n:compare_calls"] += 1;
 	return rc;

@@ -77,6 +77,35 @@ def allreduce_matrix(subst, homologs, device=None):
     return t[0], t[1]
 
 
+def exchange_homologies_device(ctx, n, rank, world, bounds, device):
+    """The same exchange with the records staying in device memory: every rank puts its
+    own lists (16-byte records) into a device buffer, one all-gather assembles all of
+    them on every GPU, and the context projects straight from that buffer."""
+    qb, qe = bounds[rank], bounds[rank + 1]
+    call = np.zeros(n, np.int64)
+    call[qb:qe] = ctx.hom_counts(qb, qe).astype(np.int64)
+    ct = torch.from_numpy(call).to(device)
+    td.all_reduce(ct, op=td.ReduceOp.SUM)
+    call = ct.cpu().numpy()
+    sizes = [int(call[bounds[r]:bounds[r + 1]].sum()) for r in range(world)]
+    cap = max(max(sizes), 1)
+    item = PACKED.itemsize
+    mine = torch.empty(cap * item, dtype=torch.uint8, device=device)
+    gathered = torch.empty(world * cap * item, dtype=torch.uint8, device=device)
+    torch.cuda.current_stream(device).synchronize()  # the library writes on its own stream
+    ctx.export_packed_device(qb, qe, mine.data_ptr(), cap)
+    td.all_gather_into_tensor(gathered, mine)
+    torch.cuda.current_stream(device).synchronize()
+    begin = np.zeros(n, np.uint64)
+    for r in range(world):
+        b0, b1 = bounds[r], bounds[r + 1]
+        if b1 > b0:
+            c = call[b0:b1]
+            begin[b0:b1] = r * cap + np.concatenate(([0], np.cumsum(c[:-1])))
+    ctx.attach_packed_device(gathered.data_ptr(), begin, call.astype(np.uint64), qb, qe)
+    return gathered  # borrowed by the context: the caller keeps it alive until the comparison is done
+
+
 def process_sharded(ctx, ref_idx, rank, world, device=None, lengths=None, set_reference=True):
     """process() with queries and pair tiles sharded over `world` ranks.
     ctx: an api.Context (or any object with the same methods) holding all genomes."""
@@ -86,6 +115,18 @@ def process_sharded(ctx, ref_idx, rank, world, device=None, lengths=None, set_re
     bounds = [query_shard(ctx.n, r, world, lens)[0] for r in range(world)] + [ctx.n]
     qb, qe = bounds[rank], bounds[rank + 1]
     ctx.anchor(qb, qe)
+    on_gpu = device is not None and torch.device(device).type == "cuda" and hasattr(ctx, "attach_packed_device")
+    if on_gpu and (world > 1 or _FORCE_COLLECTIVES):
+        # device-resident: records and tallies never visit the host between the ranks
+        keep = exchange_homologies_device(ctx, ctx.n, rank, world, bounds, device)
+        n = ctx.n
+        t = torch.empty(2 * n * n, dtype=torch.int64, device=device)
+        torch.cuda.current_stream(device).synchronize()
+        ctx.compare_device(rank, world, t.data_ptr(), t.data_ptr() + n * n * 8)
+        ctx._attached_records = keep  # still the source of the other ranks' lists should the caller ask for them
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+        m = t.cpu().numpy().view(np.uint64).reshape(2, n, n)
+        return m[0], m[1]
     if world > 1 or _FORCE_COLLECTIVES:
         exchange_homologies(ctx, ctx.n, rank, world, bounds, device)
     s, h = ctx.compare(rank, world)

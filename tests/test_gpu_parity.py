@@ -266,6 +266,57 @@ def test_packed_export_import_is_lossless(ctx):
             assert (after[f] == before[j][f]).all(), (j, f)
 
 
+def test_device_resident_exchange_between_two_contexts():
+    """The N>1 data flow without the collectives: two contexts stand for two ranks, each
+    anchors its half, the exported device records are laid out as an all-gather would,
+    attached to both, and the two window-range parts of phase B add up to the oracle's
+    matrix. Lists a context did not compute are read back from the attached buffer on demand."""
+    import torch
+    gs = synth.make_genomes(10, 25000, seed=83, d_range=(0.01, 0.25), indel_per_mbp=300, inv_frac=0.08, contigs=2)
+    n, ref = len(gs), 2
+    so, ho = O.Run(gs, ref).process().matrix()
+    dev = torch.device("cuda", 0)
+    bounds = [0, 4, n]
+    ctxs = [api.Context(0) for _ in range(2)]
+    try:
+        counts = np.zeros(n, np.uint64)
+        for r, c in enumerate(ctxs):
+            c.set_genomes(gs)
+            c.set_reference(ref)
+            c.anchor(bounds[r], bounds[r + 1])
+            counts[bounds[r]:bounds[r + 1]] = c.hom_counts(bounds[r], bounds[r + 1])
+        sizes = [int(counts[bounds[r]:bounds[r + 1]].sum()) for r in range(2)]
+        cap = max(sizes)
+        gathered = torch.zeros(2 * cap * 16, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        for r, c in enumerate(ctxs):
+            got = c.export_packed_device(bounds[r], bounds[r + 1], gathered.data_ptr() + r * cap * 16, cap)
+            assert (got == counts[bounds[r]:bounds[r + 1]]).all()
+        begin = np.zeros(n, np.uint64)
+        for r in range(2):
+            cc = counts[bounds[r]:bounds[r + 1]]
+            begin[bounds[r]:bounds[r + 1]] = r * cap + np.concatenate(([0], np.cumsum(cc[:-1])))
+        total = torch.zeros(2 * n * n, dtype=torch.int64, device=dev)
+        for r, c in enumerate(ctxs):
+            c.attach_packed_device(gathered.data_ptr(), begin, counts, bounds[r], bounds[r + 1])
+            t = torch.empty(2 * n * n, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
+            c.compare_device(r, 2, t.data_ptr(), t.data_ptr() + n * n * 8)
+            total += t
+        m = total.cpu().numpy().view(np.uint64).reshape(2, n, n)
+        assert (m[0] == so).all() and (m[1] == ho).all()
+        # lists of the other half come out of the attached buffer, identical to the owner's
+        for j in range(n):
+            a, b = np.array(ctxs[0].homologies(j)), np.array(ctxs[1].homologies(j))
+            assert len(a) == int(counts[j]) and (a == b).all(), j
+        # and the host-side comparison agrees once they are there
+        s2, h2 = ctxs[0].compare()
+        assert (s2 == so).all() and (h2 == ho).all()
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def _two_rank_worker(rank, world, port, out):
     import torch.distributed as td
     os.environ["MASTER_ADDR"] = "127.0.0.1"
