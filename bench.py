@@ -115,6 +115,26 @@ def cpu_baseline(torch, buf, offs, lens, ref_idx, sa_ref, sample_queries, thread
                       f"{t_b:.2f}s; ESA build {t_esa:.1f}s excluded"}
 
 
+def usable_cpus():
+    """CPUs this process may actually burn: the cgroup CPU-time quota (cpu.max) when there is
+    one — the GPU boxes show 256 CPUs but meter a job to a fraction of them — else cpu_count."""
+    n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, min(n, int(int(q) / int(p)))), f"cgroup cpu.max = {int(q) / int(p):g} of {n} CPUs"
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return max(1, min(n, q // p)), f"cgroup cfs quota = {q / p:g} of {n} CPUs"
+    except Exception:
+        pass
+    return n, f"{n} CPUs, no quota"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,6 +148,8 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not time kernels with HIP events")
     ap.add_argument("--check", action="store_true", help="verify a sample of the result against the oracle")
     ap.add_argument("--chunk", type=int, default=0, help="dev: force the phase-A chunk length")
+    ap.add_argument("--host-threads", type=int, default=0, help="dev: size of the library's host worker pool")
+    ap.add_argument("--kmer", type=int, default=0, help="dev: force the bucket k of the reference index")
     ap.add_argument("--d-range", default="", help="dev: lo,hi — override the workload's divergence range")
     ap.add_argument("--emulate-rank", default="", help="dev: R/N — time rank R of N's share of the work on this one GPU "
                     "(no collectives; the printed value is NOT a bench result)")
@@ -174,6 +196,10 @@ def main():
     ctx.set_option("profile", 0 if args.no_profile else 1)
     if args.chunk:
         ctx.set_option("chunk", args.chunk)
+    if args.kmer:
+        ctx.set_option("kmer", args.kmer)
+    if args.host_threads:
+        ctx.set_option("host_threads", args.host_threads)
     ctx.set_genomes_device(buf.data_ptr(), offs, lens)
     t_ref = time.time()
     ctx.set_reference(ref_idx)  # host suffix array + tables: outside the metric
@@ -307,8 +333,10 @@ def main():
                 refb = buf[offs[ref_idx]:offs[ref_idx] + lens[ref_idx]].cpu().numpy().tobytes()
                 S = refb + b"#" + O.revcomp(refb)
                 sa_ref = api.host_suffix_array(S)  # the suffix array is unique; saves the oracle's slow sorter
-                threads = min(os.cpu_count() or 1, 64, 1 + min(args.cpu_sample, n - 1))
+                ncpu, cpu_note = usable_cpus()
+                threads = min(ncpu, 64, 1 + min(args.cpu_sample, n - 1))
                 cpu = cpu_baseline(torch, buf, offs, lens, ref_idx, sa_ref, min(args.cpu_sample, n - 1), threads)
+                cpu["sample"] += f"; {threads} threads ({cpu_note})"
             except Exception as e:  # the baseline is a report, never a reason to lose the bench line
                 cpu = {"value": None, "unit": "Gbp/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
         if args.check:
@@ -335,7 +363,7 @@ def main():
                                             "ms:host_sort_filter", "ms:compare_total")},
             "extra_ms": {k[3:]: round(v / K, 3) for k, v in stats.items()
                          if k in ("ms:compare_project_phase", "ms:compare_pairs_phase", "ms:compare_symmetrise",
-                                  "ms:compare_hom_flatten", "ms:compare_hom_upload")},
+                                  "ms:compare_hom_flatten", "ms:compare_hom_upload", "ms:stage_send_done", "ms:stage_all")},
             "kernels": kernels,
             "compared_sites": sites, "alg_bytes": {"anchor": bytes_a, "compare": bytes_b},
             "path_alg_GBps": round((bytes_a + bytes_b) * K / dt / 1e9, 2),

@@ -46,11 +46,16 @@ struct Pileup {
 	uint32_t N, Npad;
 	uint32_t L;
 };
-// hom_rng[2g], hom_rng[2g+1]: genome g's sorted, disjoint list is homs[begin, end)
-void launch_tile_index(const Pileup &P, const DevHom *homs, const uint32_t *hom_rng, uint32_t *first, hipStream_t st);
+// hom_rng[2g], hom_rng[2g+1]: genome g's sorted, disjoint list is homs[begin, end).
+// Both take a range — genomes [g0, g1), genome tiles [tg0, tg1) of project_genomes_per_tile()
+// genomes — so that the projection can run for the genomes whose lists are ready.
+void launch_tile_index(const Pileup &P, const DevHom *homs, const uint32_t *hom_rng, uint32_t *first, uint32_t g0,
+					   uint32_t g1, hipStream_t st);
 // five_planes = false: V, N0, N1 only; *bang_flag is raised when '!' was projected and D, B are needed after all
 void launch_project(const Pileup &P, bool five_planes, const uint8_t *gbase, const uint64_t *goff, const DevHom *homs,
-					const uint32_t *hom_rng, const uint32_t *first, uint32_t *bang_flag, hipStream_t st);
+					const uint32_t *hom_rng, const uint32_t *first, uint32_t *bang_flag, uint32_t tg0, uint32_t tg1,
+					hipStream_t st);
+uint32_t project_genomes_per_tile();
 size_t project_index_entries(const Pileup &P);
 // tiles: list of (ig, jt) pairs packed as ig<<16|jt
 void launch_pairs(const Pileup &P, bool with_bang, const uint32_t *tiles, uint32_t ntiles, uint32_t wchunk,

@@ -137,11 +137,17 @@ class WorkerPool
 		for (auto &t : threads) t.join();
 	}
 	size_t size() const { return threads.size(); }
-	void run(size_t n, std::function<void(size_t)> f)
+	// f(i) for i in [0, n) on the pool; `meanwhile`, if given, runs on the calling thread
+	// while the pool works (it is the one thread that talks to the GPU).
+	// The threads sleep between jobs and are not spun up ahead of one: the GPU boxes this
+	// runs on give a process a CPU-time quota (cgroup cpu.max, 16 CPUs' worth here), and
+	// 48 spinning threads run into it within a few milliseconds.
+	void run(size_t n, std::function<void(size_t)> f, const std::function<void()> &meanwhile = nullptr)
 	{
 		if (n == 0) return;
 		if (threads.empty() || n < 8) { // waking the pool costs more than a handful of lists
 			for (size_t i = 0; i < n; i++) f(i);
+			if (meanwhile) meanwhile();
 			return;
 		}
 		std::unique_lock<std::mutex> lk(m);
@@ -151,6 +157,11 @@ class WorkerPool
 		running = threads.size();
 		generation++;
 		cv_work.notify_all();
+		if (meanwhile) {
+			lk.unlock();
+			meanwhile();
+			lk.lock();
+		}
 		cv_done.wait(lk, [&] { return running == 0; });
 	}
 };
@@ -160,6 +171,8 @@ class WorkerPool
 struct phylo_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
+	hipStream_t copy_stream = nullptr; // uploads that run beside kernels of `stream` (ordered by events)
+	std::vector<hipEvent_t> copy_events;
 	std::string err;
 	int n_cu = 256;
 
@@ -205,6 +218,8 @@ struct phylo_ctx {
 	DevBuf<uint32_t> b_planes, b_hom_rng, b_tiles, b_flag, b_first;
 	// phase A over all genomes leaves the filtered lists on the device already (see phylo_anchor)
 	bool homs_staged = false;
+	// ... and has projected them for the whole reference (part 0 of 1); with five planes or three
+	bool eager_valid = false, eager_five = false;
 	PinBuf<uint32_t> h_rng;
 	// lists attached by phylo_attach_packed_device: borrowed device records + per-genome ranges
 	const DevHom *att_homs = nullptr;
@@ -350,7 +365,8 @@ int phylo_ctx_create(phylo_ctx **out, int device)
 	}
 	phylo_ctx *c = new phylo_ctx();
 	c->device = device;
-	if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess) {
+	if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess ||
+		(e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)) != hipSuccess) {
 		g_last_error = std::string("cannot initialise device: ") + hipGetErrorString(e);
 		delete c;
 		return 4;
@@ -414,6 +430,8 @@ void phylo_ctx_destroy(phylo_ctx *c)
 		(void)hipEventDestroy(s.b);
 	}
 	for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+	for (hipEvent_t e : c->copy_events) (void)hipEventDestroy(e);
+	if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
 	(void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -664,6 +682,28 @@ __global__ void compact_raw_kernel(const RawHom *__restrict__ src, const uint64_
 	for (uint32_t t = threadIdx.x; t < cnt[j]; t += blockDim.x) d[t] = s[t];
 }
 
+// The pileup of part `part` of `nparts`: a range of 64-window tiles of the reference.
+// Every part projects and compares ALL genomes over its own range, so both kernels
+// shrink with the number of parts and the partial tallies simply add up.
+static int make_pileup(phylo_ctx *c, size_t part, size_t nparts, Pileup *out)
+{
+	Pileup P;
+	P.N = (uint32_t)c->n;
+	P.Npad = (uint32_t)((c->n + 63) / 64 * 64);
+	P.L = c->L;
+	uint32_t Wall = (c->L + 31) / 32;
+	uint32_t ntile = (Wall + 63) / 64;
+	uint32_t t0 = (uint32_t)((uint64_t)ntile * part / nparts), t1 = (uint32_t)((uint64_t)ntile * (part + 1) / nparts);
+	P.w0 = t0 * 64;
+	uint32_t wend = std::min<uint32_t>(Wall, t1 * 64);
+	P.W = wend > P.w0 ? wend - P.w0 : 0;
+	size_t plane_words = (size_t)P.W * P.Npad;
+	HIPOK(c, c->b_planes.ensure(plane_words * 5));
+	for (int p = 0; p < 5; p++) P.plane[p] = c->b_planes.p + plane_words * p;
+	*out = P;
+	return 0;
+}
+
 int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 {
 	if (!c) return 1;
@@ -815,14 +855,25 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	// When this call makes every genome's list, phase B's device copy of them is staged
 	// here as well: a worker writes its list in the 16-byte device form into pinned
 	// memory (slot cbase[j] + j: the raw count bounds the filtered one, and the self
-	// query keeps one entry of zero raw ones), and the last worker of each group of
-	// queries sends the group's slots off, so the upload runs under the sorting.
+	// query keeps one entry of zero raw ones) and counts its group down; the calling
+	// thread sends every finished group off — records and ranges go up through the
+	// copy stream, and the projection of those genomes (phase B's first kernel, for
+	// the whole reference = part 0 of 1) starts behind them — so upload and projection
+	// run while the other lists are still being sorted.
 	const bool stage = q_begin == 0 && q_end == c->n && nq > 0;
 	c->homs_staged = false;
 	c->att_homs = nullptr; // an attached buffer is only borrowed until the next phase A
 	c->host_stale.clear();
-	const size_t ngroups = stage ? std::min<size_t>(16, nq) : 0;
+	// genomes per group: a whole number of projection tiles — three, or an eighth of all of them
+	// (measured on C3 and C4: every group pays ~30 us of hand-over between the copy engine and
+	// the compute queue, one big group overlaps nothing)
+	const size_t tsz = project_genomes_per_tile();
+	const size_t gsz = tsz * std::max<size_t>(3, ((nq + tsz - 1) / tsz) / 8);
+	const size_t ngroups = stage ? (nq + gsz - 1) / gsz : 0;
 	std::vector<std::atomic<uint32_t>> group_left(ngroups);
+	const bool eager = stage && c->backend == 0;
+	c->eager_valid = false;
+	Pileup EP;
 	std::atomic<int> stage_err{0};
 	uint32_t *rng = nullptr;
 	DevHom *dh = nullptr;
@@ -833,8 +884,19 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 		HIPOK(c, c->b_hom_rng.ensure(2 * nq));
 		rng = c->h_rng.p;
 		dh = c->h_devhom.p;
-		for (size_t g = 0; g < ngroups; g++)
-			group_left[g] = (uint32_t)((g + 1) * nq / ngroups - g * nq / ngroups);
+		for (size_t g = 0; g < ngroups; g++) group_left[g] = (uint32_t)(std::min(nq, (g + 1) * gsz) - g * gsz);
+		while (c->copy_events.size() < ngroups) {
+			hipEvent_t e;
+			HIPOK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+			c->copy_events.push_back(e);
+		}
+		if (eager) {
+			if (make_pileup(c, 0, 1, &EP)) return 1;
+			HIPOK(c, c->b_flag.ensure(4));
+			HIPOK(c, c->b_first.ensure(project_index_entries(EP) + 1));
+			HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 16, st));
+			c->eager_five = c->pileup_five;
+		}
 	}
 	auto stage_list = [&](size_t j, const std::vector<phylo_homology> &list) {
 		const size_t o = cbase[j] + j;
@@ -843,16 +905,32 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 							   (uint32_t)list[t].length, (uint32_t)list[t].direction};
 		rng[2 * j] = (uint32_t)o;
 		rng[2 * j + 1] = (uint32_t)(o + list.size());
-		size_t g = 0; // the group whose range [g*nq/G, (g+1)*nq/G) holds j
-		while ((g + 1) * nq / ngroups <= j) g++;
-		if (group_left[g].fetch_sub(1, std::memory_order_acq_rel) == 1) {
-			const size_t j0 = g * nq / ngroups, j1 = (g + 1) * nq / ngroups;
-			const size_t o0 = cbase[j0] + j0, o1 = cbase[j1] + j1;
-			if (hipSetDevice(c->device) != hipSuccess ||
-				hipMemcpyAsync(c->b_homs.p + o0, dh + o0, (o1 - o0) * sizeof(DevHom), hipMemcpyHostToDevice, st) != hipSuccess)
-				stage_err = 1;
-		}
+		group_left[j / gsz].fetch_sub(1, std::memory_order_acq_rel);
 	};
+	double t_send_done = 0;
+	auto send_groups = [&]() {
+		for (size_t g = 0; g < ngroups; g++) {
+			while (group_left[g].load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+			const size_t j0 = g * gsz, j1 = std::min(nq, (g + 1) * gsz);
+			const size_t o0 = cbase[j0] + j0, o1 = cbase[j1] + j1;
+			// the upload goes through the copy stream (DMA engine), so group g+1 travels while
+			// group g is being projected; an event orders the group's kernels after its upload
+			if (hipMemcpyAsync(c->b_homs.p + o0, dh + o0, (o1 - o0) * sizeof(DevHom), hipMemcpyHostToDevice, c->copy_stream) != hipSuccess ||
+				hipMemcpyAsync(c->b_hom_rng.p + 2 * j0, rng + 2 * j0, (j1 - j0) * 8, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess ||
+				hipEventRecord(c->copy_events[g], c->copy_stream) != hipSuccess ||
+				hipStreamWaitEvent(st, c->copy_events[g], 0) != hipSuccess) {
+				stage_err = 1;
+			} else if (eager) {
+				launch_tile_index(EP, c->b_homs.p, c->b_hom_rng.p, c->b_first.p, (uint32_t)j0, (uint32_t)j1, st);
+				KernelSpan s(c, c->eager_five ? "pileup_project5" : "pileup_project");
+				launch_project(EP, c->eager_five, c->d_genomes, c->d_goff.p, c->b_homs.p, c->b_hom_rng.p, c->b_first.p,
+							   c->b_flag.p, (uint32_t)(j0 / tsz), g + 1 == ngroups ? EP.Npad / (uint32_t)tsz : (uint32_t)(j1 / tsz), st);
+			}
+		}
+		t_send_done = now_ms();
+	};
+	std::unique_ptr<KernelSpan> stage_span; // GPU-side time from here until the last group's projection is done
+	if (stage) stage_span.reset(new KernelSpan(c, "stage_all"));
 	workers(c).run(nq, [&](size_t j) {
 		std::vector<phylo_homology> &dst = c->homs[q_begin + j];
 		if (q_begin + j == c->ref_idx) {
@@ -882,11 +960,14 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 			tie_lists.fetch_add(1, std::memory_order_relaxed);
 		}
 		if (stage) stage_list(j, dst);
-	});
+	}, stage ? std::function<void()>(send_groups) : std::function<void()>());
+	stage_span.reset();
 	if (stage) {
 		if (stage_err) return c->fail("staging the homology lists on the device failed");
-		HIPOK(c, hipMemcpyAsync(c->b_hom_rng.p, rng, 2 * nq * 4, hipMemcpyHostToDevice, st));
+		HIPOK(c, hipGetLastError());
+		c->stats["ms:stage_send_done"] += t_send_done - t3;
 		c->homs_staged = true;
+		c->eager_valid = eager;
 	}
 	double t4 = now_ms();
 	c->stats["ms:anchor_setup"] += t1 - t0;
@@ -1111,6 +1192,7 @@ int phylo_attach_packed_device(phylo_ctx *c, const void *dev_records, const uint
 	c->host_stale.assign(N, 1);
 	for (size_t g = keep_begin; g < keep_end; g++) c->host_stale[g] = 0;
 	c->homs_staged = true;
+	c->eager_valid = false;
 	return 0;
 }
 
@@ -1215,23 +1297,7 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 	size_t N = c->n;
 	hipStream_t st = c->stream;
 	Pileup P;
-	P.N = (uint32_t)N;
-	P.Npad = (uint32_t)((N + 63) / 64 * 64);
-	P.L = c->L;
-	// this part's share of the reference: a range of 64-window tiles.  Every part
-	// projects and compares ALL genomes over its own range, so both kernels
-	// shrink with the number of parts and the partial tallies simply add up.
-	{
-		uint32_t Wall = (c->L + 31) / 32;
-		uint32_t ntile = (Wall + 63) / 64;
-		uint32_t t0 = (uint32_t)((uint64_t)ntile * part / nparts), t1 = (uint32_t)((uint64_t)ntile * (part + 1) / nparts);
-		P.w0 = t0 * 64;
-		uint32_t wend = std::min<uint32_t>(Wall, t1 * 64);
-		P.W = wend > P.w0 ? wend - P.w0 : 0;
-	}
-	size_t plane_words = (size_t)P.W * P.Npad;
-	HIPOK(c, c->b_planes.ensure(plane_words * 5));
-	for (int p = 0; p < 5; p++) P.plane[p] = c->b_planes.p + plane_words * p;
+	if (make_pileup(c, part, nparts, &P)) return 1;
 
 	// filtered homologies → device, unless phase A staged them there already
 	double t0 = now_ms();
@@ -1278,20 +1344,26 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		acc_h = c->b_homologs.p;
 	}
 	HIPOK(c, c->h_mat.ensure(2 * N * N + 8));
-	HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 16, st));
 	HIPOK(c, hipMemsetAsync(acc_s, 0, N * N * 8, st));
 	HIPOK(c, hipMemsetAsync(acc_h, 0, N * N * 8, st));
 	const DevHom *dev_homs = c->att_homs ? c->att_homs : c->b_homs.p;
-	launch_tile_index(P, dev_homs, c->b_hom_rng.p, c->b_first.p, st);
+	// phase A may have projected the lists already (whole reference, i.e. part 0 of 1)
+	const bool projected = c->homs_staged && c->eager_valid && part == 0 && nparts == 1;
+	if (!projected) {
+		HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 16, st));
+		launch_tile_index(P, dev_homs, c->b_hom_rng.p, c->b_first.p, 0, (uint32_t)N, st);
+	}
 	// Three planes unless '!' turns up among the projected bytes (the flag says so);
 	// then all five are made.  A context remembers the outcome for its next call.
 	uint32_t *flagp = (uint32_t *)(c->h_mat.p + 2 * N * N);
 	uint32_t flag = 0;
 	for (int pass = 0; pass < 2; pass++) {
-		const bool five = pass == 1 || c->pileup_five;
-		{
+		const bool five = pass == 1 || (projected ? c->eager_five : c->pileup_five);
+		if (pass == 1) HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 16, st));
+		if (pass == 1 || !projected) {
 			KernelSpan s(c, five ? "pileup_project5" : "pileup_project");
-			launch_project(P, five, c->d_genomes, c->d_goff.p, dev_homs, c->b_hom_rng.p, c->b_first.p, c->b_flag.p, st);
+			launch_project(P, five, c->d_genomes, c->d_goff.p, dev_homs, c->b_hom_rng.p, c->b_first.p, c->b_flag.p, 0,
+						   P.Npad / project_genomes_per_tile(), st);
 		}
 		HIPOK(c, hipGetLastError());
 		HIPOK(c, hipMemcpyAsync(flagp, c->b_flag.p, 4, hipMemcpyDeviceToHost, st));

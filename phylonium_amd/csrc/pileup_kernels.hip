@@ -76,12 +76,13 @@ static const uint32_t PROJ_GPW = PROJ_TG / 4; // genomes per wavefront
 // the projection's wavefronts.
 __global__ __launch_bounds__(256) void tile_index_kernel(Pileup P, const DevHom *__restrict__ homs,
 														  const uint32_t *__restrict__ hom_rng,
-														  uint32_t *__restrict__ first)
+														  uint32_t *__restrict__ first, uint32_t g0, uint32_t g1)
 {
 	const uint32_t ntw = (P.W + PROJ_TW - 1) / PROJ_TW;
-	const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (tid >= (uint64_t)P.N * ntw) return;
-	const uint32_t g = (uint32_t)(tid / ntw), tw = (uint32_t)(tid % ntw);
+	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= (uint64_t)(g1 - g0) * ntw) return;
+	const uint32_t g = g0 + (uint32_t)(t / ntw), tw = (uint32_t)(t % ntw);
+	const uint64_t tid = (uint64_t)g * ntw + tw;
 	const uint32_t span0 = (P.w0 + tw * PROJ_TW) * 32u;
 	uint32_t lo = hom_rng[2 * g], hi = hom_rng[2 * g + 1]; // genome g's list is homs[lo, hi)
 	while (lo < hi) {
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void project_kernel(Pileup P, const uint8_t *_
 													   const DevHom *__restrict__ homs,
 													   const uint32_t *__restrict__ hom_rng,
 													   const uint32_t *__restrict__ first,
-													   uint32_t *__restrict__ bang_flag)
+													   uint32_t *__restrict__ bang_flag, uint32_t tg0)
 {
 	constexpr uint32_t NP = FIVE ? 5u : 3u;
 	__shared__ uint32_t tile[NP][PROJ_TW][PROJ_TG + 1];
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void project_kernel(Pileup P, const uint8_t *_
 	__shared__ uint32_t hlo[PROJ_TG], hend[PROJ_TG];
 	__shared__ uint32_t below[33]; // below[t] = plane-order mask of the positions < t
 	const uint32_t ntw = (P.W + PROJ_TW - 1) / PROJ_TW;
-	const uint32_t tw = blockIdx.x % ntw, tg = blockIdx.x / ntw;
+	const uint32_t tw = blockIdx.x % ntw, tg = tg0 + blockIdx.x / ntw;
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	if (threadIdx.x < 33) {
 		uint32_t m = 0;
@@ -340,23 +341,32 @@ void launch_symmetrise(uint32_t N, unsigned long long *a, unsigned long long *b,
 	if (n) hipLaunchKernelGGL(symmetrise_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, N, a, b);
 }
 
-void launch_tile_index(const Pileup &P, const DevHom *homs, const uint32_t *hom_rng, uint32_t *first, hipStream_t st)
+// genomes [g0, g1) / genome tiles [tg0, tg1) of PROJ_TG genomes: the whole pileup, or the part
+// of it whose lists are ready (phase A projects eagerly, group by group)
+void launch_tile_index(const Pileup &P, const DevHom *homs, const uint32_t *hom_rng, uint32_t *first, uint32_t g0,
+					   uint32_t g1, hipStream_t st)
 {
 	uint32_t ntw = (P.W + PROJ_TW - 1) / PROJ_TW;
-	if (!ntw || !P.N) return;
-	uint64_t entries = (uint64_t)P.N * ntw;
-	hipLaunchKernelGGL(tile_index_kernel, dim3((uint32_t)((entries + 255) / 256)), dim3(256), 0, st, P, homs, hom_rng, first);
+	if (g1 > P.N) g1 = P.N;
+	if (!ntw || g0 >= g1) return;
+	uint64_t entries = (uint64_t)(g1 - g0) * ntw;
+	hipLaunchKernelGGL(tile_index_kernel, dim3((uint32_t)((entries + 255) / 256)), dim3(256), 0, st, P, homs, hom_rng, first,
+					   g0, g1);
 }
 void launch_project(const Pileup &P, bool five_planes, const uint8_t *gbase, const uint64_t *goff, const DevHom *homs,
-					const uint32_t *hom_rng, const uint32_t *first, uint32_t *bang_flag, hipStream_t st)
+					const uint32_t *hom_rng, const uint32_t *first, uint32_t *bang_flag, uint32_t tg0, uint32_t tg1,
+					hipStream_t st)
 {
 	uint32_t ntw = (P.W + PROJ_TW - 1) / PROJ_TW, ntg = P.Npad / PROJ_TG;
-	if (!ntw || !ntg) return;
+	if (tg1 > ntg) tg1 = ntg;
+	if (!ntw || tg0 >= tg1) return;
+	dim3 grid(ntw * (tg1 - tg0));
 	if (five_planes)
-		hipLaunchKernelGGL(project_kernel<true>, dim3(ntw * ntg), dim3(256), 0, st, P, gbase, goff, homs, hom_rng, first, bang_flag);
+		hipLaunchKernelGGL(project_kernel<true>, grid, dim3(256), 0, st, P, gbase, goff, homs, hom_rng, first, bang_flag, tg0);
 	else
-		hipLaunchKernelGGL(project_kernel<false>, dim3(ntw * ntg), dim3(256), 0, st, P, gbase, goff, homs, hom_rng, first, bang_flag);
+		hipLaunchKernelGGL(project_kernel<false>, grid, dim3(256), 0, st, P, gbase, goff, homs, hom_rng, first, bang_flag, tg0);
 }
+uint32_t project_genomes_per_tile() { return PROJ_TG; }
 size_t project_index_entries(const Pileup &P) { return (size_t)P.N * ((P.W + PROJ_TW - 1) / PROJ_TW); }
 
 void launch_pairs(const Pileup &P, bool with_bang, const uint32_t *tiles, uint32_t ntiles, uint32_t wchunk,
