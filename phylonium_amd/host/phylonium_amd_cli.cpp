@@ -8,7 +8,10 @@
 // (bootstrap).  The hot path itself — process() — is libphylonium_amd.so.
 // Written from the behaviour, not from the reference's text.
 #include <algorithm>
+#include <array>
+#include <atomic>
 #include <cerrno>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -21,6 +24,8 @@
 #include <random>
 #include <string>
 #include <strings.h>
+#include <sys/stat.h>
+#include <thread>
 #include <unistd.h>
 #include <vector>
 
@@ -64,49 +69,101 @@ std::string genome_name(const std::string &path)
 }
 
 // FASTA records of one file → nucleotides filtered to ACGT (upper-cased,
-// sequence.cxx:109-146), contigs joined by '!'
-Genome read_genome(const std::string &path)
-{
-	std::ifstream in(path, std::ios::binary);
-	if (!in) die(path + ": " + strerror(errno));
+// sequence.cxx:109-146), contigs joined by '!'.  The file is read in one piece
+// and filtered through a 256-entry table; errors are returned, not raised, so
+// that files can be read by several threads and the first bad one *in command
+// line order* is still the one reported (the reference reads them in order).
+struct ReadResult {
 	Genome g;
-	g.name = genome_name(path);
-	std::string line;
-	bool in_record = false, any = false;
-	std::string contig;
-	auto flush = [&]() {
-		if (!in_record) return;
-		if (any) g.nucl += '!';
-		g.nucl += contig;
-		contig.clear();
-		any = true;
-	};
-	while (std::getline(in, line)) {
-		if (!line.empty() && line[0] == '>') {
-			flush();
+	std::string error;
+};
+
+ReadResult read_genome(const std::string &path)
+{
+	ReadResult R;
+	R.g.name = genome_name(path);
+	FILE *f = fopen(path.c_str(), "rb");
+	if (!f) {
+		R.error = path + ": " + strerror(errno);
+		return R;
+	}
+	std::string buf;
+	struct stat st;
+	if (fstat(fileno(f), &st) == 0 && st.st_size > 0) buf.reserve((size_t)st.st_size);
+	char chunk[1 << 16];
+	size_t got;
+	while ((got = fread(chunk, 1, sizeof chunk, f)) > 0) buf.append(chunk, got);
+	fclose(f);
+
+	static const auto lut = [] {
+		std::array<char, 256> t{};
+		t[(unsigned char)'A'] = t[(unsigned char)'a'] = 'A';
+		t[(unsigned char)'C'] = t[(unsigned char)'c'] = 'C';
+		t[(unsigned char)'G'] = t[(unsigned char)'g'] = 'G';
+		t[(unsigned char)'T'] = t[(unsigned char)'t'] = 'T';
+		return t;
+	}();
+	std::string &out = R.g.nucl;
+	out.resize(buf.size() + 1);
+	size_t w = 0;
+	bool in_record = false;
+	size_t records = 0;
+	const char *p = buf.data(), *end = p + buf.size();
+	while (p < end) {
+		const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+		const char *le = nl ? nl : end;
+		if (le > p && *p == '>') {
+			// a record starts; every record after the first is preceded by the separator
+			if (records++) out[w++] = '!';
 			in_record = true;
-			continue;
-		}
-		if (!in_record) {
-			bool blank = true;
-			for (char c : line)
-				if (!isspace((unsigned char)c)) blank = false;
-			if (blank) continue;
-			die(path + ": File is not in FASTA format.");
-		}
-		for (unsigned char c : line) {
-			switch (c) {
-				case 'A': case 'a': contig += 'A'; break;
-				case 'C': case 'c': contig += 'C'; break;
-				case 'G': case 'g': contig += 'G'; break;
-				case 'T': case 't': contig += 'T'; break;
-				default: break;
+		} else if (!in_record) {
+			for (const char *c = p; c < le; c++)
+				if (!isspace((unsigned char)*c)) {
+					R.error = path + ": File is not in FASTA format.";
+					return R;
+				}
+		} else {
+			for (const char *c = p; c < le; c++) {
+				const char v = lut[(unsigned char)*c];
+				out[w] = v;
+				w += v != 0;
 			}
 		}
+		p = nl ? nl + 1 : end;
 	}
-	flush();
-	if (!any) die(path + ": Empty file.");
-	return g;
+	out.resize(w);
+	if (!records) R.error = path + ": Empty file.";
+	return R;
+}
+
+// All files, in parallel over up to `threads` host threads.
+std::vector<Genome> read_genomes(const std::vector<std::string> &files, size_t threads)
+{
+	std::vector<ReadResult> res(files.size());
+	std::atomic<size_t> next{0};
+	auto work = [&] {
+		for (;;) {
+			size_t i = next.fetch_add(1);
+			if (i >= files.size()) break;
+			res[i] = read_genome(files[i]);
+		}
+	};
+	threads = std::max<size_t>(1, std::min(threads, files.size()));
+	std::vector<std::thread> pool;
+	for (size_t t = 1; t < threads; t++) pool.emplace_back(work);
+	work();
+	for (auto &t : pool) t.join();
+	std::vector<Genome> q(files.size());
+	for (size_t i = 0; i < files.size(); i++) {
+		if (!res[i].error.empty()) die(res[i].error);
+		q[i] = std::move(res[i].g);
+	}
+	return q;
+}
+
+double now_s()
+{
+	return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
 struct Tally {
@@ -313,7 +370,8 @@ Matrix process(Run &r, size_t ref_idx)
 		"  -p FILE              Print reference positions to FILE (implies complete deletion)\n"
 		"    --progress=WHEN    Accepted for compatibility; no progress bar is drawn\n"
 		"  -r FILE              Set the reference genome\n"
-		"  -t, --threads=N      Host threads for the per-genome sort/filter step\n"
+		"  -t, --threads=N      Host threads (FASTA reading, per-genome sort/filter step)\n"
+		"      --timing         Print where the wall-clock went to stderr\n"
 		"  -d, --device=N       GPU ordinal (default 0)\n"
 		"  -v, --verbose        Print additional information\n"
 		"      --distance=OPT   Choose between raw, jc corrected and ANI\n"
@@ -329,7 +387,7 @@ int main(int argc, char *argv[])
 {
 	std::random_device rd;
 	std::mt19937 prng(rd());
-	int version_flag = 0, flags = 0, device = 0;
+	int version_flag = 0, timing = 0, flags = 0, device = 0;
 	long threads = 0;
 	bool two_pass = false;
 	unsigned long bootstrap = 0;
@@ -345,6 +403,7 @@ int main(int argc, char *argv[])
 										   {"device", required_argument, NULL, 'd'},
 										   {"verbose", no_argument, NULL, 'v'},
 										   {"version", no_argument, &version_flag, 1},
+										   {"timing", no_argument, &timing, 1},
 										   {0, 0, 0, 0}};
 	for (;;) {
 		int option_index = 0;
@@ -405,18 +464,28 @@ int main(int argc, char *argv[])
 	}
 	if (files.size() < 2) usage(EXIT_FAILURE);
 
-	std::vector<Genome> q(files.size());
-	for (size_t i = 0; i < files.size(); i++) q[i] = read_genome(files[i]);
+	// --timing: where the wall-clock goes (stderr), FASTA in to PHYLIP out
+	double t_start = now_s(), t_read, t_ctx, t_upload, t_done;
+	// The device context (HIP start-up, ~0.3 s) is created while the files are being read.
+	Run r;
+	std::string ctx_error;
+	std::thread ctx_thread([&] {
+		if (phylo_ctx_create(&r.ctx, device)) ctx_error = phylo_last_error(nullptr);
+	});
+	size_t read_threads = threads > 0 ? (size_t)threads : std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
+	std::vector<Genome> q = read_genomes(files, read_threads);
+	t_read = now_s();
+	ctx_thread.join();
+	if (!ctx_error.empty()) die(ctx_error);
+	t_ctx = now_s();
 
 	size_t ref_idx;
 	if (reference_name.empty()) ref_idx = pick_first_pass(q, flags);
 	else ref_idx = std::find(files.begin(), files.end(), reference_name) - files.begin();
 
-	Run r;
 	r.q = &q;
 	r.flags = flags;
 	r.refpos_file = refpos_file;
-	if (phylo_ctx_create(&r.ctx, device)) die(phylo_last_error(nullptr));
 	if (threads > 0) ok(r, phylo_set_option(r.ctx, "host_threads", threads));
 	std::vector<const char *> seq(q.size());
 	std::vector<size_t> len(q.size());
@@ -425,6 +494,7 @@ int main(int argc, char *argv[])
 		len[i] = q[i].nucl.size();
 	}
 	ok(r, phylo_set_genomes(r.ctx, q.size(), seq.data(), len.data()));
+	t_upload = now_s();
 
 	Matrix m = process(r, ref_idx);
 	if (two_pass) {
@@ -432,6 +502,23 @@ int main(int argc, char *argv[])
 		m = process(r, ref_idx);
 	}
 	print_matrix(q, m, flags, bootstrap, ref_idx, prng);
+	t_done = now_s();
+	if (timing) {
+		auto stat = [&](const char *k) {
+			double v = 0;
+			phylo_get_stat(r.ctx, k, &v);
+			return v / 1e3;
+		};
+		double bases = 0;
+		for (auto &g : q) bases += (double)g.nucl.size();
+		fprintf(stderr,
+				"timing: genomes %zu  bases %.0f  total %.3f s | read %.3f (%zu threads)  wait-for-device %.3f  upload %.3f  "
+				"process+print %.3f  [suffix array %.3f  index on device %.3f  anchor %.3f  compare %.3f]\n",
+				q.size(), bases, t_done - t_start, t_read - t_start, read_threads, t_ctx - t_read, t_upload - t_ctx,
+				t_done - t_upload, stat("ms:ref_suffix_array"), stat("ms:ref_total") - stat("ms:ref_suffix_array"),
+				stat("ms:anchor_total"), stat("ms:compare_total"));
+	}
 	phylo_ctx_destroy(r.ctx);
+	if (timing) fprintf(stderr, "timing: releasing the device context %.3f s\n", now_s() - t_done);
 	return RETURN_CODE;
 }

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Wall-clock FASTA -> PHYLIP of the host driver (phylonium_amd/phylonium-amd) on a synthetic
+workload, with the split the driver's --timing prints.  Run on the GPU box:
+    python tools/tools_wallclock.py [--workload c3] [--genomes N] [--out gpurun_out/wallclock.json]
+Writes the genomes as FASTA files (70 columns) under /tmp, runs the driver twice (the
+second run has the files in the page cache), and checks the matrix text against the
+library called through the Python mirror on the same genomes."""
+import argparse, json, os, re, subprocess, sys, time
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="c3", choices=sorted(bench.WORKLOADS))
+    ap.add_argument("--genomes", type=int, default=0)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "wallclock.json"))
+    args = ap.parse_args()
+    import torch
+    from phylonium_amd import api
+    n, length, d_range, indel, inv, desc = bench.WORKLOADS[args.workload]
+    n = args.genomes or n
+    dev = torch.device("cuda", 0)
+    buf, offs, lens = bench.make_genomes_gpu(torch, n, length, 20260101, dev, d_range, indel, inv,
+                                             contigs=bench.CONTIGS.get(args.workload, 1))
+    d = f"/tmp/wallclock_{args.workload}_{n}"
+    os.makedirs(d, exist_ok=True)
+    t0 = time.time()
+    files, host = [], []
+    for j in range(n):
+        g = buf[offs[j]:offs[j] + lens[j]].cpu().numpy()
+        host.append(g)
+        path = os.path.join(d, f"g{j:04d}.fasta")
+        files.append(path)
+        with open(path, "wb") as f:
+            for k, contig in enumerate(bytes(g).split(b"!")):
+                f.write(b">contig%d\n" % k)
+                a = np.frombuffer(contig, np.uint8)
+                full = len(a) // 70 * 70
+                lines = np.empty((full // 70, 71), np.uint8)
+                lines[:, :70] = a[:full].reshape(-1, 70)
+                lines[:, 70] = 10
+                f.write(lines.tobytes())
+                if full < len(a):
+                    f.write(a[full:].tobytes() + b"\n")
+    t_write = time.time() - t0
+    # expected text through the library's Python mirror (reference = genome 0, as bench.py)
+    with api.Context(0) as ctx:
+        ctx.set_genomes(host)
+        s, h = ctx.process(ref_idx=0)
+    names = [f"g{j:04d}" for j in range(n)]
+    want = api.format_phylip(names, s, h)
+    exe = os.path.join(ROOT, "phylonium_amd", "phylonium-amd")
+    runs = []
+    for label in ("first run", "files in page cache"):
+        t0 = time.time()
+        p = subprocess.run([exe, "--timing", "-r", files[0]] + files, capture_output=True)
+        wall = time.time() - t0
+        err = p.stderr.decode()
+        m = re.search(r"timing: (.*)", err)
+        runs.append({"label": label, "wall_s_including_exec": round(wall, 3), "timing": m.group(1) if m else err[-400:],
+                     "matrix_identical": p.stdout.decode() == want, "exit": p.returncode})
+    out = {"workload": f"{args.workload}: {desc}", "genomes": n, "bases": float(sum(lens)),
+           "fasta_bytes": sum(os.path.getsize(f) for f in files), "fasta_write_s": round(t_write, 2), "runs": runs}
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    json.dump(out, open(args.out, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+    for f in files:
+        os.remove(f)
+
+
+if __name__ == "__main__":
+    main()
