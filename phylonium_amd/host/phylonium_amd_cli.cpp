@@ -136,8 +136,9 @@ ReadResult read_genome(const std::string &path)
 	return R;
 }
 
-// All files, in parallel over up to `threads` host threads.
-std::vector<Genome> read_genomes(const std::vector<std::string> &files, size_t threads)
+// All files, in parallel over up to `threads` host threads.  *error receives the message of
+// the first file (in command line order) that could not be read.
+std::vector<Genome> read_genomes(const std::vector<std::string> &files, size_t threads, std::string *error)
 {
 	std::vector<ReadResult> res(files.size());
 	std::atomic<size_t> next{0};
@@ -155,7 +156,7 @@ std::vector<Genome> read_genomes(const std::vector<std::string> &files, size_t t
 	for (auto &t : pool) t.join();
 	std::vector<Genome> q(files.size());
 	for (size_t i = 0; i < files.size(); i++) {
-		if (!res[i].error.empty()) die(res[i].error);
+		if (!res[i].error.empty() && error->empty()) *error = res[i].error;
 		q[i] = std::move(res[i].g);
 	}
 	return q;
@@ -473,9 +474,11 @@ int main(int argc, char *argv[])
 		if (phylo_ctx_create(&r.ctx, device)) ctx_error = phylo_last_error(nullptr);
 	});
 	size_t read_threads = threads > 0 ? (size_t)threads : std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
-	std::vector<Genome> q = read_genomes(files, read_threads);
+	std::string read_error;
+	std::vector<Genome> q = read_genomes(files, read_threads, &read_error);
 	t_read = now_s();
 	ctx_thread.join();
+	if (!read_error.empty()) die(read_error);
 	if (!ctx_error.empty()) die(ctx_error);
 	t_ctx = now_s();
 

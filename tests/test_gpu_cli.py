@@ -94,3 +94,49 @@ def test_two_pass_picks_the_central_genome(tmp_path):
     assert refs[1] == names[second]
     s2, h2 = O.Run(gs, second).process().matrix()
     assert out == O.phylip(names, s2, h2)
+
+
+def test_fasta_reader_semantics(tmp_path):
+    """sequence.cxx:109-199 / io.cxx:36-104 as the driver restates them: ACGT kept (lower case
+    upper-cased), everything else dropped, records joined by '!', CRLF and blank lines harmless."""
+    rng = np.random.default_rng(9)
+    a = synth.random_base(30000, rng)
+    b = synth.mutate(a, 0.05, rng) if hasattr(synth, "mutate") else a.copy()
+    sa, sb = bytes(a), bytes(b)
+    # plain files
+    write_fasta(tmp_path / "a.fa", a)
+    write_fasta(tmp_path / "b.fa", b)
+    rc0, want, _ = run(["a.fa", "b.fa"], tmp_path)
+    assert rc0 == 0
+    # the same sequences dressed up: lower case, CRLF, Ns and digits sprinkled in, leading blank lines
+    def dress(seq, path):
+        with open(path, "wb") as f:
+            f.write(b"\n  \r\n")
+            f.write(b">rec one\r\n")
+            low = seq.lower()
+            for i in range(0, len(low), 61):
+                f.write(low[i:i + 30] + b"N7-" + low[i + 30:i + 61] + b"\r\n")
+    dress(sa, tmp_path / "a2.fa")
+    dress(sb, tmp_path / "b2.fa")
+    rc, out, _ = run(["a2.fa", "b2.fa"], tmp_path)
+    assert rc == 0 and out.replace("a2", "a").replace("b2", "b") == want
+    # two records, the second one empty: the separator is still there (same result as via the oracle)
+    with open(tmp_path / "c.fa", "wb") as f:
+        f.write(b">x\n" + sa[:15000] + b"\n>y\n" + sa[15000:] + b"\n>empty\n")
+    gs = [np.frombuffer(sa[:15000] + b"!" + sa[15000:] + b"!", np.uint8), np.frombuffer(sb, np.uint8)]
+    s, h = O.Run(gs, 1).process().matrix()
+    rc, out, _ = run(["-r", "b.fa", "c.fa", "b.fa"], tmp_path)
+    assert out == O.phylip(["b", "c"], s[::-1, ::-1], h[::-1, ::-1])  # -r sorts the names: b, c
+
+
+def test_fasta_reader_errors_in_command_line_order(tmp_path):
+    rng = np.random.default_rng(10)
+    write_fasta(tmp_path / "ok.fa", synth.random_base(5000, rng))
+    (tmp_path / "notfasta.fa").write_bytes(b"hello\n>x\nACGT\n")
+    (tmp_path / "empty.fa").write_bytes(b"\n\n")
+    rc, out, err = run(["ok.fa", "notfasta.fa", "empty.fa"], tmp_path)
+    assert rc == 1 and out == "" and "notfasta.fa: File is not in FASTA format." in err and "empty.fa" not in err
+    rc, out, err = run(["ok.fa", "empty.fa", "notfasta.fa"], tmp_path)
+    assert rc == 1 and "empty.fa: Empty file." in err and "notfasta" not in err
+    rc, out, err = run(["ok.fa", "missing.fa"], tmp_path)
+    assert rc == 1 and "missing.fa" in err
