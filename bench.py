@@ -91,7 +91,8 @@ def make_genomes_gpu(torch, n, length, seed, device, d_range, indel_per_mbp, inv
     for c, o, l in zip(codes, offs, lens):
         buf[o:o + l] = lut[c.long()]
         if contigs > 1:  # contig breaks: '!' replaces a base (src/sequence.cxx:171-199 joins contigs with '!')
-            cuts = torch.from_numpy(np.sort(rng.choice(np.arange(1000, l - 1000), size=contigs - 1, replace=False))).to(device)
+            cuts = np.unique(rng.integers(1000, l - 1000, size=contigs - 1))  # (rng.choice without replacement shuffles all l positions)
+            cuts = torch.from_numpy(cuts).to(device)
             buf[o + cuts] = ord("!")
     del codes
     return buf, offs, lens
@@ -201,10 +202,13 @@ def main():
     if args.host_threads:
         ctx.set_option("host_threads", args.host_threads)
     ctx.set_genomes_device(buf.data_ptr(), offs, lens)
+    print(f"# genomes generated in {t_gen:.1f} s", file=sys.stderr, flush=True)
     t_ref = time.time()
     ctx.set_reference(ref_idx)  # host suffix array + tables: outside the metric
     t_ref = time.time() - t_ref
     ref_stats = {k: ctx.stat(k) for k in ("ms:ref_suffix_array", "ms:ref_lcp_table", "ms:ref_total")}
+    print(f"# reference index built in {t_ref:.1f} s (suffix array {(ref_stats['ms:ref_suffix_array'] or 0) / 1e3:.1f} s)",
+          file=sys.stderr, flush=True)
     total_bases = float(sum(lens))
 
     emu = None

@@ -775,6 +775,7 @@ struct run_port {
 	size_t n = 0;
 	size_t ref_idx = 0;
 	size_t threshold = 0;
+	size_t forced_threshold = 0; // tests: stand in for a longer reference's threshold (0 = process.cxx:416-417)
 	double gc = 0;
 	std::vector<std::string> seqs;
 	std::vector<std::vector<hom>> raw;      // anchor_homologies output
@@ -798,6 +799,7 @@ static void process_port(run_port &r, bool complete_deletion, const int64_t *sa,
 	r.t_esa = c1 - c0;
 	r.gc = gc_content_port(subject.data(), subject.size());
 	r.threshold = min_anchor_length_port(0.025, r.gc, (size_t)r.esa->size);
+	if (r.forced_threshold) r.threshold = r.forced_threshold;
 	r.raw.assign(N, {});
 	r.filtered.assign(N, {});
 	(void)threads;
@@ -1046,6 +1048,9 @@ void orc_run_times(void *rp, double out[3])
 	out[2] = r->t_compare;
 }
 size_t orc_run_threshold(void *rp) { return ((run_port *)rp)->threshold; }
+// The threshold is a function of the reference's length and GC (13-17 for 1 Mbp-100 Mbp);
+// forcing it lets small test inputs walk the code paths a 100 Mbp reference takes.
+void orc_run_force_threshold(void *rp, size_t threshold) { ((run_port *)rp)->forced_threshold = threshold; }
 double orc_run_gc(void *rp) { return ((run_port *)rp)->gc; }
 void *orc_run_esa(void *rp) { return ((run_port *)rp)->esa; }
 size_t orc_run_hom_count(void *rp, size_t j, int filtered)

@@ -194,6 +194,19 @@ template <int MODE> __global__ __launch_bounds__(256) void chain_kernel(PhaseA A
 		}
 		if (__all(done && !active)) break;
 		const bool live = active;
+		// A lane can arrive here in ST_T: when the threshold exceeds the 16 bytes the lucky
+		// check sees in the STEP phase, the check continues in EXT, and if it then fails the
+		// k-mer lookup is still owed (thresholds >= 17, i.e. references beyond ~60 Mbp).
+		if (live && ch.st == ST_T) {
+			const uint8_t *sa = ch.issue_T(R);
+			const U4 hdr = load16(sa);
+			Data d;
+			d.w[0] = load16(sa + 16);
+			d.w[1] = load16(sa + 32);
+			d.w[2] = load16(sa + 48);
+			d.w[3] = load16(sa + 64);
+			ch.consume_T(R, hdr, d);
+		}
 		if (live && ch.st == ST_CAND) {
 			Data d;
 			d.w[0] = load16(R.S + ch.c_pos0);

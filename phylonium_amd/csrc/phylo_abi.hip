@@ -805,20 +805,35 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	RefIndex R = {c->d_S.p, c->d_SAX.p, c->d_LCP.p, c->d_SLOT.p, c->ns, c->k, c->threshold};
 
 	double t1 = now_ms();
+	const bool dbg = getenv("PHY_DEBUG_SYNC") != nullptr; // name the kernel a hang is in
+	if (dbg) {
+		hipError_t e = hipStreamSynchronize(st);
+		fprintf(stderr, "[phylonium_amd] phase A set up (%s): %zu queries, %u chunks of %u, cap %u, k %u, |S| %u, threshold %u\n",
+				hipGetErrorString(e), nq, nch, P.C, P.cap, c->k, c->ns, c->threshold);
+	}
+	auto dbg_sync = [&](const char *what) {
+		if (!dbg) return;
+		hipError_t e = hipStreamSynchronize(st);
+		fprintf(stderr, "[phylonium_amd] %s finished at +%.1f ms (%s), chunks %u of %u positions\n", what, now_ms() - t1,
+				hipGetErrorString(e), nch, P.C);
+	};
 	if (nch) {
 		{
 			KernelSpan s(c, "anchor_spec");
 			launch_spec(A, R, c->n_cu, st);
 		}
+		dbg_sync("anchor_spec");
 		{
 			KernelSpan s(c, "anchor_bridge");
 			launch_bridge(A, R, c->n_cu, st);
 		}
+		dbg_sync("anchor_bridge");
 	}
 	{
 		KernelSpan s(c, "anchor_fold");
 		launch_fold(A, (uint32_t)nq, c->L, c->threshold, c->a_raw.p, c->a_out_base.p, c->a_out_cap.p, c->a_out_cnt.p, st);
 	}
+	dbg_sync("anchor_fold");
 	HIPOK(c, hipGetLastError());
 	HIPOK(c, c->h_cnt.ensure(nq + 4));
 	uint32_t *cnt = c->h_cnt.p, *misc = c->h_cnt.p + nq;

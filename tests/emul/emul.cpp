@@ -31,6 +31,7 @@ static void run_lane(Lane &ln, const RefIndex &R, Begin begin, Done done, uint64
 		*len = i;
 		*less = (i < n && sp[i] < qp[i]) ? 1u : 0u;
 	};
+	uint64_t lane_trips = 0;
 	for (;;) {
 		if (ln.ch.fin) {
 			done();
@@ -40,6 +41,12 @@ static void run_lane(Lane &ln, const RefIndex &R, Begin begin, Done done, uint64
 		if (ln.ch.st == ST_STEP && !begin()) break;
 		chain_trip(ln.ch, R, tail);
 		(*trips)++;
+		if (++lane_trips > 50000000ull) { // a chunk is a few thousand positions: this lane is stuck
+			const Chain &c = ln.ch;
+			fprintf(stderr, "emul: lane stuck: st %u q %u qlen %u qv %u qcode %08x lo %u hi %u mid %u l_lo %u l_hi %u c_rank0 %u c_n %u e_kind %u e_pos %u e_p %u\n",
+					(unsigned)c.st, c.q, c.qlen, c.qv, c.qcode, c.lo, c.hi, c.mid, c.l_lo, c.l_hi, c.c_rank0, c.c_n, (unsigned)c.e_kind, c.e_pos, c.e_p);
+			abort();
+		}
 	}
 }
 
@@ -57,7 +64,10 @@ void *emul_run(size_t n, const char *const *seq, const size_t *len, size_t ref_i
 	S[L] = '#';
 	revcomp((const uint8_t *)seq[ref_idx], L, S.data() + L + 1);
 	std::vector<uint32_t> SA((size_t)ns + 4, 0), LCP((size_t)ns + 1 + 4, 0), T;
+	const bool chatty = getenv("EMUL_PROGRESS") != nullptr;
+	if (chatty) fprintf(stderr, "emul: suffix array of %u\n", ns);
 	suffix_array_u32(S.data(), ns, SA.data());
+	if (chatty) fprintf(stderr, "emul: lcp, tables\n");
 	lcp_kasai(S.data(), ns, SA.data(), LCP.data());
 	uint32_t k = forced_k ? forced_k : choose_k(ns);
 	kmer_table(S.data(), ns, k, T);
@@ -78,6 +88,9 @@ void *emul_run(size_t n, const char *const *seq, const size_t *len, size_t ref_i
 	for (size_t j = 0; j < n; j++) {
 		qoff[j] = tot;
 		qlen[j] = (uint32_t)len[j];
+		// debugging large inputs: the reference against itself costs O(L^2/C) here (the product
+		// writes that list directly, phylo_abi.hip) — leave it out
+		if (j == ref_idx && getenv("EMUL_SKIP_SELF")) qlen[j] = 0;
 		tot += ((len[j] + 63) / 64) * 64 + 64;
 	}
 	std::vector<uint8_t> qbase(tot, 0);
@@ -114,6 +127,7 @@ void *emul_run(size_t n, const char *const *seq, const size_t *len, size_t ref_i
 	A.error = &error;
 	A.fetch = fetch;
 
+	if (chatty) fprintf(stderr, "emul: index done (k %u), %u chunks of %u\n", k, P.nchunks, P.C);
 	// K1: speculative chains
 	for (uint32_t it = 0; it < P.nchunks; it++) {
 		SpecLane ln;

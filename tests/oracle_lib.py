@@ -76,6 +76,8 @@ def lib():
     L.orc_run_times.argtypes = [vp, C.POINTER(C.c_double)]
     L.orc_run_threshold.restype = sz
     L.orc_run_threshold.argtypes = [vp]
+    L.orc_run_force_threshold.restype = None
+    L.orc_run_force_threshold.argtypes = [vp, sz]
     L.orc_run_gc.restype = C.c_double
     L.orc_run_gc.argtypes = [vp]
     L.orc_run_esa.restype = vp
@@ -256,13 +258,15 @@ def compare_lists(sa, ha, sb, hb):
 class Run:
     """process(subject, queries) of src/process.cxx:408-556 on in-memory genomes."""
 
-    def __init__(self, genomes, ref_idx):
+    def __init__(self, genomes, ref_idx, threshold=0):
         self.n = len(genomes)
         self._arrs = [np.frombuffer(bytes(g), dtype=np.uint8) if isinstance(g, (bytes, bytearray))
                       else np.ascontiguousarray(g, dtype=np.uint8) for g in genomes]
         ptrs = (C.c_void_p * self.n)(*[a.ctypes.data for a in self._arrs])
         lens = (C.c_size_t * self.n)(*[a.size for a in self._arrs])
         self.h = lib().orc_run_create(self.n, ptrs, lens, ref_idx)
+        if threshold:
+            lib().orc_run_force_threshold(self.h, threshold)
 
     def process(self, complete_deletion=False, sa=None, threads=1, q_begin=0, q_end=None, compare=True):
         q_end = self.n if q_end is None else q_end

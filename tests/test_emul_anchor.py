@@ -13,9 +13,9 @@ import oracle_lib as O
 from phylonium_amd import synth
 
 
-def assert_same(gs, ref, chunk=0, kmer=0, allow_quirk=False):
-    r = O.Run(gs, ref).process(compare=False)
-    e = E.EmulRun(gs, ref, chunk=chunk, kmer=kmer)
+def assert_same(gs, ref, chunk=0, kmer=0, allow_quirk=False, threshold=0):
+    r = O.Run(gs, ref, threshold=threshold).process(compare=False)
+    e = E.EmulRun(gs, ref, chunk=chunk, kmer=kmer, threshold=threshold)
     assert e.error == 0
     assert e.threshold == r.threshold
     for j in range(len(gs)):
@@ -146,3 +146,11 @@ def test_suffix_array_and_tables_against_oracle():
                 break
     S = (b"AAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA" * 30)
     assert (E.suffix_array(S).astype(np.int64) == O.suffix_array(S)).all()
+
+
+@pytest.mark.parametrize("threshold", [17, 24, 40])
+def test_thresholds_of_long_references(threshold):
+    """Thresholds a 60 Mbp+ reference has (forced here): the lucky check needs more than one 16-byte window."""
+    gs = synth.make_genomes(4, 30000, seed=threshold, d_range=(0.01, 0.15), indel_per_mbp=300, inv_frac=0.06, contigs=2)
+    assert_same(gs, 0, threshold=threshold)
+    assert_same(gs, 2, chunk=128, threshold=threshold)

@@ -31,13 +31,13 @@ def hom_tuples_orc(h):
     return [(int(a["rev"]), int(a["iref"]), int(a["iproj"]), int(a["iq"]), int(a["len"])) for a in h]
 
 
-def check_process(ctx, gs, ref, chunk=0, kmer=0, backend=0, complete_deletion=False):
+def check_process(ctx, gs, ref, chunk=0, kmer=0, backend=0, complete_deletion=False, threshold=0):
     ctx.set_option("chunk", chunk)
     ctx.set_option("kmer", kmer)
     ctx.set_option("compare_backend", backend)
     ctx.set_genomes(gs)
-    ctx.set_reference(ref)
-    r = O.Run(gs, ref).process(complete_deletion=complete_deletion)
+    ctx.set_reference(ref, threshold=threshold)
+    r = O.Run(gs, ref, threshold=threshold).process(complete_deletion=complete_deletion)
     assert ctx.threshold == r.threshold
     ctx.anchor()
     if complete_deletion:
@@ -231,6 +231,17 @@ def test_medium_scale_parity_and_properties(ctx):
     assert (s == so).all() and (h == ho).all()
     assert (s == s.T).all() and (h == h.T).all() and (s <= h).all()
     assert (np.diag(h) == 0).all()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("threshold", [16, 17, 18, 24, 33, 40])
+def test_thresholds_of_long_references(ctx, threshold):
+    """min_anchor_length grows with the reference (13-14 at 1 Mbp, 17 from ~60 Mbp on). Beyond 16 the
+    lucky-anchor check no longer fits the 16 bytes of the STEP phase and continues in EXT; a failed
+    check there still owes the k-mer lookup (the kernel once had no phase for that and hung)."""
+    gs = synth.make_genomes(5, 40000, seed=threshold, d_range=(0.01, 0.15), indel_per_mbp=300, inv_frac=0.06, contigs=2)
+    check_process(ctx, gs, 0, threshold=threshold)
+    check_process(ctx, gs, 3, chunk=128, threshold=threshold, backend=1)
 
 
 def test_export_import_roundtrip(ctx):
