@@ -270,7 +270,7 @@ template <int MODE> __global__ __launch_bounds__(256) void chain_kernel(PhaseA A
 //      stays in query order (the host's std::sort depends on the input order).
 
 static const uint32_t FOLD_WCH = 1024;  // chunks of metadata per window
-static const uint32_t FOLD_SEGS = 3072; // anchor segments per window
+static const uint32_t FOLD_SEGS = 5120; // anchor segments per window (a chunk contributes 1-3; 5 per chunk on average would overflow, reported as error 4)
 static const uint32_t FOLD_APT = 8;     // anchors per thread and iteration
 static const uint32_t FOLD_ITER = 256 * FOLD_APT;
 

@@ -154,3 +154,22 @@ def test_thresholds_of_long_references(threshold):
     gs = synth.make_genomes(4, 30000, seed=threshold, d_range=(0.01, 0.15), indel_per_mbp=300, inv_frac=0.06, contigs=2)
     assert_same(gs, 0, threshold=threshold)
     assert_same(gs, 2, chunk=128, threshold=threshold)
+
+
+def _long_repeat_set():
+    """Two identical 70 kbp copies in the reference: LCP values beyond the 16-bit clip of the SAX
+    records (and beyond the device LCP builder's cap), matches that run past 65535 characters."""
+    rng = np.random.default_rng(77)
+    R = synth.random_base(70000, rng)
+    X = [synth.random_base(3000, rng) for _ in range(4)]
+    ref = np.concatenate([X[0], R, X[1], R, X[2]])
+    q1 = np.concatenate([X[0], R, synth.mutate(X[1], 0.02, rng)])          # unique only beyond the repeat
+    q2 = np.concatenate([X[3], R[:68000], synth.random_base(500, rng)])     # ends inside the repeat: never unique
+    q3 = synth.mutate(ref, 0.01, rng)
+    q4 = np.concatenate([synth.revcomp(R)[:69000], X[3]])                   # the same on the reverse strand
+    return [ref, q1, q2, q3, q4]
+
+def test_long_repeat_beyond_the_lcp_clip():
+    gs = _long_repeat_set()
+    assert_same(gs, 0)
+    assert_same(gs, 3, chunk=1024)

@@ -421,3 +421,23 @@ def test_rccl_collectives_in_a_one_rank_group(tmp_path):
     gs = synth.make_genomes(6, 20000, seed=91, d_range=(0.01, 0.2), inv_frac=0.05)
     so, ho = O.Run(gs, 1).process().matrix()
     assert (np.load(out + ".s.npy") == so).all() and (np.load(out + ".h.npy") == ho).all()
+
+
+def _long_repeat_set():
+    """Two identical 70 kbp copies in the reference: LCP values beyond the 16-bit clip of the SAX
+    records (and beyond the device LCP builder's cap), matches that run past 65535 characters."""
+    rng = np.random.default_rng(77)
+    R = synth.random_base(70000, rng)
+    X = [synth.random_base(3000, rng) for _ in range(4)]
+    ref = np.concatenate([X[0], R, X[1], R, X[2]])
+    q1 = np.concatenate([X[0], R, synth.mutate(X[1], 0.02, rng)])          # unique only beyond the repeat
+    q2 = np.concatenate([X[3], R[:68000], synth.random_base(500, rng)])     # ends inside the repeat: never unique
+    q3 = synth.mutate(ref, 0.01, rng)
+    q4 = np.concatenate([synth.revcomp(R)[:69000], X[3]])                   # the same on the reverse strand
+    return [ref, q1, q2, q3, q4]
+
+def test_long_repeat_beyond_the_lcp_clip(ctx):
+    gs = _long_repeat_set()
+    check_process(ctx, gs, 0)
+    check_process(ctx, gs, 0, chunk=1024, backend=1)
+    check_process(ctx, gs, 3)
