@@ -255,7 +255,7 @@ template <int MODE> __global__ __launch_bounds__(256) void chain_kernel(PhaseA A
 }
 
 // ───────────────────────── fold: anchors → homologies ─────────────────────────
-// One 256-thread block per query.
+// One block of FOLD_THREADS threads per query.
 //  (1) The chunk metadata of a window of FOLD_WCH chunks (bridge target, merge
 //      index, bridge size, log size) is copied into LDS with coalesced loads.
 //  (2) One thread walks the true chain inside LDS — chunk 0's log, its bridge,
@@ -271,8 +271,11 @@ template <int MODE> __global__ __launch_bounds__(256) void chain_kernel(PhaseA A
 
 static const uint32_t FOLD_WCH = 1024;  // chunks of metadata per window
 static const uint32_t FOLD_SEGS = 5120; // anchor segments per window (a chunk contributes 1-3; 5 per chunk on average would overflow, reported as error 4)
-static const uint32_t FOLD_APT = 8;     // anchors per thread and iteration
-static const uint32_t FOLD_ITER = 256 * FOLD_APT;
+static const uint32_t FOLD_APT = 4;     // anchors per thread and iteration
+static const uint32_t FOLD_THREADS = 1024; // per block (= per query)
+static const uint32_t FOLD_WAVES = FOLD_THREADS / 64;
+static const uint32_t FOLD_PPT = FOLD_WCH / FOLD_THREADS; // chain positions per thread when segments are laid out
+static const uint32_t FOLD_ITER = FOLD_THREADS * FOLD_APT;
 
 // Workgroup barrier that orders LDS traffic only: global loads issued before it may
 // still be in flight afterwards (__syncthreads would wait for them).
@@ -293,14 +296,14 @@ struct FoldShared {
 	uint16_t dist[FOLD_WCH + 1];     // links from t until the window is left
 	uint16_t path[FOLD_WCH];         // live chunks in chain order
 	uint8_t live[FOLD_WCH + 1];
-	uint32_t scan_s[4], scan_a[4];
+	uint32_t scan_s[FOLD_WAVES], scan_a[FOLD_WAVES];
 	// per-iteration exchange between the four waves
-	uint32_t wl_q[4], wl_s[4], wl_len[4], wl_r[4]; // last anchor of each wave and its right flag
-	uint32_t st_has[4], st_s[4], st_q[4];          // latest non-right anchor of each wave
-	uint32_t ecnt[4];
+	uint32_t wl_q[FOLD_WAVES], wl_s[FOLD_WAVES], wl_len[FOLD_WAVES], wl_r[FOLD_WAVES]; // last anchor of each wave and its right flag
+	uint32_t st_has[FOLD_WAVES], st_s[FOLD_WAVES], st_q[FOLD_WAVES]; // latest non-right anchor of each wave
+	uint32_t ecnt[FOLD_WAVES];
 };
 
-__global__ __launch_bounds__(256) void fold_kernel(PhaseA A, uint32_t nq, uint32_t border, uint32_t thr,
+__global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t nq, uint32_t border, uint32_t thr,
 												   RawHom *out, const uint64_t *out_base, const uint32_t *out_cap,
 												   uint32_t *out_cnt)
 {
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(256) void fold_kernel(PhaseA A, uint32_t nq, uint32
 		// (1) metadata window [gc, gc + FOLD_WCH)
 		const uint32_t wbeg = gc;
 		const uint32_t wn = (c_end - wbeg < FOLD_WCH) ? c_end - wbeg : FOLD_WCH;
-		for (uint32_t t = tid; t < wn; t += 256) {
+		for (uint32_t t = tid; t < wn; t += FOLD_THREADS) {
 			const BridgeRec *b = &A.bridge[wbeg + t];
 			sh.tgt[t] = b->target;
 			sh.idxm[t] = b->idx_m;
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(256) void fold_kernel(PhaseA A, uint32_t nq, uint32
 		// Then block-wide prefix sums over the chain give every live chunk its segment
 		// slots and anchor offsets.
 		const uint32_t SINK = wn; // any node >= wn means "outside the window"
-		for (uint32_t t = tid; t <= wn; t += 256) {
+		for (uint32_t t = tid; t <= wn; t += FOLD_THREADS) {
 			uint32_t nx = SINK;
 			if (t < wn) {
 				uint32_t tg = sh.tgt[t];
@@ -351,15 +354,15 @@ __global__ __launch_bounds__(256) void fold_kernel(PhaseA A, uint32_t nq, uint32
 		}
 		__syncthreads();
 		for (uint32_t k = 0; k < 10; k++) {
-			uint32_t nd[5], nj[5], c = 0;
-			for (uint32_t t = tid; t <= wn; t += 256, c++) {
+			uint32_t nd[FOLD_WCH / FOLD_THREADS + 1], nj[FOLD_WCH / FOLD_THREADS + 1], c = 0;
+			for (uint32_t t = tid; t <= wn; t += FOLD_THREADS, c++) {
 				uint32_t jt = sh.jump[k][t];
 				nd[c] = (uint32_t)sh.dist[t] + (uint32_t)sh.dist[jt];
 				nj[c] = sh.jump[k][jt];
 			}
 			__syncthreads();
 			c = 0;
-			for (uint32_t t = tid; t <= wn; t += 256, c++) {
+			for (uint32_t t = tid; t <= wn; t += FOLD_THREADS, c++) {
 				sh.dist[t] = (uint16_t)nd[c];
 				sh.jump[k + 1][t] = (uint16_t)nj[c];
 			}
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(256) void fold_kernel(PhaseA A, uint32_t nq, uint32
 		if (tid == 0) sh.live[entry] = 1;
 		__syncthreads();
 		for (int k = 10; k >= 0; k--) {
-			for (uint32_t t = tid; t < wn; t += 256)
+			for (uint32_t t = tid; t < wn; t += FOLD_THREADS)
 				if (sh.live[t]) {
 					uint32_t jt = sh.jump[k][t];
 					if (jt < wn) sh.live[jt] = 1;
@@ -377,16 +380,16 @@ __global__ __launch_bounds__(256) void fold_kernel(PhaseA A, uint32_t nq, uint32
 			__syncthreads();
 		}
 		const uint32_t npath = sh.dist[entry]; // live chunks in this window
-		for (uint32_t t = tid; t < wn; t += 256)
+		for (uint32_t t = tid; t < wn; t += FOLD_THREADS)
 			if (sh.live[t]) sh.path[npath - sh.dist[t]] = (uint16_t)t;
 		__syncthreads();
-		// segments: every thread takes 4 consecutive chain positions
+		// segments: every thread takes FOLD_PPT consecutive chain positions
 		{
-			uint32_t my_seg[4], my_an[4], my_spec[4], my_idx[4];
+			uint32_t my_seg[FOLD_PPT], my_an[FOLD_PPT], my_spec[FOLD_PPT], my_idx[FOLD_PPT];
 			uint32_t ssum = 0, asum = 0;
 #pragma unroll
-			for (uint32_t e = 0; e < 4; e++) {
-				const uint32_t pz = tid * 4 + e;
+			for (uint32_t e = 0; e < FOLD_PPT; e++) {
+				const uint32_t pz = tid * FOLD_PPT + e;
 				my_seg[e] = my_an[e] = my_spec[e] = my_idx[e] = 0;
 				if (pz < npath) {
 					const uint32_t t = sh.path[pz];
@@ -422,15 +425,18 @@ __global__ __launch_bounds__(256) void fold_kernel(PhaseA A, uint32_t nq, uint32
 				bs += sh.scan_s[w2];
 				ba += sh.scan_a[w2];
 			}
-			const uint32_t tot_s = sh.scan_s[0] + sh.scan_s[1] + sh.scan_s[2] + sh.scan_s[3];
-			const uint32_t tot_a = sh.scan_a[0] + sh.scan_a[1] + sh.scan_a[2] + sh.scan_a[3];
+			uint32_t tot_s = 0, tot_a = 0;
+			for (uint32_t w2 = 0; w2 < FOLD_WAVES; w2++) {
+				tot_s += sh.scan_s[w2];
+				tot_a += sh.scan_a[w2];
+			}
 			uint32_t slot = bs + ps - ssum, off = ba + pa - asum;
 			if (tot_s > FOLD_SEGS) {
 				if (tid == 0) *A.error = 4; // more anchor segments than a window's list holds
 			} else {
 #pragma unroll
-				for (uint32_t e = 0; e < 4; e++) {
-					const uint32_t pz = tid * 4 + e;
+				for (uint32_t e = 0; e < FOLD_PPT; e++) {
+					const uint32_t pz = tid * FOLD_PPT + e;
 					if (pz >= npath) break;
 					const uint32_t t = sh.path[pz], g = wbeg + t;
 					if (my_spec[e]) {
@@ -621,12 +627,12 @@ __global__ __launch_bounds__(256) void fold_kernel(PhaseA A, uint32_t nq, uint32
 			}
 			// carry out (same values in every thread)
 			const uint32_t lw = ((m - 1) / FOLD_APT) >> 6;
-			cnt += sh.ecnt[0] + sh.ecnt[1] + sh.ecnt[2] + sh.ecnt[3];
+			for (uint32_t w2 = 0; w2 < FOLD_WAVES; w2++) cnt += sh.ecnt[w2];
 			lq = sh.wl_q[lw];
 			ls = sh.wl_s[lw];
 			ll = sh.wl_len[lw];
 			lr = sh.wl_r[lw];
-			for (int w2 = 3; w2 >= 0; w2--)
+			for (int w2 = (int)FOLD_WAVES - 1; w2 >= 0; w2--)
 				if (sh.st_has[w2]) {
 					cs = sh.st_s[w2];
 					cq = sh.st_q[w2];
@@ -697,7 +703,7 @@ void launch_bridge(const PhaseA &A, const RefIndex &R, int n_cu, hipStream_t st)
 void launch_fold(const PhaseA &A, uint32_t nq, uint32_t border, uint32_t thr, RawHom *out,
 				 const uint64_t *out_base, const uint32_t *out_cap, uint32_t *out_cnt, hipStream_t st)
 {
-	hipLaunchKernelGGL(fold_kernel, dim3(nq), dim3(256), 0, st, A, nq, border, thr, out, out_base, out_cap, out_cnt);
+	hipLaunchKernelGGL(fold_kernel, dim3(nq), dim3(FOLD_THREADS), 0, st, A, nq, border, thr, out, out_base, out_cap, out_cnt);
 }
 
 } // namespace phy
