@@ -744,7 +744,7 @@ struct PhaseA {
 	const uint64_t *qoff;      // [nq] byte offset of genome j in qbase
 	const uint32_t *qlen;      // [nq]
 	const uint32_t *qchunk0;   // [nq+1] first global chunk id of each query
-	const uint32_t *items;     // [nchunks] work order: global chunk ids, round-robin over queries
+	const uint32_t *items;     // [nchunks] work order: global chunk ids, runs of one query (hostlogic.hpp: plan_chunks)
 	const uint32_t *chunk_query; // [nchunks] query id of each global chunk
 	uint32_t nchunks;
 	uint32_t C;                // chunk length (a multiple of 64)

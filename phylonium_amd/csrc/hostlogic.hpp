@@ -507,14 +507,13 @@ struct ChunkPlan {
 	uint32_t C = 0, cap = 0, nchunks = 0;
 	std::vector<uint32_t> qchunk0;     // [nq+1]
 	std::vector<uint32_t> chunk_query; // [nchunks]
-	std::vector<uint32_t> items;       // [nchunks] round-robin over queries
+	std::vector<uint32_t> items;       // [nchunks] work order (see plan_chunks)
 };
 
 static const uint32_t CHUNK_MIN = 1536, CHUNK_MAX = 10240;
+static const uint32_t ITEM_RUN = 256; // consecutive chunks of one query in the work order (= lanes of a block)
 
-// Chunks of C positions per query; the work order interleaves queries so the 64
-// lanes of a wavefront hold chunks of different genomes (a near-identical
-// genome's long matches are then spread over many wavefronts).
+// Chunks of C positions per query and the order they are worked on.
 // `lanes` = chains the device keeps resident (CUs x blocks per CU x 256).  A chain
 // is a dependent sequence, so a chunk's latency is proportional to C whatever
 // the load, and when the work queue runs dry the device idles while the last
@@ -563,10 +562,17 @@ static inline ChunkPlan plan_chunks(const std::vector<uint32_t> &qlen, uint32_t 
 	P.chunk_query.resize(acc);
 	for (size_t j = 0; j < nq; j++)
 		for (uint32_t c = P.qchunk0[j]; c < P.qchunk0[j + 1]; c++) P.chunk_query[c] = (uint32_t)j;
+	// Work order: runs of ITEM_RUN consecutive chunks of one query, the runs dealt round-robin
+	// over the queries.  A block's 256 lanes then hold chunks of the same genome, which behave
+	// alike (divergence decides how many steps a chunk has and how long its matches run), so
+	// the wavefronts stay in the same phases: 8 % faster on C3 than one chunk per query in turn
+	// (4.9 vs 5.3 ms), and better than whole queries one after the other when the queue is
+	// several rounds long (C4: 18.1 vs 18.8 ms).
 	P.items.reserve(acc);
-	for (uint32_t r = 0; r < maxc; r++)
+	for (uint32_t r = 0; r < maxc; r += ITEM_RUN)
 		for (size_t j = 0; j < nq; j++)
-			if (P.qchunk0[j] + r < P.qchunk0[j + 1]) P.items.push_back(P.qchunk0[j] + r);
+			for (uint32_t e = 0; e < ITEM_RUN; e++)
+				if (P.qchunk0[j] + r + e < P.qchunk0[j + 1]) P.items.push_back(P.qchunk0[j] + r + e);
 	return P;
 }
 
