@@ -67,6 +67,19 @@ PHY_HD uint32_t ctz32(uint32_t x)
 #endif
 }
 
+// Index (0..15) of the first nonzero byte of four dwords, 16 if all are zero.  Four
+// independent bit scans and a minimum: a chain of ?: here compiles to nested branches,
+// and this sits in every step of every chain.
+PHY_HD uint32_t first_set_byte(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3)
+{
+	const uint32_t t0 = x0 ? ctz32(x0) : 128u;
+	const uint32_t t1 = x1 ? 32u + ctz32(x1) : 128u;
+	const uint32_t t2 = x2 ? 64u + ctz32(x2) : 128u;
+	const uint32_t t3 = x3 ? 96u + ctz32(x3) : 128u;
+	const uint32_t m01 = t0 < t1 ? t0 : t1, m23 = t2 < t3 ? t2 : t3;
+	return (m01 < m23 ? m01 : m23) >> 3;
+}
+
 // A<C<G<T → 0..3; returns 4 for anything else.
 PHY_HD uint32_t nuc_code(uint8_t b)
 {
@@ -98,8 +111,7 @@ PHY_HD uint32_t window_code(const U4 &q, uint32_t *valid)
 {
 	uint32_t b0, b1, b2, b3;
 	uint32_t c = (code4(q.x, &b0) << 24) | (code4(q.y, &b1) << 16) | (code4(q.z, &b2) << 8) | code4(q.w, &b3);
-	*valid = b0 ? (ctz32(b0) >> 3) : b1 ? 4u + (ctz32(b1) >> 3) : b2 ? 8u + (ctz32(b2) >> 3)
-										 : b3 ? 12u + (ctz32(b3) >> 3) : 16u;
+	*valid = first_set_byte(b0, b1, b2, b3);
 	return c;
 }
 
@@ -166,9 +178,7 @@ PHY_HD uint32_t sel4(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_
 // index of the first differing byte of two 16-byte windows, 16 if equal
 PHY_HD uint32_t first_diff(const U4 &a, const U4 &b)
 {
-	const uint32_t x0 = a.x ^ b.x, x1 = a.y ^ b.y, x2 = a.z ^ b.z, x3 = a.w ^ b.w;
-	return x0 ? (ctz32(x0) >> 3)
-			  : x1 ? 4u + (ctz32(x1) >> 3) : x2 ? 8u + (ctz32(x2) >> 3) : x3 ? 12u + (ctz32(x3) >> 3) : 16u;
+	return first_set_byte(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w);
 }
 
 // The query is followed by zero padding and S by zero padding, and query bytes
