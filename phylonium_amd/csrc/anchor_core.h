@@ -41,7 +41,7 @@ struct RefIndex {
 	const uint8_t *S;    // n bytes of subject + '#' + revcomp, then >= 64 zero bytes
 	const U4 *SAX;       // n records (+4 pad), one per rank: see sax_record()
 	const uint32_t *LCP; // n+1 entries (+4 pad); LCP[r] = lcp(suffix SA[r-1], suffix SA[r]); LCP[0]=LCP[n]=0
-	const U4 *SLOT;      // 4^k slots of 8 records (one 128-byte line each): see SLOT_RECS
+	const U4 *SLOT;      // 4^k slots of 64 bytes (SLOT_RECS U4 each): see slot_pack
 	uint32_t n;          // |S| = 2L+1
 	uint32_t k;          // bucket k-mer length (1..14)
 	uint32_t threshold;  // minimum anchor length
@@ -127,7 +127,9 @@ PHY_HD uint32_t clz32(uint32_t x)
 // SAX record of rank r: everything a comparison with suffix SA[r] usually needs,
 // in 16 bytes — x: SA[r]; y: 2-bit codes of the suffix's first 16 bytes (bits
 // beyond the valid length are 0); z: number of leading A,C,G,T bytes (<= 16);
-// w: min(LCP[r],0xffff) | min(LCP[r+1],0xffff) << 16.
+// w: min(LCP[r],LCP_CLIP) | min(LCP[r+1],LCP_CLIP) << 16.  The clip is 13 bits so
+// that a record also fits the 12 bytes a slot has for it (slot_pack).
+static const uint32_t LCP_CLIP = 0x1fffu;
 PHY_HD U4 sax_record(const uint8_t *S, uint32_t sa, uint32_t lcp_r, uint32_t lcp_r1)
 {
 	U4 w = load16(S + sa);
@@ -139,15 +141,33 @@ PHY_HD U4 sax_record(const uint8_t *S, uint32_t sa, uint32_t lcp_r, uint32_t lcp
 	r.x = sa;
 	r.y = code;
 	r.z = valid;
-	r.w = (lcp_r < 0xffffu ? lcp_r : 0xffffu) | ((lcp_r1 < 0xffffu ? lcp_r1 : 0xffffu) << 16);
+	r.w = (lcp_r < LCP_CLIP ? lcp_r : LCP_CLIP) | ((lcp_r1 < LCP_CLIP ? lcp_r1 : LCP_CLIP) << 16);
 	return r;
 }
 
-// Slot of k-mer c (one 128-byte line): record 0 = {lo = T[c], hi = T[c+1], 0, 0};
-// records 1..5 = SAX[base .. base+4] with base = lo ? lo-1 : 0, i.e. the bucket's
-// predecessor, up to two members... and its successor for buckets of <= 2 suffixes.
-// A whole small-bucket search is therefore ONE line fetch.
-static const uint32_t SLOT_RECS = 8;
+// Slot of k-mer c: 64 bytes = 16 dwords: lo = T[c], hi = T[c+1], then the SAX records of
+// ranks base .. base+3 (base = lo ? lo-1 : 0: the bucket's predecessor, up to two
+// members and its successor for buckets of <= 2 suffixes) at 12 bytes each — SA, prefix
+// code, and valid length (5 bits) | LCP[r] (13) | LCP[r+1] (13) in one dword.  A whole
+// small-bucket search is therefore ONE fetch of half a cache line.  64 rather than 128
+// bytes because the table is gathered from at random and what that costs on this chip is
+// set by how many pages are in play (TLB reach, ~3 GB: csrc/gather_bench.hip), not by the
+// bytes: at 128 B the table alone is 2.1 GB for a 5 Mbp reference.
+static const uint32_t SLOT_RECS = 4; // U4 units per slot
+
+PHY_HD void slot_pack(uint32_t lo, uint32_t hi, const U4 rec[4], U4 out[4])
+{
+	uint32_t d[16];
+	d[0] = lo;
+	d[1] = hi;
+	for (int i = 0; i < 4; i++) {
+		d[2 + 3 * i] = rec[i].x;
+		d[3 + 3 * i] = rec[i].y;
+		d[4 + 3 * i] = (rec[i].z & 31u) | ((rec[i].w & LCP_CLIP) << 5) | (((rec[i].w >> 16) & LCP_CLIP) << 18);
+	}
+	d[14] = d[15] = 0;
+	for (int i = 0; i < 4; i++) out[i] = U4{d[4 * i], d[4 * i + 1], d[4 * i + 2], d[4 * i + 3]};
+}
 
 // Compare the query window (code qcode, qv valid bytes, n bytes left in the query)
 // with a suffix prefix (code pre, sv valid bytes).  0: decided (*len,*less);
@@ -209,6 +229,22 @@ static const uint32_t EXT_COOP_AT = 16 + 8 * 32; // lanes extend this far alone,
 struct Data {
 	U4 w[4];
 };
+
+// the 64 bytes of a slot → its header {lo, hi} and the four SAX records (slot_pack)
+PHY_HD void slot_unpack(const U4 &r0, const U4 &r1, const U4 &r2, const U4 &r3, U4 *hdr, Data *d)
+{
+	const uint32_t w[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+	hdr->x = w[0];
+	hdr->y = w[1];
+	hdr->z = hdr->w = 0;
+	for (int i = 0; i < 4; i++) {
+		const uint32_t p = w[4 + 3 * i];
+		d->w[i].x = w[2 + 3 * i];
+		d->w[i].y = w[3 + 3 * i];
+		d->w[i].z = p & 31u;
+		d->w[i].w = ((p >> 5) & LCP_CLIP) | (((p >> 18) & LCP_CLIP) << 16);
+	}
+}
 
 // One chain = the loop of anchor_homologies (process.cxx:245-282) without the
 // homology bookkeeping (that is a fold over the accepted anchors, done later).
@@ -638,7 +674,7 @@ struct Chain {
 	// The only neighbour attaining lmax is unique iff the next suffix outward does
 	// not share lmax characters with it: LCP[best] < lmax for the predecessor,
 	// LCP[best+1] < lmax for the successor.  Both values travel with the record,
-	// clipped to 16 bits; returns true when the clipped value cannot decide and
+	// clipped to LCP_CLIP; returns true when the clipped value cannot decide and
 	// the full LCP array has to be read.
 	PHY_HD bool fin_needs_lcp(const RefIndex &R)
 	{
@@ -646,7 +682,7 @@ struct Chain {
 		const bool pbest = lp > lsu;
 		const uint32_t l = pbest ? (lcp_p & 0xffffu) : (lcp_s >> 16);
 		const bool cand = lp != lsu && lmax >= R.threshold;
-		if (cand && l == 0xffffu && lmax >= 0xffffu) return true; // clipped: read the full LCP array
+		if (cand && l == LCP_CLIP && lmax >= LCP_CLIP) return true; // clipped: read the full LCP array
 		finish_step(pbest ? pp : psu, lmax, cand && l < lmax);
 		return false;
 	}
@@ -679,8 +715,8 @@ template <class Tail> PHY_HD void chain_trip(Chain &ch, const RefIndex &R, Tail 
 	}
 	if (ch.st == ST_T) {
 		const uint8_t *a = ch.issue_T(R);
-		U4 hdr = load16(a);
-		for (int i = 0; i < 4; i++) d.w[i] = load16(a + 16 * (i + 1));
+		U4 hdr;
+		slot_unpack(load16(a), load16(a + 16), load16(a + 32), load16(a + 48), &hdr, &d);
 		ch.consume_T(R, hdr, d);
 	}
 	if (ch.st == ST_CAND) {

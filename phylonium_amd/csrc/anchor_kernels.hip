@@ -177,13 +177,7 @@ template <int MODE> __global__ __launch_bounds__(256) void chain_kernel(PhaseA A
 					Data d;
 					d.w[0] = d.w[1] = d.w[2] = d.w[3] = sw;
 					if (nl > 1) sw = load16(a1);
-					if (sa) {
-						hdr = load16(sa);
-						d.w[0] = load16(sa + 16);
-						d.w[1] = load16(sa + 32);
-						d.w[2] = load16(sa + 48);
-						d.w[3] = load16(sa + 64);
-					}
+					if (sa) slot_unpack(load16(sa), load16(sa + 16), load16(sa + 32), load16(sa + 48), &hdr, &d);
 					ch.post_step(R, sw);
 					if (ch.st == ST_T) ch.consume_T(R, hdr, d); // st == ST_T implies the k-mer was valid, so sa != nullptr
 				}
@@ -199,12 +193,9 @@ template <int MODE> __global__ __launch_bounds__(256) void chain_kernel(PhaseA A
 		// k-mer lookup is still owed (thresholds >= 17, i.e. references beyond ~60 Mbp).
 		if (live && ch.st == ST_T) {
 			const uint8_t *sa = ch.issue_T(R);
-			const U4 hdr = load16(sa);
+			U4 hdr;
 			Data d;
-			d.w[0] = load16(sa + 16);
-			d.w[1] = load16(sa + 32);
-			d.w[2] = load16(sa + 48);
-			d.w[3] = load16(sa + 64);
+			slot_unpack(load16(sa), load16(sa + 16), load16(sa + 32), load16(sa + 48), &hdr, &d);
 			ch.consume_T(R, hdr, d);
 		}
 		if (live && ch.st == ST_CAND) {

@@ -8,7 +8,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
-template <int ILP>
+// LINE_U4: line length in 16-byte units (8 = 128 B, 4 = 64 B); READS of them are loaded
+template <int ILP, int LINE_U4 = 8, int READS = 5>
 __global__ __launch_bounds__(256) void gather_kernel(const uint4 *__restrict__ table, uint64_t lines, uint32_t iters,
 													 uint32_t *__restrict__ out)
 {
@@ -16,20 +17,20 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint4 *__restrict__ t
 	x *= 0x9E3779B97F4A7C15ull;
 	uint32_t acc = 0;
 	for (uint32_t it = 0; it < iters; it++) {
-		uint4 v[ILP][5];
+		uint4 v[ILP][READS];
 #pragma unroll
 		for (int k = 0; k < ILP; k++) {
 			x ^= x << 13;
 			x ^= x >> 7;
 			x ^= x << 17;
-			const uint4 *p = table + (x % lines) * 8;
+			const uint4 *p = table + (x % lines) * LINE_U4;
 #pragma unroll
-			for (int j = 0; j < 5; j++) v[k][j] = p[j];
+			for (int j = 0; j < READS; j++) v[k][j] = p[j];
 		}
 #pragma unroll
 		for (int k = 0; k < ILP; k++)
 #pragma unroll
-			for (int j = 0; j < 5; j++) acc ^= v[k][j].x ^ v[k][j].w;
+			for (int j = 0; j < READS; j++) acc ^= v[k][j].x ^ v[k][j].w;
 	}
 	out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
@@ -68,6 +69,26 @@ int main(int argc, char **argv)
 			}
 			double n = (double)blocks * 256 * iters * ilp;
 			printf(", \"b%d_ilp%d_Glines_s\": %.2f", blocks_per_cu[bi], ilp, n / (best * 1e-3) / 1e9);
+		}
+	}
+	// the same with 64-byte lines (4 x 16 bytes read per line): what a slot half the size would cost
+	{
+		const uint64_t lines64 = table_bytes / 64;
+		for (int bi = 2; bi < 4; bi++) {
+			int blocks = prop.multiProcessorCount * blocks_per_cu[bi];
+			uint32_t iters = 256;
+			float best = 1e30f;
+			for (int rep = 0; rep < 3; rep++) {
+				hipEventRecord(a, 0);
+				hipLaunchKernelGGL((gather_kernel<4, 4, 4>), dim3(blocks), dim3(256), 0, 0, table, lines64, iters, out);
+				hipEventRecord(b, 0);
+				hipEventSynchronize(b);
+				float ms;
+				hipEventElapsedTime(&ms, a, b);
+				if (ms < best) best = ms;
+			}
+			double n = (double)blocks * 256 * iters * 4;
+			printf(", \"line64_b%d_ilp4_Glines_s\": %.2f", blocks_per_cu[bi], n / (best * 1e-3) / 1e9);
 		}
 	}
 	printf("}\n");

@@ -211,9 +211,10 @@ static inline void build_slots(const std::vector<uint32_t> &T, const std::vector
 	for (size_t c = 0; c < codes; c++) {
 		uint32_t lo = T[c], hi = T[c + 1];
 		uint32_t base = lo ? lo - 1 : 0;
-		out[c * SLOT_RECS] = U4{lo, hi, 0, 0};
-		for (uint32_t i = 0; i < 5; i++)
-			if (base + i < n) out[c * SLOT_RECS + 1 + i] = sax[base + i];
+		U4 rec[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+		for (uint32_t i = 0; i < 4; i++)
+			if (base + i < n) rec[i] = sax[base + i];
+		slot_pack(lo, hi, rec, &out[c * SLOT_RECS]);
 	}
 }
 

@@ -564,25 +564,20 @@ int phylo_set_genomes_device(phylo_ctx *c, size_t n, const void *dev_base, const
 
 // ───────────────────────── reference index ─────────────────────────
 
-// One 128-byte slot per k-mer (anchor_core.h: SLOT_RECS): header {T[c], T[c+1]}
-// and the SAX records of ranks base..base+4, base = T[c] ? T[c]-1 : 0.
+// One 64-byte slot per k-mer (anchor_core.h: slot_pack): {T[c], T[c+1]} and the SAX
+// records of ranks base..base+3, base = T[c] ? T[c]-1 : 0.  One thread per slot.
 __global__ __launch_bounds__(256) void build_slots_kernel(const uint32_t *__restrict__ T, const U4 *__restrict__ sax,
 														   uint32_t n, uint64_t codes, U4 *__restrict__ slot)
 {
-	const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	const uint64_t c = tid >> 3;
-	const uint32_t r = (uint32_t)(tid & 7u);
+	const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= codes) return;
 	const uint32_t lo = T[c], hi = T[c + 1];
-	U4 v = {0, 0, 0, 0};
-	if (r == 0) {
-		v.x = lo;
-		v.y = hi;
-	} else if (r <= 5) {
-		uint32_t rank = (lo ? lo - 1 : 0) + (r - 1);
-		if (rank < n) v = sax[rank];
-	}
-	slot[tid] = v;
+	const uint32_t base = lo ? lo - 1 : 0;
+	U4 rec[4];
+	for (uint32_t i = 0; i < 4; i++) rec[i] = base + i < n ? sax[base + i] : U4{0, 0, 0, 0};
+	U4 out[4];
+	slot_pack(lo, hi, rec, out);
+	for (uint32_t i = 0; i < 4; i++) slot[c * SLOT_RECS + i] = out[i];
 }
 
 int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t threshold)
@@ -641,8 +636,7 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 	launch_kmer_table(c->d_S.p, ns, k, c->d_T.p, c->d_T.p + codes + 1 + 4, st);
 	launch_sax(c->d_S.p, c->d_SA.p, c->d_LCP.p, ns, c->d_SAX.p, st);
 	{
-		uint64_t threads = codes * SLOT_RECS;
-		hipLaunchKernelGGL(build_slots_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, st, c->d_T.p,
+		hipLaunchKernelGGL(build_slots_kernel, dim3((uint32_t)((codes + 255) / 256)), dim3(256), 0, st, c->d_T.p,
 						   c->d_SAX.p, ns, codes, c->d_SLOT.p);
 	}
 	HIPOK(c, hipGetLastError());
