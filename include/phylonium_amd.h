@@ -57,7 +57,9 @@ void phylo_ctx_destroy(phylo_ctx *ctx);
 const char *phylo_last_error(const phylo_ctx *ctx);
 /* Tunables, mostly for tests: "chunk" (phase-A chunk length, a multiple of 64),
  * "kmer" (bucket k), "profile" (1: time every kernel with HIP events),
- * "compare_backend" (0 pileup, 1 segment list). */
+ * "compare_backend" (0 pileup, 1 segment list), "filter" (where phase A's sort + chain filter
+ * runs: 0 on the device for 128 queries or more and on the host cores below, 1 host, 2 device;
+ * the results are the same), "host_threads". */
 int phylo_set_option(phylo_ctx *ctx, const char *key, long value);
 /* Accumulated since the last phylo_reset_stats: "ms:<kernel>", "n:<kernel>"
  * (HIP-event time and launch count per kernel when profiling is on),

@@ -1,0 +1,313 @@
+// filter_kernels.hip — phase A's last step on the device: reverseEh, the sort by
+// projected start and filter_overlaps_max for one query per block
+// (/root/reference/src/process.cxx:438-443, 354-401; src/process.h:72-80).
+//
+// The reference sorts with std::sort, which is not stable: when two homologies of
+// a query share a projected start, their order — and with it the chain the filter
+// picks — is whatever libstdc++'s introsort leaves.  For lists without such a tie
+// the order is unique, and that is what this kernel handles; a list with a tie,
+// or one that does not fit the block's LDS, is flagged and done by the host
+// exactly as before (hostlogic.hpp: sort_filter_order / sort_and_filter).
+//
+// The chain DP is the O(n log n) form of hostlogic.hpp::filter_overlaps_max: the
+// candidates of entry i are a prefix of the pile ordered by end, and a running
+// (max score, smallest index) over that order gives the reference's predecessor.
+// Sorting is parallel (bitonic, in LDS); the DP, a dependent scan, goes 64 entries
+// at a time (see the kernel).
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace phy {
+
+static const uint32_t FILT_MAX = 4096;   // entries per query the block's LDS holds
+static const uint32_t FILT_THREADS = 1024;
+static const uint32_t FILT_WAVES = FILT_THREADS / 64;
+static const uint16_t NONE16 = 0xffff;
+
+// (score, pile index) as one integer whose maximum is "highest score, then smallest index":
+// exactly the reference's choice of predecessor (the first k with the largest score,
+// process.cxx:374-381).  Scores are sums of lengths (< 2^32), indices < 4096.  0 = nothing.
+static __device__ __forceinline__ uint64_t sk_key(uint32_t score, uint32_t idx) { return (uint64_t)score << 12 | (4095u - idx); }
+static __device__ __forceinline__ uint32_t sk_index(uint64_t key) { return 4095u - (uint32_t)(key & 4095u); }
+
+struct FilterShared {
+	uint64_t by_start[FILT_MAX]; // start << 32 | raw index, sorted: pile order
+	uint64_t by_end[FILT_MAX];   // end << 32 | pile position, sorted; later K: sk_key of the finished entries by end position
+	uint32_t len[FILT_MAX];      // by pile position
+	uint32_t score[FILT_MAX];
+	uint16_t pred[FILT_MAX];     // pile position of the predecessor, NONE16 = none
+	uint16_t endpos[FILT_MAX];   // position of pile entry p in end order
+	uint16_t npred[FILT_MAX];    // P(i): how many entries end at or before entry i starts
+	uint16_t jump[FILT_MAX];     // pointer doubling over pred for the backtrack
+	uint8_t keep[FILT_MAX];
+	uint64_t wred[FILT_WAVES];
+	uint32_t wsum[FILT_WAVES];
+	uint32_t tie, base, top;
+};
+
+// in-place bitonic sort of n2 (a power of two) keys in LDS
+static __device__ void bitonic_sort(uint64_t *a, uint32_t n2)
+{
+	for (uint32_t k = 2; k <= n2; k <<= 1)
+		for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+			for (uint32_t t = threadIdx.x; t < n2; t += FILT_THREADS) {
+				const uint32_t x = t ^ j;
+				if (x > t) {
+					const uint64_t u = a[t], v = a[x];
+					const bool up = (t & k) == 0;
+					if ((u > v) == up) {
+						a[t] = v;
+						a[x] = u;
+					}
+				}
+			}
+			__syncthreads();
+		}
+}
+
+static __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src)
+{
+	return (uint64_t)(uint32_t)__shfl((int)(uint32_t)v, src, 64) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64) << 32;
+}
+
+// raw: fold_kernel's output (index_reference, index_query, length before reverseEh), query j at
+// raw[raw_base[j] .. + raw_cnt[j]).  Output: the filtered list in device form at
+// out[rng[2j] .. rng[2j+1]) — slots are handed out by an atomic counter, their order is
+// irrelevant — or flag[j] = 1 when the host has to do this query.  ref_local: the query that
+// is the reference itself (its list is [(0,0,L)] iff L/2 >= threshold, process.cxx:285-292),
+// or 0xffffffff.
+//
+// The chain DP  score(i) = len(i) + max{score(k) : end(k) <= start(i)}  is a dependent scan, and
+// done by one lane it costs ~700 cycles per entry (every LDS access a round trip).  Here one
+// wavefront takes 64 entries per round (see the loop).
+__global__ __launch_bounds__(FILT_THREADS) void sort_filter_kernel(const RawHom *__restrict__ raw,
+																	const uint64_t *__restrict__ raw_base,
+																	const uint32_t *__restrict__ raw_cnt, uint32_t border,
+																	uint32_t threshold, uint32_t ref_local,
+																	DevHom *__restrict__ out, uint32_t *__restrict__ rng,
+																	uint32_t *__restrict__ total, uint32_t *__restrict__ flag)
+{
+	__shared__ FilterShared sh;
+	const uint32_t j = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const RawHom *r = raw + raw_base[j];
+	const uint32_t n = raw_cnt[j];
+	if (j == ref_local) {
+		if (tid == 0) {
+			uint32_t b = 0, w = border / 2 >= threshold ? 1u : 0u;
+			if (w) {
+				b = atomicAdd(total, 1u);
+				out[b] = DevHom{0u, 0u, border, 0u};
+			}
+			rng[2 * j] = b;
+			rng[2 * j + 1] = b + w;
+			flag[j] = 0;
+		}
+		return;
+	}
+	if (n > FILT_MAX) {
+		if (tid == 0) {
+			flag[j] = 1;
+			rng[2 * j] = rng[2 * j + 1] = 0; // an empty list until the host has done this query
+		}
+		return;
+	}
+	uint32_t n2 = 1;
+	while (n2 < n) n2 <<= 1;
+	if (tid == 0) sh.tie = 0;
+	// reverseEh (process.h:72-80): a hit in the reverse half of S projects to 2L+1-len-iref
+	for (uint32_t t = tid; t < n2; t += FILT_THREADS) {
+		uint64_t key = ~0ull; // padding sorts last
+		if (t < n) {
+			const RawHom h = r[t];
+			const uint32_t start = h.iref >= border ? 2u * border + 1u - h.len - h.iref : h.iref;
+			key = (uint64_t)start << 32 | t;
+		}
+		sh.by_start[t] = key;
+	}
+	__syncthreads();
+	bitonic_sort(sh.by_start, n2);
+	for (uint32_t p = tid; p < n; p += FILT_THREADS) {
+		const uint64_t key = sh.by_start[p];
+		if (p + 1 < n && (uint32_t)(sh.by_start[p + 1] >> 32) == (uint32_t)(key >> 32)) sh.tie = 1; // benign race: same value
+		const uint32_t l = r[(uint32_t)key].len;
+		sh.len[p] = l;
+		sh.by_end[p] = ((key >> 32) + l) << 32 | p;
+	}
+	for (uint32_t p = n + tid; p < n2; p += FILT_THREADS) sh.by_end[p] = ~0ull;
+	__syncthreads();
+	if (sh.tie) {
+		if (tid == 0) {
+			flag[j] = 1;
+			rng[2 * j] = rng[2 * j + 1] = 0;
+		}
+		return;
+	}
+	bitonic_sort(sh.by_end, n2);
+	// end order: position of every entry, and P(i) = #{q : end(q) <= start(i)} by binary search
+	for (uint32_t q = tid; q < n; q += FILT_THREADS) sh.endpos[(uint32_t)sh.by_end[q] & 0xffffu] = (uint16_t)q;
+	for (uint32_t i = tid; i < n; i += FILT_THREADS) {
+		const uint32_t start_i = (uint32_t)(sh.by_start[i] >> 32);
+		uint32_t lo = 0, hi = n; // first q with end(q) > start_i
+		while (lo < hi) {
+			const uint32_t mid = (lo + hi) >> 1;
+			if ((uint32_t)(sh.by_end[mid] >> 32) <= start_i) lo = mid + 1;
+			else hi = mid;
+		}
+		sh.npred[i] = (uint16_t)lo;
+		sh.keep[i] = 0;
+	}
+	__syncthreads();
+	uint64_t *K = sh.by_end; // the ends are not needed any more (end = start + len): now sk_key of every finished entry, by end position
+	for (uint32_t q = tid; q < n; q += FILT_THREADS) K[q] = 0;
+	__syncthreads();
+	if (wave == 0) {
+		// One wavefront, 64 entries per round, no block barriers.  The candidates of entry i are the
+		// entries at end positions < P(i); P is nondecreasing in i, and an entry that ends before
+		// the round's first entry starts is already finished (its index is smaller), so
+		//   G    = best key at end positions < gpos, kept in a register and advanced by scans of K,
+		//   base = max(G, K[P(first) .. P(i)-1])  — a prefix maximum over a few dozen positions,
+		// cover everything finished in earlier rounds, and the predecessors inside the round are
+		// settled lane after lane with v_readlane broadcasts.
+		uint64_t G = 0;
+		uint32_t gpos = 0;
+		for (uint32_t a = 0; a < n; a += 64) {
+			const uint32_t cnt = n - a < 64 ? n - a : 64;
+			const uint32_t i = a + lane;
+			const bool on = lane < cnt;
+			uint32_t start_i = 0, len_i = 0, np = 0, ep = 0;
+			if (on) {
+				start_i = (uint32_t)(sh.by_start[i] >> 32);
+				len_i = sh.len[i];
+				np = sh.npred[i];
+				ep = sh.endpos[i];
+			}
+			const uint32_t end_i = start_i + len_i;
+			const uint32_t np0 = (uint32_t)__builtin_amdgcn_readlane((int)np, 0);
+			const uint32_t np_last = (uint32_t)__builtin_amdgcn_readlane((int)np, (int)(cnt - 1));
+			for (uint32_t q0 = gpos; q0 < np0; q0 += 64) {
+				uint64_t v = q0 + lane < np0 ? K[q0 + lane] : 0;
+				for (uint32_t d = 32; d > 0; d >>= 1) {
+					const uint64_t o = shfl64(v, (int)(lane ^ d));
+					if (o > v) v = o;
+				}
+				if (v > G) G = v;
+			}
+			if (np0 > gpos) gpos = np0;
+			uint64_t running = G;
+			for (uint32_t q0 = np0; q0 < np_last; q0 += 64) {
+				uint64_t v = q0 + lane < np_last ? K[q0 + lane] : 0;
+				for (uint32_t d = 1; d < 64; d <<= 1) { // inclusive prefix maximum
+					const uint64_t o = shfl64(v, (int)(lane >= d ? lane - d : lane));
+					if (lane >= d && o > v) v = o;
+				}
+				const bool need = on && np > q0;
+				const uint32_t src = need ? (np - 1 - q0 < 63 ? np - 1 - q0 : 63) : 0;
+				const uint64_t t = shfl64(v, (int)src);
+				if (need && t > running) running = t;
+			}
+			uint64_t key_i = 0;
+			for (uint32_t s = 0; s < cnt; s++) {
+				// lane s has seen every earlier lane's result: its own is final now
+				if (lane == s) key_i = sk_key((uint32_t)(running >> 12) + len_i, i);
+				const uint64_t key_s = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key_i, (int)s) |
+									   (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key_i >> 32), (int)s) << 32;
+				const uint32_t end_s = (uint32_t)__builtin_amdgcn_readlane((int)end_i, (int)s);
+				if (on && lane > s && end_s <= start_i && key_s > running) running = key_s;
+			}
+			if (on) {
+				sh.score[i] = (uint32_t)(key_i >> 12);
+				sh.pred[i] = running ? (uint16_t)sk_index(running) : NONE16;
+				K[ep] = key_i;
+			}
+		}
+	}
+	__syncthreads();
+	// std::max_element over (0, score[0..n)): the first maximum — the largest (score, smallest index)
+	{
+		uint64_t best = 0;
+		for (uint32_t i = tid; i < n; i += FILT_THREADS) {
+			const uint64_t k2 = sk_key(sh.score[i], i);
+			if (k2 > best) best = k2;
+		}
+		for (uint32_t d = 32; d > 0; d >>= 1) {
+			const uint64_t o = shfl64(best, (int)(lane ^ d));
+			if (o > best) best = o;
+		}
+		if (lane == 0) sh.wred[wave] = best;
+		__syncthreads();
+		if (tid == 0) {
+			uint64_t b2 = 0;
+			for (uint32_t w2 = 0; w2 < FILT_WAVES; w2++)
+				if (sh.wred[w2] > b2) b2 = sh.wred[w2];
+			sh.top = n ? sk_index(b2) : 0xffffffffu; // lengths are positive, so any entry beats the initial 0
+		}
+		__syncthreads();
+	}
+	// backtrack from the top along pred: reachability by pointer doubling
+	for (uint32_t i = tid; i < n; i += FILT_THREADS) sh.jump[i] = sh.pred[i];
+	if (tid == 0 && n) sh.keep[sh.top] = 1;
+	__syncthreads();
+	for (uint32_t round = 0; (1u << round) < n; round++) {
+		for (uint32_t i = tid; i < n; i += FILT_THREADS)
+			if (sh.keep[i] && sh.jump[i] != NONE16) sh.keep[sh.jump[i]] = 1;
+		__syncthreads();
+		uint16_t nj[FILT_MAX / FILT_THREADS];
+		uint32_t c = 0;
+		for (uint32_t i = tid; i < n; i += FILT_THREADS, c++) {
+			const uint16_t j1 = sh.jump[i];
+			nj[c] = j1 == NONE16 ? NONE16 : sh.jump[j1];
+		}
+		__syncthreads();
+		c = 0;
+		for (uint32_t i = tid; i < n; i += FILT_THREADS, c++) sh.jump[i] = nj[c];
+		__syncthreads();
+	}
+	// the kept entries leave in pile order: block-wide prefix count of keep[]
+	uint32_t done = 0, base = 0;
+	{
+		uint32_t mine = 0;
+		for (uint32_t i = tid; i < n; i += FILT_THREADS) mine += sh.keep[i];
+		for (uint32_t d = 32; d > 0; d >>= 1) mine += (uint32_t)__shfl((int)mine, (int)(lane ^ d), 64);
+		if (lane == 0) sh.wsum[wave] = mine;
+		__syncthreads();
+		if (tid == 0) {
+			uint32_t w = 0;
+			for (uint32_t w2 = 0; w2 < FILT_WAVES; w2++) w += sh.wsum[w2];
+			const uint32_t b = w ? atomicAdd(total, w) : 0u;
+			sh.base = b;
+			rng[2 * j] = b;
+			rng[2 * j + 1] = b + w;
+			flag[j] = 0;
+		}
+		__syncthreads();
+		base = sh.base;
+	}
+	for (uint32_t p0 = 0; p0 < n; p0 += FILT_THREADS) {
+		const uint32_t p = p0 + tid;
+		const uint32_t k = (p < n && sh.keep[p]) ? 1u : 0u;
+		const uint64_t m = __ballot(k);
+		if (lane == 0) sh.wsum[wave] = (uint32_t)__popcll(m);
+		__syncthreads();
+		uint32_t off = done + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+		for (uint32_t w2 = 0; w2 < wave; w2++) off += sh.wsum[w2];
+		if (k) {
+			const uint64_t key = sh.by_start[p];
+			const RawHom h = r[(uint32_t)key];
+			out[base + off] = DevHom{(uint32_t)(key >> 32), h.iq, h.len, h.iref >= border ? 1u : 0u};
+		}
+		for (uint32_t w2 = 0; w2 < FILT_WAVES; w2++) done += sh.wsum[w2];
+		__syncthreads();
+	}
+}
+
+void launch_sort_filter(const RawHom *raw, const uint64_t *raw_base, const uint32_t *raw_cnt, uint32_t nq, uint32_t border,
+						uint32_t threshold, uint32_t ref_local, DevHom *out, uint32_t *rng, uint32_t *total, uint32_t *flag,
+						hipStream_t st)
+{
+	if (!nq) return;
+	hipLaunchKernelGGL(sort_filter_kernel, dim3(nq), dim3(FILT_THREADS), 0, st, raw, raw_base, raw_cnt, border, threshold,
+					   ref_local, out, rng, total, flag);
+}
+
+} // namespace phy

@@ -15,6 +15,13 @@ void launch_bridge(const PhaseA &A, const RefIndex &R, int n_cu, hipStream_t st)
 void launch_fold(const PhaseA &A, uint32_t nq, uint32_t border, uint32_t thr, RawHom *out,
 				 const uint64_t *out_base, const uint32_t *out_cap, uint32_t *out_cnt, hipStream_t st);
 
+// filter_kernels.hip: reverseEh + sort + filter_overlaps_max per query on the device; flag[j] = 1
+// leaves query j to the host (two entries share a projected start, or the list is too long)
+struct DevHom;
+void launch_sort_filter(const RawHom *raw, const uint64_t *raw_base, const uint32_t *raw_cnt, uint32_t nq, uint32_t border,
+						uint32_t threshold, uint32_t ref_local, DevHom *out, uint32_t *rng, uint32_t *total, uint32_t *flag,
+						hipStream_t st);
+
 // index_kernels.hip
 void launch_lcp(const uint8_t *S, const uint32_t *SA, uint32_t n, uint32_t cap, uint32_t *LCP, uint32_t *capped,
 				hipStream_t st);

@@ -217,6 +217,8 @@ struct phylo_ctx {
 	// phase B scratch
 	DevBuf<uint32_t> b_planes, b_hom_rng, b_tiles, b_flag, b_first;
 	// phase A over all genomes leaves the filtered lists on the device already (see phylo_anchor)
+	int filter_mode = 0; // option "filter": 0 device sort + filter for 128 queries or more, host below; 1 host; 2 device
+	DevBuf<uint32_t> a_flt; // [0] kept total, [1..nq] per-query flags of the device sort + filter
 	bool homs_staged = false;
 	// ... and has projected them for the whole reference (part 0 of 1); with five planes or three
 	bool eager_valid = false, eager_five = false;
@@ -452,6 +454,9 @@ int phylo_set_option(phylo_ctx *c, const char *key, long value)
 		c->have_ref = false;
 	} else if (k == "profile") {
 		c->profile = value != 0;
+	} else if (k == "filter") {
+		if (value < 0 || value > 2) return c->fail("filter must be 0 (auto), 1 (host) or 2 (device)");
+		c->filter_mode = (int)value;
 	} else if (k == "compare_backend") {
 		if (value != 0 && value != 1) return c->fail("compare_backend must be 0 (pileup) or 1 (segments)");
 		c->backend = (int)value;
@@ -676,6 +681,8 @@ __global__ void compact_raw_kernel(const RawHom *__restrict__ src, const uint64_
 	for (uint32_t t = threadIdx.x; t < cnt[j]; t += blockDim.x) d[t] = s[t];
 }
 
+static int ensure_host_lists(phylo_ctx *c, size_t g0, size_t g1);
+
 // The pileup of part `part` of `nparts`: a range of 64-window tiles of the reference.
 // Every part projects and compares ALL genomes over its own range, so both kernels
 // shrink with the number of parts and the partial tallies simply add up.
@@ -706,6 +713,12 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	HIPOK(c, hipSetDevice(c->device));
 	size_t nq = q_end - q_begin;
 	if (nq == 0) return 0;
+	// Lists of an earlier call that still live only in this context's device buffer (about to be
+	// reused) and lie outside the range computed now are read back first.  Lists attached from a
+	// caller's buffer are not: that buffer is borrowed only until this call.
+	if (!c->host_stale.empty() && c->att_homs == c->b_homs.p) {
+		if (ensure_host_lists(c, 0, q_begin) || ensure_host_lists(c, q_end, c->n)) return 1;
+	}
 	double t0 = now_ms();
 
 	hipStream_t st = c->stream;
@@ -829,6 +842,84 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	}
 	dbg_sync("anchor_fold");
 	HIPOK(c, hipGetLastError());
+	c->homs_staged = false;
+	c->eager_valid = false;
+	c->att_homs = nullptr; // an attached buffer is only borrowed until the next phase A
+	c->host_stale.clear();
+	// One query's list takes the device ~0.1-0.4 ms however many there are (a block per query, all
+	// at once); the host pool does a few dozen lists in less than that, many only as fast.
+	if (c->filter_mode == 2 || (c->filter_mode == 0 && nq >= 128)) {
+		// reverseEh + sort + filter_overlaps_max on the device (filter_kernels.hip).  The lists stay
+		// there in the 16-byte device form, the projection (phase B's first kernel, for the whole
+		// reference = part 0 of 1) follows on the stream at once when this call covers all genomes,
+		// and the host reads a list back only when somebody asks for it.  A query whose list has
+		// two entries with the same projected start, or more entries than the kernel holds, is
+		// flagged: then everything below runs on the host as it always did.
+		const bool full = q_begin == 0 && q_end == c->n;
+		HIPOK(c, c->b_homs.ensure(c->plan_raw_total + nq + 1));
+		HIPOK(c, c->b_hom_rng.ensure(2 * std::max(nq, c->n)));
+		HIPOK(c, c->a_flt.ensure(nq + 1));
+		HIPOK(c, c->h_rng.ensure(3 * nq + 8));
+		HIPOK(c, hipMemsetAsync(c->a_flt.p, 0, 4, st));
+		const uint32_t ref_local = (c->ref_idx >= q_begin && c->ref_idx < q_end) ? (uint32_t)(c->ref_idx - q_begin) : 0xffffffffu;
+		{
+			KernelSpan s(c, "anchor_filter");
+			launch_sort_filter(c->a_raw.p, c->a_out_base.p, c->a_out_cnt.p, (uint32_t)nq, c->L, c->threshold, ref_local,
+							   c->b_homs.p, c->b_hom_rng.p, c->a_flt.p, c->a_flt.p + 1, st);
+		}
+		const bool eager = full && c->backend == 0;
+		if (eager) {
+			Pileup EP;
+			if (make_pileup(c, 0, 1, &EP)) return 1;
+			HIPOK(c, c->b_flag.ensure(4));
+			HIPOK(c, c->b_first.ensure(project_index_entries(EP) + 1));
+			HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 16, st));
+			c->eager_five = c->pileup_five;
+			launch_tile_index(EP, c->b_homs.p, c->b_hom_rng.p, c->b_first.p, 0, (uint32_t)nq, st);
+			KernelSpan s(c, c->eager_five ? "pileup_project5" : "pileup_project");
+			launch_project(EP, c->eager_five, c->d_genomes, c->d_goff.p, c->b_homs.p, c->b_hom_rng.p, c->b_first.p, c->b_flag.p,
+						   0, EP.Npad / project_genomes_per_tile(), st);
+		}
+		uint32_t *hr = c->h_rng.p; // [0, 2nq) ranges, [2nq, 3nq) flags, then total and the four misc words
+		HIPOK(c, hipMemcpyAsync(hr, c->b_hom_rng.p, 2 * nq * 4, hipMemcpyDeviceToHost, st));
+		HIPOK(c, hipMemcpyAsync(hr + 2 * nq, c->a_flt.p + 1, nq * 4, hipMemcpyDeviceToHost, st));
+		HIPOK(c, hipMemcpyAsync(hr + 3 * nq, c->a_flt.p, 4, hipMemcpyDeviceToHost, st));
+		HIPOK(c, hipMemcpyAsync(hr + 3 * nq + 1, c->a_misc.p, 16, hipMemcpyDeviceToHost, st));
+		HIPOK(c, hipGetLastError());
+		if (sync_stream(c)) return 1;
+		double t2d = now_ms();
+		const uint32_t *dmisc = hr + 3 * nq + 1;
+		if (dmisc[3]) return c->fail("phase A scratch overflow (code %u: 1 chunk log, 2 bridge pool, 3 homology buffer)", dmisc[3]);
+		size_t flagged = 0;
+		for (size_t j = 0; j < nq; j++) flagged += hr[2 * nq + j] != 0;
+		if (!flagged) {
+			const size_t N = c->n;
+			c->att_homs = c->b_homs.p;
+			if (c->att_begin.size() != N) {
+				c->att_begin.assign(N, 0);
+				c->att_count.assign(N, 0);
+			}
+			c->host_stale.assign(N, 0);
+			for (size_t j = 0; j < nq; j++) {
+				c->att_begin[q_begin + j] = hr[2 * j];
+				c->att_count[q_begin + j] = hr[2 * j + 1] - hr[2 * j];
+				c->host_stale[q_begin + j] = 1;
+			}
+			c->homs_staged = full;
+			c->eager_valid = eager;
+			c->stats["ms:anchor_setup"] += t1 - t0;
+			c->stats["ms:anchor_gpu"] += t2d - t1;
+			c->stats["ms:anchor_total"] += now_ms() - t0;
+			c->stats["n:anchor_calls"] += 1;
+			c->stats["count:query_bases"] += (double)total;
+			c->stats["count:chunks"] += nch;
+			c->stats["count:filtered_homologies"] += (double)hr[3 * nq];
+			c->stats["count:pool_blocks_used"] += dmisc[2];
+			c->stats["anchor:chunk"] = P.C;
+			return 0;
+		}
+		c->stats["count:queries_left_to_the_host"] += (double)flagged;
+	}
 	HIPOK(c, c->h_cnt.ensure(nq + 4));
 	uint32_t *cnt = c->h_cnt.p, *misc = c->h_cnt.p + nq;
 	HIPOK(c, hipMemcpyAsync(cnt, c->a_out_cnt.p, nq * 4, hipMemcpyDeviceToHost, st));
@@ -1146,13 +1237,47 @@ int phylo_import_packed(phylo_ctx *c, size_t q_begin, size_t q_end, const uint64
 
 static_assert(sizeof(DevHom) == sizeof(phylo_packed_homology), "the wire record is the device record");
 
+// lists that are device-resident already → back to back in query order: one block per genome
+__global__ void gather_lists_kernel(const DevHom *__restrict__ src, const uint64_t *__restrict__ desc, DevHom *__restrict__ dst)
+{
+	const uint64_t begin = desc[3 * blockIdx.x], count = desc[3 * blockIdx.x + 1], to = desc[3 * blockIdx.x + 2];
+	for (uint64_t t = threadIdx.x; t < count; t += blockDim.x) dst[to + t] = src[begin + t];
+}
+
 int phylo_export_packed_device(phylo_ctx *c, size_t q_begin, size_t q_end, void *dev_dst, size_t cap, uint64_t *counts,
 							   size_t *total)
 {
 	if (!c) return 1;
 	if (q_begin > q_end || q_end > c->n || !counts || !total) return c->fail("phylo_export_packed_device: bad arguments");
-	if (ensure_host_lists(c, q_begin, q_end)) return 1;
 	HIPOK(c, hipSetDevice(c->device));
+	// phase A may have left these lists on the device only (device sort + filter): copy from there
+	bool on_device = !c->host_stale.empty() && c->att_homs && q_end > q_begin;
+	for (size_t j = q_begin; j < q_end && on_device; j++) on_device = c->host_stale[j] != 0;
+	if (on_device) {
+		const size_t m = q_end - q_begin;
+		size_t tot = 0;
+		for (size_t j = q_begin; j < q_end; j++) {
+			counts[j - q_begin] = c->att_count[j];
+			tot += c->att_count[j];
+		}
+		*total = tot;
+		if (!dev_dst || cap < tot || !tot) return 0;
+		HIPOK(c, c->h_mat.ensure(3 * m + 8));
+		HIPOK(c, c->b_subst.ensure(3 * m + 8)); // scratch for the descriptors (the tallies are not live between phases)
+		uint64_t *desc = c->h_mat.p, to = 0;
+		for (size_t j = q_begin; j < q_end; j++) {
+			desc[3 * (j - q_begin)] = c->att_begin[j];
+			desc[3 * (j - q_begin) + 1] = c->att_count[j];
+			desc[3 * (j - q_begin) + 2] = to;
+			to += c->att_count[j];
+		}
+		HIPOK(c, hipMemcpyAsync(c->b_subst.p, desc, 3 * m * 8, hipMemcpyHostToDevice, c->stream));
+		hipLaunchKernelGGL(gather_lists_kernel, dim3((uint32_t)m), dim3(256), 0, c->stream, c->att_homs,
+						   (const uint64_t *)c->b_subst.p, (DevHom *)dev_dst);
+		HIPOK(c, hipGetLastError());
+		return sync_stream(c);
+	}
+	if (ensure_host_lists(c, q_begin, q_end)) return 1;
 	size_t tot = 0;
 	for (size_t j = q_begin; j < q_end; j++) {
 		counts[j - q_begin] = c->homs[j].size();
@@ -1198,8 +1323,11 @@ int phylo_attach_packed_device(phylo_ctx *c, const void *dev_records, const uint
 	c->att_homs = (const DevHom *)dev_records;
 	c->att_begin.assign(begin, begin + N);
 	c->att_count.assign(count, count + N);
+	// lists of the kept range that this context has only on the device so far (device sort +
+	// filter) stay to be fetched — from the new buffer, which holds them too
+	std::vector<uint8_t> was = c->host_stale;
 	c->host_stale.assign(N, 1);
-	for (size_t g = keep_begin; g < keep_end; g++) c->host_stale[g] = 0;
+	for (size_t g = keep_begin; g < keep_end; g++) c->host_stale[g] = was.size() == N ? was[g] : 0;
 	c->homs_staged = true;
 	c->eager_valid = false;
 	return 0;

@@ -31,7 +31,11 @@ def hom_tuples_orc(h):
     return [(int(a["rev"]), int(a["iref"]), int(a["iproj"]), int(a["iq"]), int(a["len"])) for a in h]
 
 
-def check_process(ctx, gs, ref, chunk=0, kmer=0, backend=0, complete_deletion=False, threshold=0):
+def check_process(ctx, gs, ref, chunk=0, kmer=0, backend=0, complete_deletion=False, threshold=0, filt=None):
+    if filt is None:  # both homes of the sort + chain filter, alternating from call to call
+        check_process.flip = 3 - getattr(check_process, "flip", 1)
+        filt = check_process.flip
+    ctx.set_option("filter", filt)
     ctx.set_option("chunk", chunk)
     ctx.set_option("kmer", kmer)
     ctx.set_option("compare_backend", backend)
@@ -55,6 +59,7 @@ def check_process(ctx, gs, ref, chunk=0, kmer=0, backend=0, complete_deletion=Fa
     ctx.set_option("chunk", 0)
     ctx.set_option("kmer", 0)
     ctx.set_option("compare_backend", 0)
+    ctx.set_option("filter", 0)
     return s, h
 
 
@@ -292,6 +297,7 @@ def test_device_resident_exchange_between_two_contexts():
     try:
         counts = np.zeros(n, np.uint64)
         for r, c in enumerate(ctxs):
+            c.set_option("filter", 1 + r)  # rank 0 filters on the host, rank 1 on the device (export then copies device to device)
             c.set_genomes(gs)
             c.set_reference(ref)
             c.anchor(bounds[r], bounds[r + 1])
@@ -441,3 +447,25 @@ def test_long_repeat_beyond_the_lcp_clip(ctx):
     check_process(ctx, gs, 0)
     check_process(ctx, gs, 0, chunk=1024, backend=1)
     check_process(ctx, gs, 3)
+
+
+@pytest.mark.parametrize("filt", [1, 2])
+def test_sort_filter_on_host_and_on_device(ctx, filt):
+    """The same lists whether phase A's sort + chain filter runs on the host cores or on the device;
+    lists with equal projected starts (here: a query that is two copies of one segment, so both
+    copies anchor at the same reference position) are left to the host's std::sort by the device path."""
+    gs = synth.make_genomes(8, 60000, seed=31, d_range=(0.005, 0.25), indel_per_mbp=400, inv_frac=0.08, contigs=2)
+    dup = np.concatenate([gs[0][1000:9000], synth.random_base(300, np.random.default_rng(1)), gs[0][1000:9000]])
+    gs = gs + [dup]
+    check_process(ctx, gs, 0, filt=filt)
+    check_process(ctx, gs, 5, chunk=192, filt=filt)
+    ctx.set_option("filter", filt)
+    ctx.set_genomes(gs)
+    ctx.set_reference(0)
+    ctx.anchor(2, 7)   # a partial range keeps the other lists
+    ctx.anchor(0, 2)
+    ctx.anchor(7, 9)
+    s, h = ctx.compare()
+    so, ho = O.Run(gs, 0).process().matrix()
+    assert (s == so).all() and (h == ho).all()
+    ctx.set_option("filter", 0)
