@@ -62,7 +62,10 @@ static __device__ void bitonic_sort(uint64_t *a, uint32_t n2)
 					}
 				}
 			}
-			__syncthreads();
+			// partners less than 64 apart sit in the same wavefront (t and t ^ j differ only in the
+			// lane bits), and a wavefront's LDS accesses execute in order: no block barrier needed
+			if (j >= 64 || j == 1) __syncthreads();
+			else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 		}
 }
 
@@ -206,19 +209,24 @@ __global__ __launch_bounds__(FILT_THREADS) void sort_filter_kernel(const RawHom 
 				const uint64_t t = shfl64(v, (int)src);
 				if (need && t > running) running = t;
 			}
-			uint64_t key_i = 0;
+			// Inside the round plain scores do: lanes are visited in index order and only a strictly
+			// higher score replaces the running one, which is the smallest-index rule again.
+			uint32_t run_score = (uint32_t)(running >> 12), run_idx = running ? sk_index(running) : 0xffffu;
+			uint32_t score_i = 0;
 			for (uint32_t s = 0; s < cnt; s++) {
 				// lane s has seen every earlier lane's result: its own is final now
-				if (lane == s) key_i = sk_key((uint32_t)(running >> 12) + len_i, i);
-				const uint64_t key_s = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key_i, (int)s) |
-									   (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key_i >> 32), (int)s) << 32;
+				if (lane == s) score_i = run_score + len_i;
+				const uint32_t score_s = (uint32_t)__builtin_amdgcn_readlane((int)score_i, (int)s);
 				const uint32_t end_s = (uint32_t)__builtin_amdgcn_readlane((int)end_i, (int)s);
-				if (on && lane > s && end_s <= start_i && key_s > running) running = key_s;
+				if (lane > s && end_s <= start_i && score_s > run_score) {
+					run_score = score_s;
+					run_idx = a + s;
+				}
 			}
 			if (on) {
-				sh.score[i] = (uint32_t)(key_i >> 12);
-				sh.pred[i] = running ? (uint16_t)sk_index(running) : NONE16;
-				K[ep] = key_i;
+				sh.score[i] = score_i;
+				sh.pred[i] = (uint16_t)run_idx;
+				K[ep] = sk_key(score_i, i);
 			}
 		}
 	}
