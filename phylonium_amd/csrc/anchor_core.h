@@ -750,7 +750,7 @@ template <class Tail> PHY_HD void chain_trip(Chain &ch, const RefIndex &R, Tail 
 
 // ───────────────────────── phase-A work layout ─────────────────────────
 //
-// Every query is cut into chunks of C positions (C a power of two).  Chunk c of
+// Every query is cut into chunks of C positions (C a multiple of 64).  Chunk c of
 // query j has global id qchunk0[j] + c.  A *speculative* chain starts at every
 // chunk boundary in the state the reference has at q = 0 (last_* = 0, which is
 // lucky-ineligible for q > threshold) and runs to the end of its chunk,

@@ -249,16 +249,17 @@ template <int MODE> __global__ __launch_bounds__(256) void chain_kernel(PhaseA A
 // One block of FOLD_THREADS threads per query.
 //  (1) The chunk metadata of a window of FOLD_WCH chunks (bridge target, merge
 //      index, bridge size, log size) is copied into LDS with coalesced loads.
-//  (2) One thread walks the true chain inside LDS — chunk 0's log, its bridge,
-//      the target chunk's log from the merge index, … — and writes the list of
-//      anchor segments (address, count) with running offsets.  No global
-//      pointer chasing except through bridge overflow blocks (rare).
-//  (3) All threads fold the window's anchors, 256 per iteration, exactly as
+//  (2) The true chain inside the window — chunk 0's log, its bridge, the target
+//      chunk's log from the merge index, … — is found by pointer doubling over the
+//      bridge targets (every chunk has one outgoing link), and block-wide prefix
+//      sums give every live chunk its anchor segments (address, count, offset).
+//      No global pointer chasing except through bridge overflow blocks (rare).
+//  (3) All threads fold the window's anchors, FOLD_ITER per iteration, exactly as
 //      process.cxx:246-292 does one at a time: the right-anchor test needs only
 //      the previous anchor (neighbour lane / LDS across waves), a homology ends at
 //      every non-right anchor, its start is the latest non-right anchor before it
 //      (ballot + LDS), and the output position is a prefix count, so emission
-//      stays in query order (the host's std::sort depends on the input order).
+//      stays in query order (a std::sort over lists with equal starts depends on it).
 
 static const uint32_t FOLD_WCH = 1024;  // chunks of metadata per window
 static const uint32_t FOLD_SEGS = 5120; // anchor segments per window (a chunk contributes 1-3; 5 per chunk on average would overflow, reported as error 4)

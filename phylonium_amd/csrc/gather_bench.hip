@@ -1,8 +1,10 @@
 // gather_bench.hip — micro-benchmark (not on the product path): the ceiling for
-// what the anchor kernel does to memory, i.e. uniformly random 128-byte lines
-// fetched out of a table far larger than the Infinity Cache, 5 x 16 bytes read
-// per line, `ILP` independent lookups in flight per lane.  Gives the "peak" that
-// the anchor kernel's random-line rate is compared with.
+// what the anchor kernel does to memory, i.e. uniformly random lines fetched out of
+// a table far larger than the Infinity Cache (128-byte lines with 5 x 16 bytes read,
+// or 64-byte lines read whole), `ILP` independent lookups in flight per lane.  Gives
+// the "peak" that the anchor kernel's random-line rate is compared with, and shows
+// what that peak depends on — the pages in play (argv[1] = table bytes: 53 G lines/s
+// up to ~3 GB, ~20 G/s beyond), not the bytes per line.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
