@@ -292,14 +292,32 @@ __global__ __launch_bounds__(64) void pairs_kernel(Pileup P, const uint32_t *__r
 #pragma unroll
 	for (uint32_t t = 0; t < PAIR_IG; t++) acc_h[t] = acc_s[t] = 0;
 
+	// the lane's own words of the next window are requested before this window's pairs are
+	// counted (the loop body is ~110 VALU instructions: plenty to cover the load)
+	uint32_t vj_n = 0, aj_n = 0, bj_n = 0, dj_n = 0, gj_n = 0;
+	if (w0 < w1) {
+		const size_t row = (size_t)w0 * P.Npad;
+		vj_n = pV[row + j];
+		aj_n = p0[row + j];
+		bj_n = p1[row + j];
+		if (BANG) {
+			dj_n = pD[row + j];
+			gj_n = pB[row + j];
+		}
+	}
 	uint32_t w = w0;
 	for (; w < w1; w++) {
 		const size_t row = (size_t)w * P.Npad;
-		const uint32_t vj = pV[row + j], aj = p0[row + j], bj = p1[row + j];
-		uint32_t dj = 0, gj = 0;
-		if (BANG) {
-			dj = pD[row + j];
-			gj = pB[row + j];
+		const uint32_t vj = vj_n, aj = aj_n, bj = bj_n, dj = dj_n, gj = gj_n;
+		{
+			const size_t rn = (size_t)(w + 1 < w1 ? w + 1 : w) * P.Npad;
+			vj_n = pV[rn + j];
+			aj_n = p0[rn + j];
+			bj_n = p1[rn + j];
+			if (BANG) {
+				dj_n = pD[rn + j];
+				gj_n = pB[rn + j];
+			}
 		}
 #pragma unroll
 		for (uint32_t t = 0; t < PAIR_IG; t++) {
