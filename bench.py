@@ -203,6 +203,13 @@ def main():
         ctx.set_option("host_threads", args.host_threads)
     ctx.set_genomes_device(buf.data_ptr(), offs, lens)
     print(f"# genomes generated in {t_gen:.1f} s", file=sys.stderr, flush=True)
+    if world > 1:  # every rank must hold the same genomes (same seed, same generator): compare a checksum
+        chk = buf[::4097].to(torch.int64).sum() * 1000003 + int(sum(lens))
+        lo, hi = chk.clone(), chk.clone()
+        td.all_reduce(lo, op=td.ReduceOp.MIN)
+        td.all_reduce(hi, op=td.ReduceOp.MAX)
+        if int(lo.item()) != int(hi.item()):
+            raise SystemExit("bench.py: the ranks generated different genomes")
     t_ref = time.time()
     ctx.set_reference(ref_idx)  # host suffix array + tables: outside the metric
     t_ref = time.time() - t_ref
