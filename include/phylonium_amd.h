@@ -55,7 +55,8 @@ int phylo_ctx_create(phylo_ctx **out, int device);
 void phylo_ctx_destroy(phylo_ctx *ctx);
 /* ctx may be NULL: last error of a failed phylo_ctx_create on this thread. */
 const char *phylo_last_error(const phylo_ctx *ctx);
-/* Tunables, mostly for tests: "chunk" (phase-A chunk length, a multiple of 64),
+/* Tunables, mostly for tests: "chunk" (phase-A chunk length, a multiple of 64), "chunk_tail"
+ * (the second half of every query in chunks of this length instead),
  * "kmer" (bucket k), "profile" (1: time every kernel with HIP events),
  * "compare_backend" (0 pileup, 1 segment list), "filter" (where phase A's sort + chain filter
  * runs: 0 on the device for 128 queries or more and on the host cores below, 1 host, 2 device;

@@ -793,13 +793,18 @@ struct PhaseA {
 	const uint32_t *items;     // [nchunks] work order: global chunk ids, runs of one query (hostlogic.hpp: plan_chunks)
 	const uint32_t *chunk_query; // [nchunks] query id of each global chunk
 	uint32_t nchunks;
-	uint32_t C;                // chunk length (a multiple of 64)
-	uint32_t cap;              // anchor slots per chunk
+	// A query's first qnb[j] chunks have C positions each, the rest Cs (multiples of 64; Cs == C
+	// when all are alike): long chunks to start every lane on, short ones for the lanes that
+	// finish early (hostlogic.hpp: plan_chunks).
+	uint32_t C, Cs;
+	uint32_t cap, caps;        // anchor slots per long / short chunk
+	const uint32_t *qnb;       // [nq] long chunks of each query
+	const uint32_t *qanc0;     // [nq] first anchor slot of each query in spec_anchors
 	// speculative logs
-	Anchor *spec_anchors;      // [nchunks*cap]
+	Anchor *spec_anchors;      // [sum over chunks of their slots]: a query's chunks back to back
 	uint32_t *spec_cnt;        // [nchunks]
 	SpecExit *spec_exit;       // [nchunks]
-	uint32_t *visited;         // [nchunks*C/32] bitmap
+	uint32_t *visited;         // bitmap over the genome buffer: bit (qoff[j] + q) of query j
 	// bridges
 	BridgeRec *bridge;         // [nchunks]
 	PoolBlock *pool;
@@ -816,55 +821,92 @@ PHY_HD bool lucky_eligible(uint32_t q, uint32_t aq, uint32_t as, uint32_t al, co
 	return (as + advance < R.n) && (advance - al <= R.threshold);
 }
 
+// Where chunk lc (local index) of query j lies: first position, length, log slots and their base.
+struct ChunkGeom {
+	uint32_t q0, len, cap, log0;
+};
+PHY_HD ChunkGeom chunk_geom(const PhaseA &A, uint32_t j, uint32_t lc)
+{
+	const uint32_t nb = A.qnb[j], base = A.qanc0[j];
+	ChunkGeom g;
+	if (lc < nb) {
+		g.q0 = lc * A.C;
+		g.len = A.C;
+		g.cap = A.cap;
+		g.log0 = base + lc * A.cap;
+	} else {
+		const uint32_t s = lc - nb;
+		g.q0 = nb * A.C + s * A.Cs;
+		g.len = A.Cs;
+		g.cap = A.caps;
+		g.log0 = base + nb * A.cap + s * A.caps;
+	}
+	return g;
+}
+// local index of the chunk that holds position q of query j
+PHY_HD uint32_t chunk_of_pos(const PhaseA &A, uint32_t j, uint32_t q)
+{
+	const uint32_t nb = A.qnb[j], split = nb * A.C;
+	return q < split ? q / A.C : nb + (q - split) / A.Cs;
+}
+// word of the visited bitmap that holds position q of the chain's query (genomes start at
+// multiples of 64 in the buffer, chunks at multiples of 64 in the genome: a chunk owns its words)
+PHY_HD uint32_t visited_word(const PhaseA &A, const Chain &ch, uint32_t q)
+{
+	return (uint32_t)(((uint64_t)(ch.Q - A.qbase) + q) >> 5);
+}
+
 // ── speculative chain driver (one lane) ──
 struct SpecLane {
 	Chain ch;
 	uint32_t gc;        // global chunk id; BRIDGE_END when out of work
-	uint32_t q0;        // chunk start; the chunk ends at min(q0 + C, query length)
+	uint32_t q_end;     // chunk end (clipped to the query length)
 	uint32_t cnt;       // anchors logged
+	uint32_t log0, cap; // the chunk's log in spec_anchors
 	uint32_t vis_word;  // visited bits being accumulated
-	uint32_t vis_idx;   // word index (global) of vis_word, or NO_BLOCK
+	uint32_t vis_idx;   // word index (global) of vis_word
 
 	PHY_HD void start(const PhaseA &A, uint32_t chunk)
 	{
 		gc = chunk;
-		uint32_t j = A.chunk_query[chunk];
-		uint32_t c = chunk - A.qchunk0[j];
-		q0 = c * A.C;
-		ch.reset(A.qbase + A.qoff[j], A.qlen[j], q0, 0, 0, 0);
+		const uint32_t j = A.chunk_query[chunk];
+		const ChunkGeom g = chunk_geom(A, j, chunk - A.qchunk0[j]);
+		const uint32_t ql = A.qlen[j], e = g.q0 + g.len;
+		q_end = e < ql ? e : ql;
+		log0 = g.log0;
+		cap = g.cap;
+		ch.reset(A.qbase + A.qoff[j], ql, g.q0, 0, 0, 0);
 		cnt = 0;
 		vis_word = 0;
-		vis_idx = chunk * (A.C >> 5); // the chunk's first bitmap word
+		vis_idx = visited_word(A, ch, g.q0);
 	}
 
 	// Called when ch.st == ST_STEP. Returns false when the chunk is finished.
 	PHY_HD bool begin_step(const PhaseA &A)
 	{
-		const uint32_t e = q0 + A.C;
-		if (ch.q >= (e < ch.qlen ? e : ch.qlen)) {
+		if (ch.q >= q_end) {
 			A.visited[vis_idx] = vis_word;
 			A.spec_cnt[gc] = cnt;
 			SpecExit x = {ch.q, ch.lq, ch.ls, ch.ll};
 			A.spec_exit[gc] = x;
 			return false;
 		}
-		uint32_t local = ch.q - q0;
-		uint32_t w = gc * (A.C >> 5) + (local >> 5);
+		const uint32_t w = visited_word(A, ch, ch.q);
 		if (w != vis_idx) { // positions only grow: the previous word is complete
 			A.visited[vis_idx] = vis_word;
 			vis_idx = w;
 			vis_word = 0;
 		}
-		vis_word |= 1u << (local & 31);
+		vis_word |= 1u << (ch.q & 31);
 		return true;
 	}
 
 	PHY_HD void step_done(const PhaseA &A)
 	{
 		if (ch.r_accepted) {
-			if (cnt < A.cap) {
+			if (cnt < cap) {
 				Anchor a = {ch.r_q, ch.r_s, ch.r_len};
-				A.spec_anchors[(size_t)gc * A.cap + cnt] = a;
+				A.spec_anchors[(size_t)log0 + cnt] = a;
 			} else {
 				*A.error = 1;
 			}
@@ -877,9 +919,10 @@ struct SpecLane {
 struct BridgeLane {
 	Chain ch;
 	uint32_t src;      // chunk whose exit state is being continued; BRIDGE_END when idle
-	uint32_t qc0;      // first global chunk of the query
+	uint32_t qj;       // the query
 	uint32_t cur_gc;   // chunk of the speculative log being compared against
-	uint32_t cur_q0;   // its first position
+	uint32_t cur_q0, cur_len; // its first position and length
+	uint32_t cur_log;  // its log in spec_anchors
 	uint32_t sp_cnt, sp_idx;
 	Anchor Ls;         // last anchor the speculative chain had accepted before ch.q
 	uint32_t n;        // anchors accepted by this bridge
@@ -889,11 +932,11 @@ struct BridgeLane {
 	{
 		src = chunk;
 		uint32_t j = A.chunk_query[chunk];
-		qc0 = A.qchunk0[j];
+		qj = j;
 		SpecExit x = A.spec_exit[chunk];
 		ch.reset(A.qbase + A.qoff[j], A.qlen[j], x.q, x.lq, x.ls, x.ll);
 		cur_gc = BRIDGE_END;
-		cur_q0 = 0;
+		cur_q0 = cur_len = cur_log = 0;
 		sp_cnt = sp_idx = 0;
 		Ls.q = Ls.s = Ls.len = 0;
 		n = 0;
@@ -916,23 +959,25 @@ struct BridgeLane {
 			finish(A, BRIDGE_END, 0);
 			return false;
 		}
-		if (cur_gc == BRIDGE_END || ch.q - cur_q0 >= A.C) { // entered another chunk (C need not be a power of two)
-			uint32_t lc = ch.q / A.C;
-			cur_gc = qc0 + lc;
-			cur_q0 = lc * A.C;
+		if (cur_gc == BRIDGE_END || ch.q - cur_q0 >= cur_len) { // entered another chunk
+			const uint32_t lc = chunk_of_pos(A, qj, ch.q);
+			const ChunkGeom g = chunk_geom(A, qj, lc);
+			cur_gc = A.qchunk0[qj] + lc;
+			cur_q0 = g.q0;
+			cur_len = g.len;
+			cur_log = g.log0;
 			sp_cnt = A.spec_cnt[cur_gc];
 			sp_idx = 0;
 			Ls.q = Ls.s = Ls.len = 0;
 		}
 		const uint32_t gc = cur_gc;
-		const Anchor *log = A.spec_anchors + (size_t)gc * A.cap;
+		const Anchor *log = A.spec_anchors + (size_t)cur_log;
 		while (sp_idx < sp_cnt && log[sp_idx].q < ch.q) {
 			Ls = log[sp_idx];
 			sp_idx++;
 		}
-		uint32_t local = ch.q - cur_q0;
-		uint32_t w = A.visited[gc * (A.C >> 5) + (local >> 5)];
-		if ((w >> (local & 31)) & 1u) {
+		const uint32_t w = A.visited[visited_word(A, ch, ch.q)];
+		if ((w >> (ch.q & 31)) & 1u) {
 			bool eb = lucky_eligible(ch.q, ch.lq, ch.ls, ch.ll, R);
 			bool es = lucky_eligible(ch.q, Ls.q, Ls.s, Ls.len, R);
 			bool merged = false;

@@ -432,7 +432,7 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t n
 					if (pz >= npath) break;
 					const uint32_t t = sh.path[pz], g = wbeg + t;
 					if (my_spec[e]) {
-						sh.seg_ptr[slot] = A.spec_anchors + (size_t)g * A.cap + my_idx[e];
+						sh.seg_ptr[slot] = A.spec_anchors + (size_t)chunk_geom(A, j, g - c_begin).log0 + my_idx[e];
 						sh.seg_off[slot++] = off;
 						off += my_spec[e];
 					}

@@ -177,7 +177,7 @@ struct phylo_ctx {
 	int n_cu = 256;
 
 	// options
-	uint32_t opt_chunk = 0, opt_kmer = 0;
+	uint32_t opt_chunk = 0, opt_chunk_tail = 0, opt_kmer = 0;
 	bool profile = false;
 	int backend = 0;
 	int host_threads = 0;
@@ -202,7 +202,7 @@ struct phylo_ctx {
 
 	// phase A scratch
 	DevBuf<uint64_t> a_qoff;
-	DevBuf<uint32_t> a_qlen, a_qchunk0, a_items, a_chunk_query, a_spec_cnt, a_visited, a_misc;
+	DevBuf<uint32_t> a_qlen, a_qchunk0, a_qnb, a_qanc0, a_items, a_chunk_query, a_spec_cnt, a_visited, a_misc;
 	DevBuf<Anchor> a_spec_anchors;
 	DevBuf<SpecExit> a_spec_exit;
 	DevBuf<BridgeRec> a_bridge;
@@ -402,6 +402,8 @@ void phylo_ctx_destroy(phylo_ctx *c)
 	c->a_qoff.release();
 	c->a_qlen.release();
 	c->a_qchunk0.release();
+	c->a_qnb.release();
+	c->a_qanc0.release();
 	c->a_items.release();
 	c->a_chunk_query.release();
 	c->a_spec_cnt.release();
@@ -448,6 +450,10 @@ int phylo_set_option(phylo_ctx *c, const char *key, long value)
 		c->plan_valid = false;
 		c->homs_staged = false;
 	c->homs_staged = false;
+	} else if (k == "chunk_tail") {
+		if (value != 0 && (value < 64 || value % 64 || value > 65536)) return c->fail("chunk_tail must be 0 or a multiple of 64 in 64..65536");
+		c->opt_chunk_tail = (uint32_t)value;
+		c->plan_valid = false;
 	} else if (k == "kmer") {
 		if (value < 0 || value > 14) return c->fail("kmer must be in 0..14");
 		c->opt_kmer = (uint32_t)value;
@@ -736,8 +742,9 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 			// speculative chunk compare to the end of the genome.
 			if (q_begin + j == c->ref_idx) qlen[j] = 0;
 		}
-		c->plan = plan_chunks(qlen, c->threshold, c->opt_chunk, (uint32_t)spec_resident_blocks(c->n_cu) * 256u);
+		c->plan = plan_chunks(qlen, c->threshold, c->opt_chunk, (uint32_t)spec_resident_blocks(c->n_cu) * 256u, c->opt_chunk_tail);
 		const ChunkPlan &P = c->plan;
+		if (!P.C) return c->fail("phase A: more than 2^32 anchor log slots");
 		// an emitted homology spans >= 2*threshold query positions
 		c->plan_out_base.assign(nq + 1, 0);
 		std::vector<uint32_t> out_cap(nq);
@@ -756,9 +763,12 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 		HIPOK(c, c->a_items.ensure(nchp + 1));
 		HIPOK(c, c->a_chunk_query.ensure(nchp + 1));
 		HIPOK(c, c->a_spec_cnt.ensure(nchp + 1));
-		HIPOK(c, c->a_visited.ensure((size_t)nchp * (P.C / 32) + 1));
+		// one visited bit per byte of the genome buffer (chains address it by buffer offset)
+		HIPOK(c, c->a_visited.ensure((c->goff[c->n - 1] + c->glen[c->n - 1]) / 32 + 8));
 		HIPOK(c, c->a_misc.ensure(16));
-		HIPOK(c, c->a_spec_anchors.ensure((size_t)nchp * P.cap + 1));
+		HIPOK(c, c->a_spec_anchors.ensure(P.anchor_slots + 1));
+		HIPOK(c, c->a_qnb.ensure(nq));
+		HIPOK(c, c->a_qanc0.ensure(nq));
 		HIPOK(c, c->a_spec_exit.ensure(nchp + 1));
 		HIPOK(c, c->a_bridge.ensure(nchp + 1));
 		HIPOK(c, c->a_pool.ensure(nchp / 4 + 4096));
@@ -770,6 +780,8 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 		HIPOK(c, hipMemcpyAsync(c->a_qoff.p, qoff.data(), nq * 8, hipMemcpyHostToDevice, st));
 		HIPOK(c, hipMemcpyAsync(c->a_qlen.p, qlen.data(), nq * 4, hipMemcpyHostToDevice, st));
 		HIPOK(c, hipMemcpyAsync(c->a_qchunk0.p, P.qchunk0.data(), (nq + 1) * 4, hipMemcpyHostToDevice, st));
+		HIPOK(c, hipMemcpyAsync(c->a_qnb.p, P.qnb.data(), nq * 4, hipMemcpyHostToDevice, st));
+		HIPOK(c, hipMemcpyAsync(c->a_qanc0.p, P.qanc0.data(), nq * 4, hipMemcpyHostToDevice, st));
 		if (nchp) {
 			HIPOK(c, hipMemcpyAsync(c->a_items.p, P.items.data(), (size_t)nchp * 4, hipMemcpyHostToDevice, st));
 			HIPOK(c, hipMemcpyAsync(c->a_chunk_query.p, P.chunk_query.data(), (size_t)nchp * 4, hipMemcpyHostToDevice, st));
@@ -787,7 +799,10 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	uint64_t total = 0;
 	for (size_t j = 0; j < nq; j++) total += c->glen[q_begin + j];
 	HIPOK(c, hipMemsetAsync(c->a_misc.p, 0, 16 * 4, st));
-	if (nch) HIPOK(c, hipMemsetAsync(c->a_visited.p, 0, (size_t)nch * (P.C / 32) * 4, st));
+	if (nch) { // the words of this call's queries (their genomes lie back to back in the buffer)
+		const uint64_t w0 = c->goff[q_begin] / 32, w1 = (c->goff[q_end - 1] + c->glen[q_end - 1]) / 32 + 1;
+		HIPOK(c, hipMemsetAsync(c->a_visited.p + w0, 0, (size_t)(w1 - w0) * 4, st));
+	}
 
 	PhaseA A;
 	A.qbase = c->d_genomes;
@@ -798,7 +813,11 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	A.chunk_query = c->a_chunk_query.p;
 	A.nchunks = nch;
 	A.C = P.C;
+	A.Cs = P.Cs;
 	A.cap = P.cap;
+	A.caps = P.caps;
+	A.qnb = c->a_qnb.p;
+	A.qanc0 = c->a_qanc0.p;
 	A.spec_anchors = c->a_spec_anchors.p;
 	A.spec_cnt = c->a_spec_cnt.p;
 	A.spec_exit = c->a_spec_exit.p;

@@ -96,11 +96,13 @@ void *emul_run(size_t n, const char *const *seq, const size_t *len, size_t ref_i
 	std::vector<uint8_t> qbase(tot, 0);
 	for (size_t j = 0; j < n; j++) memcpy(qbase.data() + qoff[j], seq[j], len[j]);
 
-	ChunkPlan P = plan_chunks(qlen, (uint32_t)threshold, forced_C);
+	// EMUL_CHUNK_TAIL: chunk length of the short tail chunks (half of every query), as the "chunk_tail" option
+	const char *tail_env = getenv("EMUL_CHUNK_TAIL");
+	ChunkPlan P = plan_chunks(qlen, (uint32_t)threshold, forced_C, 256u * 4u * 256u, tail_env ? (uint32_t)atoi(tail_env) : 0u);
 	E->C = P.C;
 	E->nchunks = P.nchunks;
-	std::vector<Anchor> spec_anchors((size_t)P.nchunks * P.cap);
-	std::vector<uint32_t> spec_cnt(P.nchunks, 0), visited((size_t)P.nchunks * (P.C / 32), 0);
+	std::vector<Anchor> spec_anchors((size_t)P.anchor_slots + 1);
+	std::vector<uint32_t> spec_cnt(P.nchunks, 0), visited((size_t)tot / 32 + 8, 0);
 	std::vector<SpecExit> spec_exit(P.nchunks);
 	std::vector<BridgeRec> bridge(P.nchunks);
 	uint32_t pool_blocks = 1024 + P.nchunks;
@@ -116,6 +118,10 @@ void *emul_run(size_t n, const char *const *seq, const size_t *len, size_t ref_i
 	A.nchunks = P.nchunks;
 	A.C = P.C;
 	A.cap = P.cap;
+	A.Cs = P.Cs;
+	A.caps = P.caps;
+	A.qnb = P.qnb.data();
+	A.qanc0 = P.qanc0.data();
 	A.spec_anchors = spec_anchors.data();
 	A.spec_cnt = spec_cnt.data();
 	A.spec_exit = spec_exit.data();
@@ -161,7 +167,7 @@ void *emul_run(size_t n, const char *const *seq, const size_t *len, size_t ref_i
 			uint32_t gc = P.qchunk0[j], idx = 0;
 			for (;;) {
 				for (uint32_t t = idx; t < spec_cnt[gc]; t++)
-					if (fold_anchor(&f, spec_anchors[(size_t)gc * P.cap + t], border, R.threshold, &h))
+					if (fold_anchor(&f, spec_anchors[(size_t)chunk_geom(A, (uint32_t)j, gc - P.qchunk0[j]).log0 + t], border, R.threshold, &h))
 						out.push_back(h);
 				const BridgeRec &b = bridge[gc];
 				uint32_t blk = b.block;

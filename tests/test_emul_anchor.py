@@ -13,9 +13,14 @@ import oracle_lib as O
 from phylonium_amd import synth
 
 
-def assert_same(gs, ref, chunk=0, kmer=0, allow_quirk=False, threshold=0):
+def assert_same(gs, ref, chunk=0, kmer=0, allow_quirk=False, threshold=0, tail=0):
     r = O.Run(gs, ref, threshold=threshold).process(compare=False)
-    e = E.EmulRun(gs, ref, chunk=chunk, kmer=kmer, threshold=threshold)
+    if tail:
+        os.environ["EMUL_CHUNK_TAIL"] = str(tail)
+    try:
+        e = E.EmulRun(gs, ref, chunk=chunk, kmer=kmer, threshold=threshold)
+    finally:
+        os.environ.pop("EMUL_CHUNK_TAIL", None)
     assert e.error == 0
     assert e.threshold == r.threshold
     for j in range(len(gs)):
@@ -173,3 +178,12 @@ def test_long_repeat_beyond_the_lcp_clip():
     gs = _long_repeat_set()
     assert_same(gs, 0)
     assert_same(gs, 3, chunk=1024)
+
+
+@pytest.mark.parametrize("chunk,tail", [(256, 64), (512, 128), (320, 192), (1024, 256)])
+def test_long_head_and_short_tail_chunks(chunk, tail):
+    """A query's head in long chunks and its tail in short ones (what the plan does when one round of
+    chunks fills the device): the chunk grid is no longer uniform."""
+    gs = synth.make_genomes(5, 30000, seed=chunk + tail, d_range=(0.005, 0.3), indel_per_mbp=400, inv_frac=0.08, contigs=2)
+    assert_same(gs, 0, chunk=chunk, tail=tail)
+    assert_same(gs, 3, chunk=chunk, tail=tail, threshold=18)

@@ -31,12 +31,13 @@ def hom_tuples_orc(h):
     return [(int(a["rev"]), int(a["iref"]), int(a["iproj"]), int(a["iq"]), int(a["len"])) for a in h]
 
 
-def check_process(ctx, gs, ref, chunk=0, kmer=0, backend=0, complete_deletion=False, threshold=0, filt=None):
+def check_process(ctx, gs, ref, chunk=0, kmer=0, backend=0, complete_deletion=False, threshold=0, filt=None, tail=0):
     if filt is None:  # both homes of the sort + chain filter, alternating from call to call
         check_process.flip = 3 - getattr(check_process, "flip", 1)
         filt = check_process.flip
     ctx.set_option("filter", filt)
     ctx.set_option("chunk", chunk)
+    ctx.set_option("chunk_tail", tail)
     ctx.set_option("kmer", kmer)
     ctx.set_option("compare_backend", backend)
     ctx.set_genomes(gs)
@@ -57,6 +58,7 @@ def check_process(ctx, gs, ref, chunk=0, kmer=0, backend=0, complete_deletion=Fa
             a, b = api.estimate("jc", s[i, j], h[i, j]), O.estimate("jc", so[i, j], ho[i, j])
             assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= 1e-12
     ctx.set_option("chunk", 0)
+    ctx.set_option("chunk_tail", 0)
     ctx.set_option("kmer", 0)
     ctx.set_option("compare_backend", 0)
     ctx.set_option("filter", 0)
@@ -390,7 +392,8 @@ def test_fuzz_small_random_sets(ctx, seed):
     kmer = int(rng.choice([0, 0, 2, 5]))
     backend = int(rng.integers(0, 2))
     threshold = int(rng.choice([0, 0, 0, 17, 21]))  # 17+: what references beyond ~60 Mbp have
-    check_process(ctx, gs, ref, chunk=chunk, kmer=kmer, backend=backend, threshold=threshold)
+    tail = int(rng.choice([0, 0, 64, 128])) if chunk else 0  # a query's tail in shorter chunks
+    check_process(ctx, gs, ref, chunk=chunk, kmer=kmer, backend=backend, threshold=threshold, tail=tail)
 
 
 def _nccl_one_rank_worker(rank, world, port, out):
@@ -485,3 +488,10 @@ def test_many_queries_default_options(ctx):
     assert (s == so).all() and (h == ho).all()
     for j in (0, 7, 63, 139):  # read back on demand
         assert hom_tuples_gpu(ctx.homologies(j)) == hom_tuples_orc(r.homologies(j))
+
+
+@pytest.mark.parametrize("chunk,tail", [(256, 64), (512, 192), (1024, 256)])
+def test_long_head_and_short_tail_chunks(ctx, chunk, tail):
+    gs = synth.make_genomes(7, 50000, seed=chunk, d_range=(0.005, 0.3), indel_per_mbp=400, inv_frac=0.08, contigs=2)
+    check_process(ctx, gs, 0, chunk=chunk, tail=tail)
+    check_process(ctx, gs, 4, chunk=chunk, tail=tail, backend=1, threshold=17)
