@@ -263,7 +263,12 @@ def main():
                 ctx.compare_device(emu[0], W, t.data_ptr(), t.data_ptr() + n * n * 8)
                 ctx._attached_records = gathered
                 td.all_reduce(t)
-                m = t.cpu().numpy().view(np.uint64).reshape(2, n, n)
+                pin = emu_state.get("pin")
+                if pin is None:
+                    pin = emu_state["pin"] = torch.empty(t.numel(), dtype=torch.int64, pin_memory=True)
+                pin.copy_(t, non_blocking=True)
+                torch.cuda.current_stream(device).synchronize()
+                m = pin.numpy().view(np.uint64).reshape(2, n, n)  # views of the pinned buffer: valid until the next call
                 return m[0], m[1]
             return ctx.compare(emu[0], emu[1])
         return dist.process_sharded(ctx, ref_idx, rank, world, device=device, lengths=lens, set_reference=False)
