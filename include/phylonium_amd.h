@@ -95,7 +95,9 @@ size_t phylo_threshold(const phylo_ctx *ctx);
 /* ── phase A: anchor_homologies + sort + filter_overlaps_max for queries
  * [q_begin, q_end), src/process.cxx:433-458 ── */
 int phylo_anchor(phylo_ctx *ctx, size_t q_begin, size_t q_end);
-/* ctx-owned result of phase A (or of phylo_set_homologies) for genome j. */
+/* ctx-owned result of phase A (or of phylo_set_homologies) for genome j.  After phase A the
+ * lists may exist only in device memory (that is where phase B reads them); they are copied
+ * to the host on the first call that asks for them. */
 int phylo_get_homologies(phylo_ctx *ctx, size_t j, const phylo_homology **h, size_t *n);
 /* Install lists computed elsewhere (another rank). */
 int phylo_set_homologies(phylo_ctx *ctx, size_t j, const phylo_homology *h, size_t n);
