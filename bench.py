@@ -111,7 +111,8 @@ def cpu_baseline(torch, buf, offs, lens, ref_idx, sa_ref, sample_queries, thread
     t_esa, t_a, t_b = r.times()
     bases = float(sum(len(g) for g in gs))
     return {"value": bases / (t_a + t_b) / 1e9, "unit": "Gbp/s", "cores": threads, "kind": "port",
-            "sample": f"oracle (C++ restatement of process.cxx/esa.cxx, OpenMP over queries and pair rows) on "
+            "sample": f"oracle (C++ restatement of process.cxx/esa.cxx with the generic seqcmp/revseqcmp byte loops, "
+                      f"OpenMP over queries and pair rows) on "
                       f"{len(gs)} of the workload's genomes ({bases / 1e6:.0f} Mbp): anchor {t_a:.2f}s + compare "
                       f"{t_b:.2f}s; ESA build {t_esa:.1f}s excluded"}
 
