@@ -167,6 +167,10 @@ int phylo_seqcmp_batch(phylo_ctx *ctx, size_t n, const uint32_t *ga, const uint6
 
 /* ── host-side helpers (no GPU) ── */
 int phylo_host_suffix_array(const char *s, size_t n, int64_t *sa);
+/* Suffix array of S = ref + '#' + revcomp(ref) (2*len + 1 entries, src/esa.cxx:72-75), the `sa`
+ * argument of phylo_set_reference: lets a host build it on another thread while genomes are
+ * still being uploaded. */
+int phylo_host_reference_suffix_array(const char *ref, size_t len, int64_t *sa);
 size_t phylo_host_min_anchor_length(double p, double gc, size_t l);
 /* std::sort by projected start + filter_overlaps_max, in place; returns new n */
 size_t phylo_host_sort_filter(phylo_homology *h, size_t n, int do_sort);

@@ -27,7 +27,7 @@ SYMBOLS = [
     "phylo_export_homologies", "phylo_import_homologies", "phylo_export_packed", "phylo_import_packed",
     "phylo_export_packed_device", "phylo_attach_packed_device", "phylo_compare_device",
     "phylo_complete_delete", "phylo_compare", "phylo_compare_all", "phylo_process", "phylo_seqcmp",
-    "phylo_revseqcmp", "phylo_seqcmp_batch", "phylo_host_suffix_array", "phylo_host_min_anchor_length",
+    "phylo_revseqcmp", "phylo_seqcmp_batch", "phylo_host_suffix_array", "phylo_host_reference_suffix_array", "phylo_host_min_anchor_length",
     "phylo_host_sort_filter", "phylo_estimate", "phylo_format_phylip", "phylo_version",
 ]
 
@@ -82,6 +82,7 @@ def load():
     L.phylo_revseqcmp.argtypes = [vp, vp, sz]
     L.phylo_seqcmp_batch.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp]
     L.phylo_host_suffix_array.argtypes = [vp, sz, vp]
+    L.phylo_host_reference_suffix_array.argtypes = [vp, sz, vp]
     L.phylo_host_min_anchor_length.restype = sz
     L.phylo_host_min_anchor_length.argtypes = [C.c_double, C.c_double, sz]
     L.phylo_host_sort_filter.restype = sz

@@ -1727,6 +1727,16 @@ int phylo_host_suffix_array(const char *s, size_t n, int64_t *sa)
 	return 0;
 }
 
+int phylo_host_reference_suffix_array(const char *ref, size_t len, int64_t *sa)
+{
+	if (!ref || !sa || 2 * len + 1 >= 0x7fffffffull) return 1;
+	std::vector<uint8_t> S(2 * len + 1 + 64, 0);
+	memcpy(S.data(), ref, len);
+	S[len] = '#';
+	revcomp((const uint8_t *)ref, len, S.data() + len + 1);
+	return phylo_host_suffix_array((const char *)S.data(), 2 * len + 1, sa);
+}
+
 size_t phylo_host_min_anchor_length(double p, double gc, size_t l) { return min_anchor_length(p, gc, l); }
 
 size_t phylo_host_sort_filter(phylo_homology *h, size_t n, int do_sort)
