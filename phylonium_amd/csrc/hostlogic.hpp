@@ -6,10 +6,14 @@
 // Citations are to /root/reference.
 #pragma once
 #include <algorithm>
+#include <array>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/phylonium_amd.h"
@@ -134,6 +138,180 @@ static inline void suffix_array_u32(const uint8_t *s, uint32_t n, uint32_t *sa_o
 	std::vector<int32_t> SA((size_t)n + 1);
 	sais_main<uint8_t>(t.data(), SA.data(), (int32_t)n + 1, K);
 	for (uint32_t i = 0; i < n; i++) sa_out[i] = (uint32_t)SA[(size_t)i + 1]; // SA[0] is the sentinel
+}
+
+// ───────────────── suffix array on several host cores ─────────────────
+// Bucket the suffixes by their first P symbols (counting sort over position
+// chunks), then std::sort every bucket on its own by comparing the text eight
+// bytes at a time.  On sequence without long repeats a comparison ends within a
+// word or two and the buckets are independent, so the work spreads over the
+// cores.  Long repeats make the comparisons deep: the sort counts the words it
+// looks at and gives up past a budget (the caller then runs SA-IS, whose time
+// does not depend on the repeats).  The array is the same either way.
+//
+// `s` must be followed by at least 16 zero bytes and contain no zero byte itself.
+// par(ntasks, f) runs f(0..ntasks-1) on the caller's threads.
+
+struct SuffixSortGiveUp {};
+
+static inline uint64_t load_be64(const uint8_t *p)
+{
+	uint64_t v;
+	memcpy(&v, p, 8);
+	return __builtin_bswap64(v);
+}
+
+template <class Par> static bool suffix_array_buckets(const uint8_t *s, uint32_t n, uint32_t *sa, Par &&par, size_t nthreads)
+{
+	if (n < 2) {
+		if (n) sa[0] = 0;
+		return true;
+	}
+	nthreads = std::max<size_t>(1, nthreads);
+	const size_t nchunk = std::min<size_t>(nthreads * 4, std::max<size_t>(1, n / 65536));
+	const uint32_t per = (uint32_t)((n + nchunk - 1) / nchunk);
+	auto chunk_lo = [&](size_t c) { return (uint32_t)std::min<uint64_t>((uint64_t)c * per, n); };
+
+	// alphabet, dense ranks (0 = the padding past the end)
+	std::vector<std::array<uint8_t, 256>> seen_c(nchunk);
+	par(nchunk, [&](size_t c) {
+		auto &seen = seen_c[c];
+		seen.fill(0);
+		for (uint32_t i = chunk_lo(c), e = chunk_lo(c + 1); i < e; i++) seen[s[i]] = 1;
+	});
+	uint32_t rank[256];
+	uint32_t sigma = 1;
+	for (int ch = 0; ch < 256; ch++) {
+		bool any = false;
+		for (size_t c = 0; c < nchunk; c++) any |= seen_c[c][(size_t)ch] != 0;
+		if (any && ch == 0) return false;
+		rank[ch] = any ? sigma++ : 0;
+	}
+	uint32_t P = 1;
+	uint64_t nb = sigma;
+	while (nb * sigma <= 65536 && P < 8) nb *= sigma, P++;
+	const uint32_t top = (uint32_t)(nb / sigma); // weight of the first symbol
+	// bucket of the suffix at i = its first P ranks, most significant first
+	auto bucket_at = [&](uint32_t i) {
+		uint32_t id = 0;
+		for (uint32_t t = 0; t < P; t++) id = id * sigma + rank[s[i + t]]; // reads the padding past n as rank 0
+		return id;
+	};
+	// (P <= 8 < 16 bytes of padding)
+
+	std::vector<uint32_t> hist(nchunk * nb, 0);
+	par(nchunk, [&](size_t c) {
+		uint32_t lo = chunk_lo(c), hi = chunk_lo(c + 1);
+		if (lo >= hi) return;
+		uint32_t *h = hist.data() + c * nb;
+		uint32_t id = bucket_at(hi - 1);
+		h[id]++;
+		for (uint32_t i = hi - 1; i-- > lo;) {
+			id = id / sigma + rank[s[i]] * top;
+			h[id]++;
+		}
+	});
+	std::vector<uint32_t> start(nb + 1);
+	uint32_t sum = 0, largest = 0;
+	for (size_t b = 0; b < nb; b++) {
+		start[b] = sum;
+		for (size_t c = 0; c < nchunk; c++) {
+			sum += hist[c * nb + b];
+			hist[c * nb + b] = sum; // end of this chunk's share of the bucket
+		}
+		largest = std::max(largest, sum - start[b]);
+	}
+	start[nb] = sum;
+	if (n > (1u << 20) && largest > n / 8) return false; // low-complexity text: one bucket would carry the sort
+	par(nchunk, [&](size_t c) {
+		uint32_t lo = chunk_lo(c), hi = chunk_lo(c + 1);
+		if (lo >= hi) return;
+		uint32_t *h = hist.data() + c * nb;
+		// positions are walked downwards, so each bucket's share of the chunk is filled back to front
+		uint32_t id = bucket_at(hi - 1);
+		sa[--h[id]] = hi - 1;
+		for (uint32_t i = hi - 1; i-- > lo;) {
+			id = id / sigma + rank[s[i]] * top;
+			sa[--h[id]] = i;
+		}
+	});
+
+	// sort the buckets, largest work first is not needed: they are many and small
+	std::atomic<bool> give_up{false};
+	std::atomic<uint64_t> deep_words{0};
+	const uint64_t budget = 64ull * n + (1u << 20); // words of 8 bytes; SA-IS costs about as much as 100 per character
+	// tasks of about 64k suffixes
+	std::vector<uint32_t> task_lo;
+	{
+		uint32_t acc = 0;
+		task_lo.push_back(0);
+		for (size_t b = 0; b < nb; b++) {
+			acc += start[b + 1] - start[b];
+			if (acc >= 65536) {
+				task_lo.push_back((uint32_t)b + 1);
+				acc = 0;
+			}
+		}
+		if (task_lo.back() != nb) task_lo.push_back((uint32_t)nb);
+	}
+	par(task_lo.size() - 1, [&](size_t t) {
+		uint64_t local = 0;
+		auto less = [&](uint32_t a, uint32_t b) {
+			if (a == b) return false;
+			const uint8_t *x = s + a + P, *y = s + b + P;
+			for (uint32_t d = 0;; d += 8) {
+				uint64_t u = load_be64(x + d), v = load_be64(y + d);
+				if (u != v) return u < v;
+				if ((d & 0xff) == 0xf8) { // another 32 words alike
+					local += 32;
+					if (local >= 65536) {
+						uint64_t g = deep_words.fetch_add(local) + local;
+						local = 0;
+						if (g > budget) throw SuffixSortGiveUp();
+					}
+					if (give_up.load(std::memory_order_relaxed)) throw SuffixSortGiveUp();
+				}
+			}
+		};
+		try {
+			for (uint32_t b = task_lo[t]; b < task_lo[t + 1]; b++) {
+				if (give_up.load(std::memory_order_relaxed)) return;
+				uint32_t lo = start[b], hi = start[b + 1];
+				if (hi - lo > 1) std::sort(sa + lo, sa + hi, less);
+			}
+			if (local) deep_words.fetch_add(local);
+		} catch (const SuffixSortGiveUp &) {
+			give_up.store(true);
+		}
+	});
+	return !give_up.load();
+}
+
+// par() for callers without a thread pool of their own
+struct ThreadFan {
+	size_t nthreads;
+	void operator()(size_t ntasks, const std::function<void(size_t)> &f) const
+	{
+		size_t nt = std::min(nthreads, ntasks);
+		if (nt <= 1) {
+			for (size_t i = 0; i < ntasks; i++) f(i);
+			return;
+		}
+		std::atomic<size_t> next{0};
+		std::vector<std::thread> th;
+		for (size_t t = 0; t < nt; t++)
+			th.emplace_back([&] {
+				for (size_t i; (i = next.fetch_add(1)) < ntasks;) f(i);
+			});
+		for (auto &t : th) t.join();
+	}
+};
+
+// Suffix array on `nthreads` cores when the text allows, SA-IS otherwise.  `s` needs 16 zero bytes after it.
+template <class Par> static inline void suffix_array_u32_par(const uint8_t *s, uint32_t n, uint32_t *sa_out, Par &&par, size_t nthreads)
+{
+	if (nthreads > 1 && n >= (1u << 16) && suffix_array_buckets(s, n, sa_out, par, nthreads)) return;
+	suffix_array_u32(s, n, sa_out);
 }
 
 // LCP[r] = lcp(suffix SA[r-1], suffix SA[r]) for r in 1..n-1, LCP[0] = LCP[n] = 0

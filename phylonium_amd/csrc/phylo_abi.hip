@@ -613,7 +613,10 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 			SA[i] = (uint32_t)sa[i];
 		}
 	} else {
-		suffix_array_u32(S.data(), ns, SA.data()); // host cores (north star); everything below is on the device
+		// host cores (north star); everything below is on the device
+		WorkerPool &pool = workers(c);
+		auto par = [&](size_t nt, const std::function<void(size_t)> &f) { pool.run(nt, f); };
+		suffix_array_u32_par(S.data(), ns, SA.data(), par, std::max<size_t>(1, pool.size()));
 	}
 	double t2 = now_ms();
 	uint32_t k = c->opt_kmer ? c->opt_kmer : choose_k(ns);
@@ -1718,13 +1721,25 @@ size_t phylo_revseqcmp(const char *begin, const char *other, size_t length) { re
 
 // ───────────────────────── host-side helpers ─────────────────────────
 
+// `s` is followed by 16 zero bytes
+static int host_suffix_array_padded(const uint8_t *s, size_t n, int64_t *sa)
+{
+	std::vector<uint32_t> tmp(n);
+	unsigned h = std::thread::hardware_concurrency();
+	ThreadFan fan{std::min<size_t>(h ? h : 1, 16)};
+	suffix_array_u32_par(s, (uint32_t)n, tmp.data(), fan, fan.nthreads);
+	fan(64, [&](size_t t) {
+		for (size_t i = n * t / 64, e = n * (t + 1) / 64; i < e; i++) sa[i] = tmp[i];
+	});
+	return 0;
+}
+
 int phylo_host_suffix_array(const char *s, size_t n, int64_t *sa)
 {
 	if (!s || !sa || n >= 0x7fffffffull) return 1;
-	std::vector<uint32_t> tmp(n);
-	suffix_array_u32((const uint8_t *)s, (uint32_t)n, tmp.data());
-	for (size_t i = 0; i < n; i++) sa[i] = tmp[i];
-	return 0;
+	std::vector<uint8_t> padded(n + 16, 0);
+	memcpy(padded.data(), s, n);
+	return host_suffix_array_padded(padded.data(), n, sa);
 }
 
 int phylo_host_reference_suffix_array(const char *ref, size_t len, int64_t *sa)
@@ -1734,7 +1749,7 @@ int phylo_host_reference_suffix_array(const char *ref, size_t len, int64_t *sa)
 	memcpy(S.data(), ref, len);
 	S[len] = '#';
 	revcomp((const uint8_t *)ref, len, S.data() + len + 1);
-	return phylo_host_suffix_array((const char *)S.data(), 2 * len + 1, sa);
+	return host_suffix_array_padded(S.data(), 2 * len + 1, sa);
 }
 
 size_t phylo_host_min_anchor_length(double p, double gc, size_t l) { return min_anchor_length(p, gc, l); }

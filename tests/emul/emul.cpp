@@ -231,6 +231,14 @@ void emul_info(void *e, uint64_t out[8])
 
 // host-logic entry points for CPU tests
 void emul_suffix_array(const uint8_t *s, uint32_t n, uint32_t *sa) { suffix_array_u32(s, n, sa); }
+// the several-core bucket sort on its own: 1 = sorted, 0 = gave up (caller would run SA-IS)
+int emul_suffix_array_buckets(const uint8_t *s, uint32_t n, uint32_t *sa, uint32_t threads)
+{
+	std::vector<uint8_t> padded((size_t)n + 16, 0);
+	memcpy(padded.data(), s, n);
+	ThreadFan fan{threads};
+	return suffix_array_buckets(padded.data(), n, sa, fan, threads) ? 1 : 0;
+}
 void emul_lcp(const uint8_t *s, uint32_t n, const uint32_t *sa, uint32_t *lcp) { lcp_kasai(s, n, sa, lcp); }
 size_t emul_kmer_table(const uint8_t *s, uint32_t n, uint32_t k, uint32_t *out)
 {

@@ -24,7 +24,7 @@ def lib():
         return _LIB
     so = os.path.join(_DIR, "libemul.so")
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in _SRC):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, _SRC[0]])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", so, _SRC[0]])
     L = C.CDLL(so)
     L.emul_run.restype = C.c_void_p
     L.emul_run.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint, C.c_uint]
@@ -35,6 +35,8 @@ def lib():
     L.emul_get_raw.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
     L.emul_info.argtypes = [C.c_void_p, C.c_void_p]
     L.emul_suffix_array.argtypes = [C.c_void_p, C.c_uint, C.c_void_p]
+    L.emul_suffix_array_buckets.restype = C.c_int
+    L.emul_suffix_array_buckets.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_uint]
     L.emul_lcp.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p]
     L.emul_kmer_table.restype = C.c_size_t
     L.emul_kmer_table.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]
@@ -81,6 +83,14 @@ class EmulRun:
             self.close()
         except Exception:
             pass
+
+
+def suffix_array_buckets(s, threads=4):
+    """(sorted?, array) from the several-core bucket sort alone."""
+    a = np.ascontiguousarray(np.frombuffer(bytes(s), np.uint8) if isinstance(s, (bytes, bytearray)) else s, np.uint8)
+    sa = np.zeros(a.size, np.uint32)
+    ok = lib().emul_suffix_array_buckets(a.ctypes.data_as(C.c_void_p), a.size, sa.ctypes.data_as(C.c_void_p), threads)
+    return bool(ok), sa
 
 
 def suffix_array(s):

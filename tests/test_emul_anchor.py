@@ -153,6 +153,34 @@ def test_suffix_array_and_tables_against_oracle():
     assert (E.suffix_array(S).astype(np.int64) == O.suffix_array(S)).all()
 
 
+def test_suffix_array_on_several_cores():
+    """The bucket + per-bucket std::sort construction gives SA-IS's array, on any thread count, and
+    gives up (so that SA-IS runs) on text whose repeats would make its comparisons deep."""
+    rng = np.random.default_rng(27)
+    for n, contigs in ((2, 1), (3, 1), (50, 1), (257, 1), (5000, 1), (4000, 5), (150000, 3)):
+        s = synth.split_contigs(synth.random_base(n, rng), contigs, rng).tobytes()
+        S = s + b"#" + O.revcomp(s)
+        want = E.suffix_array(S)
+        for threads in (1, 3, 8):
+            ok, sa = E.suffix_array_buckets(S, threads)
+            assert ok and (sa == want).all()
+    # repeats within the budget: several copies of a 3 kbp unit (rRNA-operon-like)
+    unit = synth.random_base(3000, rng).tobytes()
+    S = b"".join(synth.random_base(20000, rng).tobytes() + unit for _ in range(7))
+    S = S + b"#" + O.revcomp(S)
+    ok, sa = E.suffix_array_buckets(S, 4)
+    assert ok and (sa == E.suffix_array(S)).all()
+    # beyond it: the sort declines, never returns a wrong array
+    for S in (b"A" * 3000, b"AC" * 5000 + b"G", synth.random_base(70000, rng).tobytes() * 3):
+        ok, sa = E.suffix_array_buckets(S, 4)
+        assert not ok or (sa == E.suffix_array(S)).all()
+    ok, _ = E.suffix_array_buckets(synth.random_base(70000, rng).tobytes() * 40, 8)
+    assert not ok
+    # a text with a zero byte cannot use the zero padding as its end marker
+    ok, _ = E.suffix_array_buckets(b"ACGT\0ACGT" * 10, 2)
+    assert not ok
+
+
 @pytest.mark.parametrize("threshold", [17, 24, 40])
 def test_thresholds_of_long_references(threshold):
     """Thresholds a 60 Mbp+ reference has (forced here): the lucky check needs more than one 16-byte window."""
