@@ -172,6 +172,18 @@ int phylo_host_suffix_array(const char *s, size_t n, int64_t *sa);
  * still being uploaded. */
 int phylo_host_reference_suffix_array(const char *ref, size_t len, int64_t *sa);
 size_t phylo_host_min_anchor_length(double p, double gc, size_t l);
+/* FASTA files -> genomes as phylo_set_genomes wants them (nucleotides filtered to ACGT and
+ * upper-cased, the records of a file joined by '!': src/sequence.cxx:109-199 over libs/pfasta.c),
+ * read on up to `threads` host threads.  out[i] receives a buffer owned by the caller (release
+ * with phylo_host_free), len[i] its length.  Returns 0, or 1 + the index of the first file in
+ * the order given that could not be read (its message: phylo_last_error(NULL)); nothing is
+ * handed over in that case. */
+int phylo_host_read_fasta(size_t n, const char *const *paths, size_t threads, char **out, size_t *len);
+void phylo_host_free(void *p);
+/* The first-pass reference of src/phylonium.cxx:360-382: the genome std::nth_element leaves at
+ * the middle position when ordering by length (for equal lengths that depends on the library's
+ * algorithm, which is why it is offered here rather than restated by each host). */
+size_t phylo_host_median_length_index(size_t n, const size_t *len);
 /* std::sort by projected start + filter_overlaps_max, in place; returns new n */
 size_t phylo_host_sort_filter(phylo_homology *h, size_t n, int do_sort);
 /* kind: 0 Jukes-Cantor, 1 raw, 2 ANI (src/evo_model.cxx:100-131) */

@@ -9,6 +9,7 @@ missing this module raises — there is no CPU fallback.
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -28,6 +29,7 @@ SYMBOLS = [
     "phylo_export_packed_device", "phylo_attach_packed_device", "phylo_compare_device",
     "phylo_complete_delete", "phylo_compare", "phylo_compare_all", "phylo_process", "phylo_seqcmp",
     "phylo_revseqcmp", "phylo_seqcmp_batch", "phylo_host_suffix_array", "phylo_host_reference_suffix_array", "phylo_host_min_anchor_length",
+    "phylo_host_read_fasta", "phylo_host_free", "phylo_host_median_length_index",
     "phylo_host_sort_filter", "phylo_estimate", "phylo_format_phylip", "phylo_version",
 ]
 
@@ -85,6 +87,11 @@ def load():
     L.phylo_host_reference_suffix_array.argtypes = [vp, sz, vp]
     L.phylo_host_min_anchor_length.restype = sz
     L.phylo_host_min_anchor_length.argtypes = [C.c_double, C.c_double, sz]
+    L.phylo_host_read_fasta.argtypes = [sz, vp, sz, vp, vp]
+    L.phylo_host_free.argtypes = [vp]
+    L.phylo_host_free.restype = None
+    L.phylo_host_median_length_index.restype = sz
+    L.phylo_host_median_length_index.argtypes = [sz, vp]
     L.phylo_host_sort_filter.restype = sz
     L.phylo_host_sort_filter.argtypes = [vp, sz, C.c_int]
     L.phylo_estimate.restype = C.c_double
@@ -322,6 +329,52 @@ def host_suffix_array(s):
     if load().phylo_host_suffix_array(s.ctypes.data_as(C.c_void_p), s.size, sa.ctypes.data_as(C.c_void_p)):
         raise PhyloniumError("phylo_host_suffix_array failed")
     return sa
+
+
+def host_reference_suffix_array(ref):
+    """Suffix array of ref + '#' + revcomp(ref): the `sa` argument of Context.set_reference."""
+    ref = _u8(ref)
+    sa = np.zeros(2 * ref.size + 1, np.int64)
+    if load().phylo_host_reference_suffix_array(ref.ctypes.data_as(C.c_void_p), ref.size, sa.ctypes.data_as(C.c_void_p)):
+        raise PhyloniumError("phylo_host_reference_suffix_array failed")
+    return sa
+
+
+def genome_name(path):
+    """File name without directory and .fa/.fas/.fasta (io.cxx:36-59)."""
+    base = path[path.rfind("/") + 1:]
+    dot = path.rfind(".")
+    if dot >= 0 and path[dot:] in (".fa", ".fas", ".fasta"):
+        return path[path.rfind("/") + 1:dot] if dot > path.rfind("/") else base
+    return base
+
+
+def read_fasta(paths, threads=16):
+    """FASTA files → genomes (uint8 arrays: ACGT, the records of a file joined by '!')."""
+    L = load()
+    n = len(paths)
+    enc = [os.fsencode(p) for p in paths]
+    arr = (C.c_char_p * n)(*enc)
+    out = (C.c_void_p * n)()
+    lens = (C.c_size_t * n)()
+    rc = L.phylo_host_read_fasta(n, arr, threads, out, lens)
+    if rc:
+        raise PhyloniumError((L.phylo_last_error(None) or b"").decode())
+    gs = []
+    for i in range(n):  # views of the library's buffers, released with the arrays
+        if lens[i]:
+            a = np.ctypeslib.as_array(C.cast(out[i], C.POINTER(C.c_uint8)), shape=(lens[i],))
+            weakref.finalize(a, L.phylo_host_free, out[i])
+            gs.append(a)
+        else:
+            L.phylo_host_free(out[i])
+            gs.append(np.zeros(0, np.uint8))
+    return gs
+
+
+def host_median_length_index(lengths):
+    a = np.ascontiguousarray(lengths, np.uint64)
+    return load().phylo_host_median_length_index(a.size, a.ctypes.data_as(C.c_void_p))
 
 
 def host_min_anchor_length(p, gc, l):

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "../../include/phylonium_amd.h"
+#include "../host/fasta_reader.hpp"
 #include "hostlogic.hpp"
 #include "kernels.h"
 
@@ -1753,6 +1754,55 @@ int phylo_host_reference_suffix_array(const char *ref, size_t len, int64_t *sa)
 }
 
 size_t phylo_host_min_anchor_length(double p, double gc, size_t l) { return min_anchor_length(p, gc, l); }
+
+int phylo_host_read_fasta(size_t n, const char *const *paths, size_t threads, char **out, size_t *len)
+{
+	if (!paths || !out || !len) return 1;
+	std::vector<std::string> files(paths, paths + n);
+	std::vector<phyfasta::ReadResult> res(n);
+	ThreadFan fan{std::max<size_t>(1, threads)};
+	std::vector<char *> bufs(n, nullptr);
+	std::vector<size_t> sizes(n, 0);
+	std::vector<std::string> errors(n);
+	fan(n, [&](size_t i) { // read, filter and hand over in the same task: the copies run on all threads
+		phyfasta::ReadResult r = phyfasta::read_genome(files[i]);
+		if (!r.error.empty()) {
+			errors[i] = r.error;
+			return;
+		}
+		const std::string &g = r.g.nucl;
+		bufs[i] = (char *)malloc(g.size() + 1);
+		if (!bufs[i]) {
+			errors[i] = files[i] + ": out of memory";
+			return;
+		}
+		memcpy(bufs[i], g.data(), g.size());
+		bufs[i][g.size()] = 0;
+		sizes[i] = g.size();
+	});
+	for (size_t i = 0; i < n; i++)
+		if (!errors[i].empty()) {
+			g_last_error = errors[i];
+			for (size_t k = 0; k < n; k++) free(bufs[k]);
+			return (int)(i + 1);
+		}
+	for (size_t i = 0; i < n; i++) {
+		out[i] = bufs[i];
+		len[i] = sizes[i];
+	}
+	return 0;
+}
+
+void phylo_host_free(void *p) { free(p); }
+
+size_t phylo_host_median_length_index(size_t n, const size_t *len)
+{
+	if (!n || !len) return 0;
+	std::vector<size_t> idx(n);
+	for (size_t i = 0; i < n; i++) idx[i] = i;
+	std::nth_element(idx.begin(), idx.begin() + n / 2, idx.end(), [&](size_t a, size_t b) { return len[a] < len[b]; });
+	return idx[n / 2];
+}
 
 size_t phylo_host_sort_filter(phylo_homology *h, size_t n, int do_sort)
 {

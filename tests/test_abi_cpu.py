@@ -101,3 +101,75 @@ def test_estimates_and_phylip(lib):
     names = ["a", "bb", "c c"]
     for kind in ("jc", "raw", "ani"):
         assert api.format_phylip(names, S, H, kind) == O.phylip(names, S, H, kind)
+
+
+def test_host_fasta_reader_and_reference_choice(lib, tmp_path):
+    """Host helpers of the drivers (no GPU): FASTA → joined, filtered genomes (sequence.cxx:109-199) and the
+    median-length reference choice (phylonium.cxx:360-382)."""
+    (tmp_path / "x.fa").write_bytes(b">c1 comment\nACGTacgtNNRY\nGG-TT\n\n>c2\nTTTT\n>empty\n>c4\nA\n")
+    (tmp_path / "y.fasta").write_bytes(b">only\nacgt")
+    (tmp_path / "bad.fa").write_bytes(b"ACGT\n>late\nAC\n")
+    (tmp_path / "none.fa").write_bytes(b"\n\n")
+    gs = api.read_fasta([str(tmp_path / "x.fa"), str(tmp_path / "y.fasta")], threads=2)
+    assert bytes(gs[0]) == b"ACGTACGTGGTT!TTTT!!A" and bytes(gs[1]) == b"ACGT"
+    with pytest.raises(api.PhyloniumError, match="bad.fa: File is not in FASTA format."):
+        api.read_fasta([str(tmp_path / "y.fasta"), str(tmp_path / "bad.fa"), str(tmp_path / "nope.fa")])
+    with pytest.raises(api.PhyloniumError, match="none.fa: Empty file."):
+        api.read_fasta([str(tmp_path / "none.fa")])
+    with pytest.raises(api.PhyloniumError, match="nope.fa"):
+        api.read_fasta([str(tmp_path / "nope.fa")])
+    assert api.genome_name("a/b/x.fasta") == "x" and api.genome_name("x.fas") == "x" and api.genome_name("d.d/x.txt") == "x.txt"
+    assert api.host_median_length_index([5, 1, 9]) == 0
+    assert api.host_median_length_index([3, 8, 1, 9, 7]) == 4
+    lens = [7, 7, 2, 7, 11, 7]
+    assert lens[api.host_median_length_index(lens)] == 7
+    S = b"ACGTTGCAAC!GGA"
+    sa = api.host_reference_suffix_array(S)
+    full = S + b"#" + O.revcomp(S)
+    assert (sa == O.suffix_array(full)).all()
+
+
+def test_mgpu_block_layout():
+    from phylonium_amd import mgpu
+    lens = [100, 64, 0, 5000, 7, 130]
+    bounds = [0, 2, 2, 5, 6]
+    cap, offs = mgpu.block_layout(lens, bounds)
+    assert cap % 4096 == 0
+    for r in range(4):
+        js = range(bounds[r], bounds[r + 1])
+        for j in js:
+            assert offs[j] % 64 == 0 and offs[j] - r * cap >= 64
+            nxt = offs[j + 1] if j + 1 in js else (r + 1) * cap - 256
+            assert offs[j] + lens[j] + 64 <= nxt
+
+
+def test_mgpu_warnings_follow_print_matrix(lib):
+    """The N-rank driver's vectorised warning pass against the per-pair statement of io.cxx:106-139."""
+    import io
+    from phylonium_amd import mgpu
+    rng = np.random.default_rng(8)
+    n = 9
+    lens = rng.integers(50, 400, n)
+    h = rng.integers(0, 60, (n, n)).astype(np.uint64)
+    h[rng.random((n, n)) < 0.2] = 0
+    s = (h * rng.random((n, n))).astype(np.uint64)
+    s[2, 1], h[2, 1] = 3, 4      # 1 - 4/3 * 0.75 == 0: log gives -inf, distance +inf, not nan
+    s[3, 1], h[3, 1] = 40, 50    # beyond: nan
+    s, h = np.tril(s) + np.tril(s, -1).T, np.tril(h) + np.tril(h, -1).T
+    for kind in ("jc", "raw", "ani"):
+        want, status = [], 0
+        for i in range(n):
+            for j in range(i):
+                v = api.estimate(kind, s[i, j], h[i, j])
+                if v != v:
+                    want.append(f"'{i}' and '{j}' the distance computation failed")
+                else:
+                    c1, c2 = float(h[i, j]) / lens[i], float(h[i, j]) / lens[j]
+                    if c1 < 0.2 or c2 < 0.2:
+                        want.append(f"'{i}' and '{j}' less than 20% homology were found ({c1:f} and {c2:f}, respectively).")
+        buf = io.StringIO()
+        st = mgpu.warnings_and_status([str(i) for i in range(n)], lens, s, h, kind, api, err=buf)
+        got = buf.getvalue().splitlines()
+        assert len(got) == len(want) and st == (1 if want else 0)
+        for g, w in zip(got, want):
+            assert w in g
