@@ -336,6 +336,10 @@ def main():
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "alg_bytes_per_launch": alg.get(dom, 0.0), "avg_launch_ms": round(avg_ms, 4),
+                    # what the HBM interface actually carried (PMC bytes of an earlier profile of this workload over
+                    # this run's launch time): the request-granular view of the same kernel
+                    "traffic_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic else None,
+                    "traffic_frac": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                     "note": "anchor_* kernels gather random 128-B lines (k-mer slots, subject windows): dependent-access "
                             "latency bound, not HBM-streaming; `traffic` = HBM-side bytes per launch from rocprofv3 PMC "
                             "(profiles/pmc_traffic.json); pileup_pairs moves far fewer HBM bytes than the reference "
