@@ -31,16 +31,21 @@ WORKLOADS = {
     "c4": (1024, 5_000_000, (0.01, 0.3), 100, 0.02, "configs[3]: 1024 x 5 Mbp, same distribution as c3"),
     "c5s": (16, 20_000_000, (0.005, 0.1), 100, 0.10, "configs[4] scaled down: 16 x 20 Mbp, 50 contigs each, 10% inverted"),
     "c5": (64, 100_000_000, (0.005, 0.1), 100, 0.10, "configs[4]: 64 x 100 Mbp, 100 contigs each, 10% inverted"),
+    "c3tree": (256, 5_000_000, (0.004, 0.04), 30, 0.005, "configs[2] on a tree (SURVEY 8d): 256 x 5 Mbp, genome k descends from genome "
+               "(k-1)//2 with branch length U(0.004,0.04): distances to the reference (the root) up to ~0.2, between leaves up to ~0.35"),
     "small": (32, 1_000_000, (0.01, 0.3), 100, 0.02, "dev: 32 x 1 Mbp"),
 }
 CONTIGS = {"c5s": 50, "c5": 100}
+TREE = {"c3tree"}  # genomes mutated from their parent in a binary tree instead of all from genome 0
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 
 
-def make_genomes_gpu(torch, n, length, seed, device, d_range, indel_per_mbp, inv_frac, inv_len=(1000, 5000), contigs=1):
+def make_genomes_gpu(torch, n, length, seed, device, d_range, indel_per_mbp, inv_frac, inv_len=(1000, 5000), contigs=1,
+                     tree=False):
     """Synthetic genome set on the GPU. Genome 0 is the unmutated base (the reference,
     like simf's S0, test/simf.cxx:32); genome g>0 = base at JC distance d_g ~ U(d_range),
-    plus indel events and inverted blocks. Returns (buffer, offsets, lengths)."""
+    plus indel events and inverted blocks; with `tree`, genome g descends from genome (g-1)//2
+    instead (a binary tree rooted at genome 0), so pair distances span a range. Returns (buffer, offsets, lengths)."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     rng = np.random.default_rng(seed)
@@ -53,6 +58,9 @@ def make_genomes_gpu(torch, n, length, seed, device, d_range, indel_per_mbp, inv
         else:
             d = float(rng.uniform(*d_range))
             p = 0.75 - 0.75 * math.exp(-(4.0 / 3.0) * d)
+            if tree:
+                base = codes[(k - 1) // 2]
+                length = int(base.numel())
             hit = torch.rand(length, generator=g, device=device) < p
             shift = torch.randint(1, 4, (length,), dtype=torch.uint8, generator=g, device=device)
             code = (base + hit.to(torch.uint8) * shift) & 3
@@ -189,7 +197,7 @@ def main():
         d_range = tuple(float(x) for x in args.d_range.split(","))
     t_gen = time.time()
     buf, offs, lens = make_genomes_gpu(torch, n, length, args.seed, device, d_range, indel, inv,
-                                       contigs=CONTIGS.get(args.workload, 1))
+                                       contigs=CONTIGS.get(args.workload, 1), tree=args.workload in TREE)
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
     ref_idx = 0
