@@ -80,7 +80,9 @@ def main():
                      "timing": m.group(1) if m else err[-600:], "matrix_identical": p.stdout.decode() == want,
                      "exit": p.returncode})
     out = {"workload": f"{args.workload}: {desc}", "genomes": n, "bases": float(sum(lens)),
-           "fasta_bytes": sum(os.path.getsize(f) for f in files), "fasta_write_s": round(t_write, 2), "runs": runs}
+           "fasta_bytes": sum(os.path.getsize(f) for f in files), "fasta_write_s": round(t_write, 2), "runs": runs,
+           "note": "exit 1 is the reference's soft-warning status (io.cxx:106-139): this workload has pairs with less than "
+                   "20 % homology; the matrix is printed all the same"}
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     json.dump(out, open(args.out, "w"), indent=1)
     print(json.dumps(out, indent=1))
