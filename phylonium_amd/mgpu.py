@@ -8,8 +8,9 @@ name clean-up, reference choice, one pass, print_matrix of src/io.cxx:106-163 wi
 warnings and exit status), laid out for N ranks:
 
   * the files are split into contiguous blocks balanced by size; a rank reads and filters
-    only its block (library host helper, several threads), stages it in one pinned buffer
-    and uploads it; one all-gather (RCCL over xGMI) makes every genome resident on every GPU
+    only its block (library host helper, several threads) and uploads it into its block of
+    the genome buffer; one in-place all-gather (RCCL over xGMI) makes every genome resident on
+    every GPU
     — the layout of each block is what `phylo_set_genomes_device` wants, so the gathered
     buffer is used as it lands, without a copy;
   * the rank that read the reference builds its suffix array on the host cores (north star)
@@ -201,23 +202,27 @@ def main(argv=None):
 
     # ── stage, upload, gather ──
     cap, offs = block_layout(lens, bounds)
-    stage = torch.zeros(cap, dtype=torch.uint8, pin_memory=True)
-    sv = stage.numpy()
-    for k, g in enumerate(mine):
-        o = int(offs[b0 + k]) - rank * cap
-        sv[o:o + g.size] = g
     ctx_thread.join()
     if "ctx" not in box:
         raise SystemExit("phylonium_amd.mgpu: the device context could not be created")
     ctx = box["ctx"]
     t_ctx = time.perf_counter()
-    if world == 1:
-        genomes = stage.to(device, non_blocking=True)
-    elif on_rccl:
-        block = stage.to(device, non_blocking=True)
-        genomes = torch.empty(world * cap, dtype=torch.uint8, device=device)
-        td.all_gather_into_tensor(genomes, block)
+    if world == 1 or on_rccl:
+        # the own genomes go straight from the reader's buffers into the own block of the buffer every
+        # rank will hold (no staging copy on the host), and the all-gather fills the other blocks in place
+        genomes = torch.zeros(world * cap, dtype=torch.uint8, device=device)
+        for k, g in enumerate(mine):
+            if g.size:
+                o = int(offs[b0 + k])
+                genomes[o:o + g.size].copy_(torch.from_numpy(g))
+        if world > 1:
+            td.all_gather_into_tensor(genomes, genomes[rank * cap:(rank + 1) * cap])
     else:
+        stage = torch.zeros(cap, dtype=torch.uint8)
+        sv = stage.numpy()
+        for k, g in enumerate(mine):
+            o = int(offs[b0 + k]) - rank * cap
+            sv[o:o + g.size] = g
         gathered = torch.empty(world * cap, dtype=torch.uint8)
         td.all_gather_into_tensor(gathered, stage)
         genomes = gathered.to(device)
