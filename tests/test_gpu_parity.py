@@ -495,3 +495,50 @@ def test_long_head_and_short_tail_chunks(ctx, chunk, tail):
     gs = synth.make_genomes(7, 50000, seed=chunk, d_range=(0.005, 0.3), indel_per_mbp=400, inv_frac=0.08, contigs=2)
     check_process(ctx, gs, 0, chunk=chunk, tail=tail)
     check_process(ctx, gs, 4, chunk=chunk, tail=tail, backend=1, threshold=17)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("workload", ["c3", "c3tree", "c5s", "c4"])
+def test_full_size_properties_and_reference_row(workload):
+    """BASELINE configs[2] and [3] at full size (256 and 1024 x 5 Mbp), the tree-shaped variant, and the
+    multi-contig, 10 %-inverted configs[4] scaled to 16 x 20 Mbp (bench.py's generator and seed).  The oracle would take
+    minutes here, so the checks are the size-independent ones: the matrices are symmetric with an empty
+    diagonal, substitutions <= homologs <= the shorter genome; every filtered list is sorted and
+    non-overlapping on the reference; and the reference's row is recomputed by another route — the B0
+    kernels (seqcmp / revseqcmp semantics over the resident genomes) summed over each query's list — which
+    shares nothing with the pileup kernels that made the matrix.  (bench.py --check compares the first six
+    genomes with the oracle at this size.)"""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    n, length, d_range, indel, inv, _ = bench.WORKLOADS[workload]
+    dev = torch.device("cuda", 0)
+    buf, offs, lens = bench.make_genomes_gpu(torch, n, length, 20260101, dev, d_range, indel, inv,
+                                             contigs=bench.CONTIGS.get(workload, 1), tree=workload in bench.TREE)
+    torch.cuda.synchronize()
+    with api.Context(0) as c:
+        c.set_genomes_device(buf.data_ptr(), offs, lens)
+        s, h = c.process(0)
+        L = np.asarray(lens, np.uint64)
+        assert (s == s.T).all() and (h == h.T).all() and (np.diag(h) == 0).all() and (np.diag(s) == 0).all()
+        assert (s <= h).all() and (h <= np.minimum(L[:, None], L[None, :])).all()
+        assert (h[0, 1:] > 0).all()
+        for j in sorted({1, 2, n // 6, n // 3 + 1, n // 2, n - 2, n - 1}):
+            hom = c.homologies(j)
+            assert hom.size > 100
+            start, ln = hom["index_reference_projected"], hom["length"]
+            assert (start[1:] >= start[:-1] + ln[:-1]).all()                     # sorted, non-overlapping
+            assert (hom["index_query"] + ln <= lens[j]).all() and (start + ln <= lens[0]).all()
+            assert int(ln.sum()) == int(h[0, j])
+            m = hom.size
+            sub = c.seqcmp_batch(np.zeros(m, np.uint32), start, np.full(m, j, np.uint32), hom["index_query"], ln,
+                                 (hom["direction"] != 0).astype(np.uint8))
+            assert int(sub.sum()) == int(s[0, j])
+        # the sharded comparison adds up to the same matrices
+        s2, h2 = np.zeros_like(s), np.zeros_like(h)
+        for part in range(3):
+            a, b = c.compare(part, 3)
+            s2 += a
+            h2 += b
+        assert (s2 == s).all() and (h2 == h).all()
