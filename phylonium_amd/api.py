@@ -279,9 +279,17 @@ class Context:
         self._chk(self.L.phylo_complete_delete(self.h))
 
     # phase B
-    def compare(self, part=0, nparts=1):
-        s = np.zeros((self.n, self.n), np.uint64)
-        h = np.zeros((self.n, self.n), np.uint64)
+    def compare(self, part=0, nparts=1, out=None):
+        """Phase B over part `part` of `nparts`; `out` = (subst, homologs), two C-contiguous N x N uint64
+        arrays to fill instead of fresh ones (a caller that runs many steps keeps them)."""
+        if out is not None:
+            s, h = out
+            for a in (s, h):
+                if a.shape != (self.n, self.n) or a.dtype != np.uint64 or not a.flags.c_contiguous:
+                    raise ValueError("out: two C-contiguous (n, n) uint64 arrays")
+        else:
+            s = np.empty((self.n, self.n), np.uint64)
+            h = np.empty((self.n, self.n), np.uint64)
         self._chk(self.L.phylo_compare(self.h, part, nparts, s.ctypes.data_as(C.c_void_p),
                                        h.ctypes.data_as(C.c_void_p)))
         return s, h

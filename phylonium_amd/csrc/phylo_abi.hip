@@ -1572,10 +1572,23 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 	HIPOK(c, hipMemcpyAsync(hh, acc_h, N * N * 8, hipMemcpyDeviceToHost, st));
 	if (sync_stream(c)) return 1;
 	double t2 = now_ms();
-	memcpy(subst, hs, N * N * 8);
-	memcpy(homologs, hh, N * N * 8);
+	// out of the pinned buffer into the caller's matrices (16 MB at N = 1024: worth several threads)
 	double sites = 0;
-	for (size_t k = 0; k < N * N; k++) sites += (double)hh[k];
+	{
+		const size_t NN = N * N, parts = NN >= ((size_t)1 << 18) ? 32 : 1;
+		std::vector<double> part_sites(parts, 0.0);
+		auto copy_part = [&](size_t t) {
+			const size_t a = NN * t / parts, b = NN * (t + 1) / parts;
+			memcpy(subst + a, hs + a, (b - a) * 8);
+			memcpy(homologs + a, hh + a, (b - a) * 8);
+			double acc = 0;
+			for (size_t k = a; k < b; k++) acc += (double)hh[k];
+			part_sites[t] = acc;
+		};
+		if (parts > 1) workers(c).run(parts, copy_part);
+		else copy_part(0);
+		for (double v : part_sites) sites += v;
+	}
 	sites *= 0.5;
 	c->stats["ms:compare_project_phase"] += t1 - t0;
 	c->stats["ms:compare_pairs_phase"] += t2 - t1;
@@ -1594,10 +1607,14 @@ int phylo_compare(phylo_ctx *c, size_t part, size_t nparts, uint64_t *subst, uin
 	HIPOK(c, hipSetDevice(c->device));
 	double t0 = now_ms();
 	size_t N = c->n;
-	std::fill(subst, subst + N * N, 0);
-	std::fill(homologs, homologs + N * N, 0);
-	int rc = c->backend == 1 ? compare_segments(c, part, nparts, subst, homologs)
-							 : compare_pileup(c, part, nparts, subst, homologs);
+	int rc;
+	if (c->backend == 1) { // the segment backend adds into the matrices; the pileup one writes every cell
+		std::fill(subst, subst + N * N, 0);
+		std::fill(homologs, homologs + N * N, 0);
+		rc = compare_segments(c, part, nparts, subst, homologs);
+	} else {
+		rc = compare_pileup(c, part, nparts, subst, homologs);
+	}
 	c->stats["ms:compare_total"] += now_ms() - t0;
 	c->stats["n:compare_calls"] += 1;
 	return rc;

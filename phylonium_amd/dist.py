@@ -106,7 +106,7 @@ def exchange_homologies_device(ctx, n, rank, world, bounds, device):
     return gathered  # borrowed by the context: the caller keeps it alive until the comparison is done
 
 
-def process_sharded(ctx, ref_idx, rank, world, device=None, lengths=None, set_reference=True):
+def process_sharded(ctx, ref_idx, rank, world, device=None, lengths=None, set_reference=True, out=None):
     """process() with queries and pair tiles sharded over `world` ranks.
     ctx: an api.Context (or any object with the same methods) holding all genomes."""
     if set_reference:
@@ -135,7 +135,7 @@ def process_sharded(ctx, ref_idx, rank, world, device=None, lengths=None, set_re
         return m[0], m[1]
     if world > 1 or _FORCE_COLLECTIVES:
         exchange_homologies(ctx, ctx.n, rank, world, bounds, device)
-    s, h = ctx.compare(rank, world)
+    s, h = ctx.compare(rank, world, out=out) if out is not None else ctx.compare(rank, world)
     if world > 1 or _FORCE_COLLECTIVES:
         s, h = allreduce_matrix(s, h, device)
     return s, h
