@@ -158,6 +158,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not time kernels with HIP events")
     ap.add_argument("--check", action="store_true", help="verify a sample of the result against the oracle")
     ap.add_argument("--chunk", type=int, default=0, help="dev: force the phase-A chunk length")
+    ap.add_argument("--filter", type=int, default=0, help="dev: sort + chain filter 1 on the host, 2 on the device (0: the library chooses)")
     ap.add_argument("--host-threads", type=int, default=0, help="dev: size of the library's host worker pool")
     ap.add_argument("--kmer", type=int, default=0, help="dev: force the bucket k of the reference index")
     ap.add_argument("--d-range", default="", help="dev: lo,hi — override the workload's divergence range")
@@ -210,6 +211,8 @@ def main():
         ctx.set_option("kmer", args.kmer)
     if args.host_threads:
         ctx.set_option("host_threads", args.host_threads)
+    if args.filter:
+        ctx.set_option("filter", args.filter)
     ctx.set_genomes_device(buf.data_ptr(), offs, lens)
     print(f"# genomes generated in {t_gen:.1f} s", file=sys.stderr, flush=True)
     if world > 1:  # every rank must hold the same genomes (same seed, same generator): compare a checksum
@@ -236,11 +239,19 @@ def main():
     # one rank: the host keeps its two N x N result matrices across steps (the N-rank path has its own pinned pair)
     out_mats = (np.empty((n, n), np.uint64), np.empty((n, n), np.uint64)) if world == 1 else None
 
+    seg = {}
+    def lap(name, t_prev):
+        t = time.perf_counter()
+        seg[name] = seg.get(name, 0.0) + (t - t_prev)
+        return t
+
     def step():
         if emu:
             bounds = [dist.query_shard(n, r, emu[1], lens)[0] for r in range(emu[1])] + [n]
             qb, qe = bounds[emu[0]], bounds[emu[0] + 1]
+            tl = time.perf_counter()
             ctx.anchor(qb, qe)
+            tl = lap("anchor", tl)
             if args.emulate_exchange:
                 # what rank emu[0] of emu[1] does around its kernels, with a one-rank RCCL group standing
                 # in for the collectives and the other ranks' records copied in from a prepared buffer
@@ -250,6 +261,7 @@ def main():
                 ct = torch.from_numpy(call).to(device)
                 td.all_reduce(ct)
                 ct.cpu()
+                tl = lap("counts all_reduce", tl)
                 call = emu_state["counts"]
                 sizes = [int(call[bounds[r]:bounds[r + 1]].sum()) for r in range(W)]
                 cap = max(max(sizes), 1)
@@ -257,6 +269,7 @@ def main():
                 gathered = torch.empty(W * cap * item, dtype=torch.uint8, device=device)
                 torch.cuda.current_stream(device).synchronize()
                 ctx.export_packed_device(qb, qe, mine.data_ptr(), cap)
+                tl = lap("export", tl)
                 td.all_gather_into_tensor(gathered[emu[0] * cap * item:(emu[0] + 1) * cap * item], mine)
                 begin = np.zeros(n, np.uint64)
                 src_off = np.concatenate(([0], np.cumsum(call)))
@@ -268,10 +281,13 @@ def main():
                             gathered[r * cap * item:r * cap * item + sizes[r] * item] = \
                                 emu_state["all"][int(src_off[b0]) * item:int(src_off[b1]) * item]
                 torch.cuda.current_stream(device).synchronize()
+                tl = lap("all_gather + stand-in copies", tl)
                 ctx.attach_packed_device(gathered.data_ptr(), begin, call.astype(np.uint64), qb, qe)
                 t = torch.empty(2 * n * n, dtype=torch.int64, device=device)
                 torch.cuda.current_stream(device).synchronize()
+                tl = lap("attach", tl)
                 ctx.compare_device(emu[0], W, t.data_ptr(), t.data_ptr() + n * n * 8)
+                tl = lap("compare_device", tl)
                 ctx._attached_records = gathered
                 td.all_reduce(t)
                 pin = emu_state.get("pin")
@@ -280,6 +296,7 @@ def main():
                 pin.copy_(t, non_blocking=True)
                 torch.cuda.current_stream(device).synchronize()
                 m = pin.numpy().view(np.uint64).reshape(2, n, n)  # views of the pinned buffer: valid until the next call
+                tl = lap("matrix all_reduce + D2H", tl)
                 return m[0], m[1]
             return ctx.compare(emu[0], emu[1])
         return dist.process_sharded(ctx, ref_idx, rank, world, device=device, lengths=lens, set_reference=False,
@@ -298,6 +315,7 @@ def main():
 
     for _ in range(args.warmup):
         s, h = step()
+    seg.clear()
     ctx.reset_stats()
     if world > 1:
         td.barrier()
@@ -315,6 +333,9 @@ def main():
         dt = float(t.item())
 
     stats = ctx.stats()
+    if seg and rank == 0:
+        print("# emulated rank, ms per step: " + "  ".join(f"{k} {v / args.steps * 1e3:.3f}" for k, v in seg.items()),
+              file=sys.stderr, flush=True)
     if rank == 0:
         K = args.steps
         P = n * (n - 1) // 2

@@ -59,8 +59,9 @@ const char *phylo_last_error(const phylo_ctx *ctx);
  * (the second half of every query in chunks of this length instead),
  * "kmer" (bucket k), "profile" (1: time every kernel with HIP events),
  * "compare_backend" (0 pileup, 1 segment list), "filter" (where phase A's sort + chain filter
- * runs: 0 on the device for 128 queries or more and on the host cores below, 1 host, 2 device;
- * the results are the same), "host_threads". */
+ * runs: 0 on the device for 128 queries or more, or when the call covers only a part of the genomes
+ * (a rank of a sharded run, whose lists are exported from the device next), and on the host cores
+ * otherwise, 1 host, 2 device; the results are the same), "host_threads". */
 int phylo_set_option(phylo_ctx *ctx, const char *key, long value);
 /* Accumulated since the last phylo_reset_stats: "ms:<kernel>", "n:<kernel>"
  * (HIP-event time and launch count per kernel when profiling is on),

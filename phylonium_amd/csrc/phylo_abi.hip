@@ -871,7 +871,11 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	c->host_stale.clear();
 	// One query's list takes the device ~0.1-0.4 ms however many there are (a block per query, all
 	// at once); the host pool does a few dozen lists in less than that, many only as fast.
-	if (c->filter_mode == 2 || (c->filter_mode == 0 && nq >= 128)) {
+	// A call for a part of the genomes is a rank of a sharded run: its lists are exported next
+	// (phylo_export_packed_device), which is a device-to-device gather when they are already there
+	// and a pack + upload when they are on the host — with that counted the device wins for any number.
+	const bool part_of_many = !(q_begin == 0 && q_end == c->n);
+	if (c->filter_mode == 2 || (c->filter_mode == 0 && (nq >= 128 || part_of_many))) {
 		// reverseEh + sort + filter_overlaps_max on the device (filter_kernels.hip).  The lists stay
 		// there in the 16-byte device form, the projection (phase B's first kernel, for the whole
 		// reference = part 0 of 1) follows on the stream at once when this call covers all genomes,
