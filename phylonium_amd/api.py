@@ -14,7 +14,7 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libphylonium_amd.so")
+LIB_PATH = os.environ.get("PHYLONIUM_AMD_LIB") or os.path.join(_HERE, "libphylonium_amd.so")  # (the variable: builds under test)
 
 PACKED = np.dtype([("start", "<u4"), ("index_query", "<u4"), ("length", "<u4"), ("direction", "<u4")])
 PHOM = np.dtype([("index_reference", "<u8"), ("index_reference_projected", "<u8"), ("index_query", "<u8"),

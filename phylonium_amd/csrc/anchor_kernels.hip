@@ -81,7 +81,10 @@ static __device__ __forceinline__ void coop_compare(const uint8_t *qp, const uin
 }
 
 static const uint32_t QRING_BYTES = 128;
-static const int CHAIN_SUBTRIPS = 2;
+#ifndef PHY_CHAIN_SUBTRIPS
+#define PHY_CHAIN_SUBTRIPS 2
+#endif
+static const int CHAIN_SUBTRIPS = PHY_CHAIN_SUBTRIPS;
 
 struct DevAlloc {
 	const PhaseA *A;
