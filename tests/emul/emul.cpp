@@ -146,11 +146,24 @@ void *emul_run(size_t n, const char *const *seq, const size_t *len, size_t ref_i
 		if (pool_next >= pool_blocks) return NO_BLOCK;
 		return pool_next++;
 	};
+	std::vector<uint32_t> bridge_steps; // EMUL_BRIDGE_STATS: how long the dependent chains of the bridge kernel are
+	const bool bstats = getenv("EMUL_BRIDGE_STATS") != nullptr;
 	for (uint32_t it = 0; it < P.nchunks; it++) {
 		BridgeLane ln;
 		ln.start(A, P.items[it]);
+		const uint64_t before = E->steps_bridge;
 		run_lane(ln, R, [&] { return ln.begin_step(A, R); }, [&] { ln.step_done(A, alloc); }, &E->steps_bridge,
 				 &E->rounds, &E->cmp_calls);
+		if (bstats) bridge_steps.push_back((uint32_t)(E->steps_bridge - before));
+	}
+	if (bstats && !bridge_steps.empty()) {
+		std::sort(bridge_steps.begin(), bridge_steps.end());
+		const size_t m = bridge_steps.size();
+		double sum = 0;
+		for (uint32_t v : bridge_steps) sum += v;
+		fprintf(stderr, "emul: %zu bridges, steps mean %.1f  median %u  p99 %u  p99.9 %u  p99.99 %u  max %u\n", m, sum / m,
+				bridge_steps[m / 2], bridge_steps[(size_t)(m * 0.99)], bridge_steps[(size_t)(m * 0.999)],
+				bridge_steps[(size_t)(m * 0.9999)], bridge_steps[m - 1]);
 	}
 	E->pool_used = pool_next;
 	E->error = (int)error;
