@@ -376,6 +376,12 @@ def main():
                             "latency bound, not HBM-streaming; `traffic` = HBM-side bytes per launch from rocprofv3 PMC "
                             "(profiles/pmc_traffic.json); pileup_pairs moves far fewer HBM bytes than the reference "
                             "layout's algorithmic 2 B/site"}
+        phase_b_traffic = None
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload, {})
+            phase_b_traffic = sum(v for k2, v in tr.items() if k2.startswith("pileup_")) or None
+        except Exception:
+            phase_b_traffic = None
         cpu = None
         if world == 1 and args.cpu_sample > 0:
             try:
@@ -426,11 +432,21 @@ def main():
             # exceed 1: the pileup moves 3/8 B per genome and reference position once instead of the reference
             # layout's 2 B per compared site, so the measured HBM bytes are far below the algorithmic ones.
             "roofline_path": {"achieved": round((bytes_a + bytes_b) * K / dt / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round((bytes_a + bytes_b) * K / dt / 1e9 / HBM_PEAK_GBS, 4)},
-            "roofline_phase_b": (lambda tb: {"achieved": round(bytes_b / world / (tb * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
-                                             "unit": "GB/s", "frac": round(bytes_b / world / (tb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                             "ms": round(tb, 3), "kernels": "pileup_project* + pileup_pairs*"} if tb > 0 else None)(
-                sum(kern[k] for k in kern if k.startswith("pileup_")) / K),
+                              "frac": round((bytes_a + bytes_b) * K / dt / 1e9 / HBM_PEAK_GBS, 4),
+                              "note": "algorithmic bytes of the reference's layout over this run's time: above 1 because the "
+                                      "bit-plane pileup moves far fewer bytes than 2 B per compared site, not because HBM "
+                                      "ran beyond its peak"},
+            "roofline_phase_b": (lambda tb, tr: {"achieved": round(bytes_b / world / (tb * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                                                 "unit": "GB/s", "frac": round(bytes_b / world / (tb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                 "ms": round(tb, 3), "kernels": "pileup_project* + pileup_pairs*",
+                                                 "traffic": tr,
+                                                 "traffic_GBps": round(tr / (tb * 1e-3) / 1e9, 1) if tr else None,
+                                                 "traffic_frac": round(tr / (tb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tr else None,
+                                                 "note": "achieved/frac price the reference layout's 2 B per compared site (above 1: "
+                                                         "see roofline_path); traffic = HBM-side bytes of these kernels from the "
+                                                         "PMC profile: the pair kernel is VALU-bound (DESIGN.md, section 10), not "
+                                                         "HBM-bound"} if tb > 0 else None)(
+                sum(kern[k] for k in kern if k.startswith("pileup_")) / K, phase_b_traffic),
             "setup_s": {"generate": round(t_gen, 2), "reference_index": round(t_ref, 2),
                         "suffix_array": round((ref_stats["ms:ref_suffix_array"] or 0) / 1e3, 2)},
         }
