@@ -10,6 +10,11 @@ timed region.  Prints ONE JSON line (see the task contract).
 
 Run:  python bench.py [--gpus N --steps K --warmup W --workload c3]
 N>1:  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+      or plain `python bench.py --gpus N`: with WORLD_SIZE unset the script starts the N rank
+      processes itself (fresh children, before anything here touches the GPU) and rank 0's
+      line is the output.  Rank r runs on GPU r over RCCL; when the box has fewer GPUs than
+      ranks (the one-GPU test box) the ranks share them and the collectives go over gloo —
+      the line then says so ("backend").
 """
 import argparse
 import json
@@ -106,23 +111,42 @@ def make_genomes_gpu(torch, n, length, seed, device, d_range, indel_per_mbp, inv
     return buf, offs, lens
 
 
-def cpu_baseline(torch, buf, offs, lens, ref_idx, sa_ref, sample_queries, threads):
-    """The oracle (CPU port of the reference path) on a bounded sample of the same
-    workload: the reference genome plus `sample_queries` others, anchor + compare
-    timed, ESA construction excluded (as the suffix-array build is on the GPU side)."""
+def cpu_baseline(torch, buf, offs, lens, ref_idx, sa_ref, sample_queries, threads, reps=3):
+    """The oracle (CPU port of the reference path, byte kernels bound as the reference's ifunc
+    resolver would bind them on this CPU: libs/seqcmp.c:32-60) on a bounded sample of the same
+    workload: the reference genome plus `sample_queries` others, anchor + compare timed, ESA
+    construction excluded (as the suffix-array build is on the GPU side).  `reps` repetitions at
+    the full thread count (median reported) and on one thread (a sixth of the sample)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     idx = [ref_idx] + [j for j in range(len(lens)) if j != ref_idx][:sample_queries]
     gs = [buf[offs[j]:offs[j] + lens[j]].cpu().numpy() for j in idx]
-    r = O.Run(gs, 0)
-    r.process(sa=sa_ref, threads=threads)
-    t_esa, t_a, t_b = r.times()
-    bases = float(sum(len(g) for g in gs))
-    return {"value": bases / (t_a + t_b) / 1e9, "unit": "Gbp/s", "cores": threads, "kind": "port",
-            "sample": f"oracle (C++ restatement of process.cxx/esa.cxx with the generic seqcmp/revseqcmp byte loops, "
-                      f"OpenMP over queries and pair rows) on "
-                      f"{len(gs)} of the workload's genomes ({bases / 1e6:.0f} Mbp): anchor {t_a:.2f}s + compare "
-                      f"{t_b:.2f}s; ESA build {t_esa:.1f}s excluded"}
+    variants = O.resolved_variants()
+
+    def timed(genomes, nthreads):
+        r = O.Run(genomes, 0)
+        rates, last = [], None
+        bases = float(sum(len(g) for g in genomes))
+        for _ in range(reps):
+            r.process(sa=sa_ref, threads=nthreads)
+            t_esa, t_a, t_b = r.times()
+            rates.append(bases / (t_a + t_b) / 1e9)
+            last = (t_esa, t_a, t_b)
+        r.close()
+        return sorted(rates), last, bases
+
+    rates, (t_esa, t_a, t_b), bases = timed(gs, threads)
+    one_n = max(2, min(len(gs), 1 + max(1, sample_queries // 6)))
+    rates1, (_, t_a1, t_b1), bases1 = timed(gs[:one_n], 1)
+    med = rates[len(rates) // 2]
+    return {"value": med, "unit": "Gbp/s", "cores": threads, "kind": "port",
+            "one_thread": rates1[len(rates1) // 2], "runs": [round(x, 4) for x in rates], "runs_one_thread": [round(x, 4) for x in rates1],
+            "seqcmp_variant": variants[0], "revseqcmp_variant": variants[1],
+            "sample": f"oracle (C++ restatement of process.cxx/esa.cxx; seqcmp -> {variants[0]}, revseqcmp -> {variants[1]} "
+                      f"as libs/seqcmp.c:32-60 / libs/revseqcmp.c:34-51 resolve on this CPU; OpenMP over queries and pair rows) on "
+                      f"{len(gs)} of the workload's genomes ({bases / 1e6:.0f} Mbp), median of {reps} runs: last run anchor {t_a:.2f}s + compare "
+                      f"{t_b:.2f}s; one thread on {one_n} genomes ({bases1 / 1e6:.0f} Mbp): anchor {t_a1:.2f}s + compare {t_b1:.2f}s; "
+                      f"ESA build {t_esa:.1f}s excluded"}
 
 
 def usable_cpus():
@@ -145,12 +169,46 @@ def usable_cpus():
     return n, f"{n} CPUs, no quota"
 
 
+def launch_ranks(n_ranks):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes (the same
+    command line, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) as fresh
+    children.  Nothing in this process has touched the GPU (torch is not even imported), the
+    children are started with subprocess (no re-exec of a process that holds a device), rank 0
+    inherits stdout so its one JSON line is this command's output, and the exit status is the
+    worst of the ranks'."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n_ranks), "LOCAL_WORLD_SIZE": str(n_ranks),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = None if r == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+    rc = 0
+    try:
+        for p in procs:
+            rc = max(rc, abs(p.wait()))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: c3 on one GPU (the configuration the 1-GPU metric is quoted on), c4 on several "
+                         "(the 1024-genome set the multi-GPU target is quoted on)")
+    ap.add_argument("--dump-matrix", default="", help="dev/tests: rank 0 saves the two N x N result matrices here (.npz)")
     ap.add_argument("--genomes", type=int, default=0, help="override genome count")
     ap.add_argument("--length", type=int, default=0, help="override genome length")
     ap.add_argument("--seed", type=int, default=20260101)
@@ -167,6 +225,11 @@ def main():
     ap.add_argument("--emulate-exchange", action="store_true", help="dev, with --emulate-rank: also pay the host side of "
                     "the two exchanges (export, one-rank RCCL collectives, import of the other ranks' lists, matrix all-reduce)")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.workload is None:
+        args.workload = "c3" if world_env == 1 else "c4"
 
     # stdout carries exactly one JSON line.  Libraries below (RCCL prints a version banner
     # through C stdio) write to fd 1 whenever they like: lend them stderr until the result
@@ -182,14 +245,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
+    ndev = torch.cuda.device_count()
+    if ndev < 1 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # one rank per GPU over RCCL; with fewer GPUs than ranks (the one-GPU test box) the ranks share
+    # them and the exchange goes through the host over gloo (RCCL refuses two ranks on one device)
+    shared = world > ndev
+    backend = "gloo" if shared else "nccl"
+    local = local % ndev
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1 or args.emulate_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
-        td.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
+        if shared:
+            td.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            td.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
+    coll_dev = torch.device("cpu") if shared else device  # where the barrier / timing tensors of the collectives live
 
     n, length, d_range, indel, inv, desc = WORKLOADS[args.workload]
     n = args.genomes or n
@@ -216,7 +289,7 @@ def main():
     ctx.set_genomes_device(buf.data_ptr(), offs, lens)
     print(f"# genomes generated in {t_gen:.1f} s", file=sys.stderr, flush=True)
     if world > 1:  # every rank must hold the same genomes (same seed, same generator): compare a checksum
-        chk = buf[::4097].to(torch.int64).sum() * 1000003 + int(sum(lens))
+        chk = (buf[::4097].to(torch.int64).sum() * 1000003 + int(sum(lens))).to(coll_dev)
         lo, hi = chk.clone(), chk.clone()
         td.all_reduce(lo, op=td.ReduceOp.MIN)
         td.all_reduce(hi, op=td.ReduceOp.MAX)
@@ -299,8 +372,8 @@ def main():
                 tl = lap("matrix all_reduce + D2H", tl)
                 return m[0], m[1]
             return ctx.compare(emu[0], emu[1])
-        return dist.process_sharded(ctx, ref_idx, rank, world, device=device, lengths=lens, set_reference=False,
-                                    out=out_mats)
+        return dist.process_sharded(ctx, ref_idx, rank, world, device=None if shared else device, lengths=lens,
+                                    set_reference=False, out=out_mats)
 
     if emu:  # the other ranks' lists must exist for the projection: compute them once, untimed
         ctx.anchor(0, n)
@@ -328,11 +401,35 @@ def main():
         td.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         dt = float(t.item())
+    # the same K steps once more without the per-kernel HIP events (reported beside the timed figure)
+    dt_plain = None
+    if not args.no_profile and not emu:
+        stats_keep = ctx.stats()
+        ctx.set_option("profile", 0)
+        for _ in range(min(2, args.warmup)):
+            step()
+        if world > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            s, h = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            td.barrier()
+        dt_plain = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dt_plain], dtype=torch.float64, device=coll_dev)
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            dt_plain = float(t.item())
+        ctx.set_option("profile", 1)
+    else:
+        stats_keep = None
 
-    stats = ctx.stats()
+    stats = stats_keep if stats_keep is not None else ctx.stats()
     if seg and rank == 0:
         print("# emulated rank, ms per step: " + "  ".join(f"{k} {v / args.steps * 1e3:.3f}" for k, v in seg.items()),
               file=sys.stderr, flush=True)
@@ -417,7 +514,11 @@ def main():
             "config": {"workload": f"{args.workload}: {desc}", "genomes": n, "genome_length": length,
                        "query_bases": total_bases, "pairs": P, "reference": "genome 0 (unmutated base)",
                        "threshold": ctx.threshold, "seed": args.seed,
-                       "parallelism": f"queries and pair tiles sharded over {world} GPU(s)"},
+                       "parallelism": f"queries (phase A) and reference-window ranges (phase B) sharded over {world} rank(s)",
+                       "backend": ("none (one rank)" if world == 1 else
+                                   "gloo: %d ranks share %d GPU(s), exchange through the host" % (world, ndev) if shared else
+                                   "nccl (RCCL), one rank per GPU, device-resident exchange")},
+            "ms_per_step_noprofile": round(dt_plain / K * 1e3, 3) if dt_plain else None,
             "roofline": roof, "cpu_baseline": cpu,
             "phases_ms_per_step": {k[3:]: round(v / K, 3) for k, v in stats.items()
                                    if k in ("ms:anchor_total", "ms:anchor_gpu", "ms:anchor_setup", "ms:anchor_copyback",
@@ -450,6 +551,8 @@ def main():
             "setup_s": {"generate": round(t_gen, 2), "reference_index": round(t_ref, 2),
                         "suffix_array": round((ref_stats["ms:ref_suffix_array"] or 0) / 1e3, 2)},
         }
+        if args.dump_matrix:
+            np.savez(args.dump_matrix, subst=np.asarray(s), homologs=np.asarray(h))
     else:
         out = None
     ctx.close()

@@ -69,6 +69,114 @@ static size_t revseqcmp_port(const char *a, const char *b, size_t n)
 	return s;
 }
 
+// ── the reference's x86 SIMD bodies and its load-time resolver ──
+// The reference binds seqcmp/revseqcmp once, by GNU ifunc, to the widest variant the CPU
+// offers (libs/seqcmp.c:32-60, libs/revseqcmp.c:34-63).  bench.py's cpu_baseline times the
+// variant that resolver would pick on the box it runs on, so the restatements below follow
+// the vector bodies, not only the byte loops above.  Checked against the byte loops on the
+// B0 length/offset sweep (tests/test_oracle_self.py).
+#if defined(__x86_64__)
+#include <immintrin.h>
+
+// libs/seqcmp_avx2.c:23-58 — 32-byte lanes, two per trip (the vector count is rounded down
+// to an even number), equal bytes counted through movemask + popcount; byte loop for the rest.
+__attribute__((target("avx2,popcnt"))) static size_t seqcmp_avx2_port(const char *a, const char *b, size_t n)
+{
+	const size_t W = 32;
+	const size_t nvec = (n / W) & ~(size_t)1;
+	size_t same = 0;
+	for (size_t v = 0; v < nvec; v += 2) {
+		for (size_t h = 0; h < 2; h++) {
+			__m256i x, y;
+			memcpy(&x, a + (v + h) * W, W);
+			memcpy(&y, b + (v + h) * W, W);
+			same += (size_t)__builtin_popcount((unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(x, y)));
+		}
+	}
+	size_t s = nvec * W - same;
+	for (size_t i = nvec * W; i < n; i++) s += (a[i] != b[i]);
+	return s;
+}
+
+// libs/seqcmp_avx512.c:14-46 — the same on 32-byte lanes with the AVX-512BW/VL mask compare
+// (one vector per trip, no rounding to pairs).
+__attribute__((target("avx512bw,avx512vl,popcnt"))) static size_t seqcmp_avx512_port(const char *a, const char *b, size_t n)
+{
+	const size_t W = 32;
+	const size_t nvec = n / W;
+	size_t same = 0;
+	for (size_t v = 0; v < nvec; v++) {
+		__m256i x, y;
+		memcpy(&x, a + v * W, W);
+		memcpy(&y, b + v * W, W);
+		same += (size_t)__builtin_popcount((unsigned)_mm256_cmpeq_epi8_mask(x, y));
+	}
+	size_t s = nvec * W - same;
+	for (size_t i = nvec * W; i < n; i++) s += (a[i] != b[i]);
+	return s;
+}
+
+// libs/revseqcmp_avx2.c:24-46 — vector v of `a` against the 32 bytes of `b` that end at
+// n - 32 v, byte-reversed: a per-128-bit-half shuffle reverses inside the halves and the halves
+// of `a` are swapped instead of those of `b` (the count does not care which side is permuted);
+// complements are the bytes whose xor has bits 1..2 equal to 100b.
+__attribute__((target("avx2,popcnt"))) static size_t revseqcmp_avx2_port(const char *a, const char *b, size_t n)
+{
+	const size_t W = 32;
+	const size_t nvec = n / W;
+	const __m256i rev = _mm256_set_epi8(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10,
+										11, 12, 13, 14, 15);
+	const __m256i six = _mm256_set1_epi8(6), four = _mm256_set1_epi8(4);
+	size_t s = nvec * W;
+	for (size_t v = 0; v < nvec; v++) {
+		__m256i x, y;
+		memcpy(&x, a + v * W, W);
+		memcpy(&y, b + (n - (v + 1) * W), W);
+		const __m256i yr = _mm256_shuffle_epi8(y, rev);
+		const __m256i xs = _mm256_permute2x128_si256(x, x, 1);
+		const __m256i hit = _mm256_cmpeq_epi8(_mm256_and_si256(_mm256_xor_si256(xs, yr), six), four);
+		s -= (size_t)__builtin_popcount((unsigned)_mm256_movemask_epi8(hit));
+	}
+	for (size_t i = nvec * W; i < n; i++) s += !complement_p(a[i], b[n - 1 - i]);
+	return s;
+}
+#endif
+
+typedef size_t (*bytecmp_fn)(const char *, const char *, size_t);
+static const char *g_seqcmp_name = "generic", *g_revseqcmp_name = "generic";
+
+// libs/seqcmp.c:32-55 — widest first: AVX-512BW+VL, then AVX2, (SSE2 not restated: every
+// x86-64 CPU with popcnt that lacks AVX2 falls to the byte loop here), always with popcnt.
+static bytecmp_fn pick_seqcmp()
+{
+#if defined(__x86_64__)
+	__builtin_cpu_init();
+	if (__builtin_cpu_supports("popcnt") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl")) {
+		g_seqcmp_name = "avx512";
+		return seqcmp_avx512_port;
+	}
+	if (__builtin_cpu_supports("popcnt") && __builtin_cpu_supports("avx2")) {
+		g_seqcmp_name = "avx2";
+		return seqcmp_avx2_port;
+	}
+#endif
+	return seqcmp_port;
+}
+// libs/revseqcmp.c:34-51 — AVX2, else (SSSE3 not restated) the byte loop.
+static bytecmp_fn pick_revseqcmp()
+{
+#if defined(__x86_64__)
+	__builtin_cpu_init();
+	if (__builtin_cpu_supports("popcnt") && __builtin_cpu_supports("avx2")) {
+		g_revseqcmp_name = "avx2";
+		return revseqcmp_avx2_port;
+	}
+#endif
+	return revseqcmp_port;
+}
+static bytecmp_fn g_seqcmp = pick_seqcmp(), g_revseqcmp = pick_revseqcmp();
+static bool g_force_generic = false; // tests: run the path through the byte loops
+
 // ───────────────────────── sequence helpers ─────────────────────────
 
 // src/sequence.cxx:73-103 — reverse complement; bytes below 'A' pass through.
@@ -667,13 +775,13 @@ struct tally { // evo_model, src/evo_model.h:13-19
 	void account(const char *a, const char *b, size_t n)
 	{
 		homologs += n;
-		subst += seqcmp_port(a, b, n);
+		subst += (g_force_generic ? seqcmp_port : g_seqcmp)(a, b, n);
 	}
 	// src/evo_model.cxx:68-75
 	void account_rev(const char *a, const char *b, size_t b_off, size_t n)
 	{
 		homologs += n;
-		subst += revseqcmp_port(a, b + b_off - n, n);
+		subst += (g_force_generic ? revseqcmp_port : g_revseqcmp)(a, b + b_off - n, n);
 	}
 	// src/evo_model.cxx:81-87
 	tally &operator+=(const tally &o)
@@ -877,6 +985,24 @@ extern "C" {
 
 size_t orc_seqcmp(const char *a, const char *b, size_t n) { return seqcmp_port(a, b, n); }
 size_t orc_revseqcmp(const char *a, const char *b, size_t n) { return revseqcmp_port(a, b, n); }
+// variant: 0 the byte loop, 1 what the reference's resolver would bind on this CPU, 2 AVX2, 3 AVX-512 (seqcmp only);
+// returns (size_t)-1 when the CPU lacks the variant
+size_t orc_seqcmp_variant(int variant, int rev, const char *a, const char *b, size_t n)
+{
+	if (variant == 0) return rev ? revseqcmp_port(a, b, n) : seqcmp_port(a, b, n);
+	if (variant == 1) return rev ? g_revseqcmp(a, b, n) : g_seqcmp(a, b, n);
+#if defined(__x86_64__)
+	__builtin_cpu_init();
+	if (variant == 2 && __builtin_cpu_supports("avx2") && __builtin_cpu_supports("popcnt"))
+		return rev ? revseqcmp_avx2_port(a, b, n) : seqcmp_avx2_port(a, b, n);
+	if (variant == 3 && !rev && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl") &&
+		__builtin_cpu_supports("popcnt"))
+		return seqcmp_avx512_port(a, b, n);
+#endif
+	return (size_t)-1;
+}
+const char *orc_seqcmp_variant_name(int rev) { return rev ? g_revseqcmp_name : g_seqcmp_name; }
+void orc_force_generic(int on) { g_force_generic = on != 0; }
 
 void orc_revcomp(const char *in, size_t n, char *out)
 {

@@ -39,6 +39,11 @@ def lib():
     L.orc_seqcmp.argtypes = [vp, vp, sz]
     L.orc_revseqcmp.restype = sz
     L.orc_revseqcmp.argtypes = [vp, vp, sz]
+    L.orc_seqcmp_variant.restype = sz
+    L.orc_seqcmp_variant.argtypes = [C.c_int, C.c_int, vp, vp, sz]
+    L.orc_seqcmp_variant_name.restype = cp
+    L.orc_seqcmp_variant_name.argtypes = [C.c_int]
+    L.orc_force_generic.argtypes = [C.c_int]
     L.orc_revcomp.argtypes = [cp, sz, cp]
     L.orc_filter_nucl.restype = sz
     L.orc_filter_nucl.argtypes = [cp, sz, cp]
@@ -109,6 +114,29 @@ def seqcmp(a, b, n=None):
     pb, lb, kb = _buf(b)
     n = min(la, lb) if n is None else n
     return lib().orc_seqcmp(pa, pb, n)
+
+
+VARIANTS = {"generic": 0, "resolved": 1, "avx2": 2, "avx512": 3}
+
+
+def seqcmp_variant(variant, rev, a, b, n, offa=0, offb=0):
+    """seqcmp (rev=0) / revseqcmp (rev=1) through one of the restated SIMD bodies
+    (libs/seqcmp_avx2.c, seqcmp_avx512.c, revseqcmp_avx2.c) or the one the reference's resolver
+    would bind on this CPU; None when the CPU lacks the variant."""
+    pa, la, ka = _buf(a)
+    pb, lb, kb = _buf(b)
+    r = lib().orc_seqcmp_variant(VARIANTS[variant], int(rev), pa.value + offa, pb.value + offb, n)
+    return None if r == C.c_size_t(-1).value else r
+
+
+def resolved_variants():
+    """Names of the variants the resolver binds here: (seqcmp, revseqcmp)."""
+    return lib().orc_seqcmp_variant_name(0).decode(), lib().orc_seqcmp_variant_name(1).decode()
+
+
+def force_generic(on):
+    """Tests: make compare_lists/process use the byte loops instead of the resolved SIMD variant."""
+    lib().orc_force_generic(int(on))
 
 
 def revseqcmp(a, b, n=None):

@@ -1,0 +1,53 @@
+"""bench.py's own N-rank launcher (`python bench.py --gpus N` with no torchrun around it)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    return env
+
+
+def test_launcher_starts_n_ranks_and_reports_their_failure_without_a_gpu():
+    """No GPU here: every rank must stop with the 'needs a GPU' message (there is no CPU
+    fallback), the launcher must come back with a nonzero status and print no JSON line."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by the gpu-marked test below")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--workload", "small", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=_env())
+    assert r.returncode != 0
+    assert r.stdout.strip() == ""
+    assert r.stderr.count("needs a GPU") == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_two_ranks_started_by_bench_itself_equal_one_rank(tmp_path):
+    """`python bench.py --gpus 2` as the driver runs it (no launcher, WORLD_SIZE unset): two rank
+    processes on the one test GPU (collectives over gloo, as the line says), n_gpus == 2, and the
+    sharded matrices equal the one-rank ones."""
+    outs = {}
+    for n in (1, 2):
+        dump = str(tmp_path / f"m{n}.npz")
+        r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--workload", "small", "--steps", "2", "--warmup", "1",
+                            "--cpu-sample", "0", "--dump-matrix", dump], capture_output=True, text=True, timeout=500, env=_env())
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1, r.stdout
+        line = json.loads(lines[0])
+        assert line["n_gpus"] == n and line["steps"] == 2
+        assert line["config"]["workload"].startswith("small")
+        if n == 2:
+            assert "gloo" in line["config"]["backend"] or "nccl" in line["config"]["backend"]
+        outs[n] = np.load(dump)
+    assert (outs[1]["subst"] == outs[2]["subst"]).all() and (outs[1]["homologs"] == outs[2]["homologs"]).all()
+    assert outs[1]["homologs"].sum() > 0

@@ -43,6 +43,40 @@ def test_seqcmp_against_numpy():
             assert O.revseqcmp(x, y, n) == want
 
 
+def test_simd_variants_equal_the_byte_loops():
+    """The restated AVX2 / AVX-512 bodies (libs/seqcmp_avx2.c:23-58, seqcmp_avx512.c:14-46,
+    revseqcmp_avx2.c:24-46) against the generic loops on the B0 sweep: every length 0..300 and a few
+    long ones, unaligned starts, bytes from ACGT and '!'."""
+    rng = np.random.default_rng(5)
+    alpha = np.frombuffer(b"ACGT!", np.uint8)
+    x = alpha[rng.integers(0, 5, 70000)]
+    y = np.where(rng.random(70000) < 0.8, x, alpha[rng.integers(0, 5, 70000)])
+    names = O.resolved_variants()
+    assert names[0] in ("generic", "avx2", "avx512") and names[1] in ("generic", "avx2")
+    for n in list(range(0, 301)) + [1023, 1024, 4097, 65536]:
+        for offa, offb in ((0, 0), (1, 3), (31, 17), (64, 5)):
+            for rev in (0, 1):
+                want = O.seqcmp_variant("generic", rev, x, y, n, offa, offb)
+                if rev == 0:
+                    assert want == int((x[offa:offa + n] != y[offb:offb + n]).sum())
+                for v in ("resolved", "avx2", "avx512"):
+                    got = O.seqcmp_variant(v, rev, x, y, n, offa, offb)
+                    assert got is None or got == want, (v, rev, n, offa, offb)
+
+
+def test_process_is_the_same_through_simd_and_byte_loops():
+    from phylonium_amd import synth
+    gs = synth.make_genomes(4, 20000, seed=3, d_range=(0.02, 0.2), indel_per_mbp=300, inv_frac=0.1, contigs=2,
+                            inv_len=(200, 1500))
+    a = O.Run(gs, 1).process().matrix()
+    O.force_generic(True)
+    try:
+        b = O.Run(gs, 1).process().matrix()
+    finally:
+        O.force_generic(False)
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+
+
 def test_bang_is_A_under_revseqcmp():
     # '!' & 6 == 'A' & 6 == 0: revseqcmp treats '!' like 'A' (libs/revseqcmp.h:19-23)
     assert O.revseqcmp(b"!", b"T", 1) == 0
