@@ -61,7 +61,9 @@ const char *phylo_last_error(const phylo_ctx *ctx);
  * "compare_backend" (0 pileup, 1 segment list), "filter" (where phase A's sort + chain filter
  * runs: 0 on the device for 128 queries or more, or when the call covers only a part of the genomes
  * (a rank of a sharded run, whose lists are exported from the device next), and on the host cores
- * otherwise, 1 host, 2 device; the results are the same), "host_threads". */
+ * otherwise, 1 host, 2 device; the results are the same), "host_threads", "anchor_kernel" (phase A's chain
+ * kernels: 1, the default, the lean kernels on 2-bit packed operands; 0 the general byte-wise ones — same
+ * results), "lean_force_slow" (1: every step of the lean kernels through their wave-cooperative slow resolver). */
 int phylo_set_option(phylo_ctx *ctx, const char *key, long value);
 /* Accumulated since the last phylo_reset_stats: "ms:<kernel>", "n:<kernel>"
  * (HIP-event time and launch count per kernel when profiling is on),

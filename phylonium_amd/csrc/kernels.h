@@ -5,8 +5,20 @@
 #include <type_traits>
 
 #include "anchor_core.h"
+#include "lean_core.h"
 
 namespace phy {
+
+// lean_kernels.hip: the chain kernels on 2-bit packed operands (default), and the packed tables
+int lean_spec_resident_blocks(int n_cu);
+void launch_lean_spec(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st);
+void launch_lean_bridge(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st);
+void launch_pack2(const uint8_t *src, uint64_t bytes, uint32_t *dst, hipStream_t st); // bytes: a multiple of 16
+uint32_t bad_segment_bytes();
+// non-ACGT positions per sequence; out == nullptr: count per segment into seg_cnt, else write from seg_off
+void launch_bad_positions(const uint8_t *base, const uint64_t *off, const uint32_t *len, const uint32_t *seg_seq,
+						  const uint32_t *seg_first, uint32_t nseg, uint32_t *seg_cnt, const uint32_t *seg_off, uint32_t *out,
+						  hipStream_t st);
 
 // anchor_kernels.hip
 int spec_resident_blocks(int n_cu); // blocks of the speculative-chain kernel the device holds at once

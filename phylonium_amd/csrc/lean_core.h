@@ -1,0 +1,738 @@
+// lean_core.h — the anchor chain's common step on 2-bit packed operands.
+//
+// Same results as anchor_core.h's Chain (which restates esa::get_match_cached,
+// lcp and the lucky_anchor / anchor lambdas of anchor_homologies,
+// /root/reference/src/esa.cxx:361-563, src/process.cxx:171-282), organised for the
+// GPU differently:
+//
+//  * Queries and the subject are held a second time as 2-bit codes, 16 bases per
+//    dword (Q2, S2), with the positions of their non-ACGT bytes in sorted lists
+//    (QBAD, SBAD).  A step whose 16-base query window is pure ACGT — every step
+//    except the handful next to a contig join or the query's end — compares
+//    codes: one xor + count-leading-zeros per candidate instead of byte loops.
+//  * A lane is always in exactly one phase, and every phase is "one batch of
+//    loads from up to three addresses (pA: 32 B, pB: 32 B, pY: 8 B), then
+//    digest".  The kernel issues that one batch for all 64 lanes whatever
+//    phases they are in — one memory round trip per loop trip — and only the
+//    digest is per phase.  Phases: STEP (k-mer slot + lucky window), SEARCH (slot
+//    again after a failed long lucky check), SCAN (four more SAX records of a
+//    bucket with more than two members), EXT (128 more bases of one
+//    comparison), REFILL (16 dwords of the query into the lane's ring).
+//  * Everything else — a window that touches '!' or the query's end, two
+//    candidates that both share 16 bases with the query, buckets beyond
+//    LEAN_SCAN_MAX, a clipped LCP that matters — goes to the *slow resolver*,
+//    which answers one whole step from the raw bytes by the definition
+//    (longest match at the insertion point, unique iff the LCP array says so).
+//    On the GPU the wavefront resolves it together (lean_kernels.hip:
+//    coop_resolve); lean_resolve_scalar below is the same definition in plain
+//    loops for the CPU emulation tests.
+//
+// Plain C++ over raw pointers: compiled by hipcc for gfx950 and by g++ for
+// tests/emul (test infrastructure; the product never runs the CPU build).
+#pragma once
+#include <string.h>
+
+#include "anchor_core.h"
+
+namespace phy {
+
+// packed companions of RefIndex / PhaseA
+struct LeanIndex {
+	const uint32_t *S2;       // S as 2-bit codes, base i of word w = S[16w + i] in bits 31-2i..30-2i; non-ACGT -> 0
+	const uint32_t *SBAD;     // sorted positions of the non-ACGT bytes of S, then n (the end of S): nsb entries
+	uint32_t nsb;
+	uint32_t sb_end;        // = n, the list's last entry
+	uint32_t sb_first;        // SBAD[0] (with nsb == 2 — one contig, only '#' and the end — no lookup touches memory)
+	const uint32_t *Q2;       // the genome buffer in the same packing: word w = buffer bytes [16w, 16w+16)
+	const uint32_t *QBAD;     // positions (genome-relative, sorted per genome) of the genomes' non-ACGT bytes
+	const uint32_t *qbad_off; // [nq+1]: query j's list is QBAD[qbad_off[j] .. qbad_off[j+1])
+	uint32_t force_slow;      // tests: every step through the slow resolver
+	unsigned long long *dbg;  // builds with PHY_LEAN_TIMING: per-segment cycle sums of the chain kernels (else unused)
+};
+
+enum LeanPhase : uint32_t { LP_STEP = 0, LP_SEARCH, LP_SCAN, LP_EXT, LP_REFILL, LP_SLOW, LP_SLOWEXT };
+
+static const uint32_t LEAN_RING_WORDS = 16;         // dwords of the query a lane keeps at hand (256 bases)
+static const uint32_t LEAN_EXT_BASES = 128;         // bases per EXT trip
+static const uint32_t LEAN_EXT_COOP = 16 + 32 * 128; // a comparison this long is handed to the wavefront
+static const uint32_t LEAN_SCAN_MAX = 24;           // buckets with more members go to the slow resolver
+static const uint32_t NO_BAD = 0xffffffffu;
+
+// why a step left the packed path (counted by the CPU emulation build only)
+enum LeanSlowWhy : uint32_t { SW_FORCED = 0, SW_QUERY_END, SW_QUERY_BAD, SW_BUCKET, SW_PEND_MANY, SW_CLIP, SW_EXT_QBAD, SW_COUNT };
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(LEAN_COUNT_WHY)
+static unsigned long long g_lean_why[SW_COUNT];
+#define LEAN_WHY(code) (g_lean_why[code]++)
+#else
+#define LEAN_WHY(code) ((void)0)
+#endif
+
+PHY_HD uint32_t popc32(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return (uint32_t)__popc(x);
+#else
+	return (uint32_t)__builtin_popcount(x);
+#endif
+}
+
+// number of leading bases two 16-base codes share
+PHY_HD uint32_t lead_eq(uint32_t x) { return x ? clz32(x) >> 1 : 16u; }
+
+// 16 bases starting `o` bases into w0 (o in 0..15), continuing in w1
+PHY_HD uint32_t code_window(uint32_t w0, uint32_t w1, uint32_t o)
+{
+	return o ? (w0 << (2u * o)) | (w1 >> (32u - 2u * o)) : w0;
+}
+
+// A pure-ACGT 16-base query window against a suffix record (code of its first 16 bytes with
+// the bases after the first non-ACGT byte zeroed, sv = number of leading ACGT bytes).
+// The byte that ends a suffix's valid prefix ('!', '#' or the NUL after S) is smaller than
+// any nucleotide, so a record that runs out before it differs is shorter AND smaller.
+PHY_HD void rec_cmp(uint32_t qcode, uint32_t code, uint32_t sv, uint32_t *len, uint32_t *less, uint32_t *pend)
+{
+	const uint32_t d = lead_eq(qcode ^ code);
+	const uint32_t l = d < sv ? d : sv;
+	*len = l;
+	*pend = l == 16u ? 1u : 0u;
+	*less = sv < 16u ? (code <= qcode ? 1u : 0u) : (code < qcode ? 1u : 0u);
+}
+
+PHY_HD uint32_t meta_of_sax(const U4 &r) // a SAX record's z, w in the slot's one-dword form (slot_pack)
+{
+	return (r.z & 31u) | ((r.w & LCP_CLIP) << 5) | (((r.w >> 16) & LCP_CLIP) << 18);
+}
+
+struct LeanLane {
+	uint32_t qw0;            // first Q2 word of the query (its byte offset in the genome buffer / 16)
+	uint32_t qlen;
+	uint32_t q, lq, ls, ll;  // this_pos_Q, last_pos_Q, last_pos_S, last_length (process.cxx:203-212)
+	uint32_t ph;
+	bool fin, r_accepted;    // a step has just finished: r_* are valid
+	uint32_t r_q, r_s, r_len;
+	uint32_t qcode;          // the window's 16 bases
+	uint32_t e_kind, e_pos, e_p, e_meta; // EXT: lucky or candidate, bases known equal, subject position, candidate's meta
+	uint32_t s_rank, s_last, p_len, p_pos, p_meta, npend; // bucket walk: next rank, last rank that matters, predecessor so far, pending records seen
+	uint32_t qb_next, qb_idx, qb_end;    // next non-ACGT position of the query at or after q (NO_BAD: none)
+	uint32_t sb_lo, sb_hi;   // S positions [sb_lo, sb_hi) are clean and sb_hi is not (cache of the last SBAD lookup)
+	uint32_t wb, wn;         // the ring holds words [wb, wb + wn) of the query
+
+	PHY_HD void reset(uint32_t word0, uint32_t query_len, uint32_t q0, uint32_t a_q, uint32_t a_s, uint32_t a_len)
+	{
+		qw0 = word0;
+		qlen = query_len;
+		q = q0;
+		lq = a_q;
+		ls = a_s;
+		ll = a_len;
+		ph = LP_STEP;
+		fin = false;
+		sb_lo = 1;
+		sb_hi = 0;
+		wb = wn = 0;
+		qb_next = NO_BAD;
+		qb_idx = qb_end = 0;
+	}
+	PHY_HD bool lucky_ok(const RefIndex &R) const
+	{
+		const uint32_t advance = q - lq;
+		return (ls + advance < R.n) && (advance - ll <= R.threshold); // process.cxx:228-235
+	}
+	PHY_HD void finish(uint32_t pos, uint32_t len, bool accepted)
+	{
+		r_q = q;
+		r_s = pos;
+		r_len = len;
+		r_accepted = accepted;
+		lq = accepted ? q : lq; // process.cxx:275-277
+		ls = accepted ? pos : ls;
+		ll = accepted ? len : ll;
+		q += len + 1; // process.cxx:281
+		ph = LP_STEP;
+		fin = true;
+	}
+	PHY_HD void start_ext(uint32_t kind, uint32_t pos, uint32_t meta)
+	{
+		e_kind = kind;
+		e_pos = 16;
+		e_p = pos;
+		e_meta = meta;
+		ph = LP_EXT;
+	}
+	// the query's bad-position cursor follows q (positions only grow)
+	PHY_HD void qbad_seek(const LeanIndex &X)
+	{
+		while (qb_next < q) {
+			qb_idx++;
+			qb_next = qb_idx < qb_end ? X.QBAD[qb_idx] : NO_BAD;
+		}
+	}
+	PHY_HD void qbad_start(const LeanIndex &X, uint32_t j)
+	{
+		uint32_t lo = X.qbad_off[j], hi = X.qbad_off[j + 1];
+		qb_end = hi;
+		while (lo < hi) { // first entry >= q
+			const uint32_t mid = lo + ((hi - lo) >> 1);
+			if (X.QBAD[mid] < q) lo = mid + 1;
+			else hi = mid;
+		}
+		qb_idx = lo;
+		qb_next = lo < qb_end ? X.QBAD[lo] : NO_BAD;
+	}
+	// smallest non-ACGT position of S at or after p (p < n; the list ends with n)
+	PHY_HD uint32_t sbad_next(const LeanIndex &X, uint32_t p)
+	{
+		if (p >= sb_lo && p < sb_hi) return sb_hi;
+		if (X.nsb == 2) { // a single-contig subject: '#' in the middle and the end
+			const bool left = p <= X.sb_first;
+			sb_lo = left ? 0u : X.sb_first + 1u;
+			sb_hi = left ? X.sb_first : X.sb_end;
+			return sb_hi;
+		}
+		uint32_t lo = 0, hi = X.nsb - 1; // the answer exists: SBAD[nsb-1] = n > p
+		while (lo < hi) {
+			const uint32_t mid = lo + ((hi - lo) >> 1);
+			if (X.SBAD[mid] < p) lo = mid + 1;
+			else hi = mid;
+		}
+		sb_hi = X.SBAD[lo];
+		sb_lo = lo ? X.SBAD[lo - 1] + 1u : 0u;
+		return sb_hi;
+	}
+};
+
+// what a trip loads for a lane: 32 bytes at pA, 32 at pB, 8 at pY (byte offsets from the named base)
+enum LeanBase : uint32_t { LB_NONE = 0, LB_SLOT, LB_SAX, LB_Q2, LB_S2 };
+struct LeanAddr {
+	uint32_t baseA, baseB, baseY;
+	uint64_t offA, offB, offY;
+};
+
+// anchor(), process.cxx:219-225, from the two neighbours of the insertion point: (length, position,
+// meta) of the predecessor and the successor (length 0: none)
+PHY_HD void lean_fin(LeanLane &ln, const RefIndex &R, uint32_t lp, uint32_t pp, uint32_t mp, uint32_t lsu, uint32_t ps,
+					 uint32_t ms)
+{
+	const bool pbest = lp > lsu;
+	const uint32_t lmax = pbest ? lp : lsu;
+	const bool cand = lp != lsu && lmax >= R.threshold;
+	const uint32_t m = pbest ? mp : ms;
+	const uint32_t l = pbest ? (m >> 5) & LCP_CLIP : (m >> 18) & LCP_CLIP; // LCP[best] resp. LCP[best+1], clipped
+	if (cand && l == LCP_CLIP && lmax >= LCP_CLIP) { // the clipped value cannot decide
+		LEAN_WHY(SW_CLIP);
+		ln.ph = LP_SLOW;
+		return;
+	}
+	ln.finish(pbest ? pp : ps, lmax, cand && l < lmax);
+}
+
+// a finished comparison (EXT, or the wavefront's long compare) goes back to whoever asked for it
+PHY_HD void lean_deliver(LeanLane &ln, const RefIndex &R, uint32_t len, uint32_t less)
+{
+	if (ln.e_kind == EXT_LUCKY) {
+		if (len >= R.threshold) ln.finish(ln.e_p, len, true); // process.cxx:241
+		else ln.ph = LP_SEARCH;
+		return;
+	}
+	// the one candidate that shares >= 16 bases with the query is the best neighbour; it is the
+	// predecessor iff it is smaller than the query
+	const uint32_t l = less ? (ln.e_meta >> 5) & LCP_CLIP : (ln.e_meta >> 18) & LCP_CLIP;
+	const bool cand = len >= R.threshold;
+	if (cand && l == LCP_CLIP && len >= LCP_CLIP) {
+		LEAN_WHY(SW_CLIP);
+		ln.ph = LP_SLOW;
+		return;
+	}
+	ln.finish(ln.e_p, len, cand && l < len);
+}
+
+// One group of up to four consecutive ranks of the bucket walk (the slot's records, then SAX records
+// four at a time): `nex` of them exist, `more` ranks follow.  In rank order the suffixes smaller
+// than the query come first, then those that share all 16 bases of the window ("pending": only a
+// longer comparison can place them), then the larger ones.  The walk remembers the last smaller
+// record (the predecessor so far) and the first pending one, and ends at the first larger record
+// — the successor — or when the ranks run out.
+PHY_HD void lean_group(LeanLane &ln, const RefIndex &R, uint32_t nex, bool more, uint32_t pos0, uint32_t pos1, uint32_t pos2,
+					   uint32_t pos3, uint32_t code0, uint32_t code1, uint32_t code2, uint32_t code3, uint32_t meta0,
+					   uint32_t meta1, uint32_t meta2, uint32_t meta3)
+{
+	uint32_t len0, len1, len2, len3, less = 0, pend = 0, ls_, pe;
+	rec_cmp(ln.qcode, code0, meta0 & 31u, &len0, &ls_, &pe);
+	less |= ls_;
+	pend |= pe;
+	rec_cmp(ln.qcode, code1, meta1 & 31u, &len1, &ls_, &pe);
+	less |= ls_ << 1;
+	pend |= pe << 1;
+	rec_cmp(ln.qcode, code2, meta2 & 31u, &len2, &ls_, &pe);
+	less |= ls_ << 2;
+	pend |= pe << 2;
+	rec_cmp(ln.qcode, code3, meta3 & 31u, &len3, &ls_, &pe);
+	less |= ls_ << 3;
+	pend |= pe << 3;
+	const uint32_t exist = (1u << nex) - 1u;
+	const uint32_t stop = exist & ~less & ~pend;                // larger than the query
+	const uint32_t before = stop ? (stop & (0u - stop)) - 1u : exist; // the records ahead of the successor
+	const uint32_t lm = less & ~pend & before, pm = pend & before;
+	if (lm) {
+		const uint32_t i = 31u - clz32(lm);
+		ln.p_len = sel4(len0, len1, len2, len3, i);
+		ln.p_pos = sel4(pos0, pos1, pos2, pos3, i);
+		ln.p_meta = sel4(meta0, meta1, meta2, meta3, i);
+	}
+	if (pm) {
+		if (ln.npend == 0) {
+			const uint32_t i = ctz32(pm);
+			ln.e_p = sel4(pos0, pos1, pos2, pos3, i);
+			ln.e_meta = sel4(meta0, meta1, meta2, meta3, i);
+		}
+		ln.npend += popc32(pm);
+	}
+	if (!stop && more) { // all smaller or pending, and the bucket goes on
+		ln.ph = LP_SCAN;
+		return;
+	}
+	if (ln.npend >= 2u) { // several suffixes share the window's 16 bases (a repeat): bytes decide
+		LEAN_WHY(SW_PEND_MANY);
+		ln.ph = LP_SLOW;
+		return;
+	}
+	if (ln.npend == 1u) { // the one that does is the best neighbour on either side: extend it
+		ln.start_ext(EXT_CAND, ln.e_p, ln.e_meta);
+		return;
+	}
+	const uint32_t is = stop ? ctz32(stop) : 0u;
+	lean_fin(ln, R, ln.p_len, ln.p_pos, ln.p_meta, stop ? sel4(len0, len1, len2, len3, is) : 0u, sel4(pos0, pos1, pos2, pos3, is),
+			 sel4(meta0, meta1, meta2, meta3, is));
+}
+
+// the slot of the window's k-mer: header {lo, hi} and the records of ranks base .. base+3
+PHY_HD void lean_search(LeanLane &ln, const RefIndex &R, const uint32_t *w)
+{
+	const uint32_t lo = w[0], hi = w[1];
+	if (hi - lo > LEAN_SCAN_MAX) {
+		LEAN_WHY(SW_BUCKET);
+		ln.ph = LP_SLOW;
+		return;
+	}
+	const uint32_t base = lo ? lo - 1 : 0;
+	const uint32_t last = hi < R.n ? hi : R.n - 1; // the successor, when there is one
+	const uint32_t c_n = last - base + 1;          // ranks base .. last matter
+	ln.p_len = ln.p_pos = ln.p_meta = 0;
+	ln.npend = 0;
+	ln.s_rank = base + 4;
+	ln.s_last = last;
+	lean_group(ln, R, c_n < 4 ? c_n : 4, c_n > 4, w[2], w[5], w[8], w[11], w[3], w[6], w[9], w[12], w[4], w[7], w[10], w[13]);
+}
+
+// four SAX records of ranks s_rank .. s_rank+3
+PHY_HD void lean_scan(LeanLane &ln, const RefIndex &R, const U4 &r0, const U4 &r1, const U4 &r2, const U4 &r3)
+{
+	const uint32_t left = ln.s_last - ln.s_rank + 1; // >= 1
+	ln.s_rank += 4;
+	lean_group(ln, R, left < 4 ? left : 4, left > 4, r0.x, r1.x, r2.x, r3.x, r0.y, r1.y, r2.y, r3.y, meta_of_sax(r0), meta_of_sax(r1),
+			   meta_of_sax(r2), meta_of_sax(r3));
+}
+
+// EXT: Q words qw[0..8) starting at the word that holds position q + e_pos, S words sw[0..9)
+// starting at the word that holds the matching subject position.  Compares up to 128 bases.
+PHY_HD void lean_ext(LeanLane &ln, const RefIndex &R, const LeanIndex &X, const uint32_t *qw, const uint32_t *sw)
+{
+	const uint32_t back = (ln.q + ln.e_pos) & 15u; // bases of the first Q word that are known equal already
+	const uint32_t e0 = ln.e_pos - back;
+	const uint32_t sp = ln.e_p + e0, so = sp & 15u;
+	uint32_t dd = LEAN_EXT_BASES, lessbit = 0;
+#pragma unroll
+	for (int w = 7; w >= 0; w--) { // descending: the first differing word wins
+		const uint32_t s = code_window(sw[w], sw[w + 1], so);
+		const uint32_t x = qw[w] ^ s;
+		if (x) {
+			dd = 16u * (uint32_t)w + (clz32(x) >> 1);
+			lessbit = s < qw[w] ? 1u : 0u;
+		}
+	}
+	const uint32_t n_left = ln.qlen - (ln.q + e0);      // bases of the query from the hop's start
+	const uint32_t ds = ln.sbad_next(X, sp) - sp;       // clean bases of S from there
+	const uint32_t dq = ln.qb_next - (ln.q + e0);       // clean bases of the query (NO_BAD: plenty)
+	uint32_t lim = LEAN_EXT_BASES;
+	lim = n_left < lim ? n_left : lim;
+	lim = ds < lim ? ds : lim;
+	lim = dq < lim ? dq : lim;
+	if (dd < lim) {
+		lean_deliver(ln, R, e0 + dd, lessbit);
+	} else if (lim == LEAN_EXT_BASES) {
+		ln.e_pos = e0 + LEAN_EXT_BASES;
+		if (ln.e_pos >= LEAN_EXT_COOP) ln.ph = LP_SLOWEXT;
+	} else if (dq <= n_left && dq <= ds) {
+		LEAN_WHY(SW_EXT_QBAD);
+		ln.ph = LP_SLOW; // the match runs into a '!' of the query: bytes decide
+	} else if (n_left <= ds) {
+		lean_deliver(ln, R, ln.qlen - ln.q, 0); // the query ends first: it is a prefix of the suffix
+	} else {
+		lean_deliver(ln, R, e0 + ds, 1); // S has a byte below 'A' here, the query a nucleotide
+	}
+}
+
+// STEP, part 1 (before the loads): can this step take the packed path, and is its window at hand?
+// Returns the phase the lane is in for this trip (STEP, REFILL or SLOW).
+PHY_HD uint32_t lean_step_phase(const LeanLane &ln, const LeanIndex &X)
+{
+	const uint32_t n = ln.qlen - ln.q;
+	if (X.force_slow || n < 17u || ln.qb_next - ln.q < 16u) {
+		LEAN_WHY(X.force_slow ? SW_FORCED : n < 17u ? SW_QUERY_END : SW_QUERY_BAD);
+		return LP_SLOW;
+	}
+	const uint32_t w = ln.q >> 4;
+	if (w < ln.wb || w + 1 >= ln.wb + ln.wn) return LP_REFILL;
+	return LP_STEP;
+}
+
+// addresses of a lane's loads for this trip (ph is STEP, SEARCH, SCAN, EXT or REFILL; qcode is set)
+PHY_HD LeanAddr lean_addr(const LeanLane &ln, const RefIndex &R)
+{
+	LeanAddr a;
+	a.baseA = a.baseB = a.baseY = LB_NONE;
+	a.offA = a.offB = a.offY = 0;
+	if (ln.ph == LP_STEP || ln.ph == LP_SEARCH) {
+		const uint64_t s = (uint64_t)(ln.qcode >> (2u * (16u - R.k))) * 64u;
+		a.baseA = a.baseB = LB_SLOT;
+		a.offA = s;
+		a.offB = s + 32;
+		if (ln.ph == LP_STEP && ln.lucky_ok(R)) {
+			a.baseY = LB_S2;
+			a.offY = (uint64_t)((ln.ls + (ln.q - ln.lq)) >> 4) * 4u;
+		}
+	} else if (ln.ph == LP_SCAN) {
+		a.baseA = a.baseB = LB_SAX;
+		a.offA = (uint64_t)ln.s_rank * 16u;
+		a.offB = a.offA + 32;
+	} else if (ln.ph == LP_EXT) {
+		const uint32_t e0 = ln.e_pos - ((ln.q + ln.e_pos) & 15u);
+		a.baseA = LB_Q2;
+		a.offA = ((uint64_t)ln.qw0 + ((ln.q + e0) >> 4)) * 4u;
+		a.baseB = a.baseY = LB_S2;
+		a.offB = (uint64_t)((ln.e_p + e0) >> 4) * 4u;
+		a.offY = a.offB + 32;
+	} else if (ln.ph == LP_REFILL) {
+		a.baseA = a.baseB = LB_Q2;
+		a.offA = ((uint64_t)ln.qw0 + (ln.q >> 4)) * 4u;
+		a.offB = a.offA + 32;
+	}
+	return a;
+}
+
+// STEP, part 2: d[0..16) = the slot, y0/y1 = the two S2 words of the lucky window
+PHY_HD void lean_step(LeanLane &ln, const RefIndex &R, const LeanIndex &X, const uint32_t *d, uint32_t y0, uint32_t y1)
+{
+	if (ln.lucky_ok(R)) { // lucky_anchor, process.cxx:227-242
+		const uint32_t try_s = ln.ls + (ln.q - ln.lq);
+		const uint32_t dcode = lead_eq(ln.qcode ^ code_window(y0, y1, try_s & 15u));
+		const uint32_t ds = ln.sbad_next(X, try_s) - try_s;
+		const uint32_t lw = dcode < ds ? dcode : ds;
+		if (lw >= 16u) {
+			ln.start_ext(EXT_LUCKY, try_s, 0);
+			return;
+		}
+		if (lw >= R.threshold) {
+			ln.finish(try_s, lw, true);
+			return;
+		}
+	}
+	lean_search(ln, R, d);
+}
+
+// ───────────────── the slow resolver's definition, in plain loops (CPU emulation) ─────────────────
+// One whole step from the raw bytes: lucky_anchor, else the longest match at the query suffix's
+// insertion point in the suffix array, unique iff the LCP array says the next suffix outward does
+// not share it (anchor_core.h's header).
+#if !defined(__HIP_DEVICE_COMPILE__)
+inline void lean_resolve_scalar(LeanLane &ln, const uint8_t *qbase, const RefIndex &R)
+{
+	const uint8_t *Q = qbase + ((uint64_t)ln.qw0 << 4) + ln.q;
+	const uint32_t n = ln.qlen - ln.q;
+	auto cmp = [&](uint32_t sa, uint32_t *len, uint32_t *less) {
+		uint32_t i = 0;
+		while (i < n && Q[i] == R.S[sa + i]) i++; // S ends in zero bytes, query bytes are never zero
+		*len = i;
+		*less = (i < n && R.S[sa + i] < Q[i]) ? 1u : 0u;
+	};
+	uint32_t len, less;
+	if (ln.lucky_ok(R)) {
+		const uint32_t try_s = ln.ls + (ln.q - ln.lq);
+		cmp(try_s, &len, &less);
+		if (len >= R.threshold) {
+			ln.finish(try_s, len, true);
+			return;
+		}
+	}
+	uint32_t lo = 0, hi = R.n;
+	while (lo < hi) {
+		const uint32_t mid = lo + ((hi - lo) >> 1);
+		cmp(R.SAX[mid].x, &len, &less);
+		if (less) lo = mid + 1;
+		else hi = mid;
+	}
+	uint32_t lp = 0, pp = 0, lsu = 0, ps = 0;
+	if (lo > 0) {
+		pp = R.SAX[lo - 1].x;
+		cmp(pp, &lp, &less);
+	}
+	if (lo < R.n) {
+		ps = R.SAX[lo].x;
+		cmp(ps, &lsu, &less);
+	}
+	const bool pbest = lp > lsu;
+	const uint32_t lmax = pbest ? lp : lsu;
+	const bool cand = lp != lsu && lmax >= R.threshold;
+	const uint32_t l = pbest ? R.LCP[lo - 1] : R.LCP[lo + 1];
+	ln.finish(pbest ? pp : ps, lmax, cand && l < lmax);
+}
+inline void lean_resolve_ext_scalar(LeanLane &ln, const uint8_t *qbase, const RefIndex &R)
+{
+	const uint8_t *Q = qbase + ((uint64_t)ln.qw0 << 4) + ln.q;
+	const uint32_t n = ln.qlen - ln.q;
+	uint32_t i = ln.e_pos - ((ln.q + ln.e_pos) & 15u);
+	while (i < n && Q[i] == R.S[ln.e_p + i]) i++;
+	lean_deliver(ln, R, i, (i < n && R.S[ln.e_p + i] < Q[i]) ? 1u : 0u);
+}
+#endif
+
+// ───────────────── chunk drivers (the same logs, exits and bridges as anchor_core.h) ─────────────────
+
+PHY_HD uint32_t lean_visited_word(const LeanLane &ln, uint32_t q)
+{
+	return (ln.qw0 >> 1) + (q >> 5); // genomes start at multiples of 64 bytes: qw0 is a multiple of 4
+}
+
+struct LeanSpec {
+	LeanLane ln;
+	uint32_t gc, q_end, cnt, log0, cap, vis_word, vis_idx;
+
+	PHY_HD void start(const PhaseA &A, const LeanIndex &X, uint32_t chunk)
+	{
+		gc = chunk;
+		const uint32_t j = A.chunk_query[chunk];
+		const ChunkGeom g = chunk_geom(A, j, chunk - A.qchunk0[j]);
+		const uint32_t ql = A.qlen[j], e = g.q0 + g.len;
+		q_end = e < ql ? e : ql;
+		log0 = g.log0;
+		cap = g.cap;
+		ln.reset((uint32_t)(A.qoff[j] >> 4), ql, g.q0, 0, 0, 0);
+		ln.qbad_start(X, j);
+		cnt = 0;
+		vis_word = 0;
+		vis_idx = lean_visited_word(ln, g.q0);
+	}
+	// called when ln.ph == LP_STEP; false when the chunk is finished
+	PHY_HD bool begin_step(const PhaseA &A, const LeanIndex &X)
+	{
+		if (ln.q >= q_end) {
+			A.visited[vis_idx] = vis_word;
+			A.spec_cnt[gc] = cnt;
+			SpecExit x = {ln.q, ln.lq, ln.ls, ln.ll};
+			A.spec_exit[gc] = x;
+			return false;
+		}
+		const uint32_t w = lean_visited_word(ln, ln.q);
+		if (w != vis_idx) {
+			A.visited[vis_idx] = vis_word;
+			vis_idx = w;
+			vis_word = 0;
+		}
+		vis_word |= 1u << (ln.q & 31);
+		ln.qbad_seek(X);
+		return true;
+	}
+	PHY_HD void step_done(const PhaseA &A)
+	{
+		if (ln.r_accepted) {
+			if (cnt < cap) {
+				Anchor a = {ln.r_q, ln.r_s, ln.r_len};
+				A.spec_anchors[(size_t)log0 + cnt] = a;
+			} else {
+				*A.error = 1;
+			}
+			cnt++;
+		}
+	}
+};
+
+struct LeanBridge {
+	LeanLane ln;
+	uint32_t src, qj, cur_gc, cur_q0, cur_len, cur_log, sp_cnt, sp_idx;
+	Anchor Ls;
+	uint32_t n, first_block, cur_block;
+
+	PHY_HD void start(const PhaseA &A, const LeanIndex &X, uint32_t chunk)
+	{
+		src = chunk;
+		const uint32_t j = A.chunk_query[chunk];
+		qj = j;
+		const SpecExit x = A.spec_exit[chunk];
+		ln.reset((uint32_t)(A.qoff[j] >> 4), A.qlen[j], x.q, x.lq, x.ls, x.ll);
+		ln.qbad_start(X, j);
+		cur_gc = BRIDGE_END;
+		cur_q0 = cur_len = cur_log = 0;
+		sp_cnt = sp_idx = 0;
+		Ls.q = Ls.s = Ls.len = 0;
+		n = 0;
+		first_block = cur_block = NO_BLOCK;
+	}
+	PHY_HD void finish(const PhaseA &A, uint32_t target, uint32_t idx_m)
+	{
+		BridgeRec *b = &A.bridge[src];
+		b->target = target;
+		b->idx_m = idx_m;
+		b->n = n;
+		b->block = first_block;
+	}
+	PHY_HD bool begin_step(const PhaseA &A, const LeanIndex &X, const RefIndex &R)
+	{
+		if (ln.q >= ln.qlen) {
+			finish(A, BRIDGE_END, 0);
+			return false;
+		}
+		if (cur_gc == BRIDGE_END || ln.q - cur_q0 >= cur_len) { // entered another chunk
+			const uint32_t lc = chunk_of_pos(A, qj, ln.q);
+			const ChunkGeom g = chunk_geom(A, qj, lc);
+			cur_gc = A.qchunk0[qj] + lc;
+			cur_q0 = g.q0;
+			cur_len = g.len;
+			cur_log = g.log0;
+			sp_cnt = A.spec_cnt[cur_gc];
+			sp_idx = 0;
+			Ls.q = Ls.s = Ls.len = 0;
+		}
+		const Anchor *log = A.spec_anchors + (size_t)cur_log;
+		while (sp_idx < sp_cnt && log[sp_idx].q < ln.q) {
+			Ls = log[sp_idx];
+			sp_idx++;
+		}
+		const uint32_t w = A.visited[lean_visited_word(ln, ln.q)];
+		if ((w >> (ln.q & 31)) & 1u) {
+			const bool eb = lucky_eligible(ln.q, ln.lq, ln.ls, ln.ll, R);
+			const bool es = lucky_eligible(ln.q, Ls.q, Ls.s, Ls.len, R);
+			bool merged = false;
+			if (!eb && !es) merged = true;
+			else if (eb && es && (ln.ls - ln.lq == Ls.s - Ls.q) && (ln.lq + ln.ll == Ls.q + Ls.len)) merged = true;
+			if (merged) {
+				finish(A, cur_gc, sp_idx);
+				return false;
+			}
+		}
+		ln.qbad_seek(X);
+		return true;
+	}
+	template <class Alloc> PHY_HD void step_done(const PhaseA &A, Alloc alloc)
+	{
+		if (!ln.r_accepted) return;
+		Anchor a = {ln.r_q, ln.r_s, ln.r_len};
+		if (n < BRIDGE_INLINE) {
+			A.bridge[src].a[n] = a;
+		} else {
+			const uint32_t k = (n - BRIDGE_INLINE) % POOL_BLOCK;
+			if (k == 0) {
+				const uint32_t nb = alloc();
+				if (nb == NO_BLOCK) {
+					*A.error = 2;
+					n++;
+					return;
+				}
+				A.pool[nb].next = NO_BLOCK;
+				if (cur_block == NO_BLOCK) first_block = nb;
+				else A.pool[cur_block].next = nb;
+				cur_block = nb;
+			}
+			if (cur_block != NO_BLOCK) A.pool[cur_block].a[k] = a;
+		}
+		n++;
+	}
+};
+
+// ───────────────── one trip of one lane on the CPU (emulation tests) ─────────────────
+#if !defined(__HIP_DEVICE_COMPILE__)
+struct LeanTables { // what the kernel reaches through the four bases
+	const uint8_t *slot, *sax, *q2, *s2;
+};
+inline const uint8_t *lean_ptr(const LeanTables &T, uint32_t base, uint64_t off)
+{
+	switch (base) {
+		case LB_SLOT: return T.slot + off;
+		case LB_SAX: return T.sax + off;
+		case LB_Q2: return T.q2 + off;
+		case LB_S2: return T.s2 + off;
+		default: return T.s2;
+	}
+}
+// ring: the lane's LEAN_RING_WORDS dwords
+inline void lean_trip_cpu(LeanLane &ln, uint32_t *ring, const uint8_t *qbase, const RefIndex &R, const LeanIndex &X,
+						  const LeanTables &T, uint64_t *slow_steps)
+{
+	if (ln.ph == LP_STEP) {
+		ln.ph = lean_step_phase(ln, X);
+		if (ln.ph == LP_STEP) {
+			const uint32_t i0 = (ln.q >> 4) - ln.wb;
+			ln.qcode = code_window(ring[i0], ring[i0 + 1], ln.q & 15u);
+		}
+	}
+	if (ln.ph == LP_SLOW) {
+		lean_resolve_scalar(ln, qbase, R);
+		(*slow_steps)++;
+		return;
+	}
+	if (ln.ph == LP_SLOWEXT) {
+		lean_resolve_ext_scalar(ln, qbase, R);
+		return;
+	}
+	const LeanAddr a = lean_addr(ln, R);
+	uint32_t d[16], y[2];
+	memcpy(d, lean_ptr(T, a.baseA, a.offA), 32);
+	memcpy(d + 8, lean_ptr(T, a.baseB, a.offB), 32);
+	memcpy(y, lean_ptr(T, a.baseY, a.offY), 8);
+	switch (ln.ph) {
+		case LP_STEP: lean_step(ln, R, X, d, y[0], y[1]); break;
+		case LP_SEARCH: lean_search(ln, R, d); break;
+		case LP_SCAN: {
+			U4 r[4];
+			memcpy(r, d, 64);
+			lean_scan(ln, R, r[0], r[1], r[2], r[3]);
+			break;
+		}
+		case LP_EXT: {
+			uint32_t sw[9];
+			memcpy(sw, d + 8, 32);
+			sw[8] = y[0];
+			for (uint32_t i = 0; i < 8; i++) ring[i] = d[i]; // the query words double as the ring's new content
+			ln.wb = (ln.q + (ln.e_pos - ((ln.q + ln.e_pos) & 15u))) >> 4;
+			ln.wn = 8;
+			lean_ext(ln, R, X, d, sw);
+			break;
+		}
+		case LP_REFILL:
+			for (uint32_t i = 0; i < 16; i++) ring[i] = d[i];
+			ln.wb = ln.q >> 4;
+			ln.wn = 16;
+			ln.ph = LP_STEP;
+			break;
+		default: break;
+	}
+}
+#endif
+
+// ───────────────── packing (host versions for the emulation; the product packs on the device) ─────────────────
+#if !defined(__HIP_DEVICE_COMPILE__)
+// 2-bit codes of `n` bytes (n a multiple of 16 is not required: the last word is padded with zero codes)
+inline void lean_pack_host(const uint8_t *s, size_t n, uint32_t *out, size_t out_words)
+{
+	for (size_t w = 0; w < out_words; w++) {
+		uint32_t c = 0;
+		for (uint32_t i = 0; i < 16; i++) {
+			const size_t p = 16 * w + i;
+			const uint32_t v = p < n ? nuc_code(s[p]) : 4u;
+			c |= (v < 4 ? v : 0u) << (30u - 2u * i);
+		}
+		out[w] = c;
+	}
+}
+#endif
+
+} // namespace phy

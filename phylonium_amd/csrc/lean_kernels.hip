@@ -1,0 +1,498 @@
+// lean_kernels.hip — phase A's chain kernels on 2-bit packed operands (lean_core.h),
+// plus the kernels that make the packed tables.
+//
+// Replaces chain_kernel<0|1> of anchor_kernels.hip as the default for the speculative
+// chunk chains and the bridges (same logs, exits and bridge records: fold_kernel and
+// everything after it are unchanged).  Reference: anchor_homologies + the ESA match
+// under it, /root/reference/src/process.cxx:198-295, src/esa.cxx:361-563.
+//
+// One loop trip = one batch of loads for all 64 lanes whatever phase each is in
+// (32 B at pA, 32 B at pB, 8 B at pY), then the per-phase digest.  Steps the packed
+// path cannot answer are resolved by the whole wavefront from the raw bytes
+// (coop_resolve): 64 suffixes compared per round, so a bucket of any size takes
+// log64 rounds, and every special case ('!' in the window, the query's end, repeats)
+// is just byte comparison there.
+//
+// Roofline: random 64-byte slot fetches out of the k-mer table (HBM, translation
+// reach) + instruction issue; algorithmic bytes per launch as anchor_kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "lean_core.h"
+
+namespace phy {
+
+typedef const uint8_t __attribute__((address_space(1))) *lean_global_bytes;
+static __device__ __forceinline__ U4 lg16(const uint8_t *p)
+{
+	U4 v;
+	__builtin_memcpy(&v, (lean_global_bytes)(uintptr_t)p, 16);
+	return v;
+}
+struct U2 {
+	uint32_t x, y;
+};
+static __device__ __forceinline__ U2 lg8(const uint8_t *p)
+{
+	U2 v;
+	__builtin_memcpy(&v, (lean_global_bytes)(uintptr_t)p, 8);
+	return v;
+}
+static __device__ __forceinline__ uint32_t lane64() { return threadIdx.x & 63u; }
+static __device__ __forceinline__ uint32_t bcast(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
+
+// ───────────────────────── wave-cooperative comparisons (raw bytes) ─────────────────────────
+
+// All 64 lanes compare qp[pos ..) with sp[pos ..): lane r takes the 16-byte piece r of every
+// 1 KiB block.  maxn = bytes of the query from qp; s_end = first byte past S's zero padding.
+static __device__ void wave_compare(const uint8_t *qp, const uint8_t *sp, uint32_t pos, uint32_t maxn,
+									const uint8_t *s_end, uint32_t *out_len, uint32_t *out_less)
+{
+	const uint32_t r = lane64();
+	uint32_t base = pos;
+	for (;;) {
+		const uint32_t off = base + r * 16u;
+		const bool in_q = off < maxn;
+		uint32_t d = 0, qb = 1, sb = 0;
+		if (in_q) {
+			const U4 a = lg16(qp + off);
+			U4 b = {0, 0, 0, 0};
+			if (sp + off + 16 <= s_end) b = lg16(sp + off); // past the end of S: the NUL the reference stops at
+			d = first_diff(a, b);
+			if (d < 16) {
+				qb = byte_at(a, d);
+				sb = byte_at(b, d);
+			}
+		}
+		const bool hit = !in_q || d < 16;
+		const uint64_t hm = __ballot(hit);
+		if (hm) {
+			const int first = __ffsll((unsigned long long)hm) - 1;
+			uint32_t len = in_q ? off + d : maxn;
+			const uint32_t less = (in_q && len < maxn) ? (sb < qb ? 1u : 0u) : 0u;
+			if (len > maxn) len = maxn;
+			*out_len = bcast(len, first);
+			*out_less = bcast(less, first);
+			return;
+		}
+		base += 64u * 16u;
+	}
+}
+
+// Every lane with `on` compares the query (qp, n bytes) with its own suffix S + sa: alone for the
+// first LONE bytes, then — one lane after the other — with the whole wavefront's help.
+static __device__ void lanes_compare(const uint8_t *qp, uint32_t n, const uint8_t *S, uint32_t sa, bool on,
+									 const uint8_t *s_end, uint32_t *out_len, uint32_t *out_less)
+{
+	const uint32_t LONE = 256;
+	uint32_t len = 0, less = 0, i = 0;
+	bool open = on;
+	while (open) { // 64 bytes per trip: the four loads of each side are in flight together
+		if (i >= n) {
+			len = n;
+			less = 0;
+			open = false;
+			break;
+		}
+		if (i >= LONE) break;
+		U4 a[4], b[4];
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			a[k] = lg16(qp + i + 16 * k);
+			b[k] = U4{0, 0, 0, 0};
+			if (S + sa + i + 16 * k + 16 <= s_end) b[k] = lg16(S + sa + i + 16 * k);
+		}
+		uint32_t d = 64, qb = 0, sb = 0;
+#pragma unroll
+		for (int k = 3; k >= 0; k--) {
+			const uint32_t dk = first_diff(a[k], b[k]);
+			if (dk < 16) {
+				d = 16u * (uint32_t)k + dk;
+				qb = byte_at(a[k], dk);
+				sb = byte_at(b[k], dk);
+			}
+		}
+		if (d < 64) {
+			len = i + d;
+			if (len >= n) {
+				len = n;
+				less = 0;
+			} else {
+				less = sb < qb ? 1u : 0u;
+			}
+			open = false;
+			break;
+		}
+		i += 64;
+	}
+	uint64_t longm = __ballot(open);
+	while (longm) {
+		const int who = __ffsll((unsigned long long)longm) - 1;
+		const uint32_t wsa = bcast(sa, who);
+		uint32_t l2, s2;
+		wave_compare(qp, S + wsa, LONE, n, s_end, &l2, &s2);
+		if ((int)lane64() == who) {
+			len = l2;
+			less = s2;
+		}
+		longm &= longm - 1;
+	}
+	*out_len = len;
+	*out_less = less;
+}
+
+// One whole step of lane `leader`, from the raw bytes, by the definition (lean_core.h:
+// lean_resolve_scalar is the same in plain loops): lucky_anchor; else the insertion point of the
+// query suffix among the suffixes of S — 64 probes per round — the longer of its two neighbours'
+// matches, unique iff the LCP array says the next suffix outward does not share it.
+static __device__ void coop_resolve(LeanLane &ln, int leader, const PhaseA &A, const RefIndex &R, const uint8_t *s_end)
+{
+	const uint32_t lane = lane64();
+	const uint32_t qw0 = bcast(ln.qw0, leader), q = bcast(ln.q, leader), qlen = bcast(ln.qlen, leader);
+	const uint32_t lq = bcast(ln.lq, leader), ls = bcast(ln.ls, leader), ll = bcast(ln.ll, leader);
+	const uint8_t *Q = A.qbase + ((uint64_t)qw0 << 4) + q;
+	const uint32_t n = qlen - q;
+	uint32_t r_pos = 0, r_len = 0;
+	bool r_acc = false, have = false;
+	const uint32_t advance = q - lq;
+	if ((ls + advance < R.n) && (advance - ll <= R.threshold)) { // lucky_anchor, process.cxx:227-242
+		uint32_t len, less;
+		wave_compare(Q, R.S + (ls + advance), 0, n, s_end, &len, &less);
+		if (len >= R.threshold) {
+			r_pos = ls + advance;
+			r_len = len;
+			r_acc = true;
+			have = true;
+		}
+	}
+	if (!have) {
+		uint32_t lo = 0, hi = R.n;
+		{ // the k-mer's bucket bounds the search when the window starts with k nucleotides
+			uint32_t valid;
+			const uint32_t code = window_code(lg16(Q), &valid);
+			const uint32_t qv = valid < n ? valid : n;
+			if (qv >= R.k) {
+				const U4 hdr = lg16((const uint8_t *)(R.SLOT + (size_t)(code >> (2u * (16u - R.k))) * SLOT_RECS));
+				lo = hdr.x;
+				hi = hdr.y;
+			}
+		}
+		while (hi - lo > 62u) {
+			const uint32_t m = hi - lo;
+			const uint32_t r = lo + (uint32_t)(((uint64_t)(lane + 1u) * m) / 65u); // lo <= r < hi, nondecreasing in lane
+			const uint32_t sa = lg16((const uint8_t *)(R.SAX + r)).x;
+			uint32_t len, less;
+			lanes_compare(Q, n, R.S, sa, true, s_end, &len, &less);
+			const uint32_t cnt = (uint32_t)__popcll(__ballot(less != 0));
+			const uint32_t nlo = cnt ? bcast(r, (int)cnt - 1) + 1u : lo;
+			const uint32_t nhi = cnt < 64u ? bcast(r, (int)cnt) : hi;
+			lo = nlo;
+			hi = nhi;
+		}
+		const uint32_t m = hi - lo; // lanes 0 .. m+1 take ranks lo-1 .. hi
+		const bool on = lane < m + 2u && !(lo == 0 && lane == 0) && lo + lane - 1u < R.n;
+		const uint32_t rank = on ? lo + lane - 1u : 0u;
+		const uint32_t sa = lg16((const uint8_t *)(R.SAX + rank)).x;
+		uint32_t len, less;
+		lanes_compare(Q, n, R.S, sa, on, s_end, &len, &less);
+		const uint32_t cnt = (uint32_t)__popcll(__ballot(on && lane >= 1u && lane <= m && less != 0));
+		const uint32_t ins = lo + cnt;
+		const uint32_t lp = ins > 0 ? bcast(len, (int)cnt) : 0u, pp = bcast(sa, (int)cnt);
+		const uint32_t lsu = ins < R.n ? bcast(len, (int)cnt + 1) : 0u, ps = bcast(sa, (int)cnt + 1);
+		const bool pbest = lp > lsu;
+		const uint32_t lmax = pbest ? lp : lsu;
+		const bool cand = lp != lsu && lmax >= R.threshold;
+		uint32_t l = 0;
+		if (cand) l = pbest ? R.LCP[ins - 1] : R.LCP[ins + 1];
+		r_pos = pbest ? pp : ps;
+		r_len = lmax;
+		r_acc = cand && l < lmax;
+	}
+	if ((int)lane == leader) ln.finish(r_pos, r_len, r_acc);
+}
+
+// the long tail of one comparison (lean_ext handed it over at e_pos bases)
+static __device__ void coop_ext(LeanLane &ln, int leader, const PhaseA &A, const RefIndex &R, const uint8_t *s_end)
+{
+	const uint32_t qw0 = bcast(ln.qw0, leader), q = bcast(ln.q, leader), qlen = bcast(ln.qlen, leader);
+	const uint32_t e_p = bcast(ln.e_p, leader), e_pos = bcast(ln.e_pos, leader);
+	const uint8_t *Q = A.qbase + ((uint64_t)qw0 << 4) + q;
+	uint32_t len, less;
+	wave_compare(Q, R.S + e_p, e_pos & ~15u, qlen - q, s_end, &len, &less);
+	if ((int)lane64() == leader) lean_deliver(ln, R, len, less);
+}
+
+struct LeanAlloc {
+	const PhaseA *A;
+	__device__ uint32_t operator()() const
+	{
+		const uint32_t b = atomicAdd(A->pool_next, 1u);
+		return b < A->pool_blocks ? b : NO_BLOCK;
+	}
+};
+
+// MODE 0: speculative chunk chains.  MODE 1: bridges.  Persistent lanes with dynamic work fetch.
+template <int MODE> __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, LeanIndex X)
+{
+	typename std::conditional<MODE == 0, LeanSpec, LeanBridge>::type L;
+	LeanLane &ln = L.ln;
+	// a lane's ring, dword-major so that lane l always hits LDS bank l
+	__shared__ uint32_t ring[LEAN_RING_WORDS][256];
+	const uint32_t tid = threadIdx.x;
+	const uint8_t *s_end = R.S + R.n + 64;
+	const uint8_t *const slot_b = (const uint8_t *)R.SLOT, *const sax_b = (const uint8_t *)R.SAX,
+						 *const q2_b = (const uint8_t *)X.Q2, *const s2_b = (const uint8_t *)X.S2;
+	bool active = false, done = false;
+	LeanAlloc alloc = {&A};
+	ln.fin = false;
+	ln.ph = LP_STEP;
+#ifdef PHY_LEAN_TIMING
+	unsigned long long tm[6] = {0, 0, 0, 0, 0, 0}, t_prev = clock64();
+#define LEAN_TICK(i)                                                                                                    \
+	{                                                                                                                   \
+		__builtin_amdgcn_s_waitcnt(0);                                                                                  \
+		const unsigned long long t_now = clock64();                                                                     \
+		tm[i] += t_now - t_prev;                                                                                        \
+		t_prev = t_now;                                                                                                 \
+	}
+#else
+#define LEAN_TICK(i)
+#endif
+
+	for (;;) {
+		LEAN_TICK(4)
+		// finish the previous step, start the next one or the next chunk
+		if (active && ln.fin) {
+			if constexpr (MODE == 0) L.step_done(A);
+			else L.step_done(A, alloc);
+			ln.fin = false;
+		}
+		if (active && ln.ph == LP_STEP) {
+			if constexpr (MODE == 0) active = L.begin_step(A, X);
+			else active = L.begin_step(A, X, R);
+		}
+		if (!active && !done) {
+			const uint32_t it = atomicAdd(&A.fetch[MODE], 1u);
+			done = it >= A.nchunks;
+			if (!done) {
+				L.start(A, X, A.items[it]);
+				if constexpr (MODE == 0) active = L.begin_step(A, X);
+				else active = L.begin_step(A, X, R);
+			}
+		}
+		if (__all(done && !active)) break;
+		LEAN_TICK(0)
+
+		// which phase is the lane in this trip; a STEP needs its window from the ring
+		uint32_t ph = active ? ln.ph : (uint32_t)LP_SLOW + 8u;
+		if (active && ph == LP_STEP) {
+			ph = lean_step_phase(ln, X);
+			ln.ph = ph;
+			if (ph == LP_STEP) {
+				const uint32_t i0 = (ln.q >> 4) - ln.wb;
+				ln.qcode = code_window(ring[i0][tid], ring[i0 + 1][tid], ln.q & 15u);
+			}
+		}
+		// one batch of loads for every phase
+		const uint8_t *pA = s2_b, *pB = s2_b, *pY = s2_b;
+		if (ph == LP_STEP || ph == LP_SEARCH) {
+			pA = slot_b + (uint64_t)(ln.qcode >> (2u * (16u - R.k))) * 64u;
+			pB = pA + 32;
+			if (ph == LP_STEP && ln.lucky_ok(R)) pY = s2_b + (uint64_t)((ln.ls + (ln.q - ln.lq)) >> 4) * 4u;
+		} else if (ph == LP_EXT) {
+			const uint32_t e0 = ln.e_pos - ((ln.q + ln.e_pos) & 15u);
+			pA = q2_b + ((uint64_t)ln.qw0 + ((ln.q + e0) >> 4)) * 4u;
+			pB = s2_b + (uint64_t)((ln.e_p + e0) >> 4) * 4u;
+			pY = pB + 32;
+		} else if (ph == LP_SCAN) {
+			pA = sax_b + (uint64_t)ln.s_rank * 16u;
+			pB = pA + 32;
+		} else if (ph == LP_REFILL) {
+			pA = q2_b + ((uint64_t)ln.qw0 + (ln.q >> 4)) * 4u;
+			pB = pA + 32;
+		}
+		LEAN_TICK(1)
+		uint32_t d[16], y[2];
+		{
+			const U4 x0 = lg16(pA), x1 = lg16(pA + 16), x2 = lg16(pB), x3 = lg16(pB + 16);
+			const U2 yy = lg8(pY);
+			y[0] = yy.x, y[1] = yy.y;
+			d[0] = x0.x, d[1] = x0.y, d[2] = x0.z, d[3] = x0.w;
+			d[4] = x1.x, d[5] = x1.y, d[6] = x1.z, d[7] = x1.w;
+			d[8] = x2.x, d[9] = x2.y, d[10] = x2.z, d[11] = x2.w;
+			d[12] = x3.x, d[13] = x3.y, d[14] = x3.z, d[15] = x3.w;
+		}
+		LEAN_TICK(2)
+		// digest
+		if (ph == LP_STEP) {
+			lean_step(ln, R, X, d, y[0], y[1]);
+		} else if (ph == LP_SEARCH) {
+			lean_search(ln, R, d);
+		} else if (ph == LP_EXT) {
+			uint32_t sw[9];
+#pragma unroll
+			for (int i = 0; i < 8; i++) {
+				sw[i] = d[8 + i];
+				ring[i][tid] = d[i]; // the query words double as the ring's new content
+			}
+			sw[8] = y[0];
+			ln.wb = (ln.q + (ln.e_pos - ((ln.q + ln.e_pos) & 15u))) >> 4;
+			ln.wn = 8;
+			lean_ext(ln, R, X, d, sw);
+		} else if (ph == LP_SCAN) {
+			lean_scan(ln, R, U4{d[0], d[1], d[2], d[3]}, U4{d[4], d[5], d[6], d[7]}, U4{d[8], d[9], d[10], d[11]},
+					  U4{d[12], d[13], d[14], d[15]});
+		} else if (ph == LP_REFILL) {
+#pragma unroll
+			for (int i = 0; i < 16; i++) ring[i][tid] = d[i];
+			ln.wb = ln.q >> 4;
+			ln.wn = 16;
+			ln.ph = LP_STEP;
+		}
+		LEAN_TICK(3)
+		// what the packed path could not answer: the wavefront resolves it, one lane at a time
+		uint64_t slow = __ballot(active && (ln.ph == LP_SLOW || ln.ph == LP_SLOWEXT));
+		while (slow) {
+			const int leader = __ffsll((unsigned long long)slow) - 1;
+			const uint32_t lph = bcast(ln.ph, leader);
+#ifdef PHY_LEAN_TIMING
+			tm[5] += lph == LP_SLOW ? 1ull : (1ull << 32);
+#endif
+			if (lph == LP_SLOW) coop_resolve(ln, leader, A, R, s_end);
+			else coop_ext(ln, leader, A, R, s_end);
+			slow &= slow - 1;
+		}
+	}
+#ifdef PHY_LEAN_TIMING
+	if (X.dbg && lane64() == 0) {
+		for (int i = 0; i < 6; i++) atomicAdd(&X.dbg[MODE * 8 + i], tm[i]);
+		atomicAdd(&X.dbg[MODE * 8 + 6], 1ull);
+	}
+#endif
+}
+
+// ───────────────────────── packed tables ─────────────────────────
+
+// 16 bytes -> one dword of 2-bit codes (first byte in bits 31..30); non-ACGT -> 0
+__global__ __launch_bounds__(256) void pack2_kernel(const uint8_t *__restrict__ src, uint64_t words, uint32_t *__restrict__ dst)
+{
+	const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= words) return;
+	const U4 v = load16(src + 16 * w);
+	uint32_t c = 0;
+#pragma unroll
+	for (uint32_t i = 0; i < 16; i++) {
+		const uint32_t code = nuc_code((uint8_t)byte_at(v, i));
+		c |= (code < 4u ? code : 0u) << (30u - 2u * i);
+	}
+	dst[w] = c;
+}
+
+// Non-ACGT positions of sequences (genomes, or S as one sequence), sorted per sequence.
+// A block takes one segment of BAD_SEG bytes of one sequence.  Pass 1 (out == nullptr) counts
+// per segment; pass 2 writes the segment's positions, in order, from seg_off[segment].
+static const uint32_t BAD_SEG = 1u << 20;
+__global__ __launch_bounds__(256) void bad_positions_kernel(const uint8_t *__restrict__ base, const uint64_t *__restrict__ off,
+															 const uint32_t *__restrict__ len, const uint32_t *__restrict__ seg_seq,
+															 const uint32_t *__restrict__ seg_first, uint32_t *__restrict__ seg_cnt,
+															 const uint32_t *__restrict__ seg_off, uint32_t *__restrict__ out)
+{
+	__shared__ uint32_t wsum[4];
+	__shared__ uint32_t carry;
+	const uint32_t sg = blockIdx.x, j = seg_seq[sg];
+	const uint32_t p0 = (sg - seg_first[j]) * BAD_SEG;
+	const uint32_t n = len[j], p1 = p0 + BAD_SEG < n ? p0 + BAD_SEG : n;
+	const uint8_t *s = base + off[j];
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	if (threadIdx.x == 0) carry = out ? seg_off[sg] : 0u;
+	__syncthreads();
+	for (uint32_t t0 = p0; t0 < p1; t0 += 4096u) {
+		const uint32_t p = t0 + threadIdx.x * 16u;
+		uint32_t mask = 0;
+		if (p < p1) {
+			const U4 v = load16(s + p);
+			uint32_t b0, b1, b2, b3;
+			(void)code4(v.x, &b0);
+			(void)code4(v.y, &b1);
+			(void)code4(v.z, &b2);
+			(void)code4(v.w, &b3);
+			// 0x80 per bad byte -> one bit per byte
+			mask = ((b0 >> 7) * 0x00204081u >> 21 & 0xfu) | (((b1 >> 7) * 0x00204081u >> 21 & 0xfu) << 4) |
+				   (((b2 >> 7) * 0x00204081u >> 21 & 0xfu) << 8) | (((b3 >> 7) * 0x00204081u >> 21 & 0xfu) << 12);
+			if (p + 16 > p1) mask &= (1u << (p1 - p)) - 1u;
+		}
+		if (!__syncthreads_or(mask != 0)) continue;
+		const uint32_t c = (uint32_t)__popc(mask);
+		uint32_t incl = c;
+#pragma unroll
+		for (int dd = 1; dd < 64; dd <<= 1) {
+			const uint32_t t = (uint32_t)__shfl_up((int)incl, dd, 64);
+			if ((int)lane >= dd) incl += t;
+		}
+		if (lane == 63) wsum[wave] = incl;
+		__syncthreads();
+		uint32_t o = carry + incl - c;
+		for (uint32_t w2 = 0; w2 < wave; w2++) o += wsum[w2];
+		if (out) {
+			uint32_t mm = mask;
+			while (mm) {
+				const uint32_t b = (uint32_t)__ffs((int)mm) - 1u;
+				out[o++] = p + b;
+				mm &= mm - 1u;
+			}
+		}
+		__syncthreads();
+		if (threadIdx.x == 255) carry = o + (out ? 0u : c); // pass 2: o already advanced past this thread's positions
+		__syncthreads();
+	}
+	if (!out && threadIdx.x == 0) seg_cnt[sg] = carry;
+}
+
+// ───────────────────────── launch wrappers ─────────────────────────
+
+void launch_pack2(const uint8_t *src, uint64_t bytes, uint32_t *dst, hipStream_t st)
+{
+	const uint64_t words = bytes / 16;
+	if (!words) return;
+	hipLaunchKernelGGL(pack2_kernel, dim3((uint32_t)((words + 255) / 256)), dim3(256), 0, st, src, words, dst);
+}
+uint32_t bad_segment_bytes() { return BAD_SEG; }
+void launch_bad_positions(const uint8_t *base, const uint64_t *off, const uint32_t *len, const uint32_t *seg_seq,
+						  const uint32_t *seg_first, uint32_t nseg, uint32_t *seg_cnt, const uint32_t *seg_off, uint32_t *out,
+						  hipStream_t st)
+{
+	if (!nseg) return;
+	hipLaunchKernelGGL(bad_positions_kernel, dim3(nseg), dim3(256), 0, st, base, off, len, seg_seq, seg_first, seg_cnt, seg_off, out);
+}
+
+static int lean_resident(const void *fn, int n_cu)
+{
+	int per_cu = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+	return per_cu * n_cu;
+}
+int lean_spec_resident_blocks(int n_cu)
+{
+	static int cached_cu = 0, cached = 0;
+	if (cached_cu != n_cu) {
+		cached = lean_resident((const void *)lean_chain_kernel<0>, n_cu);
+		cached_cu = n_cu;
+	}
+	return cached;
+}
+void launch_lean_spec(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st)
+{
+	int blocks = lean_spec_resident_blocks(n_cu);
+	const int need = (int)((A.nchunks + 255) / 256);
+	if (need < blocks) blocks = need > 0 ? need : 1;
+	hipLaunchKernelGGL(lean_chain_kernel<0>, dim3(blocks), dim3(256), 0, st, A, R, X);
+}
+void launch_lean_bridge(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st)
+{
+	int blocks = lean_resident((const void *)lean_chain_kernel<1>, n_cu);
+	const int need = (int)((A.nchunks + 255) / 256);
+	if (need < blocks) blocks = need > 0 ? need : 1;
+	hipLaunchKernelGGL(lean_chain_kernel<1>, dim3(blocks), dim3(256), 0, st, A, R, X);
+}
+
+} // namespace phy

@@ -200,6 +200,13 @@ struct phylo_ctx {
 	DevBuf<U4> d_SAX, d_SLOT;
 	DevBuf<uint32_t> d_SA;
 	DevBuf<uint32_t> d_LCP, d_T;
+	// 2-bit packed companions for the lean chain kernels (lean_core.h): genomes and S, 16 bases per
+	// dword, and the sorted positions of their non-ACGT bytes
+	DevBuf<uint32_t> d_Q2, d_QBAD, d_qbad_off, d_S2, d_SBAD, d_badscr;
+	DevBuf<uint64_t> d_badoff;
+	uint32_t nsb = 0, sb_first = 0;
+	int anchor_kernel = 1; // option "anchor_kernel": 1 lean 2-bit chains (default), 0 the general byte-wise chains
+	int lean_force_slow = 0;
 
 	// phase A scratch
 	DevBuf<uint64_t> a_qoff;
@@ -400,6 +407,13 @@ void phylo_ctx_destroy(phylo_ctx *c)
 	c->d_SA.release();
 	c->d_LCP.release();
 	c->d_T.release();
+	c->d_Q2.release();
+	c->d_QBAD.release();
+	c->d_qbad_off.release();
+	c->d_S2.release();
+	c->d_SBAD.release();
+	c->d_badscr.release();
+	c->d_badoff.release();
 	c->a_qoff.release();
 	c->a_qlen.release();
 	c->a_qchunk0.release();
@@ -459,6 +473,12 @@ int phylo_set_option(phylo_ctx *c, const char *key, long value)
 		if (value < 0 || value > 14) return c->fail("kmer must be in 0..14");
 		c->opt_kmer = (uint32_t)value;
 		c->have_ref = false;
+	} else if (k == "anchor_kernel") {
+		if (value != 0 && value != 1) return c->fail("anchor_kernel must be 1 (lean 2-bit chains) or 0 (general byte-wise chains)");
+		c->anchor_kernel = (int)value;
+		c->plan_valid = false;
+	} else if (k == "lean_force_slow") {
+		c->lean_force_slow = value != 0;
 	} else if (k == "profile") {
 		c->profile = value != 0;
 	} else if (k == "filter") {
@@ -510,6 +530,73 @@ size_t phylo_stat_keys(phylo_ctx *c, char *buf, size_t cap)
 
 // ───────────────────────── genomes ─────────────────────────
 
+// Sorted non-ACGT positions of `nseq` sequences (base + off[j], len[j] bytes; device arrays) into
+// `out` (grown as needed), list j at [list_off[j], list_off[j+1]); `extra` more slots are left
+// after the last list.  Two passes of bad_positions_kernel over segments of 1 MiB.
+static int bad_lists(phylo_ctx *c, const uint8_t *base, const uint64_t *d_off, const uint32_t *d_len,
+					 const std::vector<uint64_t> &len, DevBuf<uint32_t> &out, std::vector<uint32_t> &list_off, size_t extra)
+{
+	const size_t nseq = len.size();
+	const uint64_t SEG = bad_segment_bytes();
+	std::vector<uint32_t> seg_seq, seg_first(nseq + 1);
+	for (size_t j = 0; j < nseq; j++) {
+		seg_first[j] = (uint32_t)seg_seq.size();
+		const uint64_t ns = std::max<uint64_t>(1, (len[j] + SEG - 1) / SEG);
+		for (uint64_t t = 0; t < ns; t++) seg_seq.push_back((uint32_t)j);
+	}
+	seg_first[nseq] = (uint32_t)seg_seq.size();
+	const size_t nseg = seg_seq.size();
+	list_off.assign(nseq + 1, 0);
+	if (!nseg) return c->d_badscr.ensure(4) == hipSuccess && out.ensure(extra + 1) == hipSuccess ? 0 : c->fail("out of device memory");
+	// scratch: seg_seq | seg_first | seg_cnt | seg_off
+	HIPOK(c, c->d_badscr.ensure(3 * nseg + nseq + 1));
+	uint32_t *d_seq = c->d_badscr.p, *d_first = d_seq + nseg, *d_cnt = d_first + nseq + 1, *d_soff = d_cnt + nseg;
+	hipStream_t st = c->stream;
+	HIPOK(c, hipMemcpyAsync(d_seq, seg_seq.data(), nseg * 4, hipMemcpyHostToDevice, st));
+	HIPOK(c, hipMemcpyAsync(d_first, seg_first.data(), (nseq + 1) * 4, hipMemcpyHostToDevice, st));
+	launch_bad_positions(base, d_off, d_len, d_seq, d_first, (uint32_t)nseg, d_cnt, nullptr, nullptr, st);
+	std::vector<uint32_t> cnt(nseg), soff(nseg + 1, 0);
+	HIPOK(c, hipMemcpyAsync(cnt.data(), d_cnt, nseg * 4, hipMemcpyDeviceToHost, st));
+	HIPOK(c, hipStreamSynchronize(st));
+	uint64_t tot = 0;
+	for (size_t g = 0; g < nseg; g++) {
+		soff[g] = (uint32_t)tot;
+		tot += cnt[g];
+	}
+	if (tot + extra >= 0xffffffffull) return c->fail("more than 2^32 non-ACGT positions");
+	soff[nseg] = (uint32_t)tot;
+	for (size_t j = 0; j <= nseq; j++) list_off[j] = soff[seg_first[j]];
+	HIPOK(c, out.ensure(tot + extra + 1));
+	if (tot) {
+		HIPOK(c, hipMemcpyAsync(d_soff, soff.data(), nseg * 4, hipMemcpyHostToDevice, st));
+		launch_bad_positions(base, d_off, d_len, d_seq, d_first, (uint32_t)nseg, d_cnt, d_soff, out.p, st);
+	}
+	HIPOK(c, hipGetLastError());
+	HIPOK(c, hipStreamSynchronize(st));
+	return 0;
+}
+
+// Q2 + QBAD of the installed genomes (d_goff / d_glen are in place)
+static int pack_genomes(phylo_ctx *c)
+{
+	const size_t n = c->n;
+	double t0 = now_ms();
+	uint64_t extent = 64;
+	for (size_t j = 0; j < n; j++) extent = std::max<uint64_t>(extent, c->goff[j] + (c->glen[j] + 63) / 64 * 64 + 64);
+	if (extent / 16 + 64 >= 0xffffffffull) return c->fail("genome buffer too large for 32-bit word offsets");
+	const size_t words = (size_t)(extent / 16);
+	HIPOK(c, c->d_Q2.ensure(words + 64));
+	HIPOK(c, hipMemsetAsync(c->d_Q2.p, 0, (words + 64) * 4, c->stream));
+	if (n) launch_pack2(c->d_genomes, (uint64_t)words * 16, c->d_Q2.p, c->stream);
+	std::vector<uint32_t> off;
+	if (bad_lists(c, c->d_genomes, c->d_goff.p, c->d_glen.p, c->glen, c->d_QBAD, off, 1)) return 1;
+	HIPOK(c, c->d_qbad_off.ensure(n + 2));
+	HIPOK(c, hipMemcpy(c->d_qbad_off.p, off.data(), (n + 1) * 4, hipMemcpyHostToDevice));
+	c->stats["ms:pack_genomes"] += now_ms() - t0;
+	c->stats["count:genome_non_acgt"] = off[n];
+	return 0;
+}
+
 static int install_layout(phylo_ctx *c)
 {
 	size_t n = c->n;
@@ -529,7 +616,7 @@ static int install_layout(phylo_ctx *c)
 	c->homs_staged = false;
 	c->att_homs = nullptr; // lists that only lived in an attached buffer are gone
 	c->host_stale.clear();
-	return 0;
+	return pack_genomes(c);
 }
 
 int phylo_set_genomes(phylo_ctx *c, size_t n, const char *const *seq, const size_t *len)
@@ -563,9 +650,14 @@ int phylo_set_genomes_device(phylo_ctx *c, size_t n, const void *dev_base, const
 	if (!c) return 1;
 	if (n && (!dev_base || !offsets || !lens)) return c->fail("null genome arrays");
 	HIPOK(c, hipSetDevice(c->device));
-	for (size_t j = 0; j < n; j++)
+	for (size_t j = 0; j < n; j++) {
 		if (offsets[j] % 64 || offsets[j] < 64)
 			return c->fail("genome %zu: device offset must be a multiple of 64 and >= 64 (kernels read up to 32 bytes before a genome)", j);
+		// ascending and apart: phase A clears and addresses its visited bitmap by buffer offset, genome after genome
+		if (j && offsets[j] < offsets[j - 1] + (lens[j - 1] + 63) / 64 * 64 + 64)
+			return c->fail("genome %zu: device offsets must ascend, each genome followed by at least 64 bytes of zero padding "
+						   "(rounded up to a multiple of 64) before the next one starts", j);
+	}
 	c->n = n;
 	c->goff.assign(offsets, offsets + n);
 	c->glen.assign(lens, lens + n);
@@ -656,6 +748,26 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 	}
 	HIPOK(c, hipGetLastError());
 	HIPOK(c, hipStreamSynchronize(st));
+	{ // the lean chain's view of S: 2-bit codes and the sorted non-ACGT positions, then n
+		const size_t swords = ((size_t)ns + 64) / 16; // S's buffer is ns + 64 bytes
+		HIPOK(c, c->d_S2.ensure(swords + 64));
+		HIPOK(c, hipMemsetAsync(c->d_S2.p, 0, (swords + 64) * 4, st));
+		launch_pack2(c->d_S.p, (uint64_t)swords * 16, c->d_S2.p, st);
+		HIPOK(c, c->d_badoff.ensure(2));
+		HIPOK(c, c->d_badscr.ensure(8));
+		const uint64_t zero = 0;
+		HIPOK(c, hipMemcpyAsync(c->d_badoff.p, &zero, 8, hipMemcpyHostToDevice, st));
+		DevBuf<uint32_t> lenbuf;
+		HIPOK(c, lenbuf.ensure(2));
+		HIPOK(c, hipMemcpyAsync(lenbuf.p, &ns, 4, hipMemcpyHostToDevice, st));
+		std::vector<uint32_t> off;
+		int rc = bad_lists(c, c->d_S.p, c->d_badoff.p, lenbuf.p, std::vector<uint64_t>{ns}, c->d_SBAD, off, 1);
+		lenbuf.release();
+		if (rc) return 1;
+		HIPOK(c, hipMemcpy(c->d_SBAD.p + off[1], &ns, 4, hipMemcpyHostToDevice)); // the end of S closes the list
+		c->nsb = off[1] + 1;
+		HIPOK(c, hipMemcpy(&c->sb_first, c->d_SBAD.p, 4, hipMemcpyDeviceToHost));
+	}
 	double t3 = now_ms();
 	c->ref_idx = ref_idx;
 	c->L = (uint32_t)L;
@@ -746,7 +858,8 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 			// speculative chunk compare to the end of the genome.
 			if (q_begin + j == c->ref_idx) qlen[j] = 0;
 		}
-		c->plan = plan_chunks(qlen, c->threshold, c->opt_chunk, (uint32_t)spec_resident_blocks(c->n_cu) * 256u, c->opt_chunk_tail);
+		const int resident = c->anchor_kernel ? lean_spec_resident_blocks(c->n_cu) : spec_resident_blocks(c->n_cu);
+		c->plan = plan_chunks(qlen, c->threshold, c->opt_chunk, (uint32_t)resident * 256u, c->opt_chunk_tail);
 		const ChunkPlan &P = c->plan;
 		if (!P.C) return c->fail("phase A: more than 2^32 anchor log slots");
 		// an emitted homology spans >= 2*threshold query positions
@@ -833,6 +946,15 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	A.pool_next = c->a_misc.p + 2;
 	A.error = c->a_misc.p + 3;
 	RefIndex R = {c->d_S.p, c->d_SAX.p, c->d_LCP.p, c->d_SLOT.p, c->ns, c->k, c->threshold};
+	LeanIndex X = {c->d_S2.p, c->d_SBAD.p, c->nsb, c->ns, c->sb_first, c->d_Q2.p, c->d_QBAD.p, c->d_qbad_off.p + q_begin,
+				   (uint32_t)c->lean_force_slow, nullptr};
+#ifdef PHY_LEAN_TIMING
+	static unsigned long long *dbg_buf = nullptr;
+	if (!dbg_buf) (void)hipMalloc((void **)&dbg_buf, 16 * 8);
+	(void)hipMemsetAsync(dbg_buf, 0, 16 * 8, st);
+	X.dbg = dbg_buf;
+#endif
+	const bool lean = c->anchor_kernel != 0;
 
 	double t1 = now_ms();
 	const bool dbg = getenv("PHY_DEBUG_SYNC") != nullptr; // name the kernel a hang is in
@@ -850,12 +972,14 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	if (nch) {
 		{
 			KernelSpan s(c, "anchor_spec");
-			launch_spec(A, R, c->n_cu, st);
+			if (lean) launch_lean_spec(A, R, X, c->n_cu, st);
+			else launch_spec(A, R, c->n_cu, st);
 		}
 		dbg_sync("anchor_spec");
 		{
 			KernelSpan s(c, "anchor_bridge");
-			launch_bridge(A, R, c->n_cu, st);
+			if (lean) launch_lean_bridge(A, R, X, c->n_cu, st);
+			else launch_bridge(A, R, c->n_cu, st);
 		}
 		dbg_sync("anchor_bridge");
 	}
@@ -864,6 +988,17 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 		launch_fold(A, (uint32_t)nq, c->L, c->threshold, c->a_raw.p, c->a_out_base.p, c->a_out_cap.p, c->a_out_cnt.p, st);
 	}
 	dbg_sync("anchor_fold");
+#ifdef PHY_LEAN_TIMING
+	{
+		unsigned long long h[16];
+		(void)hipStreamSynchronize(st);
+		(void)hipMemcpy(h, X.dbg, sizeof h, hipMemcpyDeviceToHost);
+		for (int m = 0; m < 2; m++)
+			fprintf(stderr, "[lean timing] mode %d waves %llu  Mcycles: bookkeeping %.1f  phase+address %.1f  loads %.1f  digest %.1f  slow %.1f; resolves %llu, long compares %llu\n",
+					m, h[m * 8 + 6], h[m * 8 + 0] / 1e6, h[m * 8 + 1] / 1e6, h[m * 8 + 2] / 1e6, h[m * 8 + 3] / 1e6, h[m * 8 + 4] / 1e6,
+					h[m * 8 + 5] & 0xffffffffull, h[m * 8 + 5] >> 32);
+	}
+#endif
 	HIPOK(c, hipGetLastError());
 	c->homs_staged = false;
 	c->eager_valid = false;
@@ -1698,45 +1833,74 @@ int phylo_seqcmp_batch(phylo_ctx *c, size_t n, const uint32_t *ga, const uint64_
 	return sync_stream(c);
 }
 
-// seqcmp / revseqcmp with the reference's signature (libs/seqcmp.h:14,
-// libs/revseqcmp.h:25): host buffers in, count out, computed on device 0.
-static size_t b0_call(const char *a, const char *b, size_t length, int rev)
-{
-	static phylo_ctx *ctx = nullptr;
-	if (!ctx && phylo_ctx_create(&ctx, 0)) {
-		fprintf(stderr, "phylonium_amd: %s\n", g_last_error.c_str());
-		abort(); // the reference signature has no error channel; never fall back to the CPU
-	}
-	if (length == 0) return 0;
-	const char *seqs[2] = {a, b};
-	size_t lens[2] = {length, length};
-	uint64_t total = 0;
-	if (phylo_set_genomes(ctx, 2, seqs, lens)) goto fail;
+// seqcmp / revseqcmp with the reference's signature and calling convention (libs/seqcmp.h:14-25,
+// libs/revseqcmp.h:25-33): pure, borrowing both host buffers, callable from many threads at once
+// (evo_model::account* runs inside an OpenMP team, src/evo_model.cxx:53-75).  Every calling thread
+// gets its own context — stream, scratch, nothing shared — created on its first call and released
+// when the thread ends.  The signature has no error channel and the library never aborts or falls
+// back to the CPU: a failed call returns SIZE_MAX, the message is in phylo_last_error(NULL) of that
+// thread and is printed to stderr once per thread.
+namespace {
+struct B0Thread {
+	phylo_ctx *ctx = nullptr;
+	DevBuf<uint8_t> buf;
+	bool complained = false;
+	~B0Thread()
 	{
-		// pieces of < 2^32 bytes
-		const uint64_t piece = 1ull << 30;
-		std::vector<uint32_t> ga, gb;
-		std::vector<uint64_t> oa, ob, ln, out;
-		std::vector<uint8_t> rv;
-		for (uint64_t o = 0; o < length; o += piece) {
-			uint64_t m = std::min<uint64_t>(piece, length - o);
-			ga.push_back(0);
-			gb.push_back(1);
-			oa.push_back(o);
-			ob.push_back(rev ? length - o - m : o);
-			ln.push_back(m);
-			rv.push_back((uint8_t)rev);
+		if (ctx) {
+			(void)hipSetDevice(ctx->device);
+			buf.release();
+			phylo_ctx_destroy(ctx);
 		}
-		out.resize(ga.size());
-		if (phylo_seqcmp_batch(ctx, ga.size(), ga.data(), oa.data(), gb.data(), ob.data(), ln.data(), rv.data(), out.data()))
-			goto fail;
-		for (uint64_t v : out) total += v;
 	}
-	return (size_t)total;
-fail:
-	fprintf(stderr, "phylonium_amd: %s\n", ctx->err.c_str());
-	abort();
+};
+thread_local B0Thread g_b0;
+
+size_t b0_fail(const char *what)
+{
+	if (what) g_last_error = what;
+	if (!g_b0.complained) {
+		fprintf(stderr, "phylonium_amd: seqcmp/revseqcmp: %s\n", g_last_error.c_str());
+		g_b0.complained = true;
+	}
+	return (size_t)-1;
 }
+
+size_t b0_call(const char *a, const char *b, size_t length, int rev)
+{
+	if (length == 0) return 0;
+	if (!a || !b) return b0_fail("null buffer");
+	B0Thread &t = g_b0;
+	if (!t.ctx && phylo_ctx_create(&t.ctx, 0)) return b0_fail(nullptr);
+	phylo_ctx *c = t.ctx;
+	if (hipSetDevice(c->device) != hipSuccess) return b0_fail("hipSetDevice failed");
+	// both strings into this thread's scratch, 64-byte aligned starts; pieces of < 2^32 bytes
+	const uint64_t stride = (length + 63) / 64 * 64 + 64;
+	if (t.buf.ensure(2 * stride + 64) != hipSuccess) return b0_fail("out of device memory");
+	const uint64_t piece = 1ull << 30;
+	std::vector<Segment> segs;
+	for (uint64_t o = 0; o < length; o += piece) {
+		const uint64_t m = std::min<uint64_t>(piece, length - o);
+		segs.push_back(Segment{o, stride + (rev ? length - o - m : o), (uint32_t)m, rev ? 1u : 0u});
+	}
+	std::vector<uint64_t> out(segs.size());
+	if (c->s_segs.ensure(segs.size()) != hipSuccess || c->s_out.ensure(segs.size()) != hipSuccess) return b0_fail("out of device memory");
+	hipStream_t st = c->stream;
+	if (hipMemcpyAsync(t.buf.p, a, length, hipMemcpyHostToDevice, st) != hipSuccess ||
+		hipMemcpyAsync(t.buf.p + stride, b, length, hipMemcpyHostToDevice, st) != hipSuccess ||
+		hipMemcpyAsync(c->s_segs.p, segs.data(), segs.size() * sizeof(Segment), hipMemcpyHostToDevice, st) != hipSuccess)
+		return b0_fail("upload failed");
+	const int blocks = std::max<int>(1, std::min<int>(c->n_cu * 8, (int)((length / 4096) + 1)));
+	launch_seqcmp_batch(t.buf.p, c->s_segs.p, (uint32_t)segs.size(), c->s_out.p, blocks, st);
+	if (hipGetLastError() != hipSuccess ||
+		hipMemcpyAsync(out.data(), c->s_out.p, segs.size() * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+		hipStreamSynchronize(st) != hipSuccess)
+		return b0_fail("kernel launch or read-back failed");
+	uint64_t total = 0;
+	for (uint64_t v : out) total += v;
+	return (size_t)total;
+}
+} // namespace
 
 size_t phylo_seqcmp(const char *begin, const char *other, size_t length) { return b0_call(begin, other, length, 0); }
 size_t phylo_revseqcmp(const char *begin, const char *other, size_t length) { return b0_call(begin, other, length, 1); }

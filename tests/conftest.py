@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+# torch brings its own copy of the HIP runtime; it has to be the one the process loads first (the
+# product library then binds to it by SONAME), or a later torch.cuda call finds "no HIP GPUs"
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    pass
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 for p in (ROOT, HERE):

@@ -3,10 +3,12 @@
 // phase-A pipeline (speculative chunks → bridges → walk + fold → sort + filter)
 // serially on the CPU, so the algorithm can be checked against the oracle in
 // the GPU-less build container.  The product library never links this file.
+#define LEAN_COUNT_WHY 1
 #include <cstdio>
 #include <vector>
 
 #include "../../phylonium_amd/csrc/hostlogic.hpp"
+#include "../../phylonium_amd/csrc/lean_core.h"
 
 using namespace phy;
 
@@ -14,7 +16,7 @@ struct EmulOut {
 	std::vector<std::vector<RawHom>> raw;
 	std::vector<std::vector<phylo_homology>> filtered;
 	uint32_t threshold, k, C, nchunks;
-	uint64_t steps_spec = 0, steps_bridge = 0, cmp_calls = 0, pool_used = 0, rounds = 0;
+	uint64_t steps_spec = 0, steps_bridge = 0, cmp_calls = 0, pool_used = 0, rounds = 0, slow_steps = 0;
 	int error = 0;
 };
 
@@ -50,10 +52,43 @@ static void run_lane(Lane &ln, const RefIndex &R, Begin begin, Done done, uint64
 	}
 }
 
+// the lean (2-bit) chain of lean_core.h, one lane at a time
+template <class Lane, class Begin, class Done>
+static void run_lean_lane(Lane &L, const uint8_t *qbase, const RefIndex &R, const LeanIndex &X, const LeanTables &T,
+						  Begin begin, Done done, uint64_t *steps, uint64_t *trips, uint64_t *slow)
+{
+	uint32_t ring[LEAN_RING_WORDS] = {0};
+	uint64_t lane_trips = 0;
+	for (;;) {
+		if (L.ln.fin) {
+			done();
+			(*steps)++;
+			L.ln.fin = false;
+		}
+		if (L.ln.ph == LP_STEP && !begin()) break;
+		lean_trip_cpu(L.ln, ring, qbase, R, X, T, slow);
+		(*trips)++;
+		if (++lane_trips > 50000000ull) {
+			fprintf(stderr, "emul: lean lane stuck: ph %u q %u qlen %u\n", L.ln.ph, L.ln.q, L.ln.qlen);
+			abort();
+		}
+	}
+}
+
 extern "C" {
 
+// mode: bit 0 the lean chain (lean_core.h) instead of the general one, bit 1 every step through its slow resolver
+void *emul_run2(size_t n, const char *const *seq, const size_t *len, size_t ref_idx, size_t threshold,
+				unsigned forced_C, unsigned forced_k, unsigned mode);
 void *emul_run(size_t n, const char *const *seq, const size_t *len, size_t ref_idx, size_t threshold,
 			   unsigned forced_C, unsigned forced_k)
+{
+	const char *m = getenv("EMUL_MODE");
+	return emul_run2(n, seq, len, ref_idx, threshold, forced_C, forced_k, m ? (unsigned)atoi(m) : 0u);
+}
+
+void *emul_run2(size_t n, const char *const *seq, const size_t *len, size_t ref_idx, size_t threshold,
+				unsigned forced_C, unsigned forced_k, unsigned mode)
 {
 	EmulOut *E = new EmulOut();
 	// reference index
@@ -134,8 +169,50 @@ void *emul_run(size_t n, const char *const *seq, const size_t *len, size_t ref_i
 	A.fetch = fetch;
 
 	if (chatty) fprintf(stderr, "emul: index done (k %u), %u chunks of %u\n", k, P.nchunks, P.C);
+	// the lean chain's packed tables (the product builds them on the device: lean_kernels.hip)
+	const bool lean = (mode & 1u) != 0;
+	std::vector<uint32_t> S2, SBAD, Q2, QBAD, qbad_off;
+	LeanIndex X = {};
+	LeanTables LT = {};
+	if (lean) {
+		S2.resize((size_t)ns / 16 + 16);
+		lean_pack_host(S.data(), ns, S2.data(), S2.size());
+		for (uint32_t i = 0; i < ns; i++)
+			if (nuc_code(S[i]) > 3) SBAD.push_back(i);
+		SBAD.push_back(ns);
+		Q2.resize((size_t)tot / 16 + 16);
+		lean_pack_host(qbase.data(), tot, Q2.data(), Q2.size());
+		qbad_off.assign(n + 1, 0);
+		for (size_t j = 0; j < n; j++) {
+			qbad_off[j] = (uint32_t)QBAD.size();
+			for (uint32_t i = 0; i < qlen[j]; i++)
+				if (nuc_code(qbase[qoff[j] + i]) > 3) QBAD.push_back(i);
+		}
+		qbad_off[n] = (uint32_t)QBAD.size();
+		QBAD.push_back(0);
+		X.S2 = S2.data();
+		X.SBAD = SBAD.data();
+		X.nsb = (uint32_t)SBAD.size();
+		X.sb_end = ns;
+		X.sb_first = SBAD[0];
+		X.Q2 = Q2.data();
+		X.QBAD = QBAD.data();
+		X.qbad_off = qbad_off.data();
+		X.force_slow = (mode & 2u) ? 1u : 0u;
+		LT.slot = (const uint8_t *)SLOT.data();
+		LT.sax = (const uint8_t *)SAX.data();
+		LT.q2 = (const uint8_t *)Q2.data();
+		LT.s2 = (const uint8_t *)S2.data();
+	}
 	// K1: speculative chains
 	for (uint32_t it = 0; it < P.nchunks; it++) {
+		if (lean) {
+			LeanSpec ln;
+			ln.start(A, X, P.items[it]);
+			run_lean_lane(ln, qbase.data(), R, X, LT, [&] { return ln.begin_step(A, X); }, [&] { ln.step_done(A); },
+						  &E->steps_spec, &E->rounds, &E->slow_steps);
+			continue;
+		}
 		SpecLane ln;
 		ln.start(A, P.items[it]);
 		run_lane(ln, R, [&] { return ln.begin_step(A); }, [&] { ln.step_done(A); }, &E->steps_spec, &E->rounds,
@@ -149,9 +226,17 @@ void *emul_run(size_t n, const char *const *seq, const size_t *len, size_t ref_i
 	std::vector<uint32_t> bridge_steps; // EMUL_BRIDGE_STATS: how long the dependent chains of the bridge kernel are
 	const bool bstats = getenv("EMUL_BRIDGE_STATS") != nullptr;
 	for (uint32_t it = 0; it < P.nchunks; it++) {
+		const uint64_t before = E->steps_bridge;
+		if (lean) {
+			LeanBridge ln;
+			ln.start(A, X, P.items[it]);
+			run_lean_lane(ln, qbase.data(), R, X, LT, [&] { return ln.begin_step(A, X, R); }, [&] { ln.step_done(A, alloc); },
+						  &E->steps_bridge, &E->rounds, &E->slow_steps);
+			if (bstats) bridge_steps.push_back((uint32_t)(E->steps_bridge - before));
+			continue;
+		}
 		BridgeLane ln;
 		ln.start(A, P.items[it]);
-		const uint64_t before = E->steps_bridge;
 		run_lane(ln, R, [&] { return ln.begin_step(A, R); }, [&] { ln.step_done(A, alloc); }, &E->steps_bridge,
 				 &E->rounds, &E->cmp_calls);
 		if (bstats) bridge_steps.push_back((uint32_t)(E->steps_bridge - before));
@@ -228,6 +313,12 @@ void emul_get_raw(void *e, size_t j, uint32_t *out)
 		out[3 * i + 1] = E->raw[j][i].iq;
 		out[3 * i + 2] = E->raw[j][i].len;
 	}
+}
+uint64_t emul_slow_steps(void *e) { return ((EmulOut *)e)->slow_steps; }
+// how often each reason sent a step to the slow resolver since the library was loaded (lean_core.h: LeanSlowWhy)
+void emul_slow_why(unsigned long long *out)
+{
+	for (unsigned i = 0; i < SW_COUNT; i++) out[i] = g_lean_why[i];
 }
 void emul_info(void *e, uint64_t out[8])
 {

@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _DIR = os.path.join(_HERE, "emul")
 _SRC = [os.path.join(_DIR, "emul.cpp"),
         os.path.join(_HERE, "..", "phylonium_amd", "csrc", "anchor_core.h"),
+        os.path.join(_HERE, "..", "phylonium_amd", "csrc", "lean_core.h"),
         os.path.join(_HERE, "..", "phylonium_amd", "csrc", "hostlogic.hpp"),
         os.path.join(_HERE, "..", "include", "phylonium_amd.h")]
 _LIB = None
@@ -28,6 +29,10 @@ def lib():
     L = C.CDLL(so)
     L.emul_run.restype = C.c_void_p
     L.emul_run.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint, C.c_uint]
+    L.emul_run2.restype = C.c_void_p
+    L.emul_run2.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint, C.c_uint, C.c_uint]
+    L.emul_slow_steps.restype = C.c_uint64
+    L.emul_slow_steps.argtypes = [C.c_void_p]
     L.emul_free.argtypes = [C.c_void_p]
     L.emul_count.restype = C.c_size_t
     L.emul_count.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
@@ -45,13 +50,16 @@ def lib():
 
 
 class EmulRun:
-    def __init__(self, genomes, ref_idx, threshold=0, chunk=0, kmer=0):
+    def __init__(self, genomes, ref_idx, threshold=0, chunk=0, kmer=0, mode=0):
+        """mode: 0 the general chain (anchor_core.h), 1 the lean 2-bit chain (lean_core.h), 3 the lean chain with
+        every step through its slow resolver."""
         self.n = len(genomes)
         self._a = [np.frombuffer(bytes(g), np.uint8) if isinstance(g, (bytes, bytearray))
                    else np.ascontiguousarray(g, np.uint8) for g in genomes]
         ptrs = (C.c_void_p * self.n)(*[a.ctypes.data for a in self._a])
         lens = (C.c_size_t * self.n)(*[a.size for a in self._a])
-        self.h = lib().emul_run(self.n, ptrs, lens, ref_idx, threshold, chunk, kmer)
+        self.h = lib().emul_run2(self.n, ptrs, lens, ref_idx, threshold, chunk, kmer, mode)
+        self.slow_steps = int(lib().emul_slow_steps(self.h))
         info = np.zeros(8, np.uint64)
         lib().emul_info(self.h, info.ctypes.data_as(C.c_void_p))
         self.threshold, self.k, self.C, self.nchunks = (int(x) for x in info[:4])

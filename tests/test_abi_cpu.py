@@ -29,6 +29,14 @@ def test_exports_every_declared_symbol(lib):
         assert hasattr(lib, sym), sym
 
 
+def test_b0_library_exports_the_reference_names(lib):
+    """Seam B0 under the reference's own names (libs/seqcmp.h:14, libs/revseqcmp.h:25) lives in its own
+    small library; it must load and export both (no compute call without a GPU)."""
+    import ctypes as C
+    b0 = C.CDLL(os.path.join(os.path.dirname(api.LIB_PATH), "libphylonium_amd_b0.so"))
+    assert hasattr(b0, "seqcmp") and hasattr(b0, "revseqcmp")
+
+
 def test_no_cpu_fallback_without_gpu(lib):
     import torch
     if torch.cuda.is_available():

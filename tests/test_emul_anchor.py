@@ -13,28 +13,43 @@ import oracle_lib as O
 from phylonium_amd import synth
 
 
-def assert_same(gs, ref, chunk=0, kmer=0, allow_quirk=False, threshold=0, tail=0):
+MODES = (0, 1, 3)  # the general chain, the lean 2-bit chain, the lean chain with every step through its slow resolver
+
+
+def assert_same(gs, ref, chunk=0, kmer=0, allow_quirk=False, threshold=0, tail=0, modes=MODES):
     r = O.Run(gs, ref, threshold=threshold).process(compare=False)
-    if tail:
-        os.environ["EMUL_CHUNK_TAIL"] = str(tail)
-    try:
-        e = E.EmulRun(gs, ref, chunk=chunk, kmer=kmer, threshold=threshold)
-    finally:
-        os.environ.pop("EMUL_CHUNK_TAIL", None)
-    assert e.error == 0
-    assert e.threshold == r.threshold
-    for j in range(len(gs)):
-        ro = r.homologies(j, filtered=False)
-        re_ = e.raw(j)
-        got = [tuple(int(x) for x in row) for row in re_]
-        want = [(int(a["iref"]), int(a["iq"]), int(a["len"])) for a in ro]
-        assert got == want, f"raw homologies differ for query {j}"
-        fo, fe = r.homologies(j), e.filtered(j)
-        got = [(int(b["direction"]), int(b["index_reference"]), int(b["index_reference_projected"]),
-                int(b["index_query"]), int(b["length"])) for b in fe]
-        want = [(int(a["rev"]), int(a["iref"]), int(a["iproj"]), int(a["iq"]), int(a["len"])) for a in fo]
-        assert got == want, f"filtered homologies differ for query {j}"
+    e = None
+    for mode in modes:
+        if tail:
+            os.environ["EMUL_CHUNK_TAIL"] = str(tail)
+        try:
+            e = E.EmulRun(gs, ref, chunk=chunk, kmer=kmer, threshold=threshold, mode=mode)
+        finally:
+            os.environ.pop("EMUL_CHUNK_TAIL", None)
+        assert e.error == 0
+        assert e.threshold == r.threshold
+        for j in range(len(gs)):
+            ro = r.homologies(j, filtered=False)
+            re_ = e.raw(j)
+            got = [tuple(int(x) for x in row) for row in re_]
+            want = [(int(a["iref"]), int(a["iq"]), int(a["len"])) for a in ro]
+            assert got == want, f"raw homologies differ for query {j} (mode {mode})"
+            fo, fe = r.homologies(j), e.filtered(j)
+            got = [(int(b["direction"]), int(b["index_reference"]), int(b["index_reference_projected"]),
+                    int(b["index_query"]), int(b["length"])) for b in fe]
+            want = [(int(a["rev"]), int(a["iref"]), int(a["iproj"]), int(a["iq"]), int(a["len"])) for a in fo]
+            assert got == want, f"filtered homologies differ for query {j} (mode {mode})"
     return r, e
+
+
+def test_lean_chain_rarely_needs_its_slow_resolver():
+    """On ordinary genomes (substitutions, indels, inversions, a few contigs) the packed path answers
+    nearly every step; the slow resolver is for windows next to '!' or the query's end, repeats of 16+
+    bases and oversized buckets."""
+    gs = synth.make_genomes(6, 60000, seed=11, d_range=(0.01, 0.3), indel_per_mbp=300, inv_frac=0.05, contigs=3)
+    r, e = assert_same(gs, 0, modes=(1,))
+    assert e.steps_spec > 10000
+    assert e.slow_steps * 100 < e.steps_spec + e.steps_bridge, (e.slow_steps, e.steps_spec, e.steps_bridge)
 
 
 @pytest.mark.parametrize("chunk", [0, 64, 128, 192, 1024, 1088])

@@ -53,6 +53,22 @@ def check_process(ctx, gs, ref, chunk=0, kmer=0, backend=0, complete_deletion=Fa
     so, ho = r.matrix()
     assert (h == ho).all(), "homologs differ"
     assert (s == so).all(), "substitutions differ"
+    # phase A once more through the other chain kernels, alternating from call to call: the general
+    # byte-wise chains (anchor_kernel 0), and the lean chains with every step sent to the wavefront's
+    # slow resolver — the lists must come out the same
+    check_process.alt = 1 - getattr(check_process, "alt", 0)
+    ctx.set_option("anchor_kernel", 0 if check_process.alt else 1)
+    ctx.set_option("lean_force_slow", 0 if check_process.alt else 1)
+    try:
+        ctx.anchor()
+        if complete_deletion:
+            ctx.complete_delete()
+        for j in range(len(gs)):
+            assert hom_tuples_gpu(ctx.homologies(j)) == hom_tuples_orc(r.homologies(j)), \
+                f"homologies of genome {j} ({'general chains' if check_process.alt else 'slow resolver'})"
+    finally:
+        ctx.set_option("anchor_kernel", 1)
+        ctx.set_option("lean_force_slow", 0)
     for i in range(len(gs)):
         for j in range(len(gs)):
             a, b = api.estimate("jc", s[i, j], h[i, j]), O.estimate("jc", so[i, j], ho[i, j])
@@ -551,3 +567,44 @@ def test_full_size_properties_and_reference_row(workload):
             s2 += a
             h2 += b
         assert (s2 == s).all() and (h2 == h).all()
+
+
+def test_b0_under_the_reference_names_from_eight_threads():
+    """libphylonium_amd_b0.so exports seam B0 under the reference's own names and calling convention
+    (libs/seqcmp.h:14-25, libs/revseqcmp.h:25-33): pure functions over borrowed host buffers that
+    evo_model::account* calls from an OpenMP team (src/evo_model.cxx:53-75).  Eight host threads call
+    both at once, each on its own pair of strings; every result equals the oracle's."""
+    import ctypes as C
+    import threading
+    b0 = C.CDLL(os.path.join(os.path.dirname(api.LIB_PATH), "libphylonium_amd_b0.so"))
+    for f in (b0.seqcmp, b0.revseqcmp):
+        f.restype = C.c_size_t
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    rng = np.random.default_rng(8)
+    alpha = np.frombuffer(b"ACGT!", np.uint8)
+    jobs = []
+    for t in range(8):
+        n = int(rng.integers(1, 400000))
+        a = alpha[rng.integers(0, 5, n)]
+        b = np.where(rng.random(n) < 0.7, a, alpha[rng.integers(0, 5, n)])
+        jobs.append((np.ascontiguousarray(a), np.ascontiguousarray(b), n))
+    got = [None] * 8
+
+    def work(t):
+        a, b, n = jobs[t]
+        res = []
+        for rep in range(6):
+            m = n if rep == 0 else max(0, n - 37 * rep)
+            res.append((b0.seqcmp(a.ctypes.data, b.ctypes.data, m), b0.revseqcmp(a.ctypes.data, b.ctypes.data, m)))
+        got[t] = res
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for t in range(8):
+        a, b, n = jobs[t]
+        for rep in range(6):
+            m = n if rep == 0 else max(0, n - 37 * rep)
+            assert got[t][rep] == (O.seqcmp(a, b, m), O.revseqcmp(a, b, m)), (t, rep)
