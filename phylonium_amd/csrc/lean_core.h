@@ -115,7 +115,7 @@ struct LeanLane {
 	uint32_t s_rank, s_last, p_len, p_pos, p_meta, npend; // bucket walk: next rank, last rank that matters, predecessor so far, pending records seen
 	uint32_t qb_next, qb_idx, qb_end;    // next non-ACGT position of the query at or after q (NO_BAD: none)
 	uint32_t sb_lo, sb_hi;   // S positions [sb_lo, sb_hi) are clean and sb_hi is not (cache of the last SBAD lookup)
-	uint32_t wb, wn;         // the ring holds words [wb, wb + wn) of the query
+	uint32_t wb, we;         // the ring holds words [wb, we) of the query, word w in slot w mod LEAN_RING_WORDS
 
 	PHY_HD void reset(uint32_t word0, uint32_t query_len, uint32_t q0, uint32_t a_q, uint32_t a_s, uint32_t a_len)
 	{
@@ -129,7 +129,7 @@ struct LeanLane {
 		fin = false;
 		sb_lo = 1;
 		sb_hi = 0;
-		wb = wn = 0;
+		wb = we = 0;
 		qb_next = NO_BAD;
 		qb_idx = qb_end = 0;
 	}
@@ -382,7 +382,7 @@ PHY_HD uint32_t lean_step_phase(const LeanLane &ln, const LeanIndex &X)
 		return LP_SLOW;
 	}
 	const uint32_t w = ln.q >> 4;
-	if (w < ln.wb || w + 1 >= ln.wb + ln.wn) return LP_REFILL;
+	if (w < ln.wb || w + 1 >= ln.we) return LP_REFILL;
 	return LP_STEP;
 }
 
@@ -561,6 +561,9 @@ struct LeanBridge {
 	uint32_t src, qj, cur_gc, cur_q0, cur_len, cur_log, sp_cnt, sp_idx;
 	Anchor Ls;
 	uint32_t n, first_block, cur_block;
+	// what every step would otherwise fetch again: the query's chunk grid, the position of the
+	// speculative log's next anchor, the word of the visited bitmap last looked at
+	uint32_t g_nb, g_anc0, g_chunk0, nx_q, vw_idx, vw_word;
 
 	PHY_HD void start(const PhaseA &A, const LeanIndex &X, uint32_t chunk)
 	{
@@ -568,12 +571,18 @@ struct LeanBridge {
 		const uint32_t j = A.chunk_query[chunk];
 		qj = j;
 		const SpecExit x = A.spec_exit[chunk];
+		g_nb = A.qnb[j];
+		g_anc0 = A.qanc0[j];
+		g_chunk0 = A.qchunk0[j];
 		ln.reset((uint32_t)(A.qoff[j] >> 4), A.qlen[j], x.q, x.lq, x.ls, x.ll);
 		ln.qbad_start(X, j);
 		cur_gc = BRIDGE_END;
 		cur_q0 = cur_len = cur_log = 0;
 		sp_cnt = sp_idx = 0;
 		Ls.q = Ls.s = Ls.len = 0;
+		nx_q = 0xffffffffu;
+		vw_idx = 0xffffffffu;
+		vw_word = 0;
 		n = 0;
 		first_block = cur_block = NO_BLOCK;
 	}
@@ -591,24 +600,37 @@ struct LeanBridge {
 			finish(A, BRIDGE_END, 0);
 			return false;
 		}
-		if (cur_gc == BRIDGE_END || ln.q - cur_q0 >= cur_len) { // entered another chunk
-			const uint32_t lc = chunk_of_pos(A, qj, ln.q);
-			const ChunkGeom g = chunk_geom(A, qj, lc);
-			cur_gc = A.qchunk0[qj] + lc;
-			cur_q0 = g.q0;
-			cur_len = g.len;
-			cur_log = g.log0;
+		if (cur_gc == BRIDGE_END || ln.q - cur_q0 >= cur_len) { // entered another chunk (chunk_of_pos + chunk_geom)
+			const uint32_t split = g_nb * A.C;
+			const uint32_t lc = ln.q < split ? ln.q / A.C : g_nb + (ln.q - split) / A.Cs;
+			if (lc < g_nb) {
+				cur_q0 = lc * A.C;
+				cur_len = A.C;
+				cur_log = g_anc0 + lc * A.cap;
+			} else {
+				const uint32_t t = lc - g_nb;
+				cur_q0 = split + t * A.Cs;
+				cur_len = A.Cs;
+				cur_log = g_anc0 + g_nb * A.cap + t * A.caps;
+			}
+			cur_gc = g_chunk0 + lc;
 			sp_cnt = A.spec_cnt[cur_gc];
 			sp_idx = 0;
 			Ls.q = Ls.s = Ls.len = 0;
+			nx_q = sp_cnt ? A.spec_anchors[(size_t)cur_log].q : 0xffffffffu;
 		}
 		const Anchor *log = A.spec_anchors + (size_t)cur_log;
-		while (sp_idx < sp_cnt && log[sp_idx].q < ln.q) {
+		while (nx_q < ln.q) { // the speculative chain's last anchor before q
 			Ls = log[sp_idx];
 			sp_idx++;
+			nx_q = sp_idx < sp_cnt ? log[sp_idx].q : 0xffffffffu;
 		}
-		const uint32_t w = A.visited[lean_visited_word(ln, ln.q)];
-		if ((w >> (ln.q & 31)) & 1u) {
+		const uint32_t wi = lean_visited_word(ln, ln.q);
+		if (wi != vw_idx) {
+			vw_idx = wi;
+			vw_word = A.visited[wi];
+		}
+		if ((vw_word >> (ln.q & 31)) & 1u) {
 			const bool eb = lucky_eligible(ln.q, ln.lq, ln.ls, ln.ll, R);
 			const bool es = lucky_eligible(ln.q, Ls.q, Ls.s, Ls.len, R);
 			bool merged = false;
@@ -670,8 +692,8 @@ inline void lean_trip_cpu(LeanLane &ln, uint32_t *ring, const uint8_t *qbase, co
 	if (ln.ph == LP_STEP) {
 		ln.ph = lean_step_phase(ln, X);
 		if (ln.ph == LP_STEP) {
-			const uint32_t i0 = (ln.q >> 4) - ln.wb;
-			ln.qcode = code_window(ring[i0], ring[i0 + 1], ln.q & 15u);
+			const uint32_t w = ln.q >> 4;
+			ln.qcode = code_window(ring[w % LEAN_RING_WORDS], ring[(w + 1) % LEAN_RING_WORDS], ln.q & 15u);
 		}
 	}
 	if (ln.ph == LP_SLOW) {
@@ -701,16 +723,16 @@ inline void lean_trip_cpu(LeanLane &ln, uint32_t *ring, const uint8_t *qbase, co
 			uint32_t sw[9];
 			memcpy(sw, d + 8, 32);
 			sw[8] = y[0];
-			for (uint32_t i = 0; i < 8; i++) ring[i] = d[i]; // the query words double as the ring's new content
 			ln.wb = (ln.q + (ln.e_pos - ((ln.q + ln.e_pos) & 15u))) >> 4;
-			ln.wn = 8;
+			ln.we = ln.wb + 8;
+			for (uint32_t i = 0; i < 8; i++) ring[(ln.wb + i) % LEAN_RING_WORDS] = d[i]; // the query words double as the ring's new content
 			lean_ext(ln, R, X, d, sw);
 			break;
 		}
 		case LP_REFILL:
-			for (uint32_t i = 0; i < 16; i++) ring[i] = d[i];
 			ln.wb = ln.q >> 4;
-			ln.wn = 16;
+			ln.we = ln.wb + 16;
+			for (uint32_t i = 0; i < 16; i++) ring[(ln.wb + i) % LEAN_RING_WORDS] = d[i];
 			ln.ph = LP_STEP;
 			break;
 		default: break;

@@ -87,7 +87,7 @@ static __device__ void lanes_compare(const uint8_t *qp, uint32_t n, const uint8_
 	const uint32_t LONE = 256;
 	uint32_t len = 0, less = 0, i = 0;
 	bool open = on;
-	while (open) { // 64 bytes per trip: the four loads of each side are in flight together
+	while (open) { // 32 bytes per trip: the two loads of each side are in flight together
 		if (i >= n) {
 			len = n;
 			less = 0;
@@ -95,16 +95,16 @@ static __device__ void lanes_compare(const uint8_t *qp, uint32_t n, const uint8_
 			break;
 		}
 		if (i >= LONE) break;
-		U4 a[4], b[4];
+		U4 a[2], b[2];
 #pragma unroll
-		for (int k = 0; k < 4; k++) {
+		for (int k = 0; k < 2; k++) {
 			a[k] = lg16(qp + i + 16 * k);
 			b[k] = U4{0, 0, 0, 0};
 			if (S + sa + i + 16 * k + 16 <= s_end) b[k] = lg16(S + sa + i + 16 * k);
 		}
-		uint32_t d = 64, qb = 0, sb = 0;
+		uint32_t d = 32, qb = 0, sb = 0;
 #pragma unroll
-		for (int k = 3; k >= 0; k--) {
+		for (int k = 1; k >= 0; k--) {
 			const uint32_t dk = first_diff(a[k], b[k]);
 			if (dk < 16) {
 				d = 16u * (uint32_t)k + dk;
@@ -112,7 +112,7 @@ static __device__ void lanes_compare(const uint8_t *qp, uint32_t n, const uint8_
 				sb = byte_at(b[k], dk);
 			}
 		}
-		if (d < 64) {
+		if (d < 32) {
 			len = i + d;
 			if (len >= n) {
 				len = n;
@@ -123,7 +123,7 @@ static __device__ void lanes_compare(const uint8_t *qp, uint32_t n, const uint8_
 			open = false;
 			break;
 		}
-		i += 64;
+		i += 32;
 	}
 	uint64_t longm = __ballot(open);
 	while (longm) {
@@ -289,8 +289,8 @@ template <int MODE> __global__ __launch_bounds__(256) void lean_chain_kernel(Pha
 			ph = lean_step_phase(ln, X);
 			ln.ph = ph;
 			if (ph == LP_STEP) {
-				const uint32_t i0 = (ln.q >> 4) - ln.wb;
-				ln.qcode = code_window(ring[i0][tid], ring[i0 + 1][tid], ln.q & 15u);
+				const uint32_t w = ln.q >> 4;
+				ln.qcode = code_window(ring[w & 15u][tid], ring[(w + 1u) & 15u][tid], ln.q & 15u);
 			}
 		}
 		// one batch of loads for every phase
@@ -330,23 +330,23 @@ template <int MODE> __global__ __launch_bounds__(256) void lean_chain_kernel(Pha
 			lean_search(ln, R, d);
 		} else if (ph == LP_EXT) {
 			uint32_t sw[9];
+			ln.wb = (ln.q + (ln.e_pos - ((ln.q + ln.e_pos) & 15u))) >> 4;
+			ln.we = ln.wb + 8;
 #pragma unroll
 			for (int i = 0; i < 8; i++) {
 				sw[i] = d[8 + i];
-				ring[i][tid] = d[i]; // the query words double as the ring's new content
+				ring[(ln.wb + (uint32_t)i) & 15u][tid] = d[i]; // the query words double as the ring's new content
 			}
 			sw[8] = y[0];
-			ln.wb = (ln.q + (ln.e_pos - ((ln.q + ln.e_pos) & 15u))) >> 4;
-			ln.wn = 8;
 			lean_ext(ln, R, X, d, sw);
 		} else if (ph == LP_SCAN) {
 			lean_scan(ln, R, U4{d[0], d[1], d[2], d[3]}, U4{d[4], d[5], d[6], d[7]}, U4{d[8], d[9], d[10], d[11]},
 					  U4{d[12], d[13], d[14], d[15]});
 		} else if (ph == LP_REFILL) {
-#pragma unroll
-			for (int i = 0; i < 16; i++) ring[i][tid] = d[i];
 			ln.wb = ln.q >> 4;
-			ln.wn = 16;
+			ln.we = ln.wb + 16;
+#pragma unroll
+			for (int i = 0; i < 16; i++) ring[(ln.wb + (uint32_t)i) & 15u][tid] = d[i];
 			ln.ph = LP_STEP;
 		}
 		LEAN_TICK(3)
