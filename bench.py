@@ -39,14 +39,17 @@ WORKLOADS = {
     "c3tree": (256, 5_000_000, (0.004, 0.04), 30, 0.005, "configs[2] on a tree (SURVEY 8d): 256 x 5 Mbp, genome k descends from genome "
                "(k-1)//2 with branch length U(0.004,0.04): distances to the reference (the root) up to ~0.2, between leaves up to ~0.35"),
     "small": (32, 1_000_000, (0.01, 0.3), 100, 0.02, "dev: 32 x 1 Mbp"),
+    "c3dup": (64, 5_000_000, (0.01, 0.3), 100, 0.02, "dev: 64 x 5 Mbp as c3, but genomes 1-8 are byte-identical to the reference and "
+              "genomes 9-16 differ from it in ~1 base per 10 kbp (matches far longer than a chunk: phase A's overrun path)"),
 }
+DUP = {"c3dup": (8, 8)}  # (byte-identical copies of the reference, near-identical genomes at d = 1e-4)
 CONTIGS = {"c5s": 50, "c5": 100}
 TREE = {"c3tree"}  # genomes mutated from their parent in a binary tree instead of all from genome 0
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 
 
 def make_genomes_gpu(torch, n, length, seed, device, d_range, indel_per_mbp, inv_frac, inv_len=(1000, 5000), contigs=1,
-                     tree=False):
+                     tree=False, dup=(0, 0)):
     """Synthetic genome set on the GPU. Genome 0 is the unmutated base (the reference,
     like simf's S0, test/simf.cxx:32); genome g>0 = base at JC distance d_g ~ U(d_range),
     plus indel events and inverted blocks; with `tree`, genome g descends from genome (g-1)//2
@@ -58,10 +61,12 @@ def make_genomes_gpu(torch, n, length, seed, device, d_range, indel_per_mbp, inv
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
     codes = []
     for k in range(n):
-        if k == 0:
+        if k == 0 or 1 <= k <= dup[0]:
             code = base
         else:
             d = float(rng.uniform(*d_range))
+            if dup[0] < k <= dup[0] + dup[1]:
+                d = 1e-4
             p = 0.75 - 0.75 * math.exp(-(4.0 / 3.0) * d)
             if tree:
                 base = codes[(k - 1) // 2]
@@ -71,6 +76,8 @@ def make_genomes_gpu(torch, n, length, seed, device, d_range, indel_per_mbp, inv
             code = (base + hit.to(torch.uint8) * shift) & 3
             n_indel = int(round(indel_per_mbp * length / 1e6))
             n_inv = int(round(inv_frac * length / (0.5 * (inv_len[0] + inv_len[1]))))
+            if dup[0] < k <= dup[0] + dup[1]:
+                n_indel, n_inv = 2, 1
             if n_indel or n_inv:
                 ev = [(int(x), 0) for x in rng.integers(0, length, n_indel)] + \
                      [(int(x), 1) for x in rng.integers(0, length, n_inv)]
@@ -271,7 +278,8 @@ def main():
         d_range = tuple(float(x) for x in args.d_range.split(","))
     t_gen = time.time()
     buf, offs, lens = make_genomes_gpu(torch, n, length, args.seed, device, d_range, indel, inv,
-                                       contigs=CONTIGS.get(args.workload, 1), tree=args.workload in TREE)
+                                       contigs=CONTIGS.get(args.workload, 1), tree=args.workload in TREE,
+                                       dup=DUP.get(args.workload, (0, 0)))
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
     ref_idx = 0

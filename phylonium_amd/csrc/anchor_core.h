@@ -813,6 +813,9 @@ struct PhaseA {
 	uint32_t *error;           // set nonzero on pool exhaustion / capacity overflow
 	// counters for dynamic work fetch
 	uint32_t *fetch;           // [2]
+	// lean chains: set nonzero when a speculative chain stopped a comparison that ran a chunk length past its
+	// chunk's end (lean_core.h: overruns); such chunks have bit 31 of spec_cnt set until they are resolved
+	uint32_t *overrun;
 };
 
 PHY_HD bool lucky_eligible(uint32_t q, uint32_t aq, uint32_t as, uint32_t al, const RefIndex &R)

@@ -30,6 +30,8 @@
 // Plain C++ over raw pointers: compiled by hipcc for gfx950 and by g++ for
 // tests/emul (test infrastructure; the product never runs the CPU build).
 #pragma once
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "anchor_core.h"
@@ -57,6 +59,9 @@ static const uint32_t LEAN_EXT_BASES = 128;         // bases per EXT trip
 static const uint32_t LEAN_EXT_COOP = 16 + 32 * 128; // a comparison this long is handed to the wavefront
 static const uint32_t LEAN_SCAN_MAX = 24;           // buckets with more members go to the slow resolver
 static const uint32_t NO_BAD = 0xffffffffu;
+static const uint32_t LEAN_OVERRUN_BIT = 0x80000000u; // in spec_cnt: the chunk's last anchor and exit are lower bounds
+static const uint32_t LEAN_LINK_BIT = 0x40000000u;    // ... and its match is continued by the next chunk's (GPU resolve, pass 1)
+static const uint32_t LEAN_COUNT_MASK = 0x3fffffffu;
 
 // why a step left the packed path (counted by the CPU emulation build only)
 enum LeanSlowWhy : uint32_t { SW_FORCED = 0, SW_QUERY_END, SW_QUERY_BAD, SW_BUCKET, SW_PEND_MANY, SW_CLIP, SW_EXT_QBAD, SW_COUNT };
@@ -116,6 +121,13 @@ struct LeanLane {
 	uint32_t qb_next, qb_idx, qb_end;    // next non-ACGT position of the query at or after q (NO_BAD: none)
 	uint32_t sb_lo, sb_hi;   // S positions [sb_lo, sb_hi) are clean and sb_hi is not (cache of the last SBAD lookup)
 	uint32_t wb, we;         // the ring holds words [wb, we) of the query, word w in slot w mod LEAN_RING_WORDS
+	// A speculative chain needs a match's exact length only while the match ends inside its chunk: a
+	// match that is still running at position q_cap (chunk end + one chunk length) ends the chunk
+	// whatever its length, and is left open ("overrun", resolved later: lean_overrun_*).  Without the
+	// cap every chunk of a genome that equals the reference over megabases would compare to the end of
+	// that stretch — O(L^2 / C) bytes.  NO_BAD: no cap (bridges, which are the true chain).
+	uint32_t q_cap;
+	bool ovr;                // the step that just finished was cut at q_cap: r_len is a lower bound
 
 	PHY_HD void reset(uint32_t word0, uint32_t query_len, uint32_t q0, uint32_t a_q, uint32_t a_s, uint32_t a_len)
 	{
@@ -132,6 +144,23 @@ struct LeanLane {
 		wb = we = 0;
 		qb_next = NO_BAD;
 		qb_idx = qb_end = 0;
+		q_cap = NO_BAD;
+		ovr = false;
+	}
+	// may the running comparison (e_pos bases equal so far) stop here?  Only when the answer no longer
+	// depends on its length: a lucky anchor past the threshold, or a candidate whose neighbours' LCPs
+	// (both sides, clipped) are already below what has been verified — unique whatever it grows to.
+	PHY_HD bool may_cut(uint32_t verified) const
+	{
+		if (q_cap == NO_BAD || q + verified < q_cap) return false;
+		if (e_kind == EXT_LUCKY) return true;
+		const uint32_t l1 = (e_meta >> 5) & LCP_CLIP, l2 = (e_meta >> 18) & LCP_CLIP;
+		return l1 < verified && l2 < verified && l1 != LCP_CLIP && l2 != LCP_CLIP;
+	}
+	PHY_HD void finish_cut(uint32_t verified)
+	{
+		finish(e_p, verified, true);
+		ovr = true;
 	}
 	PHY_HD bool lucky_ok(const RefIndex &R) const
 	{
@@ -361,7 +390,8 @@ PHY_HD void lean_ext(LeanLane &ln, const RefIndex &R, const LeanIndex &X, const 
 		lean_deliver(ln, R, e0 + dd, lessbit);
 	} else if (lim == LEAN_EXT_BASES) {
 		ln.e_pos = e0 + LEAN_EXT_BASES;
-		if (ln.e_pos >= LEAN_EXT_COOP) ln.ph = LP_SLOWEXT;
+		if (ln.may_cut(ln.e_pos)) ln.finish_cut(ln.e_pos);
+		else if (ln.e_pos >= LEAN_EXT_COOP) ln.ph = LP_SLOWEXT;
 	} else if (dq <= n_left && dq <= ds) {
 		LEAN_WHY(SW_EXT_QBAD);
 		ln.ph = LP_SLOW; // the match runs into a '!' of the query: bytes decide
@@ -460,6 +490,12 @@ inline void lean_resolve_scalar(LeanLane &ln, const uint8_t *qbase, const RefInd
 		const uint32_t try_s = ln.ls + (ln.q - ln.lq);
 		cmp(try_s, &len, &less);
 		if (len >= R.threshold) {
+			const uint32_t cap_rel = (ln.q_cap != NO_BAD && ln.q_cap > ln.q && ln.q_cap - ln.q < n) ? ln.q_cap - ln.q : NO_BAD;
+			if (cap_rel != NO_BAD && len >= cap_rel) { // as the wavefront's resolver: a speculative chain stops at its cap
+				ln.finish(try_s, cap_rel, true);
+				ln.ovr = true;
+				return;
+			}
 			ln.finish(try_s, len, true);
 			return;
 		}
@@ -485,13 +521,20 @@ inline void lean_resolve_scalar(LeanLane &ln, const uint8_t *qbase, const RefInd
 	const bool cand = lp != lsu && lmax >= R.threshold;
 	const uint32_t l = pbest ? R.LCP[lo - 1] : R.LCP[lo + 1];
 	ln.finish(pbest ? pp : ps, lmax, cand && l < lmax);
+	// (the GPU resolver also cuts a search result at the cap when it is unique whichever side it lies on;
+	// here the exact answer is at hand, and a cut one would only be made exact again)
 }
 inline void lean_resolve_ext_scalar(LeanLane &ln, const uint8_t *qbase, const RefIndex &R)
 {
 	const uint8_t *Q = qbase + ((uint64_t)ln.qw0 << 4) + ln.q;
 	const uint32_t n = ln.qlen - ln.q;
 	uint32_t i = ln.e_pos - ((ln.q + ln.e_pos) & 15u);
-	while (i < n && Q[i] == R.S[ln.e_p + i]) i++;
+	const uint32_t lim = ln.may_cut(ln.q_cap - ln.q) ? ln.q_cap - ln.q : n; // (q_cap NO_BAD: may_cut is false)
+	while (i < n && i < lim && Q[i] == R.S[ln.e_p + i]) i++;
+	if (i < n && i >= lim) {
+		ln.finish_cut(i);
+		return;
+	}
 	lean_deliver(ln, R, i, (i < n && R.S[ln.e_p + i] < Q[i]) ? 1u : 0u);
 }
 #endif
@@ -518,6 +561,7 @@ struct LeanSpec {
 		cap = g.cap;
 		ln.reset((uint32_t)(A.qoff[j] >> 4), ql, g.q0, 0, 0, 0);
 		ln.qbad_start(X, j);
+		ln.q_cap = e + g.len < e ? NO_BAD : e + g.len;
 		cnt = 0;
 		vis_word = 0;
 		vis_idx = lean_visited_word(ln, g.q0);
@@ -527,7 +571,8 @@ struct LeanSpec {
 	{
 		if (ln.q >= q_end) {
 			A.visited[vis_idx] = vis_word;
-			A.spec_cnt[gc] = cnt;
+			A.spec_cnt[gc] = cnt | (ln.ovr ? LEAN_OVERRUN_BIT : 0u); // only a chunk's last step can be cut
+			if (ln.ovr) *A.overrun = 1;
 			SpecExit x = {ln.q, ln.lq, ln.ls, ln.ll};
 			A.spec_exit[gc] = x;
 			return false;
@@ -669,6 +714,69 @@ struct LeanBridge {
 		n++;
 	}
 };
+
+// ───────────────── overruns: the open-ended last match of a speculative chunk ─────────────────
+// A cut match (q_s, pos, verified) lies on the diagonal pos - q_s and is known to cover the whole
+// next chunk.  If that chunk's chain also ends in a cut match that starts at the chunk's first
+// position on the same diagonal, the two are the same maximal match from there on and END AT THE
+// SAME POSITION.  So the ends are handed down a run of such chunks from its last member, whose own
+// open end is at most two chunk lengths of comparing (the reference's lcp, process.cxx:171-184).
+// A genome that equals the reference over megabases costs O(L) bytes this way instead of O(L^2/C).
+struct LeanOverrun {
+	uint32_t flagged, q_s, pos, verified;
+};
+PHY_HD LeanOverrun lean_overrun_of(const PhaseA &A, uint32_t gc)
+{
+	const SpecExit x = A.spec_exit[gc];
+	LeanOverrun o = {A.spec_cnt[gc] & LEAN_OVERRUN_BIT, x.lq, x.ls, x.ll};
+	return o;
+}
+// does chunk `nxt` (the next chunk of the same query, first position nxt_q0) continue `o`'s match?
+PHY_HD bool lean_overrun_links(const LeanOverrun &o, const LeanOverrun &nxt, uint32_t nxt_q0)
+{
+	return o.flagged && nxt.flagged && nxt.q_s == nxt_q0 && nxt.pos - nxt.q_s == o.pos - o.q_s;
+}
+// the match's end is known: fix the chunk's exit state, its last anchor, and clear the flag
+PHY_HD void lean_overrun_close(const PhaseA &A, uint32_t j, uint32_t gc, const LeanOverrun &o, uint32_t end_q, bool clear_flags = true)
+{
+	const uint32_t len = end_q - o.q_s;
+	const uint32_t cnt = A.spec_cnt[gc] & LEAN_COUNT_MASK;
+	SpecExit x = {o.q_s + len + 1u, o.q_s, o.pos, len};
+	A.spec_exit[gc] = x;
+	A.spec_anchors[(size_t)chunk_geom(A, j, gc - A.qchunk0[j]).log0 + cnt - 1u].len = len;
+	if (clear_flags) A.spec_cnt[gc] = cnt;
+}
+#if !defined(__HIP_DEVICE_COMPILE__)
+// CPU emulation: all of query j's overruns, last chunk first
+inline void lean_overrun_resolve_query(const PhaseA &A, const RefIndex &R, uint32_t j)
+{
+	const uint32_t c0 = A.qchunk0[j], c1 = A.qchunk0[j + 1];
+	const uint8_t *Q = A.qbase + A.qoff[j];
+	const uint32_t qlen = A.qlen[j];
+	LeanOverrun nxt = {0, 0, 0, 0};
+	uint32_t nxt_end = 0, nxt_q0 = 0;
+	for (uint32_t gc = c1; gc-- > c0;) {
+		const LeanOverrun o = lean_overrun_of(A, gc);
+		uint32_t end = 0;
+		if (o.flagged) {
+			if (gc + 1 < c1 && lean_overrun_links(o, nxt, nxt_q0)) {
+				end = nxt_end;
+			} else {
+				uint32_t i = o.verified;
+				while (o.q_s + i < qlen && Q[o.q_s + i] == R.S[o.pos + i]) i++;
+				end = o.q_s + i;
+				if (getenv("EMUL_OVERRUN_TRACE"))
+					fprintf(stderr, "direct: query %u chunk %u q_s %u pos %u verified %u -> len %u; next flagged %u q_s %u pos %u q0 %u\n", j, gc - c0,
+							o.q_s, o.pos, o.verified, i, nxt.flagged ? 1u : 0u, nxt.q_s, nxt.pos, nxt_q0);
+			}
+			lean_overrun_close(A, j, gc, o, end);
+		}
+		nxt = o;
+		nxt_end = end;
+		nxt_q0 = chunk_geom(A, j, gc - c0).q0;
+	}
+}
+#endif
 
 // ───────────────── one trip of one lane on the CPU (emulation tests) ─────────────────
 #if !defined(__HIP_DEVICE_COMPILE__)

@@ -150,22 +150,30 @@ static __device__ void coop_resolve(LeanLane &ln, int leader, const PhaseA &A, c
 	const uint32_t lane = lane64();
 	const uint32_t qw0 = bcast(ln.qw0, leader), q = bcast(ln.q, leader), qlen = bcast(ln.qlen, leader);
 	const uint32_t lq = bcast(ln.lq, leader), ls = bcast(ln.ls, leader), ll = bcast(ln.ll, leader);
+	const uint32_t q_cap = bcast(ln.q_cap, leader);
 	const uint8_t *Q = A.qbase + ((uint64_t)qw0 << 4) + q;
 	const uint32_t n = qlen - q;
+	// A speculative chain's comparisons stop at its cap (lean_core.h: q_cap) when the step's outcome no
+	// longer depends on the length: first with the cap; if that leaves anything open, once more without.
+	const uint32_t cap_rel = (q_cap != NO_BAD && q_cap > q && q_cap - q < n) ? q_cap - q : NO_BAD;
 	uint32_t r_pos = 0, r_len = 0;
-	bool r_acc = false, have = false;
-	const uint32_t advance = q - lq;
-	if ((ls + advance < R.n) && (advance - ll <= R.threshold)) { // lucky_anchor, process.cxx:227-242
-		uint32_t len, less;
-		wave_compare(Q, R.S + (ls + advance), 0, n, s_end, &len, &less);
-		if (len >= R.threshold) {
-			r_pos = ls + advance;
-			r_len = len;
-			r_acc = true;
-			have = true;
+	bool r_acc = false, r_cut = false;
+	for (int pass = 0; pass < 2; pass++) {
+		const uint32_t neff = (pass == 0 && cap_rel != NO_BAD) ? cap_rel : n;
+		const bool capped = neff < n;
+		bool redo = false;
+		const uint32_t advance = q - lq;
+		if ((ls + advance < R.n) && (advance - ll <= R.threshold)) { // lucky_anchor, process.cxx:227-242
+			uint32_t len, less;
+			wave_compare(Q, R.S + (ls + advance), 0, neff, s_end, &len, &less);
+			if (len >= R.threshold) {
+				r_pos = ls + advance;
+				r_len = len;
+				r_acc = true;
+				r_cut = capped && len >= neff;
+				break;
+			}
 		}
-	}
-	if (!have) {
 		uint32_t lo = 0, hi = R.n;
 		{ // the k-mer's bucket bounds the search when the window starts with k nucleotides
 			uint32_t valid;
@@ -182,19 +190,43 @@ static __device__ void coop_resolve(LeanLane &ln, int leader, const PhaseA &A, c
 			const uint32_t r = lo + (uint32_t)(((uint64_t)(lane + 1u) * m) / 65u); // lo <= r < hi, nondecreasing in lane
 			const uint32_t sa = lg16((const uint8_t *)(R.SAX + r)).x;
 			uint32_t len, less;
-			lanes_compare(Q, n, R.S, sa, true, s_end, &len, &less);
+			lanes_compare(Q, neff, R.S, sa, true, s_end, &len, &less);
+			if (capped && __ballot(len >= neff)) { // a probe ran into the cap: its order is unknown
+				redo = true;
+				break;
+			}
 			const uint32_t cnt = (uint32_t)__popcll(__ballot(less != 0));
 			const uint32_t nlo = cnt ? bcast(r, (int)cnt - 1) + 1u : lo;
 			const uint32_t nhi = cnt < 64u ? bcast(r, (int)cnt) : hi;
 			lo = nlo;
 			hi = nhi;
 		}
+		if (redo) continue;
 		const uint32_t m = hi - lo; // lanes 0 .. m+1 take ranks lo-1 .. hi
 		const bool on = lane < m + 2u && !(lo == 0 && lane == 0) && lo + lane - 1u < R.n;
 		const uint32_t rank = on ? lo + lane - 1u : 0u;
 		const uint32_t sa = lg16((const uint8_t *)(R.SAX + rank)).x;
 		uint32_t len, less;
-		lanes_compare(Q, n, R.S, sa, on, s_end, &len, &less);
+		lanes_compare(Q, neff, R.S, sa, on, s_end, &len, &less);
+		if (capped) {
+			const uint64_t hit = __ballot(on && len >= neff);
+			if (hit) {
+				// one suffix alone reaches the cap: it is the best neighbour whichever side it is on; unique
+				// iff neither of its neighbours in the suffix array shares that much with it
+				if ((hit & (hit - 1)) == 0) {
+					const int who = __ffsll((unsigned long long)hit) - 1;
+					const uint32_t wr = bcast(rank, who);
+					if (R.LCP[wr] < neff && R.LCP[wr + 1] < neff) {
+						r_pos = bcast(sa, who);
+						r_len = neff;
+						r_acc = true;
+						r_cut = true;
+						break;
+					}
+				}
+				continue; // open: once more without the cap
+			}
+		}
 		const uint32_t cnt = (uint32_t)__popcll(__ballot(on && lane >= 1u && lane <= m && less != 0));
 		const uint32_t ins = lo + cnt;
 		const uint32_t lp = ins > 0 ? bcast(len, (int)cnt) : 0u, pp = bcast(sa, (int)cnt);
@@ -207,19 +239,118 @@ static __device__ void coop_resolve(LeanLane &ln, int leader, const PhaseA &A, c
 		r_pos = pbest ? pp : ps;
 		r_len = lmax;
 		r_acc = cand && l < lmax;
+		break;
 	}
-	if ((int)lane == leader) ln.finish(r_pos, r_len, r_acc);
+	if ((int)lane == leader) {
+		ln.finish(r_pos, r_len, r_acc);
+		ln.ovr = r_cut;
+	}
 }
 
-// the long tail of one comparison (lean_ext handed it over at e_pos bases)
+// the long tail of one comparison (lean_ext handed it over at e_pos bases); a speculative chain's
+// comparison stops at its cap when it may (lean_core.h: may_cut)
 static __device__ void coop_ext(LeanLane &ln, int leader, const PhaseA &A, const RefIndex &R, const uint8_t *s_end)
 {
 	const uint32_t qw0 = bcast(ln.qw0, leader), q = bcast(ln.q, leader), qlen = bcast(ln.qlen, leader);
-	const uint32_t e_p = bcast(ln.e_p, leader), e_pos = bcast(ln.e_pos, leader);
+	const uint32_t e_p = bcast(ln.e_p, leader), e_pos = bcast(ln.e_pos, leader), q_cap = bcast(ln.q_cap, leader);
+	const bool cut_ok = bcast(ln.q_cap != NO_BAD && ln.may_cut(ln.q_cap - ln.q) ? 1u : 0u, leader) != 0;
 	const uint8_t *Q = A.qbase + ((uint64_t)qw0 << 4) + q;
+	const uint32_t n = qlen - q;
+	const uint32_t lim = cut_ok && q_cap - q < n ? q_cap - q : n;
 	uint32_t len, less;
-	wave_compare(Q, R.S + e_p, e_pos & ~15u, qlen - q, s_end, &len, &less);
-	if ((int)lane64() == leader) lean_deliver(ln, R, len, less);
+	wave_compare(Q, R.S + e_p, e_pos & ~15u, lim, s_end, &len, &less);
+	if ((int)lane64() == leader) {
+		if (len >= lim && lim < n) ln.finish_cut(lim);
+		else lean_deliver(ln, R, len, less);
+	}
+}
+
+// The open ends of the comparisons that speculative chains cut (lean_core.h: overruns), in two passes.
+// Pass 1, one lane per chunk: does the next chunk continue this chunk's cut match (then its end is that
+// chunk's end: LINK bit), or is this the last chunk of such a run — then the match is compared on, by
+// the whole wavefront, at most two chunk lengths, and the chunk is closed except for its flag bits
+// (neighbouring lanes still read them).
+__global__ __launch_bounds__(64) void lean_overrun_direct_kernel(PhaseA A, RefIndex R)
+{
+	if (*A.overrun == 0) return;
+	const uint32_t lane = lane64();
+	const uint32_t gc0 = blockIdx.x * 64u + lane;
+	const bool on = gc0 < A.nchunks;
+	const uint32_t gc = on ? gc0 : 0u;
+	const uint8_t *s_end = R.S + R.n + 64;
+	const uint32_t j = A.chunk_query[gc];
+	LeanOverrun o = lean_overrun_of(A, gc);
+	if (!on) o.flagged = 0;
+	bool link = false;
+	if (o.flagged && gc + 1u < A.qchunk0[j + 1]) {
+		const LeanOverrun nx = lean_overrun_of(A, gc + 1u);
+		link = lean_overrun_links(o, nx, chunk_geom(A, j, gc + 1u - A.qchunk0[j]).q0);
+	}
+	if (link) A.spec_cnt[gc] |= LEAN_LINK_BIT;
+	uint64_t direct = __ballot(o.flagged && !link);
+	while (direct) {
+		const int who = __ffsll((unsigned long long)direct) - 1;
+		const uint32_t wj = bcast(j, who), wq = bcast(o.q_s, who), wp = bcast(o.pos, who), wv = bcast(o.verified, who);
+		uint32_t len, less;
+		wave_compare(A.qbase + A.qoff[wj] + wq, R.S + wp, wv & ~15u, A.qlen[wj] - wq, s_end, &len, &less);
+		if ((int)lane == who) {
+			lean_overrun_close(A, j, gc, o, wq + len, false);
+			atomicAdd(A.overrun + 1, 1u); // statistics: runs closed, bytes compared for them
+			atomicAdd(A.overrun + 2, len - (wv & ~15u));
+		}
+		direct &= direct - 1;
+	}
+}
+
+// Pass 2, one wavefront per query, its chunks from the last to the first, 64 at a time: a linked chunk
+// takes the end of the nearest closed chunk above it (pointer doubling inside the group, a carry between
+// groups); all flag bits are cleared.
+__global__ __launch_bounds__(64) void lean_overrun_chain_kernel(PhaseA A, uint32_t nq)
+{
+	if (*A.overrun == 0) return;
+	const uint32_t j = blockIdx.x;
+	if (j >= nq) return;
+	const uint32_t c0 = A.qchunk0[j], c1 = A.qchunk0[j + 1];
+	const uint32_t lane = lane64();
+	uint32_t car_end = 0;
+	for (uint32_t top = c1; top > c0;) {
+		const uint32_t base = top - c0 >= 64u ? top - 64u : c0; // this group: chunks [base, top)
+		const uint32_t m = top - base;
+		const bool on = lane < m;
+		const uint32_t gc = base + (on ? lane : 0u);
+		const uint32_t word = on ? A.spec_cnt[gc] : 0u;
+		const SpecExit x = A.spec_exit[gc];
+		const bool flagged = (word & LEAN_OVERRUN_BIT) != 0, link = (word & LEAN_LINK_BIT) != 0;
+		uint32_t end = x.lq + x.ll; // a closed chunk's end (others: overwritten below or unused)
+		uint32_t known = link ? 0u : 1u, hop = 1;
+		if (link && lane == m - 1u) {
+			end = car_end;
+			known = 1;
+		}
+#pragma unroll
+		for (int it = 0; it < 6; it++) { // an unknown lane's end is the end of lane + hop
+			const int t = (int)(lane + hop < 64u ? lane + hop : 63u);
+			const uint32_t tk = bcast(known, t), te = bcast(end, t), th = bcast(hop, t);
+			if (!known) {
+				if (tk) {
+					end = te;
+					known = 1;
+				} else {
+					hop += th;
+				}
+			}
+		}
+		if (flagged) {
+			if (link) {
+				const LeanOverrun o = {1u, x.lq, x.ls, x.ll};
+				lean_overrun_close(A, j, gc, o, end, true);
+			} else {
+				A.spec_cnt[gc] = word & LEAN_COUNT_MASK;
+			}
+		}
+		car_end = bcast(end, 0);
+		top = base;
+	}
 }
 
 struct LeanAlloc {
@@ -463,6 +594,13 @@ void launch_bad_positions(const uint8_t *base, const uint64_t *off, const uint32
 {
 	if (!nseg) return;
 	hipLaunchKernelGGL(bad_positions_kernel, dim3(nseg), dim3(256), 0, st, base, off, len, seg_seq, seg_first, seg_cnt, seg_off, out);
+}
+
+void launch_lean_overruns(const PhaseA &A, const RefIndex &R, uint32_t nq, hipStream_t st)
+{
+	if (!nq || !A.nchunks) return;
+	hipLaunchKernelGGL(lean_overrun_direct_kernel, dim3((A.nchunks + 63u) / 64u), dim3(64), 0, st, A, R);
+	hipLaunchKernelGGL(lean_overrun_chain_kernel, dim3(nq), dim3(64), 0, st, A, nq);
 }
 
 static int lean_resident(const void *fn, int n_cu)

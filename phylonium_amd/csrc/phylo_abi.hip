@@ -948,6 +948,7 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	A.fetch = c->a_misc.p;          // [0] spec, [1] bridge
 	A.pool_next = c->a_misc.p + 2;
 	A.error = c->a_misc.p + 3;
+	A.overrun = c->a_misc.p + 4;
 	RefIndex R = {c->d_S.p, c->d_SAX.p, c->d_LCP.p, c->d_SLOT.p, c->ns, c->k, c->threshold};
 	LeanIndex X = {c->d_S2.p, c->d_SBAD.p, c->nsb, c->ns, c->sb_first, c->d_Q2.p, c->d_QBAD.p, c->d_qbad_off.p + q_begin,
 				   (uint32_t)c->lean_force_slow, nullptr};
@@ -979,6 +980,10 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 			else launch_spec(A, R, c->n_cu, st);
 		}
 		dbg_sync("anchor_spec");
+		if (lean) {
+			KernelSpan s(c, "anchor_overruns");
+			launch_lean_overruns(A, R, (uint32_t)nq, st);
+		}
 		{
 			KernelSpan s(c, "anchor_bridge");
 			if (lean) launch_lean_bridge(A, R, X, c->n_cu, st);
@@ -1024,7 +1029,7 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 		HIPOK(c, c->b_homs.ensure(c->plan_raw_total + nq + 1));
 		HIPOK(c, c->b_hom_rng.ensure(2 * std::max(nq, c->n)));
 		HIPOK(c, c->a_flt.ensure(nq + 1));
-		HIPOK(c, c->h_rng.ensure(3 * nq + 8));
+		HIPOK(c, c->h_rng.ensure(3 * nq + 16));
 		HIPOK(c, hipMemsetAsync(c->a_flt.p, 0, 4, st));
 		const uint32_t ref_local = (c->ref_idx >= q_begin && c->ref_idx < q_end) ? (uint32_t)(c->ref_idx - q_begin) : 0xffffffffu;
 		{
@@ -1049,7 +1054,7 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 		HIPOK(c, hipMemcpyAsync(hr, c->b_hom_rng.p, 2 * nq * 4, hipMemcpyDeviceToHost, st));
 		HIPOK(c, hipMemcpyAsync(hr + 2 * nq, c->a_flt.p + 1, nq * 4, hipMemcpyDeviceToHost, st));
 		HIPOK(c, hipMemcpyAsync(hr + 3 * nq, c->a_flt.p, 4, hipMemcpyDeviceToHost, st));
-		HIPOK(c, hipMemcpyAsync(hr + 3 * nq + 1, c->a_misc.p, 16, hipMemcpyDeviceToHost, st));
+		HIPOK(c, hipMemcpyAsync(hr + 3 * nq + 1, c->a_misc.p, 32, hipMemcpyDeviceToHost, st));
 		HIPOK(c, hipGetLastError());
 		if (sync_stream(c)) return 1;
 		double t2d = now_ms();
@@ -1080,15 +1085,17 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 			c->stats["count:chunks"] += nch;
 			c->stats["count:filtered_homologies"] += (double)hr[3 * nq];
 			c->stats["count:pool_blocks_used"] += dmisc[2];
+			c->stats["count:overrun_runs"] += dmisc[5];
+			c->stats["count:overrun_bytes_compared"] += dmisc[6];
 			c->stats["anchor:chunk"] = P.C;
 			return 0;
 		}
 		c->stats["count:queries_left_to_the_host"] += (double)flagged;
 	}
-	HIPOK(c, c->h_cnt.ensure(nq + 4));
+	HIPOK(c, c->h_cnt.ensure(nq + 8));
 	uint32_t *cnt = c->h_cnt.p, *misc = c->h_cnt.p + nq;
 	HIPOK(c, hipMemcpyAsync(cnt, c->a_out_cnt.p, nq * 4, hipMemcpyDeviceToHost, st));
-	HIPOK(c, hipMemcpyAsync(misc, c->a_misc.p, 16, hipMemcpyDeviceToHost, st));
+	HIPOK(c, hipMemcpyAsync(misc, c->a_misc.p, 32, hipMemcpyDeviceToHost, st));
 	if (sync_stream(c)) return 1;
 	double t2 = now_ms();
 	if (misc[3]) return c->fail("phase A scratch overflow (code %u: 1 chunk log, 2 bridge pool, 3 homology buffer)", misc[3]);
@@ -1246,6 +1253,8 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	c->stats["count:raw_homologies"] += (double)ctot;
 	c->stats["count:lists_with_equal_starts"] += (double)tie_lists.load();
 	c->stats["count:pool_blocks_used"] += misc[2];
+	c->stats["count:overrun_runs"] += misc[5];
+	c->stats["count:overrun_bytes_compared"] += misc[6];
 	(void)pool_blocks;
 	c->stats["anchor:chunk"] = P.C;
 	return 0;

@@ -16,7 +16,7 @@ struct EmulOut {
 	std::vector<std::vector<RawHom>> raw;
 	std::vector<std::vector<phylo_homology>> filtered;
 	uint32_t threshold, k, C, nchunks;
-	uint64_t steps_spec = 0, steps_bridge = 0, cmp_calls = 0, pool_used = 0, rounds = 0, slow_steps = 0;
+	uint64_t steps_spec = 0, steps_bridge = 0, cmp_calls = 0, pool_used = 0, rounds = 0, slow_steps = 0, overruns = 0;
 	int error = 0;
 };
 
@@ -142,7 +142,7 @@ void *emul_run2(size_t n, const char *const *seq, const size_t *len, size_t ref_
 	std::vector<BridgeRec> bridge(P.nchunks);
 	uint32_t pool_blocks = 1024 + P.nchunks;
 	std::vector<PoolBlock> pool(pool_blocks);
-	uint32_t pool_next = 0, error = 0, fetch[2] = {0, 0};
+	uint32_t pool_next = 0, error = 0, fetch[2] = {0, 0}, overrun = 0;
 	PhaseA A;
 	A.qbase = qbase.data();
 	A.qoff = qoff.data();
@@ -167,6 +167,7 @@ void *emul_run2(size_t n, const char *const *seq, const size_t *len, size_t ref_
 	A.pool_next = &pool_next;
 	A.error = &error;
 	A.fetch = fetch;
+	A.overrun = &overrun;
 
 	if (chatty) fprintf(stderr, "emul: index done (k %u), %u chunks of %u\n", k, P.nchunks, P.C);
 	// the lean chain's packed tables (the product builds them on the device: lean_kernels.hip)
@@ -217,6 +218,12 @@ void *emul_run2(size_t n, const char *const *seq, const size_t *len, size_t ref_
 		ln.start(A, P.items[it]);
 		run_lane(ln, R, [&] { return ln.begin_step(A); }, [&] { ln.step_done(A); }, &E->steps_spec, &E->rounds,
 				 &E->cmp_calls);
+	}
+	// K1b: the open ends of cut comparisons (lean chains)
+	E->overruns = 0;
+	if (lean && overrun) {
+		for (uint32_t gc = 0; gc < P.nchunks; gc++) E->overruns += (spec_cnt[gc] & LEAN_OVERRUN_BIT) ? 1 : 0;
+		for (size_t j = 0; j < n; j++) lean_overrun_resolve_query(A, R, (uint32_t)j);
 	}
 	// K2: bridges
 	auto alloc = [&]() -> uint32_t {
@@ -315,6 +322,7 @@ void emul_get_raw(void *e, size_t j, uint32_t *out)
 	}
 }
 uint64_t emul_slow_steps(void *e) { return ((EmulOut *)e)->slow_steps; }
+uint64_t emul_overruns(void *e) { return ((EmulOut *)e)->overruns; }
 // how often each reason sent a step to the slow resolver since the library was loaded (lean_core.h: LeanSlowWhy)
 void emul_slow_why(unsigned long long *out)
 {

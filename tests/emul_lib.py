@@ -33,6 +33,8 @@ def lib():
     L.emul_run2.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint, C.c_uint, C.c_uint]
     L.emul_slow_steps.restype = C.c_uint64
     L.emul_slow_steps.argtypes = [C.c_void_p]
+    L.emul_overruns.restype = C.c_uint64
+    L.emul_overruns.argtypes = [C.c_void_p]
     L.emul_free.argtypes = [C.c_void_p]
     L.emul_count.restype = C.c_size_t
     L.emul_count.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
@@ -60,6 +62,7 @@ class EmulRun:
         lens = (C.c_size_t * self.n)(*[a.size for a in self._a])
         self.h = lib().emul_run2(self.n, ptrs, lens, ref_idx, threshold, chunk, kmer, mode)
         self.slow_steps = int(lib().emul_slow_steps(self.h))
+        self.overruns = int(lib().emul_overruns(self.h))
         info = np.zeros(8, np.uint64)
         lib().emul_info(self.h, info.ctypes.data_as(C.c_void_p))
         self.threshold, self.k, self.C, self.nchunks = (int(x) for x in info[:4])

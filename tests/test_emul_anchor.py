@@ -230,3 +230,37 @@ def test_long_head_and_short_tail_chunks(chunk, tail):
     gs = synth.make_genomes(5, 30000, seed=chunk + tail, d_range=(0.005, 0.3), indel_per_mbp=400, inv_frac=0.08, contigs=2)
     assert_same(gs, 0, chunk=chunk, tail=tail)
     assert_same(gs, 3, chunk=chunk, tail=tail, threshold=18)
+
+
+@pytest.mark.parametrize("chunk", [64, 256, 1024, 0])
+def test_overruns_of_near_identical_genomes(chunk):
+    """Genomes that equal the reference over many chunk lengths: the lean chains cut every speculative
+    comparison one chunk length past its chunk's end and hand the true end down the run of chunks
+    afterwards (lean_core.h: overruns) — same homologies as the reference's sequential chain."""
+    rng = np.random.default_rng(31)
+    a = synth.random_base(40000, rng)
+    b = a.copy()
+    b[[7000, 7001, 23000]] = synth.random_base(3, rng)            # three substitutions in 40 kbp
+    c = np.concatenate([a[:15000], a[15010:]])                    # a deletion
+    d = np.concatenate([a[:5000], synth.revcomp(a[5000:30000]), a[30000:]])  # a 25 kbp inversion
+    e = synth.split_contigs(a.copy(), 3, rng)                     # '!' inside otherwise identical sequence
+    gs = [a, a.copy(), b, c, d, e, synth.mutate(a, 0.0003, rng)]
+    r, em = assert_same(gs, 0, chunk=chunk, modes=(1,))
+    if chunk and chunk <= 1024:
+        assert em.overruns > 20
+    assert_same(gs, 6, chunk=chunk, modes=(1, 3))
+
+
+def test_overruns_with_long_repeats():
+    """A 6 kbp stretch present three times in the reference, queries near-identical to it: cut comparisons
+    whose neighbours in the suffix array share kilobases (the LCP test of may_cut) and runs that end
+    because the next chunk's longest match lies on another diagonal."""
+    rng = np.random.default_rng(32)
+    rep = synth.random_base(6000, rng)
+    a = np.concatenate([synth.random_base(9000, rng), rep, synth.random_base(4000, rng), rep, synth.random_base(7000, rng), rep,
+                        synth.random_base(3000, rng)])
+    b = a.copy()
+    b[[12000, 20500, 31000]] = synth.random_base(3, rng)
+    for chunk in (128, 512, 2048):
+        assert_same([a, b, a.copy()], 0, chunk=chunk, modes=(1,))
+        assert_same([a, b, a.copy()], 1, chunk=chunk, modes=(1,))

@@ -178,6 +178,30 @@ def test_process_complete_deletion(ctx):
     check_process(ctx, gs, 1, complete_deletion=True)
 
 
+@pytest.mark.parametrize("chunk", [64, 256, 0])
+def test_process_near_identical_genomes(ctx, chunk):
+    """Genomes equal to the reference over many chunk lengths (copies, three substitutions in 40 kbp, a
+    deletion, a 25 kbp inversion, '!' inside identical sequence): the speculative chains cut their
+    comparisons one chunk length past the chunk's end and the ends are resolved afterwards
+    (lean_core.h: overruns); lists and tallies equal the oracle's."""
+    rng = np.random.default_rng(31)
+    a = synth.random_base(40000, rng)
+    b = a.copy()
+    b[[7000, 7001, 23000]] = synth.random_base(3, rng)
+    c = np.concatenate([a[:15000], a[15010:]])
+    d = np.concatenate([a[:5000], synth.revcomp(a[5000:30000]), a[30000:]])
+    e = synth.split_contigs(a.copy(), 3, rng)
+    gs = [a, a.copy(), b, c, d, e, synth.mutate(a, 0.0003, rng)]
+    check_process(ctx, gs, 0, chunk=chunk)
+    check_process(ctx, gs, 6, chunk=chunk)
+    rep = synth.random_base(6000, rng)
+    f = np.concatenate([synth.random_base(9000, rng), rep, synth.random_base(4000, rng), rep, synth.random_base(7000, rng), rep,
+                        synth.random_base(3000, rng)])
+    g = f.copy()
+    g[[12000, 20500, 31000]] = synth.random_base(3, rng)
+    check_process(ctx, [f, g, f.copy()], 1, chunk=chunk or 512)
+
+
 def test_process_repeats(ctx):
     rng = np.random.default_rng(23)
     unit = synth.random_base(700, rng)
