@@ -298,12 +298,12 @@ struct FoldShared {
 	uint32_t ecnt[FOLD_WAVES];
 };
 
-__global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t nq, uint32_t border, uint32_t thr,
+__global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j0, uint32_t nq, uint32_t border, uint32_t thr,
 												   RawHom *out, const uint64_t *out_base, const uint32_t *out_cap,
 												   uint32_t *out_cnt)
 {
 	__shared__ FoldShared sh;
-	const uint32_t j = blockIdx.x;
+	const uint32_t j = j0 + blockIdx.x;
 	if (j >= nq) return;
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	RawHom *dst = out + out_base[j];
@@ -695,10 +695,12 @@ void launch_bridge(const PhaseA &A, const RefIndex &R, int n_cu, hipStream_t st)
 	if (need < blocks) blocks = need > 0 ? need : 1;
 	hipLaunchKernelGGL(chain_kernel<1>, dim3(blocks), dim3(256), 0, st, A, R);
 }
-void launch_fold(const PhaseA &A, uint32_t nq, uint32_t border, uint32_t thr, RawHom *out,
+// queries [j0, j1)
+void launch_fold(const PhaseA &A, uint32_t j0, uint32_t j1, uint32_t border, uint32_t thr, RawHom *out,
 				 const uint64_t *out_base, const uint32_t *out_cap, uint32_t *out_cnt, hipStream_t st)
 {
-	hipLaunchKernelGGL(fold_kernel, dim3(nq), dim3(FOLD_THREADS), 0, st, A, nq, border, thr, out, out_base, out_cap, out_cnt);
+	if (j1 <= j0) return;
+	hipLaunchKernelGGL(fold_kernel, dim3(j1 - j0), dim3(FOLD_THREADS), 0, st, A, j0, j1, border, thr, out, out_base, out_cap, out_cnt);
 }
 
 } // namespace phy

@@ -24,6 +24,9 @@ static const uint32_t FILT_MAX = 4096;   // entries per query the block's LDS ho
 static const uint32_t FILT_THREADS = 1024;
 static const uint32_t FILT_WAVES = FILT_THREADS / 64;
 static const uint16_t NONE16 = 0xffff;
+static const uint32_t FLAG_HOST = 1;    // flag[j]: the host does this query (equal starts, or too long a list)
+static const uint32_t FLAG_GENERAL = 2; // ... the general kernel below does (an entangled stretch of more than SEG_MAX entries)
+static const uint32_t SEG_MAX = 48;     // longest stretch of mutually entangled entries one thread works out
 
 // (score, pile index) as one integer whose maximum is "highest score, then smallest index":
 // exactly the reference's choice of predecessor (the first k with the largest score,
@@ -86,13 +89,15 @@ static __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src)
 // wavefront takes 64 entries per round (see the loop).
 __global__ __launch_bounds__(FILT_THREADS) void sort_filter_kernel(const RawHom *__restrict__ raw,
 																	const uint64_t *__restrict__ raw_base,
-																	const uint32_t *__restrict__ raw_cnt, uint32_t border,
+																	const uint32_t *__restrict__ raw_cnt, uint32_t j0, uint32_t border,
 																	uint32_t threshold, uint32_t ref_local,
 																	DevHom *__restrict__ out, uint32_t *__restrict__ rng,
-																	uint32_t *__restrict__ total, uint32_t *__restrict__ flag)
+																	uint32_t *__restrict__ total, uint32_t *__restrict__ flag,
+																	uint32_t only_flagged)
 {
 	__shared__ FilterShared sh;
-	const uint32_t j = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const uint32_t j = j0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	if (only_flagged && flag[j] != FLAG_GENERAL) return; // second pass: the lists the segment-wise kernel handed over
 	const RawHom *r = raw + raw_base[j];
 	const uint32_t n = raw_cnt[j];
 	if (j == ref_local) {
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(FILT_THREADS) void sort_filter_kernel(const RawHom 
 	}
 	if (n > FILT_MAX) {
 		if (tid == 0) {
-			flag[j] = 1;
+			flag[j] = FLAG_HOST;
 			rng[2 * j] = rng[2 * j + 1] = 0; // an empty list until the host has done this query
 		}
 		return;
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(FILT_THREADS) void sort_filter_kernel(const RawHom 
 	__syncthreads();
 	if (sh.tie) {
 		if (tid == 0) {
-			flag[j] = 1;
+			flag[j] = FLAG_HOST;
 			rng[2 * j] = rng[2 * j + 1] = 0;
 		}
 		return;
@@ -309,13 +314,213 @@ __global__ __launch_bounds__(FILT_THREADS) void sort_filter_kernel(const RawHom 
 	}
 }
 
-void launch_sort_filter(const RawHom *raw, const uint64_t *raw_base, const uint32_t *raw_cnt, uint32_t nq, uint32_t border,
-						uint32_t threshold, uint32_t ref_local, DevHom *out, uint32_t *rng, uint32_t *total, uint32_t *flag,
-						hipStream_t st)
+// ── the same filter, stretch by stretch ──
+// In pile order (by projected start) put a cut before entry i when every earlier entry ends at or before
+// i starts (prefix maximum of the ends).  The stretches between cuts are independent: every entry of an
+// earlier stretch is a candidate predecessor of every entry of a later one, and any candidate inside the
+// own stretch outscores them all, so the reference's DP (process.cxx:354-401) restricted to a stretch
+// gives the same predecessors inside it, the stretch's first best-scoring entry is where the chain of all
+// later stretches continues, and the kept set is the union of the stretches' own best chains.  After
+// anchoring most stretches are single entries (homologies rarely overlap on the reference), so instead
+// of a dependent scan over the whole list (the kernel above: 0.25 ms) every thread works out the few
+// short stretches that start at its entries.  A stretch longer than SEG_MAX hands the query to the
+// kernel above (flag 2); equal starts or more than FILT_MAX entries to the host (flag 1), as there.
+struct SegShared {
+	uint64_t by_start[FILT_MAX]; // start << 32 | raw index, sorted: pile order
+	uint32_t len[FILT_MAX];
+	uint32_t score[FILT_MAX];    // first the prefix maximum of the ends, then the stretch-local scores
+	uint16_t pred[FILT_MAX];
+	uint8_t keep[FILT_MAX];      // bit 0 kept, bit 1 a stretch starts here
+	uint32_t wmax[FILT_WAVES], wsum[FILT_WAVES];
+	uint32_t tie, general, base;
+};
+
+__global__ __launch_bounds__(FILT_THREADS) void sort_filter_seg_kernel(const RawHom *__restrict__ raw,
+																		const uint64_t *__restrict__ raw_base,
+																		const uint32_t *__restrict__ raw_cnt, uint32_t j0, uint32_t border,
+																		uint32_t threshold, uint32_t ref_local,
+																		DevHom *__restrict__ out, uint32_t *__restrict__ rng,
+																		uint32_t *__restrict__ total, uint32_t *__restrict__ flag)
 {
-	if (!nq) return;
-	hipLaunchKernelGGL(sort_filter_kernel, dim3(nq), dim3(FILT_THREADS), 0, st, raw, raw_base, raw_cnt, border, threshold,
-					   ref_local, out, rng, total, flag);
+	__shared__ SegShared sh;
+	const uint32_t j = j0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const RawHom *r = raw + raw_base[j];
+	const uint32_t n = raw_cnt[j];
+	if (j == ref_local) {
+		if (tid == 0) {
+			uint32_t b = 0, w = border / 2 >= threshold ? 1u : 0u;
+			if (w) {
+				b = atomicAdd(total, 1u);
+				out[b] = DevHom{0u, 0u, border, 0u};
+			}
+			rng[2 * j] = b;
+			rng[2 * j + 1] = b + w;
+			flag[j] = 0;
+		}
+		return;
+	}
+	if (n > FILT_MAX) {
+		if (tid == 0) {
+			flag[j] = FLAG_HOST;
+			rng[2 * j] = rng[2 * j + 1] = 0;
+		}
+		return;
+	}
+	uint32_t n2 = 1;
+	while (n2 < n) n2 <<= 1;
+	if (tid == 0) sh.tie = sh.general = 0;
+	for (uint32_t t = tid; t < n2; t += FILT_THREADS) { // reverseEh (process.h:72-80)
+		uint64_t key = ~0ull;
+		if (t < n) {
+			const RawHom h = r[t];
+			const uint32_t start = h.iref >= border ? 2u * border + 1u - h.len - h.iref : h.iref;
+			key = (uint64_t)start << 32 | t;
+		}
+		sh.by_start[t] = key;
+	}
+	__syncthreads();
+	bitonic_sort(sh.by_start, n2);
+	// lengths by pile position, equal starts, and the prefix maximum of the ends (4 consecutive entries per thread)
+	const uint32_t p4 = tid * 4u;
+	uint32_t e[4], run = 0;
+#pragma unroll
+	for (uint32_t u = 0; u < 4; u++) {
+		const uint32_t p = p4 + u;
+		e[u] = 0;
+		if (p < n) {
+			const uint64_t key = sh.by_start[p];
+			if (p + 1 < n && (uint32_t)(sh.by_start[p + 1] >> 32) == (uint32_t)(key >> 32)) sh.tie = 1; // benign race: same value
+			const uint32_t l = r[(uint32_t)key].len;
+			sh.len[p] = l;
+			e[u] = (uint32_t)(key >> 32) + l;
+		}
+		run = e[u] > run ? e[u] : run;
+		e[u] = run; // inclusive maximum inside the thread
+	}
+	uint32_t incl = run;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint32_t t = (uint32_t)__shfl_up((int)incl, d, 64);
+		if ((int)lane >= d && t > incl) incl = t;
+	}
+	if (lane == 63) sh.wmax[wave] = incl;
+	__syncthreads();
+	if (sh.tie) {
+		if (tid == 0) {
+			flag[j] = FLAG_HOST;
+			rng[2 * j] = rng[2 * j + 1] = 0;
+		}
+		return;
+	}
+	uint32_t before = (uint32_t)__shfl_up((int)incl, 1, 64); // maximum of the ends of all entries of earlier threads
+	if (lane == 0) before = 0;
+	for (uint32_t w2 = 0; w2 < wave; w2++) before = sh.wmax[w2] > before ? sh.wmax[w2] : before;
+#pragma unroll
+	for (uint32_t u = 0; u < 4; u++) {
+		const uint32_t p = p4 + u;
+		if (p < n) {
+			const uint32_t prev_max = u ? (e[u - 1] > before ? e[u - 1] : before) : before;
+			sh.keep[p] = prev_max <= (uint32_t)(sh.by_start[p] >> 32) ? 2u : 0u; // a stretch starts here
+		}
+	}
+	__syncthreads();
+	// every thread: the stretches that start at its entries
+#pragma unroll 1
+	for (uint32_t u = 0; u < 4; u++) {
+		const uint32_t a = p4 + u;
+		if (a >= n || !(sh.keep[a] & 2u)) continue;
+		uint32_t b = a + 1;
+		while (b < n && !(sh.keep[b] & 2u)) b++;
+		if (b - a == 1) {
+			sh.keep[a] |= 1u;
+			continue;
+		}
+		if (b - a > SEG_MAX) {
+			sh.general = 1;
+			continue;
+		}
+		uint32_t top = a, top_score = 0;
+		for (uint32_t i = a; i < b; i++) { // filter_overlaps_max inside the stretch: first best predecessor, first best end
+			const uint32_t start_i = (uint32_t)(sh.by_start[i] >> 32);
+			uint32_t best = 0, bk = NONE16;
+			for (uint32_t k = a; k < i; k++) {
+				const uint32_t end_k = (uint32_t)(sh.by_start[k] >> 32) + sh.len[k];
+				const uint32_t sc = sh.score[k];
+				if (end_k <= start_i && sc > best) {
+					best = sc;
+					bk = k;
+				}
+			}
+			const uint32_t sc_i = best + sh.len[i];
+			sh.score[i] = sc_i;
+			sh.pred[i] = (uint16_t)bk;
+			if (sc_i > top_score) {
+				top_score = sc_i;
+				top = i;
+			}
+		}
+		for (uint32_t i = top; i != NONE16; i = sh.pred[i]) sh.keep[i] |= 1u;
+	}
+	__syncthreads();
+	if (sh.general) {
+		if (tid == 0) {
+			flag[j] = FLAG_GENERAL;
+			rng[2 * j] = rng[2 * j + 1] = 0;
+		}
+		return;
+	}
+	// the kept entries leave in pile order
+	uint32_t done = 0, base = 0;
+	{
+		uint32_t mine = 0;
+		for (uint32_t i = tid; i < n; i += FILT_THREADS) mine += sh.keep[i] & 1u;
+		for (uint32_t d = 32; d > 0; d >>= 1) mine += (uint32_t)__shfl((int)mine, (int)(lane ^ d), 64);
+		if (lane == 0) sh.wsum[wave] = mine;
+		__syncthreads();
+		if (tid == 0) {
+			uint32_t w = 0;
+			for (uint32_t w2 = 0; w2 < FILT_WAVES; w2++) w += sh.wsum[w2];
+			const uint32_t b = w ? atomicAdd(total, w) : 0u;
+			sh.base = b;
+			rng[2 * j] = b;
+			rng[2 * j + 1] = b + w;
+			flag[j] = 0;
+		}
+		__syncthreads();
+		base = sh.base;
+	}
+	for (uint32_t p0 = 0; p0 < n; p0 += FILT_THREADS) {
+		const uint32_t p = p0 + tid;
+		const uint32_t k = (p < n && (sh.keep[p] & 1u)) ? 1u : 0u;
+		const uint64_t m = __ballot(k);
+		if (lane == 0) sh.wsum[wave] = (uint32_t)__popcll(m);
+		__syncthreads();
+		uint32_t off = done + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+		for (uint32_t w2 = 0; w2 < wave; w2++) off += sh.wsum[w2];
+		if (k) {
+			const uint64_t key = sh.by_start[p];
+			const RawHom h = r[(uint32_t)key];
+			out[base + off] = DevHom{(uint32_t)(key >> 32), h.iq, h.len, h.iref >= border ? 1u : 0u};
+		}
+		for (uint32_t w2 = 0; w2 < FILT_WAVES; w2++) done += sh.wsum[w2];
+		__syncthreads();
+	}
+}
+
+void launch_sort_filter(const RawHom *raw, const uint64_t *raw_base, const uint32_t *raw_cnt, uint32_t j0, uint32_t j1, uint32_t border,
+						uint32_t threshold, uint32_t ref_local, DevHom *out, uint32_t *rng, uint32_t *total, uint32_t *flag,
+						hipStream_t st, int variant)
+{
+	if (j1 <= j0) return;
+	if (variant == 0) { // stretch by stretch, then the general kernel for what that one handed over
+		hipLaunchKernelGGL(sort_filter_seg_kernel, dim3(j1 - j0), dim3(FILT_THREADS), 0, st, raw, raw_base, raw_cnt, j0, border,
+						   threshold, ref_local, out, rng, total, flag);
+		hipLaunchKernelGGL(sort_filter_kernel, dim3(j1 - j0), dim3(FILT_THREADS), 0, st, raw, raw_base, raw_cnt, j0, border, threshold,
+						   ref_local, out, rng, total, flag, 1u);
+	} else {
+		hipLaunchKernelGGL(sort_filter_kernel, dim3(j1 - j0), dim3(FILT_THREADS), 0, st, raw, raw_base, raw_cnt, j0, border, threshold,
+						   ref_local, out, rng, total, flag, 0u);
+	}
 }
 
 } // namespace phy

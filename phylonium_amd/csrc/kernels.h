@@ -14,6 +14,9 @@ int lean_spec_resident_blocks(int n_cu);
 void launch_lean_spec(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st);
 void launch_lean_overruns(const PhaseA &A, const RefIndex &R, uint32_t nq, hipStream_t st); // between spec and bridge
 void launch_lean_bridge(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st);
+// the bridges of chunks [c_lo, c_hi) only (a group of queries), work counter A.fetch[fetch_slot]
+void launch_lean_bridge_range(const PhaseA &A, const RefIndex &R, const LeanIndex &X, uint32_t c_lo, uint32_t c_hi,
+							  uint32_t fetch_slot, int n_cu, hipStream_t st);
 void launch_pack2(const uint8_t *src, uint64_t bytes, uint32_t *dst, hipStream_t st); // bytes: a multiple of 16
 uint32_t bad_segment_bytes();
 // non-ACGT positions per sequence; out == nullptr: count per segment into seg_cnt, else write from seg_off
@@ -25,15 +28,15 @@ void launch_bad_positions(const uint8_t *base, const uint64_t *off, const uint32
 int spec_resident_blocks(int n_cu); // blocks of the speculative-chain kernel the device holds at once
 void launch_spec(const PhaseA &A, const RefIndex &R, int n_cu, hipStream_t st);
 void launch_bridge(const PhaseA &A, const RefIndex &R, int n_cu, hipStream_t st);
-void launch_fold(const PhaseA &A, uint32_t nq, uint32_t border, uint32_t thr, RawHom *out,
-				 const uint64_t *out_base, const uint32_t *out_cap, uint32_t *out_cnt, hipStream_t st);
+void launch_fold(const PhaseA &A, uint32_t j0, uint32_t j1, uint32_t border, uint32_t thr, RawHom *out,
+				 const uint64_t *out_base, const uint32_t *out_cap, uint32_t *out_cnt, hipStream_t st); // queries [j0, j1)
 
 // filter_kernels.hip: reverseEh + sort + filter_overlaps_max per query on the device; flag[j] = 1
 // leaves query j to the host (two entries share a projected start, or the list is too long)
 struct DevHom;
-void launch_sort_filter(const RawHom *raw, const uint64_t *raw_base, const uint32_t *raw_cnt, uint32_t nq, uint32_t border,
+void launch_sort_filter(const RawHom *raw, const uint64_t *raw_base, const uint32_t *raw_cnt, uint32_t j0, uint32_t j1, uint32_t border,
 						uint32_t threshold, uint32_t ref_local, DevHom *out, uint32_t *rng, uint32_t *total, uint32_t *flag,
-						hipStream_t st);
+						hipStream_t st, int variant = 0); // queries [j0, j1); variant 0: stretch by stretch (default), 1: the general kernel only
 
 // index_kernels.hip
 void launch_lcp(const uint8_t *S, const uint32_t *SA, uint32_t n, uint32_t cap, uint32_t *LCP, uint32_t *capped,

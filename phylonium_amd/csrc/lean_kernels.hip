@@ -363,7 +363,11 @@ struct LeanAlloc {
 };
 
 // MODE 0: speculative chunk chains.  MODE 1: bridges.  Persistent lanes with dynamic work fetch.
-template <int MODE> __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, LeanIndex X)
+// it_count != 0: the work items are the chunks it_base .. it_base + it_count - 1 themselves (the bridges of a group of
+// queries), counted through A.fetch[fetch_slot]; else A.items[0 .. nchunks) through A.fetch[MODE].
+template <int MODE>
+__global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, LeanIndex X, uint32_t it_base, uint32_t it_count,
+														 uint32_t fetch_slot)
 {
 	typename std::conditional<MODE == 0, LeanSpec, LeanBridge>::type L;
 	LeanLane &ln = L.ln;
@@ -403,10 +407,10 @@ template <int MODE> __global__ __launch_bounds__(256) void lean_chain_kernel(Pha
 			else active = L.begin_step(A, X, R);
 		}
 		if (!active && !done) {
-			const uint32_t it = atomicAdd(&A.fetch[MODE], 1u);
-			done = it >= A.nchunks;
+			const uint32_t it = atomicAdd(&A.fetch[it_count ? fetch_slot : (uint32_t)MODE], 1u);
+			done = it >= (it_count ? it_count : A.nchunks);
 			if (!done) {
-				L.start(A, X, A.items[it]);
+				L.start(A, X, it_count ? it_base + it : A.items[it]);
 				if constexpr (MODE == 0) active = L.begin_step(A, X);
 				else active = L.begin_step(A, X, R);
 			}
@@ -623,14 +627,23 @@ void launch_lean_spec(const PhaseA &A, const RefIndex &R, const LeanIndex &X, in
 	int blocks = lean_spec_resident_blocks(n_cu);
 	const int need = (int)((A.nchunks + 255) / 256);
 	if (need < blocks) blocks = need > 0 ? need : 1;
-	hipLaunchKernelGGL(lean_chain_kernel<0>, dim3(blocks), dim3(256), 0, st, A, R, X);
+	hipLaunchKernelGGL(lean_chain_kernel<0>, dim3(blocks), dim3(256), 0, st, A, R, X, 0u, 0u, 0u);
 }
 void launch_lean_bridge(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st)
 {
 	int blocks = lean_resident((const void *)lean_chain_kernel<1>, n_cu);
 	const int need = (int)((A.nchunks + 255) / 256);
 	if (need < blocks) blocks = need > 0 ? need : 1;
-	hipLaunchKernelGGL(lean_chain_kernel<1>, dim3(blocks), dim3(256), 0, st, A, R, X);
+	hipLaunchKernelGGL(lean_chain_kernel<1>, dim3(blocks), dim3(256), 0, st, A, R, X, 0u, 0u, 0u);
+}
+void launch_lean_bridge_range(const PhaseA &A, const RefIndex &R, const LeanIndex &X, uint32_t c_lo, uint32_t c_hi,
+							  uint32_t fetch_slot, int n_cu, hipStream_t st)
+{
+	if (c_hi <= c_lo) return;
+	int blocks = lean_resident((const void *)lean_chain_kernel<1>, n_cu);
+	const int need = (int)((c_hi - c_lo + 255) / 256);
+	if (need < blocks) blocks = need;
+	hipLaunchKernelGGL(lean_chain_kernel<1>, dim3(blocks), dim3(256), 0, st, A, R, X, c_lo, c_hi - c_lo, fetch_slot);
 }
 
 } // namespace phy

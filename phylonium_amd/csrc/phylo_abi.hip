@@ -174,6 +174,14 @@ struct phylo_ctx {
 	hipStream_t stream = nullptr;
 	hipStream_t copy_stream = nullptr; // uploads that run beside kernels of `stream` (ordered by events)
 	std::vector<hipEvent_t> copy_events;
+	// Phase A's per-query tail — bridges, fold, sort + filter, projection — is issued per group of queries,
+	// every group on its own stream, so that one group's fold / filter / projection run under the other
+	// groups' bridge tails (a bridge kernel ends with a few long dependent chains and an idle device)
+	static const int TAIL_GROUPS = 3;
+	hipStream_t tail_stream[TAIL_GROUPS - 1] = {nullptr, nullptr};
+	hipEvent_t tail_event[TAIL_GROUPS] = {nullptr, nullptr, nullptr};
+	int opt_filter_kernel = 0; // option "filter_kernel": 0 stretch-wise chain filter (then the general kernel for what it hands over), 1 general only
+	int opt_tail_groups = 1; // option "tail_groups": streams the tail is spread over (default 1: measured, the groups run in lockstep and nothing is hidden — DESIGN.md)
 	std::string err;
 	int n_cu = 256;
 
@@ -297,18 +305,19 @@ struct KernelSpan {
 	phylo_ctx *c;
 	hipEvent_t a = nullptr, b = nullptr;
 	const char *name;
-	KernelSpan(phylo_ctx *ctx, const char *nm) : c(ctx), name(nm)
+	hipStream_t st;
+	KernelSpan(phylo_ctx *ctx, const char *nm, hipStream_t on = nullptr) : c(ctx), name(nm), st(on ? on : ctx->stream)
 	{
 		if (c->profile) {
 			a = get_event(c);
 			b = get_event(c);
-			(void)hipEventRecord(a, c->stream);
+			(void)hipEventRecord(a, st);
 		}
 	}
 	~KernelSpan()
 	{
 		if (c->profile) {
-			(void)hipEventRecord(b, c->stream);
+			(void)hipEventRecord(b, st);
 			c->spans.push_back(TimedSpan{name, a, b});
 		}
 	}
@@ -450,6 +459,10 @@ void phylo_ctx_destroy(phylo_ctx *c)
 	}
 	for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
 	for (hipEvent_t e : c->copy_events) (void)hipEventDestroy(e);
+	for (hipStream_t ts : c->tail_stream)
+		if (ts) (void)hipStreamDestroy(ts);
+	for (hipEvent_t e : c->tail_event)
+		if (e) (void)hipEventDestroy(e);
 	if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
 	(void)hipStreamDestroy(c->stream);
 	delete c;
@@ -477,6 +490,12 @@ int phylo_set_option(phylo_ctx *c, const char *key, long value)
 		if (value != 0 && value != 1) return c->fail("anchor_kernel must be 1 (lean 2-bit chains) or 0 (general byte-wise chains)");
 		c->anchor_kernel = (int)value;
 		c->plan_valid = false;
+	} else if (k == "filter_kernel") {
+		if (value != 0 && value != 1) return c->fail("filter_kernel must be 0 (stretch-wise) or 1 (general)");
+		c->opt_filter_kernel = (int)value;
+	} else if (k == "tail_groups") {
+		if (value < 1 || value > phylo_ctx::TAIL_GROUPS) return c->fail("tail_groups must be in 1..%d", phylo_ctx::TAIL_GROUPS);
+		c->opt_tail_groups = (int)value;
 	} else if (k == "lean_force_slow") {
 		c->lean_force_slow = value != 0;
 	} else if (k == "profile") {
@@ -984,18 +1003,94 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 			KernelSpan s(c, "anchor_overruns");
 			launch_lean_overruns(A, R, (uint32_t)nq, st);
 		}
-		{
-			KernelSpan s(c, "anchor_bridge");
-			if (lean) launch_lean_bridge(A, R, X, c->n_cu, st);
-			else launch_bridge(A, R, c->n_cu, st);
+	}
+	// One query's list takes the device ~0.1-0.4 ms however many there are (a block per query, all
+	// at once); the host pool does a few dozen lists in less than that, many only as fast.
+	// A call for a part of the genomes is a rank of a sharded run: its lists are exported next
+	// (phylo_export_packed_device), which is a device-to-device gather when they are already there
+	// and a pack + upload when they are on the host — with that counted the device wins for any number.
+	const bool part_of_many = !(q_begin == 0 && q_end == c->n);
+	const bool device_filter = c->filter_mode == 2 || (c->filter_mode == 0 && (nq >= 128 || part_of_many));
+	const bool full = q_begin == 0 && q_end == c->n;
+	const bool tail_eager = device_filter && full && c->backend == 0;
+	const uint32_t ref_local = (c->ref_idx >= q_begin && c->ref_idx < q_end) ? (uint32_t)(c->ref_idx - q_begin) : 0xffffffffu;
+	// groups of queries for the tail: whole projection tiles, balanced by chunks
+	const uint32_t tsz_q = project_genomes_per_tile();
+	int tgroups = 1;
+	if (lean && device_filter && nch && c->opt_tail_groups > 1) {
+		tgroups = c->opt_tail_groups;
+		tgroups = (int)std::min<size_t>((size_t)tgroups, nq / (2 * tsz_q));
+		if (tgroups < 1) tgroups = 1;
+	}
+	std::vector<uint32_t> gb(tgroups + 1, 0); // group g: queries [gb[g], gb[g+1])
+	gb[tgroups] = (uint32_t)nq;
+	for (int g = 1; g < tgroups; g++) {
+		const uint32_t want = (uint32_t)((uint64_t)nch * g / tgroups);
+		uint32_t j = (uint32_t)(std::lower_bound(P.qchunk0.begin(), P.qchunk0.begin() + nq, want) - P.qchunk0.begin());
+		j = (j + tsz_q / 2) / tsz_q * tsz_q;
+		gb[g] = std::min<uint32_t>(std::max(j, gb[g - 1]), (uint32_t)nq);
+	}
+	Pileup TP;
+	if (device_filter) {
+		HIPOK(c, c->b_homs.ensure(c->plan_raw_total + nq + 1));
+		HIPOK(c, c->b_hom_rng.ensure(2 * std::max(nq, c->n)));
+		HIPOK(c, c->a_flt.ensure(nq + 1));
+		HIPOK(c, c->h_rng.ensure(3 * nq + 16));
+		HIPOK(c, hipMemsetAsync(c->a_flt.p, 0, 4, st));
+		if (tail_eager) {
+			if (make_pileup(c, 0, 1, &TP)) return 1;
+			HIPOK(c, c->b_flag.ensure(4));
+			HIPOK(c, c->b_first.ensure(project_index_entries(TP) + 1));
+			HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 16, st));
+			c->eager_five = c->pileup_five;
 		}
-		dbg_sync("anchor_bridge");
 	}
-	{
-		KernelSpan s(c, "anchor_fold");
-		launch_fold(A, (uint32_t)nq, c->L, c->threshold, c->a_raw.p, c->a_out_base.p, c->a_out_cap.p, c->a_out_cnt.p, st);
+	if (tgroups > 1) {
+		for (int g = 0; g < tgroups; g++) {
+			if (g && !c->tail_stream[g - 1]) HIPOK(c, hipStreamCreateWithFlags(&c->tail_stream[g - 1], hipStreamNonBlocking));
+			if (!c->tail_event[g]) HIPOK(c, hipEventCreateWithFlags(&c->tail_event[g], hipEventDisableTiming));
+		}
+		HIPOK(c, hipEventRecord(c->tail_event[0], st)); // the speculative chains (and their overruns) are done
 	}
-	dbg_sync("anchor_fold");
+	for (int g = 0; g < tgroups; g++) {
+		hipStream_t sg = g ? c->tail_stream[g - 1] : st;
+		const uint32_t j0 = gb[g], j1 = gb[g + 1];
+		if (g) HIPOK(c, hipStreamWaitEvent(sg, c->tail_event[0], 0));
+		if (nch) {
+			KernelSpan s(c, "anchor_bridge", sg);
+			if (!lean) launch_bridge(A, R, c->n_cu, st);
+			else if (tgroups == 1) launch_lean_bridge(A, R, X, c->n_cu, st);
+			else launch_lean_bridge_range(A, R, X, P.qchunk0[j0], P.qchunk0[j1], 8u + (uint32_t)g, c->n_cu, sg);
+		}
+		{
+			KernelSpan s(c, "anchor_fold", sg);
+			launch_fold(A, j0, j1, c->L, c->threshold, c->a_raw.p, c->a_out_base.p, c->a_out_cap.p, c->a_out_cnt.p, sg);
+		}
+		if (device_filter) {
+			// reverseEh + sort + filter_overlaps_max on the device (filter_kernels.hip).  The lists stay
+			// there in the 16-byte device form, the projection (phase B's first kernel, for the whole
+			// reference = part 0 of 1) follows at once when this call covers all genomes, and the host
+			// reads a list back only when somebody asks for it.  A query whose list has two entries
+			// with the same projected start, or more entries than the kernel holds, is flagged: then
+			// everything below runs on the host as it always did.
+			{
+				KernelSpan s(c, "anchor_filter", sg);
+				launch_sort_filter(c->a_raw.p, c->a_out_base.p, c->a_out_cnt.p, j0, j1, c->L, c->threshold, ref_local, c->b_homs.p,
+								   c->b_hom_rng.p, c->a_flt.p, c->a_flt.p + 1, sg, c->opt_filter_kernel);
+			}
+			if (tail_eager && j1 > j0) {
+				launch_tile_index(TP, c->b_homs.p, c->b_hom_rng.p, c->b_first.p, j0, j1, sg);
+				KernelSpan s(c, c->eager_five ? "pileup_project5" : "pileup_project", sg);
+				launch_project(TP, c->eager_five, c->d_genomes, c->d_goff.p, c->b_homs.p, c->b_hom_rng.p, c->b_first.p, c->b_flag.p,
+							   j0 / tsz_q, g + 1 == tgroups ? TP.Npad / tsz_q : j1 / tsz_q, sg);
+			}
+		}
+		if (g) {
+			HIPOK(c, hipEventRecord(c->tail_event[g], sg));
+			HIPOK(c, hipStreamWaitEvent(st, c->tail_event[g], 0));
+		}
+	}
+	dbg_sync("anchor tail (bridge, fold, filter, projection)");
 #ifdef PHY_LEAN_TIMING
 	{
 		unsigned long long h[16];
@@ -1012,44 +1107,7 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	c->eager_valid = false;
 	c->att_homs = nullptr; // an attached buffer is only borrowed until the next phase A
 	c->host_stale.clear();
-	// One query's list takes the device ~0.1-0.4 ms however many there are (a block per query, all
-	// at once); the host pool does a few dozen lists in less than that, many only as fast.
-	// A call for a part of the genomes is a rank of a sharded run: its lists are exported next
-	// (phylo_export_packed_device), which is a device-to-device gather when they are already there
-	// and a pack + upload when they are on the host — with that counted the device wins for any number.
-	const bool part_of_many = !(q_begin == 0 && q_end == c->n);
-	if (c->filter_mode == 2 || (c->filter_mode == 0 && (nq >= 128 || part_of_many))) {
-		// reverseEh + sort + filter_overlaps_max on the device (filter_kernels.hip).  The lists stay
-		// there in the 16-byte device form, the projection (phase B's first kernel, for the whole
-		// reference = part 0 of 1) follows on the stream at once when this call covers all genomes,
-		// and the host reads a list back only when somebody asks for it.  A query whose list has
-		// two entries with the same projected start, or more entries than the kernel holds, is
-		// flagged: then everything below runs on the host as it always did.
-		const bool full = q_begin == 0 && q_end == c->n;
-		HIPOK(c, c->b_homs.ensure(c->plan_raw_total + nq + 1));
-		HIPOK(c, c->b_hom_rng.ensure(2 * std::max(nq, c->n)));
-		HIPOK(c, c->a_flt.ensure(nq + 1));
-		HIPOK(c, c->h_rng.ensure(3 * nq + 16));
-		HIPOK(c, hipMemsetAsync(c->a_flt.p, 0, 4, st));
-		const uint32_t ref_local = (c->ref_idx >= q_begin && c->ref_idx < q_end) ? (uint32_t)(c->ref_idx - q_begin) : 0xffffffffu;
-		{
-			KernelSpan s(c, "anchor_filter");
-			launch_sort_filter(c->a_raw.p, c->a_out_base.p, c->a_out_cnt.p, (uint32_t)nq, c->L, c->threshold, ref_local,
-							   c->b_homs.p, c->b_hom_rng.p, c->a_flt.p, c->a_flt.p + 1, st);
-		}
-		const bool eager = full && c->backend == 0;
-		if (eager) {
-			Pileup EP;
-			if (make_pileup(c, 0, 1, &EP)) return 1;
-			HIPOK(c, c->b_flag.ensure(4));
-			HIPOK(c, c->b_first.ensure(project_index_entries(EP) + 1));
-			HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 16, st));
-			c->eager_five = c->pileup_five;
-			launch_tile_index(EP, c->b_homs.p, c->b_hom_rng.p, c->b_first.p, 0, (uint32_t)nq, st);
-			KernelSpan s(c, c->eager_five ? "pileup_project5" : "pileup_project");
-			launch_project(EP, c->eager_five, c->d_genomes, c->d_goff.p, c->b_homs.p, c->b_hom_rng.p, c->b_first.p, c->b_flag.p,
-						   0, EP.Npad / project_genomes_per_tile(), st);
-		}
+	if (device_filter) {
 		uint32_t *hr = c->h_rng.p; // [0, 2nq) ranges, [2nq, 3nq) flags, then total and the four misc words
 		HIPOK(c, hipMemcpyAsync(hr, c->b_hom_rng.p, 2 * nq * 4, hipMemcpyDeviceToHost, st));
 		HIPOK(c, hipMemcpyAsync(hr + 2 * nq, c->a_flt.p + 1, nq * 4, hipMemcpyDeviceToHost, st));
@@ -1076,7 +1134,7 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 				c->host_stale[q_begin + j] = 1;
 			}
 			c->homs_staged = full;
-			c->eager_valid = eager;
+			c->eager_valid = tail_eager;
 			c->stats["ms:anchor_setup"] += t1 - t0;
 			c->stats["ms:anchor_gpu"] += t2d - t1;
 			c->stats["ms:anchor_total"] += now_ms() - t0;

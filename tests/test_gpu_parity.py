@@ -36,6 +36,9 @@ def check_process(ctx, gs, ref, chunk=0, kmer=0, backend=0, complete_deletion=Fa
         check_process.flip = 3 - getattr(check_process, "flip", 1)
         filt = check_process.flip
     ctx.set_option("filter", filt)
+    # the device filter's two kernels, alternating: stretch by stretch (default) / the general dependent scan
+    check_process.fk = (getattr(check_process, "fk", 0) + 1) % 3
+    ctx.set_option("filter_kernel", 1 if check_process.fk == 2 else 0)
     ctx.set_option("chunk", chunk)
     ctx.set_option("chunk_tail", tail)
     ctx.set_option("kmer", kmer)
@@ -78,6 +81,7 @@ def check_process(ctx, gs, ref, chunk=0, kmer=0, backend=0, complete_deletion=Fa
     ctx.set_option("kmer", 0)
     ctx.set_option("compare_backend", 0)
     ctx.set_option("filter", 0)
+    ctx.set_option("filter_kernel", 0)
     return s, h
 
 
@@ -200,6 +204,23 @@ def test_process_near_identical_genomes(ctx, chunk):
     g = f.copy()
     g[[12000, 20500, 31000]] = synth.random_base(3, rng)
     check_process(ctx, [f, g, f.copy()], 1, chunk=chunk or 512)
+
+
+def test_device_filter_on_entangled_lists(ctx):
+    """Reference with a 3 kbp stretch present eight times and queries that carry diverged copies of it: the
+    raw lists hold many overlapping homologies, i.e. long entangled stretches for the stretch-wise chain
+    filter (some beyond what one thread takes: handed to the general kernel on the device)."""
+    rng = np.random.default_rng(41)
+    rep = synth.random_base(3000, rng)
+    parts = []
+    for i in range(8):
+        parts += [synth.random_base(int(rng.integers(500, 4000)), rng), synth.mutate(rep, 0.01 * i, rng)]
+    a = np.concatenate(parts + [synth.random_base(2000, rng)])
+    gs = [a] + [synth.mutate(a, d, rng) for d in (0.005, 0.02, 0.05, 0.1)]
+    for fk in (0, 1):
+        ctx.set_option("filter_kernel", fk)
+        for ref in (0, 2):
+            check_process(ctx, gs, ref, filt=2)
 
 
 def test_process_repeats(ctx):
