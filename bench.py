@@ -384,7 +384,7 @@ def main():
                 return m[0], m[1]
             return ctx.compare(emu[0], emu[1])
         return dist.process_sharded(ctx, ref_idx, rank, world, device=None if shared else device, lengths=lens,
-                                    set_reference=False, out=out_mats)
+                                    set_reference=False, out=out_mats, copy=False)
 
     if emu:  # the other ranks' lists must exist for the projection: compute them once, untimed
         ctx.anchor(0, n)

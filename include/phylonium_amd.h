@@ -94,6 +94,12 @@ int phylo_set_genomes_device(phylo_ctx *ctx, size_t n, const void *dev_base, con
  * min_anchor_length(0.025, gc, 2L+1) as src/process.cxx:416-417. */
 int phylo_set_reference(phylo_ctx *ctx, size_t ref_idx, const int64_t *sa, size_t threshold);
 size_t phylo_threshold(const phylo_ctx *ctx);
+/* 1 when the reference build would NOT give the longest match on this subject: its 6-mer interval cache
+ * stores an over-deep interval when a nucleotide string of <= 4 characters occurs at least twice in S and
+ * only in front of the same contig join (src/esa.cxx:174-199) — possible for references of a few kbp
+ * in several contigs, never beyond.  This library always computes the true longest match; results can
+ * then differ from the reference's, and a host should say so (phylonium-amd -v does). */
+int phylo_reference_cache_quirk(const phylo_ctx *ctx);
 
 /* ── phase A: anchor_homologies + sort + filter_overlaps_max for queries
  * [q_begin, q_end), src/process.cxx:433-458 ── */
@@ -135,7 +141,11 @@ int phylo_import_packed(phylo_ctx *ctx, size_t q_begin, size_t q_end, const uint
  * all-gather of every rank's export.  The buffer is borrowed until the next
  * phylo_anchor / phylo_set_* call.  Host-side lists of genomes in
  * [keep_begin, keep_end) are kept as they are (the caller computed them here);
- * the others are read back from the buffer only if somebody asks for them. */
+ * the others are read back from the buffer only if somebody asks for them.  Every list must be sorted by
+ * projected start, pairwise disjoint and inside the reference (what phase A leaves; checked on the device:
+ * the call fails otherwise).  Lists installed through the host forms (phylo_set_homologies, phylo_import_*)
+ * may be anything compare() of src/process.cxx:566-611 accepts: overlapping or unsorted ones are tallied by
+ * the segment backend. */
 int phylo_export_packed_device(phylo_ctx *ctx, size_t q_begin, size_t q_end, void *dev_dst, size_t cap,
 							   uint64_t *counts, size_t *total);
 int phylo_attach_packed_device(phylo_ctx *ctx, const void *dev_records, const uint64_t *begin,

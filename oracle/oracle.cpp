@@ -35,6 +35,7 @@
 #include <cstring>
 #include <iostream>
 #include <numeric>
+#include <random>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -1196,6 +1197,84 @@ void orc_run_matrix(void *rp, uint64_t *subst, uint64_t *homologs)
 		subst[i] = r->matrix[i].subst;
 		homologs[i] = r->matrix[i].homologs;
 	}
+}
+
+// ── -p FILE: the reference positions of the core alignment with every block's segregating sites ──
+// src/process.cxx:684-698 — a[i] != b[i]
+static void is_segsite_port(const char *a, const char *b, char *out, size_t n)
+{
+	for (size_t i = 0; i < n; i++) out[i] = a[i] != b[i];
+}
+// src/process.cxx:700-708 — a[i] against b[n-1-i] under the complement test
+static void is_segsite_rev_port(const char *a, const char *b, char *out, size_t n)
+{
+	for (size_t i = 0; i < n; i++) out[i] = (((int)a[i] ^ (int)b[n - i - 1]) & 6) != 4;
+}
+// src/process.cxx:671-712 — the segregating sites of two homologies over their common stretch
+static std::vector<char> get_segsites_port(const std::string &sa, const hom &ha, const std::string &sb, const hom &hb)
+{
+	if (!ha.overlaps(hb)) return {};
+	size_t cs = std::max(ha.start(), hb.start()), ce = std::min(ha.end(), hb.end());
+	size_t n = ce - cs;
+	hom hat = ha.trim(cs, ce), hbt = hb.trim(cs, ce);
+	std::vector<char> ret(n, 0);
+	if (ha.rev == hb.rev && ha.rev == 0) {
+		is_segsite_port(sa.c_str() + hat.start_query(), sb.c_str() + hbt.start_query(), ret.data(), n);
+	} else if (ha.rev == hb.rev) {
+		is_segsite_port(sa.c_str() + hat.start_query(), sb.c_str() + hbt.start_query(), ret.data(), n);
+		std::reverse(ret.begin(), ret.end());
+	} else if (hb.rev == 1) {
+		is_segsite_rev_port(sa.c_str() + hat.start_query(), sb.c_str() + hbt.end_query() - n, ret.data(), n);
+	} else {
+		is_segsite_rev_port(sb.c_str() + hbt.start_query(), sa.c_str() + hat.end_query() - n, ret.data(), n);
+	}
+	return ret;
+}
+// src/process.cxx:471-513 — the text of the -p file, from the lists after complete deletion
+static std::string positions_port(const run_port &r)
+{
+	std::ostringstream out;
+	const std::string &subject = r.seqs[r.ref_idx];
+	const auto &homos = r.filtered[0];
+	size_t counter = 1;
+	for (size_t i = 0; i < homos.size(); i++) {
+		const hom &h = homos[i];
+		std::vector<char> seg(h.len, 0);
+		for (size_t m = 0; m < r.n; m++) {
+			auto f = get_segsites_port(r.seqs[0], h, r.seqs[m], r.filtered[m][i]);
+			for (size_t t = 0; t < f.size(); t++) seg[t] |= f[t];
+		}
+		std::vector<size_t> pos;
+		for (size_t t = 0; t < seg.size(); t++)
+			if (seg[t]) pos.push_back(t);
+		size_t start = h.start(), end = h.end();
+		out << ">part" << counter++ << "\t(" << (start + 1) << ".." << (end + 1) << ")  " << pos.size();
+		for (size_t p : pos) out << "  " << (p + 1);
+		out << std::endl;
+		out << std::string(subject.begin() + start, subject.begin() + end) << std::endl;
+	}
+	return out.str();
+}
+size_t orc_run_positions(void *rp, char *out, size_t cap)
+{
+	std::string s = positions_port(*(run_port *)rp);
+	if (out && cap >= s.size() + 1) memcpy(out, s.c_str(), s.size() + 1);
+	return s.size() + 1;
+}
+
+// evo_model::bootstrap (src/evo_model.cxx:136-147) for a whole matrix, in print_matrix's order
+// (src/io.cxx:192-203): substitutions redrawn from Binomial(homologs, substitutions / homologs) with one
+// std::mt19937 running through all cells, `rounds` matrices one after the other.  The reference seeds the
+// engine from std::random_device (src/phylonium.cxx:78-91); tests seed both sides alike.
+void orc_bootstrap(uint32_t seed, size_t rounds, size_t cells, const uint64_t *subst, const uint64_t *homologs, uint64_t *out)
+{
+	std::mt19937 prng(seed);
+	for (size_t k = 0; k < rounds; k++)
+		for (size_t t = 0; t < cells; t++) {
+			double rate = subst[t] / (double)homologs[t];
+			std::binomial_distribution<> d((int)homologs[t], rate);
+			out[k * cells + t] = (uint64_t)d(prng);
+		}
 }
 
 // PHYLIP text (src/io.cxx:141-233). names: n C strings. kind: 0 jc, 1 raw, 2 ani.

@@ -22,7 +22,7 @@ PHOM = np.dtype([("index_reference", "<u8"), ("index_reference_projected", "<u8"
 
 # every symbol include/phylonium_amd.h declares
 SYMBOLS = [
-    "phylo_ctx_create", "phylo_ctx_destroy", "phylo_last_error", "phylo_set_option", "phylo_get_stat",
+    "phylo_ctx_create", "phylo_ctx_destroy", "phylo_last_error", "phylo_set_option", "phylo_get_stat", "phylo_reference_cache_quirk",
     "phylo_reset_stats", "phylo_stat_keys", "phylo_set_genomes", "phylo_set_genomes_device",
     "phylo_set_reference", "phylo_threshold", "phylo_anchor", "phylo_get_homologies", "phylo_set_homologies",
     "phylo_export_homologies", "phylo_import_homologies", "phylo_export_packed", "phylo_import_packed",
@@ -55,6 +55,7 @@ def load():
     L.phylo_last_error.restype = C.c_char_p
     L.phylo_last_error.argtypes = [vp]
     L.phylo_set_option.argtypes = [vp, C.c_char_p, C.c_long]
+    L.phylo_reference_cache_quirk.argtypes = [vp]
     L.phylo_get_stat.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double)]
     L.phylo_reset_stats.argtypes = [vp]
     L.phylo_stat_keys.restype = sz
@@ -193,6 +194,11 @@ class Context:
     @property
     def threshold(self):
         return self.L.phylo_threshold(self.h)
+
+    @property
+    def reference_cache_quirk(self):
+        """True when phylonium's 6-mer cache would over-report matches on this reference (src/esa.cxx:174-199)."""
+        return bool(self.L.phylo_reference_cache_quirk(self.h))
 
     # phase A
     def anchor(self, q_begin=0, q_end=None):

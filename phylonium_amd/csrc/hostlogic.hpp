@@ -396,6 +396,73 @@ static inline void build_slots(const std::vector<uint32_t> &T, const std::vector
 	}
 }
 
+// Does the reference's 6-mer interval cache hold an entry that claims more than its key shares with S?
+// esa::init_cache_dfs (src/esa.cxx:114-201) walks the virtual suffix tree one nucleotide at a time; when a
+// child interval is deeper than expected (all suffixes that start with the prefix so far go on identically)
+// it fast-forwards along that common stretch — and if it meets a non-ACGT byte there (esa.cxx:174-199) it
+// fills every key below the prefix with the child interval and its FULL lcp value.  get_match_cached then
+// reports that many matching characters for any query carrying such a key, although the query has a
+// nucleotide where S has '!': the reference's answer is longer than the longest match.  It takes a
+// nucleotide string of at most 4 characters that occurs at least twice in S and ONLY in front of the same
+// contig join — impossible beyond a few kbp of sequence, so the product computes the true longest match
+// and this walk (the same DFS over the suffix array: at most 4^5 nodes) says when the reference would not.
+static inline bool esa_cache_quirk(const uint8_t *S, uint32_t n, const uint32_t *SA)
+{
+	const uint32_t CACHE_LENGTH = 6;
+	auto at = [&](uint32_t r, uint32_t off) -> int { // byte at offset off of the suffix of rank r; -1 past the end
+		const uint64_t p = (uint64_t)SA[r] + off;
+		return p < n ? (int)S[p] : -1;
+	};
+	// the ranks in [lo, hi) whose suffix has byte c at offset pos (they share their first pos bytes: sorted there)
+	auto range = [&](uint32_t lo, uint32_t hi, uint32_t pos, int c, uint32_t *a, uint32_t *b) {
+		uint32_t l = lo, h = hi;
+		while (l < h) {
+			const uint32_t m = l + ((h - l) >> 1);
+			if (at(m, pos) < c) l = m + 1;
+			else h = m;
+		}
+		*a = l;
+		h = hi;
+		while (l < h) {
+			const uint32_t m = l + ((h - l) >> 1);
+			if (at(m, pos) <= c) l = m + 1;
+			else h = m;
+		}
+		*b = l;
+	};
+	struct Node {
+		uint32_t pos, lo, hi;
+	};
+	std::vector<Node> stack;
+	stack.push_back(Node{0, 0, n});
+	while (!stack.empty()) {
+		const Node nd = stack.back();
+		stack.pop_back();
+		if (nd.pos >= CACHE_LENGTH) continue;
+		for (int code = 0; code < 4; code++) {
+			uint32_t a, b;
+			range(nd.lo, nd.hi, nd.pos, "ACGT"[code], &a, &b);
+			if (b - a < 2) continue; // not found, or a singleton: filled as it is (esa.cxx:136-148)
+			uint32_t l = nd.pos + 1; // the child's lcp value: what its first and last suffix share
+			while (l <= CACHE_LENGTH && at(a, l) >= 0 && at(a, l) == at(b - 1, l)) l++;
+			if (l <= nd.pos + 1) {
+				stack.push_back(Node{nd.pos + 1, a, b}); // the usual case, esa.cxx:150-155
+				continue;
+			}
+			if (l >= CACHE_LENGTH) continue; // deeper than the cache: filled with the parent, esa.cxx:159-163
+			bool non_acgt = false;
+			for (uint32_t k = nd.pos + 1; k < l; k++)
+				if (nuc_code((uint8_t)at(a, k)) > 3) {
+					non_acgt = true;
+					break;
+				}
+			if (non_acgt) return true; // esa.cxx:195-196: keys below str[0..k) get an interval of depth l > k
+			stack.push_back(Node{l, a, b});
+		}
+	}
+	return false;
+}
+
 static inline uint32_t choose_k(uint32_t n)
 {
 	// smallest k with 4^k >= n: at most one suffix per bucket on average, so that

@@ -85,6 +85,8 @@ void launch_pairs(const Pileup &P, bool with_bang, const uint32_t *tiles, uint32
 				  unsigned long long *subst, unsigned long long *homologs, hipStream_t st);
 
 void launch_symmetrise(uint32_t N, unsigned long long *a, unsigned long long *b, hipStream_t st);
+// *bad = 1 unless every genome's list is sorted by projected start, disjoint and inside [0, L)
+void launch_check_lists(const DevHom *homs, const uint32_t *hom_rng, uint32_t N, uint32_t L, uint32_t *bad, hipStream_t st);
 
 static const uint32_t PAIR_IG = 16; // i-genomes per block (scalar side)
 static const uint32_t PAIR_JT = 64; // j-genomes per block (one per lane)

@@ -213,6 +213,7 @@ struct phylo_ctx {
 	DevBuf<uint32_t> d_Q2, d_QBAD, d_qbad_off, d_S2, d_SBAD, d_badscr;
 	DevBuf<uint64_t> d_badoff;
 	uint32_t nsb = 0, sb_first = 0;
+	bool cache_quirk = false; // the reference's 6-mer cache would over-report matches on this subject (hostlogic.hpp: esa_cache_quirk)
 	int anchor_kernel = 1; // option "anchor_kernel": 1 lean 2-bit chains (default), 0 the general byte-wise chains
 	int lean_force_slow = 0;
 
@@ -786,6 +787,10 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 		HIPOK(c, hipMemcpy(c->d_SBAD.p + off[1], &ns, 4, hipMemcpyHostToDevice)); // the end of S closes the list
 		c->nsb = off[1] + 1;
 		HIPOK(c, hipMemcpy(&c->sb_first, c->d_SBAD.p, 4, hipMemcpyDeviceToHost));
+		// The reference's 6-mer cache bug (esa.cxx:174-199) needs two contig joins behind the same few
+		// nucleotides: looked for only when S holds a '!' at all (nsb counts '#', the end and the '!'s).
+		c->cache_quirk = c->nsb > 2 && esa_cache_quirk(S.data(), ns, SA.data());
+		c->stats["ref:cache_quirk"] = c->cache_quirk ? 1 : 0;
 	}
 	double t3 = now_ms();
 	c->ref_idx = ref_idx;
@@ -809,6 +814,8 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 }
 
 size_t phylo_threshold(const phylo_ctx *c) { return c ? c->threshold : 0; }
+
+int phylo_reference_cache_quirk(const phylo_ctx *c) { return c && c->have_ref && c->cache_quirk ? 1 : 0; }
 
 // ───────────────────────── phase A ─────────────────────────
 
@@ -1551,7 +1558,15 @@ int phylo_attach_packed_device(phylo_ctx *c, const void *dev_records, const uint
 	}
 	if (total && !dev_records) return c->fail("phylo_attach_packed_device: null records");
 	HIPOK(c, hipMemcpyAsync(c->b_hom_rng.p, c->h_rng.p, 2 * N * 4, hipMemcpyHostToDevice, c->stream));
+	// the pileup needs every list sorted by projected start, disjoint and inside the reference (what phase A's
+	// filter leaves): a buffer that is anything else is refused here rather than tallied wrongly later
+	HIPOK(c, c->b_flag.ensure(4));
+	HIPOK(c, hipMemsetAsync(c->b_flag.p + 1, 0, 4, c->stream));
+	launch_check_lists((const DevHom *)dev_records, c->b_hom_rng.p, (uint32_t)N, c->L, c->b_flag.p + 1, c->stream);
+	uint32_t bad_lists = 0;
+	HIPOK(c, hipMemcpyAsync(&bad_lists, c->b_flag.p + 1, 4, hipMemcpyDeviceToHost, c->stream));
 	if (sync_stream(c)) return 1;
+	if (bad_lists) return c->fail("phylo_attach_packed_device: a genome's list is not sorted by projected start, disjoint and inside the reference");
 	c->att_homs = (const DevHom *)dev_records;
 	c->att_begin.assign(begin, begin + N);
 	c->att_count.assign(count, count + N);
@@ -1684,15 +1699,35 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		HIPOK(c, c->h_devhom.ensure(tot + 1));
 		DevHom *dh = c->h_devhom.p;
 		std::atomic<size_t> bad{(size_t)-1};
+		std::atomic<bool> entangled{false};
 		workers(c).run(N, [&](size_t g) {
 			size_t o = hom_rng[2 * g];
+			uint64_t prev_end = 0;
 			for (const phylo_homology &h : c->homs[g]) {
 				if (h.index_reference_projected + h.length > c->L) bad = g;
+				if (h.index_reference_projected < prev_end) entangled = true;
+				prev_end = h.index_reference_projected + h.length;
 				dh[o++] = DevHom{(uint32_t)h.index_reference_projected, (uint32_t)h.index_query, (uint32_t)h.length,
 								 (uint32_t)h.direction};
 			}
 		});
 		if (bad != (size_t)-1) return c->fail("genome %zu: homology reaches beyond the reference", bad.load());
+		if (entangled) {
+			// Lists installed by the caller (phylo_set_homologies, phylo_import_*) that are not sorted and disjoint on
+			// the reference: the pileup would not be compare(list, list) of process.cxx:566-611 for them — the segment
+			// backend, which restates that merge-join literally, takes the call.
+			c->stats["count:compare_calls_rerouted_to_segments"] += 1;
+			if (dev_out) {
+				std::vector<uint64_t> hs(N * N, 0), hh(N * N, 0);
+				if (compare_segments(c, part, nparts, hs.data(), hh.data())) return 1;
+				HIPOK(c, hipMemcpy(subst, hs.data(), N * N * 8, hipMemcpyHostToDevice));
+				HIPOK(c, hipMemcpy(homologs, hh.data(), N * N * 8, hipMemcpyHostToDevice));
+				return 0;
+			}
+			std::fill(subst, subst + N * N, 0);
+			std::fill(homologs, homologs + N * N, 0);
+			return compare_segments(c, part, nparts, subst, homologs);
+		}
 		HIPOK(c, c->b_hom_rng.ensure(2 * N));
 		HIPOK(c, c->b_homs.ensure(tot + 1));
 		HIPOK(c, hipMemcpyAsync(c->b_hom_rng.p, hom_rng.data(), 2 * N * 4, hipMemcpyHostToDevice, st));

@@ -353,6 +353,29 @@ __global__ __launch_bounds__(256) void symmetrise_kernel(uint32_t N, unsigned lo
 		b[t] = b[(size_t)j * N + i];
 	}
 }
+// The pileup equals compare(list, list) of process.cxx:566-611 only for lists that are sorted by projected
+// start, pairwise disjoint and inside the reference — what phase A's filter guarantees, not what a caller
+// may install.  One thread per genome walks its list; *bad is raised on the first violation.
+__global__ __launch_bounds__(64) void check_lists_kernel(const DevHom *__restrict__ homs, const uint32_t *__restrict__ hom_rng,
+														  uint32_t N, uint32_t L, uint32_t *__restrict__ bad)
+{
+	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= N) return;
+	uint32_t prev_end = 0;
+	for (uint32_t t = hom_rng[2 * g]; t < hom_rng[2 * g + 1]; t++) {
+		const DevHom h = homs[t];
+		if (h.start < prev_end || (uint64_t)h.start + h.len > L) {
+			*bad = 1;
+			return;
+		}
+		prev_end = h.start + h.len;
+	}
+}
+void launch_check_lists(const DevHom *homs, const uint32_t *hom_rng, uint32_t N, uint32_t L, uint32_t *bad, hipStream_t st)
+{
+	if (N) hipLaunchKernelGGL(check_lists_kernel, dim3((N + 63) / 64), dim3(64), 0, st, homs, hom_rng, N, L, bad);
+}
+
 void launch_symmetrise(uint32_t N, unsigned long long *a, unsigned long long *b, hipStream_t st)
 {
 	uint64_t n = (uint64_t)N * N;

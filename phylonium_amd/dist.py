@@ -106,9 +106,14 @@ def exchange_homologies_device(ctx, n, rank, world, bounds, device):
     return gathered  # borrowed by the context: the caller keeps it alive until the comparison is done
 
 
-def process_sharded(ctx, ref_idx, rank, world, device=None, lengths=None, set_reference=True, out=None):
+def process_sharded(ctx, ref_idx, rank, world, device=None, lengths=None, set_reference=True, out=None, copy=True):
     """process() with queries and pair tiles sharded over `world` ranks.
-    ctx: an api.Context (or any object with the same methods) holding all genomes."""
+    ctx: an api.Context (or any object with the same methods) holding all genomes.
+    Returns (subst, homologs), two N x N uint64 arrays.  With `out` = (subst, homologs) the result is written
+    there and those arrays are returned; without it the arrays are the caller's own (fresh copies) on every
+    path — the device-resident path keeps a pinned staging buffer of its own that the next call overwrites;
+    copy=False hands out views of that buffer instead (valid until the next call: a timing loop that looks at
+    the last result only)."""
     if set_reference:
         ctx.set_reference(ref_idx)
     lens = lengths or getattr(ctx, "lengths", None)
@@ -131,8 +136,12 @@ def process_sharded(ctx, ref_idx, rank, world, device=None, lengths=None, set_re
             ctx._pinned_matrix = pin
         pin.copy_(t, non_blocking=True)
         torch.cuda.current_stream(device).synchronize()
-        m = pin.numpy().view(np.uint64).reshape(2, n, n)  # views of the pinned buffer: valid until the next call
-        return m[0], m[1]
+        m = pin.numpy().view(np.uint64).reshape(2, n, n)  # the pinned staging buffer: overwritten by the next call
+        if out is not None:
+            np.copyto(out[0], m[0])
+            np.copyto(out[1], m[1])
+            return out[0], out[1]
+        return (m[0].copy(), m[1].copy()) if copy else (m[0], m[1])
     if world > 1 or _FORCE_COLLECTIVES:
         exchange_homologies(ctx, ctx.n, rank, world, bounds, device)
     s, h = ctx.compare(rank, world, out=out) if out is not None else ctx.compare(rank, world)

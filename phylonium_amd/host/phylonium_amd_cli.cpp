@@ -240,6 +240,9 @@ Matrix process(Run &r, size_t ref_idx, const int64_t *sa = nullptr)
 	size_t N = q.size();
 	ok(r, phylo_set_reference(r.ctx, ref_idx, sa, 0));
 	if (r.flags & F_VERBOSE) std::cerr << "ref: " << q[ref_idx].name << std::endl;
+	if ((r.flags & F_VERBOSE) && phylo_reference_cache_quirk(r.ctx))
+		std::cerr << "note: phylonium's 6-mer cache would over-report some matches on this reference (src/esa.cxx:174-199); "
+					 "distances computed here use the true longest matches and may differ from phylonium's" << std::endl;
 	ok(r, phylo_anchor(r.ctx, 0, N));
 	if (r.flags & F_COMPLETE_DELETION) ok(r, phylo_complete_delete(r.ctx));
 	if (r.flags & F_POSITIONS) write_positions(r, ref_idx);
@@ -277,8 +280,11 @@ Matrix process(Run &r, size_t ref_idx, const int64_t *sa = nullptr)
 
 int main(int argc, char *argv[])
 {
+	// the bootstrap's engine (src/phylonium.cxx:78-91 seeds it from std::random_device); PHYLONIUM_AMD_SEED
+	// fixes the seed so that tests can reproduce the resampled matrices
 	std::random_device rd;
-	std::mt19937 prng(rd());
+	const char *seed_env = getenv("PHYLONIUM_AMD_SEED");
+	std::mt19937 prng(seed_env ? (std::mt19937::result_type)strtoul(seed_env, nullptr, 10) : rd());
 	int version_flag = 0, timing = 0, flags = 0, device = 0;
 	long threads = 0;
 	bool two_pass = false;

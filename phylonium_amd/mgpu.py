@@ -188,23 +188,44 @@ def main(argv=None):
     else:
         ref_idx = api.host_median_length_index(lens)
     owner = next(r for r in range(world) if bounds[r] <= ref_idx < bounds[r + 1])
-    if lens[ref_idx] == 0:
-        print("phylonium-amd: the reference genome is empty", file=sys.stderr)
+
+    def all_ok(ok, what):
+        """Every rank learns whether any rank failed at `what` before the next collective, and all leave together
+        (a rank that raised alone would leave the others waiting in the collective until it times out)."""
+        if world > 1:
+            t = torch.tensor([0 if ok else 1], dtype=torch.int32, device=cdev)
+            td.all_reduce(t, op=td.ReduceOp.SUM)
+            ok = int(t.item()) == 0
+        if not ok and rank == 0:
+            print(f"phylonium-amd: {what}", file=sys.stderr)
+        return ok
+
+    if lens[ref_idx] == 0:  # the same lengths on every rank: all take this branch
+        if rank == 0:
+            print("phylonium-amd: the reference genome is empty", file=sys.stderr)
         ctx_thread.join()
+        if world > 1:
+            td.destroy_process_group()
         return 1
     ns = 2 * lens[ref_idx] + 1
     sa_box = {}
     sa_thread = None
     if rank == owner:
-        sa_thread = threading.Thread(
-            target=lambda: sa_box.setdefault("sa", api.host_reference_suffix_array(mine[ref_idx - b0])))
+        def build_sa():
+            try:
+                sa_box["sa"] = api.host_reference_suffix_array(mine[ref_idx - b0])
+            except Exception as e:  # reported through all_ok below
+                sa_box["error"] = e
+        sa_thread = threading.Thread(target=build_sa)
         sa_thread.start()  # ctypes releases the GIL: this runs beside the staging and the gather
 
     # ── stage, upload, gather ──
     cap, offs = block_layout(lens, bounds)
     ctx_thread.join()
-    if "ctx" not in box:
-        raise SystemExit("phylonium_amd.mgpu: the device context could not be created")
+    if not all_ok("ctx" in box, "a rank could not create its device context"):
+        if world > 1:
+            td.destroy_process_group()
+        return 1
     ctx = box["ctx"]
     t_ctx = time.perf_counter()
     if world == 1 or on_rccl:
@@ -241,9 +262,15 @@ def main(argv=None):
     t_upload = time.perf_counter()
 
     # ── suffix array to every rank ──
+    sa = None
     if sa_thread is not None:
         sa_thread.join()
-        sa = sa_box["sa"]
+        sa = sa_box.get("sa")
+    if not all_ok(rank != owner or sa is not None, "the reference's suffix array could not be built"):
+        ctx.close()
+        if world > 1:
+            td.destroy_process_group()
+        return 1
     if world > 1:
         sa_t = torch.from_numpy(sa.astype(np.int32)).to(cdev) if rank == owner else torch.empty(ns, dtype=torch.int32, device=cdev)
         td.broadcast(sa_t, src=owner)

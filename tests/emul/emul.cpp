@@ -341,6 +341,19 @@ void emul_info(void *e, uint64_t out[8])
 	out[7] = ((uint64_t)E->error << 32) | E->pool_used;
 }
 
+// the host walk behind phylo_reference_cache_quirk, on S = seq + '#' + revcomp(seq)
+int emul_cache_quirk(const uint8_t *seq, uint32_t len)
+{
+	const uint32_t ns = 2 * len + 1;
+	std::vector<uint8_t> S((size_t)ns + 64, 0);
+	memcpy(S.data(), seq, len);
+	S[len] = '#';
+	revcomp(seq, len, S.data() + len + 1);
+	std::vector<uint32_t> SA((size_t)ns + 4, 0);
+	suffix_array_u32(S.data(), ns, SA.data());
+	return esa_cache_quirk(S.data(), ns, SA.data()) ? 1 : 0;
+}
+
 // host-logic entry points for CPU tests
 void emul_suffix_array(const uint8_t *s, uint32_t n, uint32_t *sa) { suffix_array_u32(s, n, sa); }
 // the several-core bucket sort on its own: 1 = sorted, 0 = gave up (caller would run SA-IS)

@@ -33,6 +33,8 @@ def lib():
     L.emul_run2.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint, C.c_uint, C.c_uint]
     L.emul_slow_steps.restype = C.c_uint64
     L.emul_slow_steps.argtypes = [C.c_void_p]
+    L.emul_cache_quirk.restype = C.c_int
+    L.emul_cache_quirk.argtypes = [C.c_void_p, C.c_uint]
     L.emul_overruns.restype = C.c_uint64
     L.emul_overruns.argtypes = [C.c_void_p]
     L.emul_free.argtypes = [C.c_void_p]
@@ -49,6 +51,12 @@ def lib():
     L.emul_kmer_table.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]
     _LIB = L
     return L
+
+
+def cache_quirk(seq):
+    """The product's host-side detector of the reference's 6-mer cache bug (hostlogic.hpp: esa_cache_quirk)."""
+    a = np.frombuffer(bytes(seq), np.uint8) if isinstance(seq, (bytes, bytearray)) else np.ascontiguousarray(seq, np.uint8)
+    return bool(lib().emul_cache_quirk(a.ctypes.data, a.size))
 
 
 class EmulRun:

@@ -91,6 +91,9 @@ def lib():
     L.orc_run_hom_count.argtypes = [vp, sz, C.c_int]
     L.orc_run_homs.argtypes = [vp, sz, C.c_int, vp]
     L.orc_run_matrix.argtypes = [vp, vp, vp]
+    L.orc_run_positions.restype = sz
+    L.orc_run_positions.argtypes = [vp, vp, sz]
+    L.orc_bootstrap.argtypes = [C.c_uint32, sz, sz, vp, vp, vp]
     L.orc_phylip.restype = sz
     L.orc_phylip.argtypes = [sz, vp, vp, vp, C.c_int, vp, sz]
     L.orc_max_threads.restype = C.c_int
@@ -114,6 +117,16 @@ def seqcmp(a, b, n=None):
     pb, lb, kb = _buf(b)
     n = min(la, lb) if n is None else n
     return lib().orc_seqcmp(pa, pb, n)
+
+
+def bootstrap(seed, rounds, subst, homologs):
+    """evo_model::bootstrap over a whole matrix, `rounds` times, one mt19937(seed) through all cells."""
+    s = np.ascontiguousarray(subst, np.uint64).ravel()
+    h = np.ascontiguousarray(homologs, np.uint64).ravel()
+    out = np.zeros((rounds, s.size), np.uint64)
+    lib().orc_bootstrap(seed, rounds, s.size, s.ctypes.data_as(C.c_void_p), h.ctypes.data_as(C.c_void_p),
+                        out.ctypes.data_as(C.c_void_p))
+    return out.reshape((rounds,) + np.shape(subst))
 
 
 VARIANTS = {"generic": 0, "resolved": 1, "avx2": 2, "avx512": 3}
@@ -325,6 +338,13 @@ class Run:
         if cnt:
             lib().orc_run_homs(self.h, j, int(filtered), out.ctypes.data_as(C.c_void_p))
         return out
+
+    def positions_text(self):
+        """The -p file of src/process.cxx:471-513 (call after process(complete_deletion=True))."""
+        need = lib().orc_run_positions(self.h, None, 0)
+        buf = C.create_string_buffer(need)
+        lib().orc_run_positions(self.h, buf, need)
+        return buf.value.decode()
 
     def matrix(self):
         s = np.zeros((self.n, self.n), dtype=np.uint64)

@@ -67,7 +67,30 @@ def test_multi_contig_against_oracle(tmp_path):
     rc, out, err = run(["--complete-deletion", "-r", files[2], *files], tmp_path)
     assert out == O.phylip(names, s, h)
     rc, out, err = run(["-p", "pos.txt", "-r", files[2], *files], tmp_path)
-    assert out == O.phylip(names, s, h) and (tmp_path / "pos.txt").read_text().startswith(">part1\t(")
+    assert out == O.phylip(names, s, h)
+    # the -p file byte for byte against the restated process.cxx:471-513, 665-723 (forward and reverse blocks)
+    want = r.positions_text()
+    assert want.count(">part") > 3
+    assert (tmp_path / "pos.txt").read_text() == want
+
+
+def test_bootstrap_matrices_with_a_fixed_seed(tmp_path):
+    """-b N: N-1 more matrices whose substitutions are redrawn from Binomial(homologs, s/h) per cell
+    (evo_model.cxx:136-147, io.cxx:192-203).  The reference seeds its mt19937 from random_device; with
+    PHYLONIUM_AMD_SEED the driver's engine is seeded like the oracle's and the text must be identical."""
+    gs = synth.make_genomes(5, 30000, seed=9, d_range=(0.02, 0.2), indel_per_mbp=300, inv_frac=0.05)
+    names = [f"b{i}" for i in range(5)]
+    for n, g in zip(names, gs):
+        write_fasta(tmp_path / f"{n}.fa", g)
+    files = [f"{n}.fa" for n in names]
+    s, h = O.Run(gs, 1).process().matrix()
+    env = dict(os.environ, PHYLONIUM_AMD_SEED="4242")
+    r = subprocess.run([CLI, "-b", "4", "-r", files[1], *files], cwd=tmp_path, capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    boot = O.bootstrap(4242, 3, s, h)
+    want = O.phylip(names, s, h) + "".join(O.phylip(names, boot[k], h) for k in range(3))
+    assert r.stdout == want
+    assert (boot[0] != s).any()  # the resampling does change cells
 
 
 def test_unrelated_pair_reports_nan_and_fails(tmp_path):
