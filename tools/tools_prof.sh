@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 F='--kernel-include-regex phy::'
-timeout 300 rocprofv3 $F --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 $ROOT/bench.py --workload $WL --steps 5 --warmup 1 --cpu-sample 0 "$@" > $OUT/trace_bench.json 2> $OUT/trace.err
+timeout 300 rocprofv3 $F --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 $ROOT/bench.py --workload $WL --steps 5 --warmup 1 --cpu-sample 0 --no-profile "$@" > $OUT/trace_bench.json 2> $OUT/trace.err
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAIT_ANY" \

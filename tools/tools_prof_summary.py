@@ -10,12 +10,15 @@ out = {}
 
 def short(name):
     n = name
-    for key in ("chain_kernel<0>", "chain_kernel<1>", "fold_kernel", "sort_filter_kernel", "gather_lists_kernel", "compact_raw_kernel",
+    for key in ("chain_kernel<0>", "chain_kernel<1>", "fold_kernel", "sort_filter_seg_kernel", "sort_filter_kernel", "lean_overrun_direct_kernel",
+                "lean_overrun_chain_kernel", "gather_lists_kernel", "compact_raw_kernel",
                 "project_kernel<true>", "project_kernel",
                 "tile_index_kernel", "pairs_kernel<true>", "pairs_kernel<false>", "seqcmp_batch_kernel"):
         if key in n:
             return {"chain_kernel<0>": "anchor_spec", "chain_kernel<1>": "anchor_bridge", "fold_kernel": "anchor_fold",
-                    "sort_filter_kernel": "anchor_filter", "gather_lists_kernel": "export_gather",
+                    "sort_filter_kernel": "anchor_filter_general", "sort_filter_seg_kernel": "anchor_filter",
+                    "lean_overrun_direct_kernel": "anchor_overruns_direct", "lean_overrun_chain_kernel": "anchor_overruns_chain",
+                    "gather_lists_kernel": "export_gather",
                     "compact_raw_kernel": "anchor_compact", "project_kernel": "pileup_project", "project_kernel<false>": "pileup_project", "project_kernel<true>": "pileup_project5",
                     "tile_index_kernel": "pileup_tile_index", "pairs_kernel<true>": "pileup_pairs_bang",
                     "pairs_kernel<false>": "pileup_pairs", "seqcmp_batch_kernel": "seqcmp_batch"}[key]
