@@ -226,6 +226,7 @@ def main():
     ap.add_argument("--filter", type=int, default=0, help="dev: sort + chain filter 1 on the host, 2 on the device (0: the library chooses)")
     ap.add_argument("--host-threads", type=int, default=0, help="dev: size of the library's host worker pool")
     ap.add_argument("--kmer", type=int, default=0, help="dev: force the bucket k of the reference index")
+    ap.add_argument("--anchor-kernel", type=int, default=-1, help="dev: 1 lean 2-bit chains, 0 general byte-wise chains (library default when < 0)")
     ap.add_argument("--tail-groups", type=int, default=0, help="dev: phase A's tail on this many streams (library default when 0)")
     ap.add_argument("--d-range", default="", help="dev: lo,hi — override the workload's divergence range")
     ap.add_argument("--emulate-rank", default="", help="dev: R/N — time rank R of N's share of the work on this one GPU "
@@ -291,6 +292,8 @@ def main():
         ctx.set_option("chunk", args.chunk)
     if args.kmer:
         ctx.set_option("kmer", args.kmer)
+    if args.anchor_kernel >= 0:
+        ctx.set_option("anchor_kernel", args.anchor_kernel)
     if args.tail_groups > 0:
         ctx.set_option("tail_groups", args.tail_groups)
     if args.host_threads:
