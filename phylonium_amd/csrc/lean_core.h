@@ -541,6 +541,12 @@ inline void lean_resolve_ext_scalar(LeanLane &ln, const uint8_t *qbase, const Re
 
 // ───────────────── chunk drivers (the same logs, exits and bridges as anchor_core.h) ─────────────────
 
+struct VisDirect { // finished words of the visited bitmap go straight to memory
+	uint32_t *visited;
+	PHY_HD void put(uint32_t idx, uint32_t bits) { visited[idx] = bits; }
+	PHY_HD void close() {}
+};
+
 PHY_HD uint32_t lean_visited_word(const LeanLane &ln, uint32_t q)
 {
 	return (ln.qw0 >> 1) + (q >> 5); // genomes start at multiples of 64 bytes: qw0 is a multiple of 4
@@ -549,6 +555,7 @@ PHY_HD uint32_t lean_visited_word(const LeanLane &ln, uint32_t q)
 struct LeanSpec {
 	LeanLane ln;
 	uint32_t gc, q_end, cnt, log0, cap, vis_word, vis_idx;
+	uint32_t q_end_full; // the chunk's end on the grid (not clipped to the query's length)
 
 	PHY_HD void start(const PhaseA &A, const LeanIndex &X, uint32_t chunk)
 	{
@@ -557,6 +564,7 @@ struct LeanSpec {
 		const ChunkGeom g = chunk_geom(A, j, chunk - A.qchunk0[j]);
 		const uint32_t ql = A.qlen[j], e = g.q0 + g.len;
 		q_end = e < ql ? e : ql;
+		q_end_full = e;
 		log0 = g.log0;
 		cap = g.cap;
 		ln.reset((uint32_t)(A.qoff[j] >> 4), ql, g.q0, 0, 0, 0);
@@ -566,11 +574,16 @@ struct LeanSpec {
 		vis_word = 0;
 		vis_idx = lean_visited_word(ln, g.q0);
 	}
-	// called when ln.ph == LP_STEP; false when the chunk is finished
-	PHY_HD bool begin_step(const PhaseA &A, const LeanIndex &X)
+	// called when ln.ph == LP_STEP; false when the chunk is finished.  `vis` takes the finished words of the
+	// visited bitmap: put(word index, bits) for one that is complete, close() at the chunk's end.  (The GPU
+	// collects 64 bytes of them in LDS before they go out — a word on its own is evicted from the L2, which the
+	// slot fetches turn over every few microseconds, long before the lane writes its neighbour, and every such
+	// eviction is a partial-line write at the memory; the CPU emulation writes them straight through.)
+	template <class Vis> PHY_HD bool begin_step(const PhaseA &A, const LeanIndex &X, Vis &vis)
 	{
 		if (ln.q >= q_end) {
-			A.visited[vis_idx] = vis_word;
+			vis.put(vis_idx, vis_word);
+			vis.close();
 			A.spec_cnt[gc] = cnt | (ln.ovr ? LEAN_OVERRUN_BIT : 0u); // only a chunk's last step can be cut
 			if (ln.ovr) *A.overrun = 1;
 			SpecExit x = {ln.q, ln.lq, ln.ls, ln.ll};
@@ -579,7 +592,7 @@ struct LeanSpec {
 		}
 		const uint32_t w = lean_visited_word(ln, ln.q);
 		if (w != vis_idx) {
-			A.visited[vis_idx] = vis_word;
+			vis.put(vis_idx, vis_word);
 			vis_idx = w;
 			vis_word = 0;
 		}

@@ -353,6 +353,45 @@ __global__ __launch_bounds__(64) void lean_overrun_chain_kernel(PhaseA A, uint32
 	}
 }
 
+// A lane's finished words of the visited bitmap, collected in LDS until the 64-byte group they belong to is
+// complete (or the chunk ends): one full 64-byte store per 512 positions instead of sixteen lone 4-byte ones.
+// Words the chain jumped over are zero, as the cleared bitmap has them.
+struct VisLds {
+	uint32_t (*buf)[256]; // [16][256], dword-major like the ring
+	uint32_t *visited;
+	uint32_t tid;
+	uint32_t group; // word index / 16 of the group being collected; NO_BAD: none
+	uint32_t lo, hi; // the chunk's own words [lo, hi): a group that reaches beyond them is shared with a neighbouring chunk's lane
+	__device__ void flush()
+	{
+		if (group == NO_BAD) return;
+		const uint32_t w0 = group * 16u;
+		if (w0 >= lo && w0 + 16u <= hi) {
+			U4 *dst = (U4 *)(visited + (size_t)w0);
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				dst[i] = U4{buf[4 * i][tid], buf[4 * i + 1][tid], buf[4 * i + 2][tid], buf[4 * i + 3][tid]};
+				buf[4 * i][tid] = buf[4 * i + 1][tid] = buf[4 * i + 2][tid] = buf[4 * i + 3][tid] = 0;
+			}
+		} else { // the chunk's first or last group: only its own words
+			for (uint32_t i = 0; i < 16u; i++) {
+				if (w0 + i >= lo && w0 + i < hi) visited[w0 + i] = buf[i][tid];
+				buf[i][tid] = 0;
+			}
+		}
+		group = NO_BAD;
+	}
+	__device__ void put(uint32_t idx, uint32_t bits)
+	{
+		if ((idx >> 4) != group) {
+			flush();
+			group = idx >> 4;
+		}
+		buf[idx & 15u][tid] = bits;
+	}
+	__device__ void close() { flush(); }
+};
+
 struct LeanAlloc {
 	const PhaseA *A;
 	__device__ uint32_t operator()() const
@@ -373,10 +412,16 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 	LeanLane &ln = L.ln;
 	// a lane's ring, dword-major so that lane l always hits LDS bank l
 	__shared__ uint32_t ring[LEAN_RING_WORDS][256];
+	__shared__ uint32_t visbuf[MODE == 0 ? 16 : 1][256];
 	const uint32_t tid = threadIdx.x;
 	const uint8_t *s_end = R.S + R.n + 64;
 	const uint8_t *const slot_b = (const uint8_t *)R.SLOT, *const sax_b = (const uint8_t *)R.SAX,
 						 *const q2_b = (const uint8_t *)X.Q2, *const s2_b = (const uint8_t *)X.S2;
+	VisLds vis = {visbuf, A.visited, tid, NO_BAD, 0u, 0u};
+	if constexpr (MODE == 0) {
+#pragma unroll
+		for (int i = 0; i < 16; i++) visbuf[i][tid] = 0;
+	}
 	bool active = false, done = false;
 	LeanAlloc alloc = {&A};
 	ln.fin = false;
@@ -403,7 +448,7 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 			ln.fin = false;
 		}
 		if (active && ln.ph == LP_STEP) {
-			if constexpr (MODE == 0) active = L.begin_step(A, X);
+			if constexpr (MODE == 0) active = L.begin_step(A, X, vis);
 			else active = L.begin_step(A, X, R);
 		}
 		if (!active && !done) {
@@ -411,7 +456,11 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 			done = it >= (it_count ? it_count : A.nchunks);
 			if (!done) {
 				L.start(A, X, it_count ? it_base + it : A.items[it]);
-				if constexpr (MODE == 0) active = L.begin_step(A, X);
+				if constexpr (MODE == 0) {
+					vis.lo = L.vis_idx; // the chunk's words: from its first position to its end (chunks are multiples of 64 positions)
+					vis.hi = lean_visited_word(ln, L.q_end_full);
+				}
+				if constexpr (MODE == 0) active = L.begin_step(A, X, vis);
 				else active = L.begin_step(A, X, R);
 			}
 		}

@@ -210,7 +210,8 @@ void *emul_run2(size_t n, const char *const *seq, const size_t *len, size_t ref_
 		if (lean) {
 			LeanSpec ln;
 			ln.start(A, X, P.items[it]);
-			run_lean_lane(ln, qbase.data(), R, X, LT, [&] { return ln.begin_step(A, X); }, [&] { ln.step_done(A); },
+			VisDirect vd = {A.visited};
+			run_lean_lane(ln, qbase.data(), R, X, LT, [&] { return ln.begin_step(A, X, vd); }, [&] { ln.step_done(A); },
 						  &E->steps_spec, &E->rounds, &E->slow_steps);
 			continue;
 		}
