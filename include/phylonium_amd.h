@@ -59,9 +59,9 @@ const char *phylo_last_error(const phylo_ctx *ctx);
  * (the second half of every query in chunks of this length instead),
  * "kmer" (bucket k), "profile" (1: time every kernel with HIP events),
  * "compare_backend" (0 pileup, 1 segment list), "filter" (where phase A's sort + chain filter
- * runs: 0 on the device for 128 queries or more, or when the call covers only a part of the genomes
- * (a rank of a sharded run, whose lists are exported from the device next), and on the host cores
- * otherwise, 1 host, 2 device; the results are the same), "host_threads", "anchor_kernel" (phase A's chain
+ * runs: 0 and 2 on the device — a query whose list has two entries with the same projected start still goes
+ * to the host, as the reference's order of such ties is libstdc++'s — 1 on the host cores; the results are
+ * the same), "host_threads", "anchor_kernel" (phase A's chain
  * kernels: 1, the default, the lean kernels on 2-bit packed operands; 0 the general byte-wise ones — same
  * results), "lean_force_slow" (1: every step of the lean kernels through their wave-cooperative slow resolver). */
 int phylo_set_option(phylo_ctx *ctx, const char *key, long value);

@@ -27,6 +27,9 @@ static const uint16_t NONE16 = 0xffff;
 static const uint32_t FLAG_HOST = 1;    // flag[j]: the host does this query (equal starts, or too long a list)
 static const uint32_t FLAG_GENERAL = 2; // ... the general kernel below does (an entangled stretch of more than SEG_MAX entries)
 static const uint32_t SEG_MAX = 48;     // longest stretch of mutually entangled entries one thread works out
+static const uint32_t FLAG_LONG = 3;    // ... the long-list kernel does (more than FILT_MAX entries: genomes of tens of Mbp)
+static const uint32_t LONG_MAX_N = 1u << 17; // entries per list the long-list kernel takes (its scratch slot holds that many)
+static const uint32_t LONG_SLOTS = 96;       // scratch slots: that many long lists are worked on at a time; the rest go to the host
 
 // (score, pile index) as one integer whose maximum is "highest score, then smallest index":
 // exactly the reference's choice of predecessor (the first k with the largest score,
@@ -340,7 +343,8 @@ __global__ __launch_bounds__(FILT_THREADS) void sort_filter_seg_kernel(const Raw
 																		const uint32_t *__restrict__ raw_cnt, uint32_t j0, uint32_t border,
 																		uint32_t threshold, uint32_t ref_local,
 																		DevHom *__restrict__ out, uint32_t *__restrict__ rng,
-																		uint32_t *__restrict__ total, uint32_t *__restrict__ flag)
+																		uint32_t *__restrict__ total, uint32_t *__restrict__ flag,
+																		uint32_t long_ok)
 {
 	__shared__ SegShared sh;
 	const uint32_t j = j0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(FILT_THREADS) void sort_filter_seg_kernel(const Raw
 	}
 	if (n > FILT_MAX) {
 		if (tid == 0) {
-			flag[j] = FLAG_HOST;
+			flag[j] = (long_ok && n <= LONG_MAX_N) ? FLAG_LONG : FLAG_HOST;
 			rng[2 * j] = rng[2 * j + 1] = 0;
 		}
 		return;
@@ -507,14 +511,256 @@ __global__ __launch_bounds__(FILT_THREADS) void sort_filter_seg_kernel(const Raw
 	}
 }
 
+
+// ── lists of more than FILT_MAX entries (queries of tens of Mbp: ~330 homologies per Mbp) ──
+// The same stretch-wise filter with the list in global memory: keys sorted by a bitonic network whose
+// passes with partners less than a tile apart run in LDS (tiles of FILT_MAX keys), the rest in global
+// memory; prefix maximum of the ends, cuts, stretches and output tile by tile with a carry.  One block per
+// list, scratch from a pool of LONG_SLOTS slots (a list that finds none goes to the host).
+struct LongScratch {
+	uint64_t *keys; // [LONG_SLOTS][LONG_MAX_N] start << 32 | raw index
+	uint32_t *ends; // [LONG_SLOTS][LONG_MAX_N] end of the entry at that pile position
+	uint8_t *keep;  // [LONG_SLOTS][LONG_MAX_N] bit 0 kept, bit 1 a stretch starts here
+	uint32_t *next_slot;
+};
+
+__global__ __launch_bounds__(FILT_THREADS) void sort_filter_long_kernel(const RawHom *__restrict__ raw,
+																		 const uint64_t *__restrict__ raw_base,
+																		 const uint32_t *__restrict__ raw_cnt, uint32_t j0, uint32_t border,
+																		 DevHom *__restrict__ out, uint32_t *__restrict__ rng,
+																		 uint32_t *__restrict__ total, uint32_t *__restrict__ flag,
+																		 LongScratch S)
+{
+	__shared__ uint64_t tile[FILT_MAX];
+	__shared__ uint32_t wmax[FILT_WAVES], wsum[FILT_WAVES];
+	__shared__ uint32_t s_slot, s_tie, s_general, s_carry, s_base;
+	const uint32_t j = j0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	if (flag[j] != FLAG_LONG) return;
+	const RawHom *r = raw + raw_base[j];
+	const uint32_t n = raw_cnt[j];
+	if (tid == 0) {
+		s_slot = atomicAdd(S.next_slot, 1u);
+		s_tie = s_general = 0;
+	}
+	__syncthreads();
+	if (s_slot >= LONG_SLOTS) {
+		if (tid == 0) flag[j] = FLAG_HOST;
+		return;
+	}
+	uint64_t *K = S.keys + (size_t)s_slot * LONG_MAX_N;
+	uint32_t *E = S.ends + (size_t)s_slot * LONG_MAX_N;
+	uint8_t *KP = S.keep + (size_t)s_slot * LONG_MAX_N;
+	uint32_t n2 = FILT_MAX;
+	while (n2 < n) n2 <<= 1;
+	for (uint32_t t = tid; t < n2; t += FILT_THREADS) { // reverseEh (process.h:72-80)
+		uint64_t key = ~0ull;
+		if (t < n) {
+			const RawHom h = r[t];
+			const uint32_t start = h.iref >= border ? 2u * border + 1u - h.len - h.iref : h.iref;
+			key = (uint64_t)start << 32 | t;
+		}
+		K[t] = key;
+	}
+	__syncthreads();
+	// bitonic sort of n2 keys: for every k, the passes with j >= FILT_MAX in global memory, the rest per tile in LDS
+	for (uint32_t k = 2; k <= n2; k <<= 1) {
+		uint32_t jj = k >> 1;
+		for (; jj >= FILT_MAX; jj >>= 1) {
+			for (uint32_t t = tid; t < n2; t += FILT_THREADS) {
+				const uint32_t x = t ^ jj;
+				if (x > t) {
+					const uint64_t u = K[t], v = K[x];
+					if ((u > v) == ((t & k) == 0)) {
+						K[t] = v;
+						K[x] = u;
+					}
+				}
+			}
+			__syncthreads();
+		}
+		if (k > FILT_MAX && jj == 0) continue;
+		// k <= FILT_MAX: the tile phases of all such k can run back to back in LDS — done once, below, for k == 2
+		if (k <= FILT_MAX && k != 2) continue;
+		for (uint32_t base = 0; base < n2; base += FILT_MAX) {
+			for (uint32_t t = tid; t < FILT_MAX; t += FILT_THREADS) tile[t] = K[base + t];
+			__syncthreads();
+			const uint32_t k_lo = k <= FILT_MAX ? 2u : k, k_hi = k <= FILT_MAX ? FILT_MAX : k;
+			for (uint32_t kk = k_lo; kk <= k_hi; kk <<= 1) {
+				for (uint32_t j2 = (kk > FILT_MAX ? FILT_MAX : kk) >> 1; j2 > 0; j2 >>= 1) {
+					for (uint32_t t = tid; t < FILT_MAX; t += FILT_THREADS) {
+						const uint32_t x = t ^ j2;
+						if (x > t) {
+							const uint64_t u = tile[t], v = tile[x];
+							if ((u > v) == (((base + t) & kk) == 0)) {
+								tile[t] = v;
+								tile[x] = u;
+							}
+						}
+					}
+					__syncthreads();
+				}
+				if (kk == k_hi) break;
+			}
+			for (uint32_t t = tid; t < FILT_MAX; t += FILT_THREADS) K[base + t] = tile[t];
+			__syncthreads();
+		}
+	}
+	// ends, equal starts, prefix maximum of the ends and the cuts, tile by tile
+	if (tid == 0) s_carry = 0;
+	__syncthreads();
+	for (uint32_t base = 0; base < n; base += FILT_MAX) {
+		const uint32_t p4 = base + tid * 4u;
+		uint32_t e[4], st[4], run = 0;
+#pragma unroll
+		for (uint32_t u = 0; u < 4; u++) {
+			const uint32_t p = p4 + u;
+			e[u] = 0;
+			st[u] = 0;
+			if (p < n) {
+				const uint64_t key = K[p];
+				st[u] = (uint32_t)(key >> 32);
+				if (p + 1 < n && (uint32_t)(K[p + 1] >> 32) == st[u]) s_tie = 1;
+				e[u] = st[u] + r[(uint32_t)key].len;
+				E[p] = e[u];
+			}
+			run = e[u] > run ? e[u] : run;
+			e[u] = run;
+		}
+		uint32_t incl = run;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t t = (uint32_t)__shfl_up((int)incl, d, 64);
+			if ((int)lane >= d && t > incl) incl = t;
+		}
+		if (lane == 63) wmax[wave] = incl;
+		__syncthreads();
+		uint32_t before = (uint32_t)__shfl_up((int)incl, 1, 64);
+		if (lane == 0) before = 0;
+		for (uint32_t w2 = 0; w2 < wave; w2++) before = wmax[w2] > before ? wmax[w2] : before;
+		before = s_carry > before ? s_carry : before;
+#pragma unroll
+		for (uint32_t u = 0; u < 4; u++) {
+			const uint32_t p = p4 + u;
+			if (p < n) {
+				const uint32_t prev_max = u ? (e[u - 1] > before ? e[u - 1] : before) : before;
+				KP[p] = prev_max <= st[u] ? 2u : 0u;
+			}
+		}
+		__syncthreads();
+		if (tid == FILT_THREADS - 1) {
+			uint32_t m = s_carry;
+			for (uint32_t w2 = 0; w2 < FILT_WAVES; w2++) m = wmax[w2] > m ? wmax[w2] : m;
+			s_carry = m;
+		}
+		__syncthreads();
+	}
+	if (s_tie) {
+		if (tid == 0) flag[j] = FLAG_HOST;
+		return;
+	}
+	// the stretches that start at this thread's entries
+	for (uint32_t a = tid; a < n; a += FILT_THREADS) {
+		if (!(KP[a] & 2u)) continue;
+		uint32_t b = a + 1;
+		while (b < n && !(KP[b] & 2u)) b++;
+		if (b - a == 1) {
+			KP[a] |= 1u;
+			continue;
+		}
+		if (b - a > SEG_MAX) {
+			s_general = 1;
+			continue;
+		}
+		uint32_t score[SEG_MAX], start_[SEG_MAX], end_[SEG_MAX];
+		uint8_t pred[SEG_MAX];
+		uint32_t top = 0, top_score = 0;
+		const uint32_t m = b - a;
+		for (uint32_t i = 0; i < m; i++) {
+			start_[i] = (uint32_t)(K[a + i] >> 32);
+			end_[i] = E[a + i];
+			uint32_t best = 0, bk = 0xffu;
+			for (uint32_t k2 = 0; k2 < i; k2++)
+				if (end_[k2] <= start_[i] && score[k2] > best) {
+					best = score[k2];
+					bk = k2;
+				}
+			score[i] = best + (end_[i] - start_[i]);
+			pred[i] = (uint8_t)bk;
+			if (score[i] > top_score) {
+				top_score = score[i];
+				top = i;
+			}
+		}
+		for (uint32_t i = top; i != 0xffu; i = pred[i]) KP[a + i] |= 1u;
+	}
+	__syncthreads();
+	if (s_general) { // an entangled stretch beyond what a thread takes: the host does this list
+		if (tid == 0) flag[j] = FLAG_HOST;
+		return;
+	}
+	// output in pile order, tile by tile
+	{
+		uint32_t mine = 0;
+		for (uint32_t i = tid; i < n; i += FILT_THREADS) mine += KP[i] & 1u;
+		for (uint32_t d = 32; d > 0; d >>= 1) mine += (uint32_t)__shfl((int)mine, (int)(lane ^ d), 64);
+		if (lane == 0) wsum[wave] = mine;
+		__syncthreads();
+		if (tid == 0) {
+			uint32_t w = 0;
+			for (uint32_t w2 = 0; w2 < FILT_WAVES; w2++) w += wsum[w2];
+			const uint32_t b = w ? atomicAdd(total, w) : 0u;
+			s_base = b;
+			rng[2 * j] = b;
+			rng[2 * j + 1] = b + w;
+			flag[j] = 0;
+		}
+		__syncthreads();
+	}
+	const uint32_t obase = s_base;
+	uint32_t done = 0;
+	for (uint32_t p0 = 0; p0 < n; p0 += FILT_THREADS) {
+		const uint32_t p = p0 + tid;
+		const uint32_t k = (p < n && (KP[p] & 1u)) ? 1u : 0u;
+		const uint64_t mk = __ballot(k);
+		if (lane == 0) wsum[wave] = (uint32_t)__popcll(mk);
+		__syncthreads();
+		uint32_t off = done + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
+		for (uint32_t w2 = 0; w2 < wave; w2++) off += wsum[w2];
+		if (k) {
+			const uint64_t key = K[p];
+			const RawHom h = r[(uint32_t)key];
+			out[obase + off] = DevHom{(uint32_t)(key >> 32), h.iq, h.len, h.iref >= border ? 1u : 0u};
+		}
+		for (uint32_t w2 = 0; w2 < FILT_WAVES; w2++) done += wsum[w2];
+		__syncthreads();
+	}
+}
+
+size_t long_filter_scratch_bytes() { return (size_t)LONG_SLOTS * LONG_MAX_N * (8 + 4 + 1) + 64; }
+uint32_t long_filter_min_entries() { return FILT_MAX; }
+
+void launch_sort_filter_long(const RawHom *raw, const uint64_t *raw_base, const uint32_t *raw_cnt, uint32_t j0, uint32_t j1,
+							 uint32_t border, DevHom *out, uint32_t *rng, uint32_t *total, uint32_t *flag, void *scratch,
+							 uint32_t *slot_counter, hipStream_t st)
+{
+	if (j1 <= j0) return;
+	LongScratch S;
+	S.keys = (uint64_t *)scratch;
+	S.ends = (uint32_t *)(S.keys + (size_t)LONG_SLOTS * LONG_MAX_N);
+	S.keep = (uint8_t *)(S.ends + (size_t)LONG_SLOTS * LONG_MAX_N);
+	S.next_slot = slot_counter;
+	hipLaunchKernelGGL(sort_filter_long_kernel, dim3(j1 - j0), dim3(FILT_THREADS), 0, st, raw, raw_base, raw_cnt, j0, border, out, rng,
+					   total, flag, S);
+}
+
 void launch_sort_filter(const RawHom *raw, const uint64_t *raw_base, const uint32_t *raw_cnt, uint32_t j0, uint32_t j1, uint32_t border,
 						uint32_t threshold, uint32_t ref_local, DevHom *out, uint32_t *rng, uint32_t *total, uint32_t *flag,
-						hipStream_t st, int variant)
+						hipStream_t st, int variant, int long_ok)
 {
 	if (j1 <= j0) return;
 	if (variant == 0) { // stretch by stretch, then the general kernel for what that one handed over
 		hipLaunchKernelGGL(sort_filter_seg_kernel, dim3(j1 - j0), dim3(FILT_THREADS), 0, st, raw, raw_base, raw_cnt, j0, border,
-						   threshold, ref_local, out, rng, total, flag);
+						   threshold, ref_local, out, rng, total, flag, (uint32_t)long_ok);
 		hipLaunchKernelGGL(sort_filter_kernel, dim3(j1 - j0), dim3(FILT_THREADS), 0, st, raw, raw_base, raw_cnt, j0, border, threshold,
 						   ref_local, out, rng, total, flag, 1u);
 	} else {

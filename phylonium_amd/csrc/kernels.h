@@ -36,7 +36,13 @@ void launch_fold(const PhaseA &A, uint32_t j0, uint32_t j1, uint32_t border, uin
 struct DevHom;
 void launch_sort_filter(const RawHom *raw, const uint64_t *raw_base, const uint32_t *raw_cnt, uint32_t j0, uint32_t j1, uint32_t border,
 						uint32_t threshold, uint32_t ref_local, DevHom *out, uint32_t *rng, uint32_t *total, uint32_t *flag,
-						hipStream_t st, int variant = 0); // queries [j0, j1); variant 0: stretch by stretch (default), 1: the general kernel only
+						hipStream_t st, int variant = 0, int long_ok = 0); // queries [j0, j1); variant 0: stretch by stretch (default), 1: the general kernel only; long_ok: lists beyond the block's LDS are left to launch_sort_filter_long
+// lists of more than long_filter_min_entries() entries (flagged by launch_sort_filter with long_ok): sorted in global memory
+size_t long_filter_scratch_bytes();
+uint32_t long_filter_min_entries();
+void launch_sort_filter_long(const RawHom *raw, const uint64_t *raw_base, const uint32_t *raw_cnt, uint32_t j0, uint32_t j1,
+							 uint32_t border, DevHom *out, uint32_t *rng, uint32_t *total, uint32_t *flag, void *scratch,
+							 uint32_t *slot_counter, hipStream_t st);
 
 // index_kernels.hip
 void launch_lcp(const uint8_t *S, const uint32_t *SA, uint32_t n, uint32_t cap, uint32_t *LCP, uint32_t *capped,

@@ -236,6 +236,7 @@ struct phylo_ctx {
 	// phase A over all genomes leaves the filtered lists on the device already (see phylo_anchor)
 	int filter_mode = 0; // option "filter": 0 device sort + filter for 128 queries or more, host below; 1 host; 2 device
 	DevBuf<uint32_t> a_flt; // [0] kept total, [1..nq] per-query flags of the device sort + filter
+	DevBuf<uint8_t> a_long; // scratch slots of the long-list filter kernel (allocated when a query is long enough to need it)
 	bool homs_staged = false;
 	// ... and has projected them for the whole reference (part 0 of 1); with five planes or three
 	bool eager_valid = false, eager_five = false;
@@ -424,6 +425,8 @@ void phylo_ctx_destroy(phylo_ctx *c)
 	c->d_SBAD.release();
 	c->d_badscr.release();
 	c->d_badoff.release();
+	c->a_flt.release();
+	c->a_long.release();
 	c->a_qoff.release();
 	c->a_qlen.release();
 	c->a_qchunk0.release();
@@ -1011,13 +1014,10 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 			launch_lean_overruns(A, R, (uint32_t)nq, st);
 		}
 	}
-	// One query's list takes the device ~0.1-0.4 ms however many there are (a block per query, all
-	// at once); the host pool does a few dozen lists in less than that, many only as fast.
-	// A call for a part of the genomes is a rank of a sharded run: its lists are exported next
-	// (phylo_export_packed_device), which is a device-to-device gather when they are already there
-	// and a pack + upload when they are on the host — with that counted the device wins for any number.
-	const bool part_of_many = !(q_begin == 0 && q_end == c->n);
-	const bool device_filter = c->filter_mode == 2 || (c->filter_mode == 0 && (nq >= 128 || part_of_many));
+	// Sort + chain filter: on the device unless the host is asked for (option "filter" = 1).  Round 1 sent calls
+	// with fewer than 128 queries to the host pool (the device's dependent scan took ~0.4 ms whatever the
+	// number); stretch by stretch a list takes ~60 us there, and long lists have a kernel of their own.
+	const bool device_filter = c->filter_mode != 1;
 	const bool full = q_begin == 0 && q_end == c->n;
 	const bool tail_eager = device_filter && full && c->backend == 0;
 	const uint32_t ref_local = (c->ref_idx >= q_begin && c->ref_idx < q_end) ? (uint32_t)(c->ref_idx - q_begin) : 0xffffffffu;
@@ -1036,6 +1036,16 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 		uint32_t j = (uint32_t)(std::lower_bound(P.qchunk0.begin(), P.qchunk0.begin() + nq, want) - P.qchunk0.begin());
 		j = (j + tsz_q / 2) / tsz_q * tsz_q;
 		gb[g] = std::min<uint32_t>(std::max(j, gb[g - 1]), (uint32_t)nq);
+	}
+	// queries of tens of Mbp leave more entries than a block's LDS holds (~330 per Mbp): their lists go through the
+	// long-list kernel and its scratch slots; with shorter queries a list that long is an oddity and goes to the host
+	bool long_lists = false;
+	if (device_filter && c->opt_filter_kernel == 0) {
+		uint64_t longest = 0;
+		for (size_t j = 0; j < nq; j++)
+			if (q_begin + j != c->ref_idx) longest = std::max<uint64_t>(longest, c->glen[q_begin + j]);
+		long_lists = longest > 6000000;
+		if (long_lists) HIPOK(c, c->a_long.ensure(long_filter_scratch_bytes()));
 	}
 	Pileup TP;
 	if (device_filter) {
@@ -1083,7 +1093,10 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 			{
 				KernelSpan s(c, "anchor_filter", sg);
 				launch_sort_filter(c->a_raw.p, c->a_out_base.p, c->a_out_cnt.p, j0, j1, c->L, c->threshold, ref_local, c->b_homs.p,
-								   c->b_hom_rng.p, c->a_flt.p, c->a_flt.p + 1, sg, c->opt_filter_kernel);
+								   c->b_hom_rng.p, c->a_flt.p, c->a_flt.p + 1, sg, c->opt_filter_kernel, long_lists ? 1 : 0);
+				if (long_lists)
+					launch_sort_filter_long(c->a_raw.p, c->a_out_base.p, c->a_out_cnt.p, j0, j1, c->L, c->b_homs.p, c->b_hom_rng.p,
+											c->a_flt.p, c->a_flt.p + 1, c->a_long.p, c->a_misc.p + 7, sg);
 			}
 			if (tail_eager && j1 > j0) {
 				launch_tile_index(TP, c->b_homs.p, c->b_hom_rng.p, c->b_first.p, j0, j1, sg);

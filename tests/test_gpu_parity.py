@@ -282,6 +282,35 @@ def test_installed_lists_that_overlap_go_through_the_segment_backend(ctx):
         ctx.attach_packed_device(t.data_ptr(), begin, counts, 0, 0)
 
 
+@pytest.mark.timeout(600)
+def test_lists_beyond_the_filter_blocks_lds_stay_on_the_device(ctx):
+    """Queries of 16 Mbp with 400 indels per Mbp leave more than 4096 raw homologies each: sorted by the long-list
+    kernel in global memory (tiles in LDS), filtered stretch by stretch, no host step; lists equal the oracle's."""
+    gs = synth.make_genomes(3, 16_000_000, seed=61, d_range=(0.03, 0.12), indel_per_mbp=400, inv_frac=0.03, contigs=3,
+                            inv_len=(500, 4000))
+    ctx.set_option("filter", 2)
+    try:
+        ctx.set_genomes(gs)
+        refb = bytes(gs[0])
+        sa = api.host_suffix_array(refb + b"#" + O.revcomp(refb))
+        ctx.set_reference(0, sa=sa)
+        ctx.reset_stats()
+        ctx.anchor()
+        assert not ctx.stat("count:queries_left_to_the_host")
+        r = O.Run(gs, 0).process(sa=sa, threads=8)
+        assert ctx.threshold == r.threshold
+        for j in range(3):
+            got, want = hom_tuples_gpu(ctx.homologies(j)), hom_tuples_orc(r.homologies(j))
+            assert got == want, j
+            if j:
+                assert r.homologies(j, filtered=False).size > 4096
+        s, h = ctx.compare()
+        so, ho = r.matrix()
+        assert (s == so).all() and (h == ho).all()
+    finally:
+        ctx.set_option("filter", 0)
+
+
 def test_reference_cache_quirk_is_reported(ctx):
     """A reference on which phylonium's 6-mer cache stores an over-deep interval (the only two occurrences of
     a short nucleotide string stand in front of a contig join, esa.cxx:174-199): flagged; an ordinary
