@@ -355,25 +355,24 @@ __global__ __launch_bounds__(256) void symmetrise_kernel(uint32_t N, unsigned lo
 }
 // The pileup equals compare(list, list) of process.cxx:566-611 only for lists that are sorted by projected
 // start, pairwise disjoint and inside the reference — what phase A's filter guarantees, not what a caller
-// may install.  One thread per genome walks its list; *bad is raised on the first violation.
-__global__ __launch_bounds__(64) void check_lists_kernel(const DevHom *__restrict__ homs, const uint32_t *__restrict__ hom_rng,
-														  uint32_t N, uint32_t L, uint32_t *__restrict__ bad)
+// may install.  One block per genome, every entry against its predecessor; *bad is raised on a violation.
+__global__ __launch_bounds__(256) void check_lists_kernel(const DevHom *__restrict__ homs, const uint32_t *__restrict__ hom_rng,
+														   uint32_t L, uint32_t *__restrict__ bad)
 {
-	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-	if (g >= N) return;
-	uint32_t prev_end = 0;
-	for (uint32_t t = hom_rng[2 * g]; t < hom_rng[2 * g + 1]; t++) {
+	const uint32_t g = blockIdx.x, b = hom_rng[2 * g], e = hom_rng[2 * g + 1];
+	for (uint32_t t = b + threadIdx.x; t < e; t += blockDim.x) {
 		const DevHom h = homs[t];
-		if (h.start < prev_end || (uint64_t)h.start + h.len > L) {
-			*bad = 1;
-			return;
+		bool wrong = (uint64_t)h.start + h.len > L;
+		if (t > b) {
+			const DevHom p = homs[t - 1];
+			wrong = wrong || h.start < p.start + p.len;
 		}
-		prev_end = h.start + h.len;
+		if (wrong) *bad = 1;
 	}
 }
 void launch_check_lists(const DevHom *homs, const uint32_t *hom_rng, uint32_t N, uint32_t L, uint32_t *bad, hipStream_t st)
 {
-	if (N) hipLaunchKernelGGL(check_lists_kernel, dim3((N + 63) / 64), dim3(64), 0, st, homs, hom_rng, N, L, bad);
+	if (N) hipLaunchKernelGGL(check_lists_kernel, dim3(N), dim3(256), 0, st, homs, hom_rng, L, bad);
 }
 
 void launch_symmetrise(uint32_t N, unsigned long long *a, unsigned long long *b, hipStream_t st)
