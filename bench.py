@@ -483,10 +483,14 @@ def main():
                     # this run's launch time): the request-granular view of the same kernel
                     "traffic_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic else None,
                     "traffic_frac": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-                    "note": "anchor_* kernels gather random 128-B lines (k-mer slots, subject windows): dependent-access "
-                            "latency bound, not HBM-streaming; `traffic` = HBM-side bytes per launch from rocprofv3 PMC "
-                            "(profiles/pmc_traffic.json); pileup_pairs moves far fewer HBM bytes than the reference "
-                            "layout's algorithmic 2 B/site"}
+                    "traffic_source": "profiles/pmc_traffic.json (rocprofv3 PMC passes of this workload on the build of "
+                                      "profiles/r02_rocprof_c3_summary.json; regenerate with tools/tools_prof.sh + tools/tools_pmc_traffic.py "
+                                      "when the kernels change)",
+                    "note": "anchor_spec fetches one random 64-B k-mer slot (a 128-B line at the memory) per chain step: its time "
+                            "is its line transactions (~122 M per launch at ~48 G lines/s, the rate of uniformly random line "
+                            "fetches on this chip) — `frac` prices SURVEY 8d's algorithmic bytes (query bytes + one pass over the "
+                            "reference-layout ESA), `traffic` is what the HBM interface carried (PMC); pileup_pairs moves far "
+                            "fewer HBM bytes than the reference layout's algorithmic 2 B/site"}
         phase_b_traffic = None
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload, {})
