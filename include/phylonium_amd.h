@@ -87,6 +87,18 @@ int phylo_set_genomes(phylo_ctx *ctx, size_t n, const char *const *seq, const si
 int phylo_set_genomes_device(phylo_ctx *ctx, size_t n, const void *dev_base, const uint64_t *offsets,
 							 const uint64_t *lens);
 
+/* Same genomes, handed over as 2-bit codes: q2[j] holds (len[j] + 15) / 16 words, 16 bases per word, the
+ * first base in bits 31..30, A0 C1 G2 T3, codes behind the last base 0; bad[j][0..nbad[j]) are the ascending
+ * positions of the '!' separators (their code is 0).  This is the form phase A's kernels read, so it is copied
+ * into place — a quarter of the bytes of phylo_set_genomes cross PCIe — and the byte form the other kernels
+ * read is written by the device.  The FASTA side of it: phylo_host_read_fasta_packed (src/sequence.cxx:109-199
+ * fused with the packing). */
+int phylo_set_genomes_packed(phylo_ctx *ctx, size_t n, const uint32_t *const *q2, const size_t *len,
+							 const uint32_t *const *bad, const size_t *nbad);
+/* Genome i as bytes (len[i] of them, no terminator), copied from the device: a host that ingested packed
+ * genomes needs the reference's bytes for the suffix array, and all of them for -p. */
+int phylo_get_genome(phylo_ctx *ctx, size_t i, char *buf);
+
 /* ── reference: `esa ref(subject)` + threshold, src/process.cxx:413-417 ──
  * sa: suffix array of S = subject + '#' + revcomp(subject), 2L+1 entries,
  * exactly what divsufsort64 returns at src/esa.cxx:74; NULL builds it on the
@@ -192,6 +204,15 @@ size_t phylo_host_min_anchor_length(double p, double gc, size_t l);
  * the order given that could not be read (its message: phylo_last_error(NULL)); nothing is
  * handed over in that case. */
 int phylo_host_read_fasta(size_t n, const char *const *paths, size_t threads, char **out, size_t *len);
+/* The same files as 2-bit codes + separator positions, the arguments of phylo_set_genomes_packed: files are
+ * mapped, not copied, and lines of nucleotides are packed 32 bytes at a time (AVX2 + BMI2 when the CPU has
+ * them).  q2[i] and bad[i] point into storage owned by *arena (one allocation for all genomes: a thousand
+ * buffers of their own would cost a thousand munmaps under the GPU driver's MMU notifier once they have been
+ * the source of a copy); release it with phylo_host_free_packed when the genomes are on the device.  Errors as
+ * phylo_host_read_fasta. */
+int phylo_host_read_fasta_packed(size_t n, const char *const *paths, size_t threads, uint32_t **q2, size_t *len,
+								 uint32_t **bad, size_t *nbad, void **arena);
+void phylo_host_free_packed(void *arena);
 void phylo_host_free(void *p);
 /* The first-pass reference of src/phylonium.cxx:360-382: the genome std::nth_element leaves at
  * the middle position when ordering by length (for equal lengths that depends on the library's

@@ -23,13 +23,13 @@ PHOM = np.dtype([("index_reference", "<u8"), ("index_reference_projected", "<u8"
 # every symbol include/phylonium_amd.h declares
 SYMBOLS = [
     "phylo_ctx_create", "phylo_ctx_destroy", "phylo_last_error", "phylo_set_option", "phylo_get_stat", "phylo_reference_cache_quirk",
-    "phylo_reset_stats", "phylo_stat_keys", "phylo_set_genomes", "phylo_set_genomes_device",
+    "phylo_reset_stats", "phylo_stat_keys", "phylo_set_genomes", "phylo_set_genomes_device", "phylo_set_genomes_packed", "phylo_get_genome",
     "phylo_set_reference", "phylo_threshold", "phylo_anchor", "phylo_get_homologies", "phylo_set_homologies",
     "phylo_export_homologies", "phylo_import_homologies", "phylo_export_packed", "phylo_import_packed",
     "phylo_export_packed_device", "phylo_attach_packed_device", "phylo_compare_device",
     "phylo_complete_delete", "phylo_compare", "phylo_compare_all", "phylo_process", "phylo_seqcmp",
     "phylo_revseqcmp", "phylo_seqcmp_batch", "phylo_host_suffix_array", "phylo_host_reference_suffix_array", "phylo_host_min_anchor_length",
-    "phylo_host_read_fasta", "phylo_host_free", "phylo_host_median_length_index",
+    "phylo_host_read_fasta", "phylo_host_read_fasta_packed", "phylo_host_free_packed", "phylo_host_free", "phylo_host_median_length_index",
     "phylo_host_sort_filter", "phylo_estimate", "phylo_format_phylip", "phylo_version",
 ]
 
@@ -62,6 +62,8 @@ def load():
     L.phylo_stat_keys.argtypes = [vp, vp, sz]
     L.phylo_set_genomes.argtypes = [vp, sz, vp, vp]
     L.phylo_set_genomes_device.argtypes = [vp, sz, vp, vp, vp]
+    L.phylo_set_genomes_packed.argtypes = [vp, sz, vp, vp, vp, vp]
+    L.phylo_get_genome.argtypes = [vp, sz, vp]
     L.phylo_set_reference.argtypes = [vp, sz, vp, sz]
     L.phylo_threshold.restype = sz
     L.phylo_threshold.argtypes = [vp]
@@ -89,6 +91,9 @@ def load():
     L.phylo_host_min_anchor_length.restype = sz
     L.phylo_host_min_anchor_length.argtypes = [C.c_double, C.c_double, sz]
     L.phylo_host_read_fasta.argtypes = [sz, vp, sz, vp, vp]
+    L.phylo_host_read_fasta_packed.argtypes = [sz, vp, sz, vp, vp, vp, vp, C.POINTER(vp)]
+    L.phylo_host_free_packed.argtypes = [vp]
+    L.phylo_host_free_packed.restype = None
     L.phylo_host_free.argtypes = [vp]
     L.phylo_host_free.restype = None
     L.phylo_host_median_length_index.restype = sz
@@ -174,6 +179,24 @@ class Context:
         self._chk(self.L.phylo_set_genomes(self.h, n, ptrs, lens))
         self.n = n
         self.lengths = [a.size for a in arrs]
+
+    def set_genomes_packed(self, packed):
+        """packed: (q2 words, length, separator positions) per genome, as read_fasta_packed returns them."""
+        n = len(packed)
+        q2 = [np.ascontiguousarray(p[0], np.uint32) for p in packed]
+        bad = [np.ascontiguousarray(p[2], np.uint32) for p in packed]
+        qp = (C.c_void_p * n)(*[a.ctypes.data for a in q2])
+        bp = (C.c_void_p * n)(*[a.ctypes.data for a in bad])
+        lens = (C.c_size_t * n)(*[int(p[1]) for p in packed])
+        nb = (C.c_size_t * n)(*[a.size for a in bad])
+        self._chk(self.L.phylo_set_genomes_packed(self.h, n, qp, lens, bp, nb))
+        self.n = n
+        self.lengths = [int(p[1]) for p in packed]
+
+    def get_genome(self, i):
+        out = np.empty(self.lengths[i], np.uint8)
+        self._chk(self.L.phylo_get_genome(self.h, i, out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def set_genomes_device(self, dev_ptr, offsets, lens):
         off = np.ascontiguousarray(offsets, dtype=np.uint64)
@@ -384,6 +407,56 @@ def read_fasta(paths, threads=16):
             L.phylo_host_free(out[i])
             gs.append(np.zeros(0, np.uint8))
     return gs
+
+
+def read_fasta_packed(paths, threads=16):
+    """FASTA files → (q2, length, separator positions) per genome: 2-bit codes, 16 bases per uint32 word with the
+    first base in bits 31..30 (A0 C1 G2 T3), and the positions of the '!' between records."""
+    L = load()
+    n = len(paths)
+    enc = [os.fsencode(p) for p in paths]
+    arr = (C.c_char_p * n)(*enc)
+    q2, bad = (C.c_void_p * n)(), (C.c_void_p * n)()
+    lens, nbad = (C.c_size_t * n)(), (C.c_size_t * n)()
+    arena = C.c_void_p()
+    rc = L.phylo_host_read_fasta_packed(n, arr, threads, q2, lens, bad, nbad, C.byref(arena))
+    if rc:
+        raise PhyloniumError((L.phylo_last_error(None) or b"").decode())
+    out = []
+    for i in range(n):
+        words = (lens[i] + 15) // 16
+        a = np.ctypeslib.as_array(C.cast(q2[i], C.POINTER(C.c_uint32)), shape=(words,)).copy() if words else np.zeros(0, np.uint32)
+        b = np.ctypeslib.as_array(C.cast(bad[i], C.POINTER(C.c_uint32)), shape=(nbad[i],)).copy() if nbad[i] else np.zeros(0, np.uint32)
+        out.append((a, int(lens[i]), b))
+    L.phylo_host_free_packed(arena)
+    return out
+
+
+def pack_genome(g):
+    """Bytes (A, C, G, T, '!') → (q2, length, separator positions), the layout of read_fasta_packed (numpy; tests
+    and small hosts — the reader packs while it parses)."""
+    g = _u8(g)
+    bad = np.flatnonzero(g == ord("!")).astype(np.uint32)
+    if (~np.isin(g, np.frombuffer(b"ACGT!", np.uint8))).any():
+        raise PhyloniumError("a genome holds bytes other than A, C, G, T and '!'")
+    code = (((g >> 1) & 3) ^ ((g >> 2) & 1)).astype(np.uint32)
+    code[bad] = 0
+    words = (g.size + 15) // 16
+    padded = np.zeros(words * 16, np.uint32)
+    padded[:g.size] = code
+    shifts = np.arange(30, -2, -2, dtype=np.uint32)
+    q2 = (padded.reshape(words, 16) << shifts[None, :]).sum(axis=1, dtype=np.uint64).astype(np.uint32) if words else np.zeros(0, np.uint32)
+    return q2, int(g.size), bad
+
+
+def unpack_genome(q2, length, bad):
+    """The bytes of a packed genome (numpy; tests and small hosts)."""
+    q2 = np.asarray(q2, np.uint32)
+    shifts = np.arange(30, -2, -2, dtype=np.uint32)
+    codes = ((q2[:, None] >> shifts[None, :]) & 3).reshape(-1)[:length]
+    g = np.frombuffer(b"ACGT", np.uint8)[codes].copy()
+    g[np.asarray(bad, np.int64)] = ord("!")
+    return g
 
 
 def host_median_length_index(lengths):

@@ -40,7 +40,12 @@ int RETURN_CODE = EXIT_SUCCESS;
 enum Flags { F_VERBOSE = 1, F_EXTRA_VERBOSE = 2, F_COMPLETE_DELETION = 4, F_PROGRESS = 8, F_POSITIONS = 16, F_ANI = 32, F_RAW = 64 };
 
 using phyfasta::Genome;
+using phyfasta::PackedGenome;
 using phyfasta::read_genomes;
+
+// Length of every genome (nucleotides + separators).  With the packed ingest (the default) the bytes of a
+// genome exist on the host only where something asks for them: the reference (suffix array), -p.
+std::vector<size_t> GLEN;
 
 [[noreturn]] void die(const std::string &msg)
 {
@@ -69,18 +74,33 @@ double dist_of(const Tally &t, int flags, bool zero_on_error = false)
 	return phylo_estimate(kind, t.subst, t.homologs, zero_on_error);
 }
 
-// just_print, io.cxx:141-163
+// just_print, io.cxx:141-163: "%.4e" ("%.4g" for ANI: std::dec leaves the float field at its default) is what
+// the stream formats print.  Rows are formatted on the host threads and written in order.
+size_t PRINT_THREADS = 1;
 void print_phylip(const std::vector<Genome> &q, const std::vector<double> &d, int flags)
 {
 	size_t N = q.size();
+	const char *fmt = (flags & F_ANI) ? "  %.4g" : "  %.4e";
+	const size_t nt = std::max<size_t>(1, std::min(PRINT_THREADS, N / 16 + 1));
+	std::vector<std::string> part(nt);
+	auto work = [&](size_t t) {
+		std::string &o = part[t];
+		const size_t i0 = N * t / nt, i1 = N * (t + 1) / nt;
+		o.reserve((i1 - i0) * (N * 12 + 32));
+		char buf[64];
+		for (size_t i = i0; i < i1; i++) {
+			o += q[i].name;
+			for (size_t j = 0; j < N; j++) o.append(buf, (size_t)snprintf(buf, sizeof buf, fmt, i == j ? 0.0 : d[i * N + j]));
+			o += '\n';
+		}
+	};
+	std::vector<std::thread> pool;
+	for (size_t t = 1; t < nt; t++) pool.emplace_back(work, t);
+	work(0);
+	for (auto &t : pool) t.join();
 	std::cout << N << std::endl;
-	std::cout.precision(4);
-	std::cout << ((flags & F_ANI) ? std::dec : std::scientific);
-	for (size_t i = 0; i < N; i++) {
-		std::cout << q[i].name;
-		for (size_t j = 0; j < N; j++) std::cout << "  " << (i == j ? 0.0 : d[i * N + j]);
-		std::cout << std::endl;
-	}
+	for (auto &o : part) std::cout.write(o.data(), (std::streamsize)o.size());
+	std::cout.flush();
 }
 
 // print_matrix, io.cxx:165-233
@@ -101,8 +121,8 @@ void print_matrix(const std::vector<Genome> &q, const Matrix &m, int flags, unsi
 						 q[i].name.c_str(), q[j].name.c_str());
 				soft_err(buf);
 			} else {
-				double c1 = (double)m[i * N + j].homologs / q[i].nucl.size();
-				double c2 = (double)m[i * N + j].homologs / q[j].nucl.size();
+				double c1 = (double)m[i * N + j].homologs / GLEN[i];
+				double c2 = (double)m[i * N + j].homologs / GLEN[j];
 				if (c1 < 0.2 || c2 < 0.2) {
 					snprintf(buf, sizeof buf,
 							 "For the two sequences '%s' and '%s' less than 20%% homology were found (%f and %f, "
@@ -130,14 +150,14 @@ void print_matrix(const std::vector<Genome> &q, const Matrix &m, int flags, unsi
 		for (size_t i = 0; i < N; i++)
 			for (size_t j = 0; j < i; j++) {
 				if (std::isnan(d[i * N + j])) continue;
-				sum += (double)m[i * N + j].homologs / q[i].nucl.size() + (double)m[i * N + j].homologs / q[j].nucl.size();
+				sum += (double)m[i * N + j].homologs / GLEN[i] + (double)m[i * N + j].homologs / GLEN[j];
 				counter += 2;
 			}
 		size_t aligned = 0, total = 0;
 		for (size_t i = 0; i < N; i++) {
 			if (i == ref_idx) continue;
 			aligned += m[ref_idx * N + i].homologs;
-			total += q[i].nucl.size();
+			total += GLEN[i];
 		}
 		std::cerr << "avg coverage:\t" << sum / counter << std::endl;
 		std::cerr << "alignment:\t" << aligned << "\t" << total << "\t" << aligned / (double)total << std::endl;
@@ -146,16 +166,20 @@ void print_matrix(const std::vector<Genome> &q, const Matrix &m, int flags, unsi
 
 // pick_first_pass, phylonium.cxx:360-382 — median length by nth_element, then
 // the first genome equal to it
-size_t pick_first_pass(const std::vector<Genome> &q, int flags)
+size_t pick_first_pass(const std::vector<Genome> &q, const std::vector<PackedGenome> &pk, int flags)
 {
 	std::vector<size_t> idx(q.size());
 	std::iota(idx.begin(), idx.end(), 0);
-	std::nth_element(idx.begin(), idx.begin() + idx.size() / 2, idx.end(),
-					 [&](size_t a, size_t b) { return q[a].nucl.size() < q[b].nucl.size(); });
+	std::nth_element(idx.begin(), idx.begin() + idx.size() / 2, idx.end(), [&](size_t a, size_t b) { return GLEN[a] < GLEN[b]; });
 	size_t chosen = idx[idx.size() / 2];
 	size_t ref = chosen;
+	auto same = [&](size_t a, size_t b) {
+		if (q[a].name != q[b].name || GLEN[a] != GLEN[b]) return false;
+		if (pk.empty()) return q[a].nucl == q[b].nucl;
+		return pk[a].bad == pk[b].bad && memcmp(pk[a].q2, pk[b].q2, (GLEN[a] + 15) / 16 * sizeof(uint32_t)) == 0;
+	};
 	for (size_t i = 0; i < q.size(); i++)
-		if (q[i].name == q[chosen].name && q[i].nucl == q[chosen].nucl) {
+		if (same(i, chosen)) {
 			ref = i;
 			break;
 		}
@@ -200,6 +224,11 @@ void write_positions(Run &r, size_t ref_idx)
 	std::vector<const phylo_homology *> H(N);
 	std::vector<size_t> n(N);
 	for (size_t g = 0; g < N; g++) ok(r, phylo_get_homologies(r.ctx, g, &H[g], &n[g]));
+	for (size_t g = 0; g < N; g++) // packed ingest: the bytes come back from the device
+		if (q[g].nucl.size() != GLEN[g]) {
+			q[g].nucl.resize(GLEN[g]);
+			ok(r, phylo_get_genome(r.ctx, g, q[g].nucl.data()));
+		}
 	std::ofstream out(r.refpos_file);
 	size_t counter = 1;
 	const std::string &subject = q[ref_idx].nucl;
@@ -266,6 +295,8 @@ Matrix process(Run &r, size_t ref_idx, const int64_t *sa = nullptr)
 		"    --progress=WHEN    Accepted for compatibility; no progress bar is drawn\n"
 		"  -r FILE              Set the reference genome\n"
 		"  -t, --threads=N      Host threads (FASTA reading, per-genome sort/filter step)\n"
+		"      --ingest=HOW     packed (default: 2-bit codes made while reading, a quarter of the\n"
+		"                       bytes uploaded) or bytes\n"
 		"      --timing         Print where the wall-clock went to stderr\n"
 		"  -d, --device=N       GPU ordinal (default 0)\n"
 		"  -v, --verbose        Print additional information\n"
@@ -286,6 +317,7 @@ int main(int argc, char *argv[])
 	const char *seed_env = getenv("PHYLONIUM_AMD_SEED");
 	std::mt19937 prng(seed_env ? (std::mt19937::result_type)strtoul(seed_env, nullptr, 10) : rd());
 	int version_flag = 0, timing = 0, flags = 0, device = 0;
+	bool packed_ingest = true;
 	long threads = 0;
 	bool two_pass = false;
 	unsigned long bootstrap = 0;
@@ -302,6 +334,7 @@ int main(int argc, char *argv[])
 										   {"verbose", no_argument, NULL, 'v'},
 										   {"version", no_argument, &version_flag, 1},
 										   {"timing", no_argument, &timing, 1},
+										   {"ingest", required_argument, NULL, 0},
 										   {0, 0, 0, 0}};
 	for (;;) {
 		int option_index = 0;
@@ -311,6 +344,10 @@ int main(int argc, char *argv[])
 			case 0: {
 				std::string name = long_options[option_index].name;
 				if (name == "complete-deletion") flags |= F_COMPLETE_DELETION;
+				if (name == "ingest") {
+					if (strcasecmp(optarg, "bytes") == 0) packed_ingest = false;
+					else if (strcasecmp(optarg, "packed") != 0) usage(EXIT_FAILURE);
+				}
 				if (name == "distance") {
 					if (strcasecmp(optarg, "raw") == 0) flags |= F_RAW;
 					else if (strcasecmp(optarg, "jc") == 0) {
@@ -371,19 +408,32 @@ int main(int argc, char *argv[])
 		if (phylo_ctx_create(&r.ctx, device)) ctx_error = phylo_last_error(nullptr);
 	});
 	size_t read_threads = threads > 0 ? (size_t)threads : std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
+	PRINT_THREADS = read_threads;
 	std::string read_error;
-	std::vector<Genome> q = read_genomes(files, read_threads, &read_error);
+	std::vector<Genome> q;
+	std::vector<PackedGenome> pk;
+	uint32_t *pk_arena = nullptr;
+	if (packed_ingest) {
+		pk = phyfasta::read_genomes_packed(files, read_threads, &read_error, &pk_arena);
+		q.resize(pk.size());
+		for (size_t i = 0; i < pk.size(); i++) q[i].name = pk[i].name;
+	} else {
+		q = read_genomes(files, read_threads, &read_error);
+	}
 	t_read = now_s();
 	ctx_thread.join();
 	if (!read_error.empty()) die(read_error);
 	if (!ctx_error.empty()) die(ctx_error);
 	t_ctx = now_s();
+	GLEN.resize(q.size());
+	for (size_t i = 0; i < q.size(); i++) GLEN[i] = packed_ingest ? (size_t)pk[i].len : q[i].nucl.size();
 
 	size_t ref_idx;
-	if (reference_name.empty()) ref_idx = pick_first_pass(q, flags);
+	if (reference_name.empty()) ref_idx = pick_first_pass(q, pk, flags);
 	else ref_idx = std::find(files.begin(), files.end(), reference_name) - files.begin();
 	// The reference's suffix array (the longest host step, one thread) is built while the device
 	// context finishes starting and the genomes are uploaded.
+	if (packed_ingest) q[ref_idx].nucl = phyfasta::unpack_genome(pk[ref_idx]);
 	std::vector<int64_t> sa(2 * q[ref_idx].nucl.size() + 1);
 	int sa_rc = 0;
 	std::thread sa_thread([&] { sa_rc = phylo_host_reference_suffix_array(q[ref_idx].nucl.data(), q[ref_idx].nucl.size(), sa.data()); });
@@ -392,13 +442,25 @@ int main(int argc, char *argv[])
 	r.flags = flags;
 	r.refpos_file = refpos_file;
 	if (threads > 0) ok(r, phylo_set_option(r.ctx, "host_threads", threads));
-	std::vector<const char *> seq(q.size());
-	std::vector<size_t> len(q.size());
-	for (size_t i = 0; i < q.size(); i++) {
-		seq[i] = q[i].nucl.data();
-		len[i] = q[i].nucl.size();
+	if (packed_ingest) {
+		std::vector<const uint32_t *> q2(q.size()), bad(q.size());
+		std::vector<size_t> nbad(q.size());
+		for (size_t i = 0; i < q.size(); i++) {
+			q2[i] = pk[i].q2;
+			bad[i] = pk[i].bad.data();
+			nbad[i] = pk[i].bad.size();
+		}
+		ok(r, phylo_set_genomes_packed(r.ctx, q.size(), q2.data(), GLEN.data(), bad.data(), nbad.data()));
+		// pk_arena stays mapped until the process ends: unmapping 1.3 GB that has just been the source of
+		// device copies costs 0.3 s here (measured at 1024 genomes; the GPU driver's MMU notifier walks the
+		// range), the process's exit does not
+		for (auto &g : pk)
+			if (!g.own) g.q2 = nullptr;
+	} else {
+		std::vector<const char *> seq(q.size());
+		for (size_t i = 0; i < q.size(); i++) seq[i] = q[i].nucl.data();
+		ok(r, phylo_set_genomes(r.ctx, q.size(), seq.data(), GLEN.data()));
 	}
-	ok(r, phylo_set_genomes(r.ctx, q.size(), seq.data(), len.data()));
 	t_upload = now_s();
 	sa_thread.join();
 	double t_sa = now_s();
@@ -418,12 +480,14 @@ int main(int argc, char *argv[])
 			return v / 1e3;
 		};
 		double bases = 0;
-		for (auto &g : q) bases += (double)g.nucl.size();
+		for (size_t l : GLEN) bases += (double)l;
 		fprintf(stderr,
-				"timing: genomes %zu  bases %.0f  total %.3f s | read %.3f (%zu threads)  wait-for-device %.3f  upload %.3f  "
+				"timing: genomes %zu  bases %.0f  total %.3f s | read %.3f (%zu threads, %s)  wait-for-device %.3f  upload %.3f (device memory %.3f  copies %.3f  "
+				"install %.3f)  "
 				"wait-for-suffix-array %.3f (built on a thread since the files were read)  process+print %.3f  "
 				"[suffix array hand-over %.3f  index on device %.3f  anchor %.3f  compare %.3f]\n",
-				q.size(), bases, t_done - t_start, t_read - t_start, read_threads, t_ctx - t_read, t_upload - t_ctx,
+				q.size(), bases, t_done - t_start, t_read - t_start, read_threads, packed_ingest ? "packed" : "bytes", t_ctx - t_read, t_upload - t_ctx, stat("ms:genomes_alloc"), stat("ms:genomes_copy"),
+				stat("ms:genomes_install"),
 				t_sa - t_upload, t_done - t_sa, stat("ms:ref_suffix_array"), stat("ms:ref_total") - stat("ms:ref_suffix_array"),
 				stat("ms:anchor_total"), stat("ms:compare_total"));
 	}

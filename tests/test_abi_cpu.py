@@ -3,6 +3,7 @@ header declares, refuses to run without a GPU (no fallback), and its host-side
 helpers agree with the oracle."""
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -181,3 +182,73 @@ def test_mgpu_warnings_follow_print_matrix(lib):
         assert len(got) == len(want) and st == (1 if want else 0)
         for g, w in zip(got, want):
             assert w in g
+
+
+def _fasta_zoo(tmp_path, rng):
+    """FASTA files that exercise the reader: line widths around the 32-byte pieces, lower case, IUPAC codes and
+    gaps, CRLF, blank lines, many records, an empty record, no newline at the end."""
+    def rnd(n, alphabet):
+        return bytes(np.frombuffer(alphabet, np.uint8)[rng.integers(0, len(alphabet), n)])
+    paths = []
+    for k, (width, alpha, nrec, crlf) in enumerate([(70, b"ACGT", 1, False), (60, b"ACGTacgt", 3, False), (80, b"ACGTNRYacgtn-", 5, True),
+                                                    (1, b"ACGT", 2, False), (31, b"ACGT", 2, False), (32, b"ACGT", 1, False),
+                                                    (33, b"ACGTn", 4, False), (100000, b"ACGT", 2, False), (17, b"ACGT", 40, True)]):
+        p = tmp_path / f"g{k}.fa"
+        with open(p, "wb") as f:
+            for r in range(nrec):
+                f.write((b">rec%d some text ACGT" % r) + (b"\r\n" if crlf else b"\n"))
+                n = int(rng.integers(0, 5000)) if r != 2 else 0
+                s = rnd(n, alpha)
+                for i in range(0, n, width):
+                    f.write(s[i:i + width] + (b"\r\n" if crlf else b"\n"))
+                if r == 1:
+                    f.write(b"\n\n")
+            if k == 5:
+                f.seek(-1, 2)
+                f.truncate()
+        paths.append(str(p))
+    return paths
+
+
+def test_packed_fasta_reader_equals_the_byte_reader(lib, tmp_path):
+    """phylo_host_read_fasta_packed (mapped files, 32 bytes at a time, 2-bit codes + separator positions) holds the
+    same genomes as phylo_host_read_fasta (sequence.cxx:109-199), with the SIMD path and without it."""
+    from phylonium_amd import api
+    paths = _fasta_zoo(tmp_path, np.random.default_rng(5))
+    ref = api.read_fasta(paths, threads=3)
+    pk = api.read_fasta_packed(paths, threads=3)
+    for k, (g, (q2, ln, bad)) in enumerate(zip(ref, pk)):
+        assert ln == g.size and q2.size == (ln + 15) // 16, k
+        assert np.array_equal(np.flatnonzero(g == ord("!")), bad), k
+        shifts = np.arange(30, -2, -2, dtype=np.uint32)
+        codes = ((q2[:, None] >> shifts[None, :]) & 3).reshape(-1)
+        assert not codes[ln:].any() and not codes[bad].any(), k  # codes behind the end and under a separator are 0
+        assert np.array_equal(api.unpack_genome(q2, ln, bad), g), k
+    # the same through the byte-wise loop only (the switch is read once per process)
+    code = ("import sys, pickle; sys.path.insert(0, %r); from phylonium_amd import api; "
+            "pickle.dump(api.read_fasta_packed(%r, threads=2), sys.stdout.buffer)" % (ROOT, paths))
+    import pickle
+    import subprocess
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, env=dict(os.environ, PHYLONIUM_AMD_NO_SIMD="1"), check=True)
+    for a, b in zip(pk, pickle.loads(out.stdout)):
+        assert a[1] == b[1] and np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])
+    # something that cannot be mapped and has no size (a FIFO) still reads: it gets a place of its own in the arena
+    import threading
+    fifo = str(tmp_path / "pipe.fa")
+    os.mkfifo(fifo)
+    text = open(paths[2], "rb").read()
+    w = threading.Thread(target=lambda: open(fifo, "wb").write(text))
+    w.start()
+    got = api.read_fasta_packed([paths[0], fifo, paths[1]], threads=1)
+    w.join()
+    for a, b in zip(got, (pk[0], pk[2], pk[1])):
+        assert a[1] == b[1] and np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])
+    # errors as the byte reader's
+    (tmp_path / "bad.fa").write_bytes(b"hello\n>x\nACGT\n")
+    (tmp_path / "none.fa").write_bytes(b"")
+    with pytest.raises(api.PhyloniumError, match="bad.fa: File is not in FASTA format."):
+        api.read_fasta_packed([paths[0], str(tmp_path / "bad.fa"), str(tmp_path / "nope.fa")])
+    with pytest.raises(api.PhyloniumError, match="none.fa: Empty file."):
+        api.read_fasta_packed([str(tmp_path / "none.fa")])
+    with pytest.raises(api.PhyloniumError, match="nope.fa"):
+        api.read_fasta_packed([str(tmp_path / "nope.fa")])

@@ -74,6 +74,43 @@ def test_multi_contig_against_oracle(tmp_path):
     assert (tmp_path / "pos.txt").read_text() == want
 
 
+def test_packed_and_byte_ingest_print_the_same(tmp_path):
+    """The driver's default ingest (2-bit codes made while the mapped files are read, unpacked on the device) and
+    --ingest=bytes agree on stdout, stderr and the -p file — lower case, IUPAC codes, CRLF and ragged lines included —
+    and the first-pass reference (median length, first genome equal to it) is chosen from the packed form."""
+    rng = np.random.default_rng(17)
+    gs = synth.make_genomes(5, 30000, seed=9, d_range=(0.01, 0.15), indel_per_mbp=300, inv_frac=0.05, contigs=3, inv_len=(200, 900))
+    names = [f"g{i}" for i in range(5)]
+    for k, (n, g) in enumerate(zip(names, gs)):
+        contigs = bytes(g).split(b"!")
+        with open(tmp_path / f"{n}.fa", "wb") as f:
+            for r, c in enumerate(contigs):
+                f.write(b">c%d\r\n" % r if k == 1 else b">c%d\n" % r)
+                if k == 2:
+                    c = c.lower()
+                width, i = (61, 0)
+                while i < len(c):
+                    w = int(rng.integers(1, 90)) if k == 3 else width
+                    line = c[i:i + w]
+                    if k == 4 and i % 7 == 0:
+                        line = line[:w // 2] + b"NNRY-" + line[w // 2:]  # dropped by the filter (sequence.cxx:109-146)
+                    f.write(line + (b"\r\n" if k == 1 else b"\n"))
+                    i += w
+    files = [f"{n}.fa" for n in names]
+    for extra in ([], ["-v"], ["-r", files[3]], ["--complete-deletion"]):
+        a = run([*extra, *files], tmp_path)
+        b = run(["--ingest=bytes", *extra, *files], tmp_path)
+        assert a == b and a[1].startswith("5\n")
+    a = run(["-p", "pa.txt", *files], tmp_path)
+    b = run(["--ingest=bytes", "-p", "pb.txt", *files], tmp_path)
+    assert a == b and (tmp_path / "pa.txt").read_bytes() == (tmp_path / "pb.txt").read_bytes()
+    assert (tmp_path / "pa.txt").read_text().count(">part") > 3
+    # against the oracle on the same genomes (the filter must have removed exactly the inserted codes)
+    for ref in range(5):
+        sm, hm = O.Run(gs, ref).process().matrix()
+        assert run(["-r", files[ref], *files], tmp_path)[1] == O.phylip(names, sm, hm)
+
+
 def test_bootstrap_matrices_with_a_fixed_seed(tmp_path):
     """-b N: N-1 more matrices whose substitutions are redrawn from Binomial(homologs, s/h) per cell
     (evo_model.cxx:136-147, io.cxx:192-203).  The reference seeds its mt19937 from random_device; with

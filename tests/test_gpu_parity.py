@@ -43,7 +43,12 @@ def check_process(ctx, gs, ref, chunk=0, kmer=0, backend=0, complete_deletion=Fa
     ctx.set_option("chunk_tail", tail)
     ctx.set_option("kmer", kmer)
     ctx.set_option("compare_backend", backend)
-    ctx.set_genomes(gs)
+    # genomes arrive as bytes or as 2-bit codes + separator positions (phylo_set_genomes_packed), alternating
+    check_process.pk = 1 - getattr(check_process, "pk", 0)
+    if check_process.pk:
+        ctx.set_genomes_packed([api.pack_genome(g) for g in gs])
+    else:
+        ctx.set_genomes(gs)
     ctx.set_reference(ref, threshold=threshold)
     r = O.Run(gs, ref, threshold=threshold).process(complete_deletion=complete_deletion)
     assert ctx.threshold == r.threshold
@@ -430,6 +435,42 @@ def test_export_import_roundtrip(ctx):
     ctx.import_homologies(2, 7, counts, flat)
     s2, h2 = ctx.compare()
     assert (s == s2).all() and (h == h2).all()
+
+
+def test_packed_genomes_are_the_same_genomes(ctx):
+    """phylo_set_genomes_packed: Q2 copied into place, the byte arena written by the device.  The genomes read back
+    byte for byte and both phases give what they give after phylo_set_genomes — for lengths around the 16-base
+    words, separators at either end and next to each other, and an empty genome."""
+    rng = np.random.default_rng(3)
+    gs = [synth.random_base(n, rng) for n in (1, 15, 16, 17, 63, 64, 65, 1000, 4097, 70001)]
+    gs += [np.frombuffer(b"!ACGT!!TTGA!", np.uint8), np.zeros(0, np.uint8), np.frombuffer(b"!", np.uint8)]
+    big = synth.make_genomes(4, 50000, seed=12, d_range=(0.02, 0.1), inv_frac=0.05, contigs=5)
+    gs += big
+    ctx.set_genomes_packed([api.pack_genome(g) for g in gs])
+    for j, g in enumerate(gs):
+        assert np.array_equal(ctx.get_genome(j), np.asarray(g, np.uint8)), j
+    ref = len(gs) - 3
+    ctx.set_reference(ref)
+    ctx.anchor()
+    lists = [hom_tuples_gpu(ctx.homologies(j)) for j in range(len(gs))]
+    s1, h1 = ctx.compare()
+    ctx.set_genomes(gs)
+    for j, g in enumerate(gs):
+        assert np.array_equal(ctx.get_genome(j), np.asarray(g, np.uint8)), j
+    ctx.set_reference(ref)
+    ctx.anchor()
+    assert lists == [hom_tuples_gpu(ctx.homologies(j)) for j in range(len(gs))]
+    s2, h2 = ctx.compare()
+    assert (s1 == s2).all() and (h1 == h2).all() and h1[ref, -1] > 30000
+    r = O.Run(big, 1).process()  # the four related genomes alone, against the oracle
+    ctx.set_genomes_packed([api.pack_genome(g) for g in big])
+    ctx.set_reference(1)
+    ctx.anchor()
+    s3, h3 = ctx.compare()
+    so, ho = r.matrix()
+    assert (s3 == so).all() and (h3 == ho).all()
+    with pytest.raises(api.PhyloniumError, match="separator positions"):
+        ctx.set_genomes_packed([(np.zeros(1, np.uint32), 4, np.array([4], np.uint32))])
 
 
 def test_packed_export_import_is_lossless(ctx):

@@ -57,9 +57,10 @@ def main():
     want = api.format_phylip(names, s, h)
     exe = os.path.join(ROOT, "phylonium_amd", "phylonium-amd")
     runs = []
-    for label in ("first run", "files in page cache"):
+    for label, extra in (("first run", []), ("files in page cache", []), ("files in page cache, --ingest=bytes", ["--ingest=bytes"]),
+                         ("files in page cache, again", [])):
         t0 = time.time()
-        p = subprocess.run([exe, "--timing", "-r", files[0]] + files, capture_output=True)
+        p = subprocess.run([exe, "--timing", "-r", files[0]] + extra + files, capture_output=True)
         wall = time.time() - t0
         err = p.stderr.decode()
         m = re.search(r"timing: (.*)", err)
