@@ -47,6 +47,54 @@ inline std::string genome_name(const std::string &path)
 	return path.substr(left, right - left);
 }
 
+// A file's bytes: mapped when it can be (no copy through a read buffer), read otherwise (pipes)
+struct FileBytes {
+	const char *data = nullptr;
+	size_t size = 0;
+	std::string error; // strerror text when the file could not be opened
+	FileBytes(const std::string &path)
+	{
+		const int fd = open(path.c_str(), O_RDONLY);
+		if (fd < 0) {
+			error = strerror(errno);
+			return;
+		}
+		struct stat st;
+		if (fstat(fd, &st) != 0 || S_ISDIR(st.st_mode)) {
+			error = strerror(S_ISDIR(st.st_mode) ? EISDIR : errno);
+			close(fd);
+			return;
+		}
+		if (st.st_size > 0) {
+			map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+			if (map != MAP_FAILED) {
+				madvise(map, (size_t)st.st_size, MADV_SEQUENTIAL);
+				data = (const char *)map;
+				size = map_size = (size_t)st.st_size;
+			}
+		}
+		if (!data) {
+			char chunk[1 << 16];
+			ssize_t got;
+			while ((got = read(fd, chunk, sizeof chunk)) > 0) slurp.append(chunk, (size_t)got);
+			data = slurp.data();
+			size = slurp.size();
+		}
+		close(fd);
+	}
+	~FileBytes()
+	{
+		if (map != MAP_FAILED) munmap(map, map_size);
+	}
+	FileBytes(const FileBytes &) = delete;
+	FileBytes &operator=(const FileBytes &) = delete;
+
+  private:
+	void *map = MAP_FAILED;
+	size_t map_size = 0;
+	std::string slurp;
+};
+
 // FASTA records of one file → nucleotides filtered to ACGT (upper-cased,
 // sequence.cxx:109-146), contigs joined by '!'.  The file is read in one piece
 // and filtered through a 256-entry table; errors are returned, not raised, so
@@ -61,18 +109,11 @@ inline ReadResult read_genome(const std::string &path)
 {
 	ReadResult R;
 	R.g.name = genome_name(path);
-	FILE *f = fopen(path.c_str(), "rb");
-	if (!f) {
-		R.error = path + ": " + strerror(errno);
+	FileBytes buf(path);
+	if (!buf.error.empty()) {
+		R.error = path + ": " + buf.error;
 		return R;
 	}
-	std::string buf;
-	struct stat st;
-	if (fstat(fileno(f), &st) == 0 && st.st_size > 0) buf.reserve((size_t)st.st_size);
-	char chunk[1 << 16];
-	size_t got;
-	while ((got = fread(chunk, 1, sizeof chunk, f)) > 0) buf.append(chunk, got);
-	fclose(f);
 
 	static const auto lut = [] {
 		std::array<char, 256> t{};
@@ -83,11 +124,11 @@ inline ReadResult read_genome(const std::string &path)
 		return t;
 	}();
 	std::string &out = R.g.nucl;
-	out.resize(buf.size() + 1);
+	out.resize(buf.size + 1);
 	size_t w = 0;
 	bool in_record = false;
 	size_t records = 0;
-	const char *p = buf.data(), *end = p + buf.size();
+	const char *p = buf.data, *end = p + buf.size;
 	while (p < end) {
 		const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
 		const char *le = nl ? nl : end;
@@ -258,49 +299,19 @@ inline PackedResult read_genome_packed(const std::string &path, int simd = -1, u
 {
 	PackedResult R;
 	R.g.name = genome_name(path);
-	const int fd = open(path.c_str(), O_RDONLY);
-	if (fd < 0) {
-		R.error = path + ": " + strerror(errno);
+	FileBytes file(path);
+	if (!file.error.empty()) {
+		R.error = path + ": " + file.error;
 		return R;
 	}
-	struct stat st;
-	if (fstat(fd, &st) != 0) {
-		R.error = path + ": " + strerror(errno);
-		close(fd);
-		return R;
-	}
-	if (S_ISDIR(st.st_mode)) {
-		R.error = path + ": " + strerror(EISDIR);
-		close(fd);
-		return R;
-	}
-	const size_t size = (size_t)st.st_size;
-	const char *base = nullptr;
-	std::string slurp; // pipes and other things that cannot be mapped
-	void *map = MAP_FAILED;
-	if (size) {
-		map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
-		if (map != MAP_FAILED) {
-			madvise(map, size, MADV_SEQUENTIAL);
-			base = (const char *)map;
-		}
-	}
-	size_t n = size;
-	if (!base) {
-		char chunk[1 << 16];
-		ssize_t got;
-		while ((got = read(fd, chunk, sizeof chunk)) > 0) slurp.append(chunk, (size_t)got);
-		base = slurp.data();
-		n = slurp.size();
-	}
-	close(fd);
+	const char *base = file.data;
+	const size_t n = file.size;
 
 	uint32_t *out = dst;
 	const bool own = !dst || packed_words_bound(n) > dst_words;
 	if (own) out = (uint32_t *)malloc(packed_words_bound(n) * sizeof(uint32_t));
 	if (!out) {
 		R.error = path + ": out of memory";
-		if (map != MAP_FAILED) munmap(map, size);
 		return R;
 	}
 	Packer P{out};
@@ -323,7 +334,6 @@ inline PackedResult read_genome_packed(const std::string &path, int simd = -1, u
 				if (!isspace((unsigned char)*c)) {
 					R.error = path + ": File is not in FASTA format.";
 					if (own) free(out);
-					if (map != MAP_FAILED) munmap(map, size);
 					return R;
 				}
 		} else {
@@ -338,7 +348,6 @@ inline PackedResult read_genome_packed(const std::string &path, int simd = -1, u
 	(void)vec;
 	R.g.len = P.bases();
 	P.finish();
-	if (map != MAP_FAILED) munmap(map, size);
 	if (!records) {
 		R.error = path + ": Empty file.";
 		if (own) free(out);
