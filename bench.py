@@ -228,6 +228,7 @@ def main():
     ap.add_argument("--kmer", type=int, default=0, help="dev: force the bucket k of the reference index")
     ap.add_argument("--anchor-kernel", type=int, default=-1, help="dev: 1 lean 2-bit chains, 0 general byte-wise chains (library default when < 0)")
     ap.add_argument("--tail-groups", type=int, default=0, help="dev: phase A's tail on this many streams (library default when 0)")
+    ap.add_argument("--pairs-wchunk", type=int, default=0, help="dev: windows per chunk of the pair kernel (library's choice when 0)")
     ap.add_argument("--d-range", default="", help="dev: lo,hi — override the workload's divergence range")
     ap.add_argument("--emulate-rank", default="", help="dev: R/N — time rank R of N's share of the work on this one GPU "
                     "(no collectives; the printed value is NOT a bench result)")
@@ -296,6 +297,8 @@ def main():
         ctx.set_option("anchor_kernel", args.anchor_kernel)
     if args.tail_groups > 0:
         ctx.set_option("tail_groups", args.tail_groups)
+    if args.pairs_wchunk > 0:
+        ctx.set_option("pairs_wchunk", args.pairs_wchunk)
     if args.host_threads:
         ctx.set_option("host_threads", args.host_threads)
     if args.filter:

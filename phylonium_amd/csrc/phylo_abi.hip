@@ -181,6 +181,7 @@ struct phylo_ctx {
 	hipStream_t tail_stream[TAIL_GROUPS - 1] = {nullptr, nullptr};
 	hipEvent_t tail_event[TAIL_GROUPS] = {nullptr, nullptr, nullptr};
 	int opt_filter_kernel = 0; // option "filter_kernel": 0 stretch-wise chain filter (then the general kernel for what it hands over), 1 general only
+	uint32_t opt_pairs_wchunk = 0; // option "pairs_wchunk": windows per chunk of the pair kernel (0: chosen from the L2 size)
 	int opt_tail_groups = 1; // option "tail_groups": streams the tail is spread over (default 1: measured, the groups run in lockstep and nothing is hidden — DESIGN.md)
 	std::string err;
 	int n_cu = 256;
@@ -500,6 +501,9 @@ int phylo_set_option(phylo_ctx *c, const char *key, long value)
 	} else if (k == "tail_groups") {
 		if (value < 1 || value > phylo_ctx::TAIL_GROUPS) return c->fail("tail_groups must be in 1..%d", phylo_ctx::TAIL_GROUPS);
 		c->opt_tail_groups = (int)value;
+	} else if (k == "pairs_wchunk") {
+		if (value < 0 || value > (1 << 20)) return c->fail("pairs_wchunk must be in 0..2^20");
+		c->opt_pairs_wchunk = (uint32_t)value;
 	} else if (k == "lean_force_slow") {
 		c->lean_force_slow = value != 0;
 	} else if (k == "profile") {
@@ -1914,9 +1918,16 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		// tiles x chunks fills the chip several times over; at least 64 windows
 		uint32_t row_bytes = (flag ? 5u : 3u) * P.Npad * 4u;
 		uint32_t l2_fit = std::max<uint32_t>(64, (3u << 20) / row_bytes);
-		uint32_t want_chunks = std::max<uint32_t>(1, ((uint32_t)c->n_cu * 32u) / (uint32_t)tiles.size());
+		// (four rounds of the chip's n_cu x 32 wavefront slots: with one round — what n_cu x 32 gave at N = 256 — the
+		// wavefronts all end together and the tail is a whole wavefront long; measured 1.30 -> 1.13 ms on C3)
+		uint32_t want_chunks = std::max<uint32_t>(1, ((uint32_t)c->n_cu * 128u) / (uint32_t)tiles.size());
 		uint32_t wchunk = std::max<uint32_t>(64, (P.W + want_chunks - 1) / want_chunks);
 		wchunk = std::min(wchunk, l2_fit);
+		{ // chunks are dealt round-robin over the 8 XCDs: a multiple of 8 of them keeps the XCDs level
+			const uint32_t groups = (P.W + 8u * wchunk - 1) / (8u * wchunk);
+			wchunk = std::max<uint32_t>(1, (P.W + 8u * groups - 1) / (8u * groups));
+		}
+		if (c->opt_pairs_wchunk) wchunk = c->opt_pairs_wchunk;
 		{
 			KernelSpan s(c, flag ? "pileup_pairs_bang" : "pileup_pairs");
 			launch_pairs(P, flag != 0, c->b_tiles.p, (uint32_t)tiles.size(), wchunk, acc_s, acc_h, st);
