@@ -78,13 +78,21 @@ struct Pileup {
 	uint32_t N, Npad;
 	uint32_t L;
 };
+// where the projection reads the query side: the genomes as 2-bit codes (lean_core.h: Q2; word offset of genome g =
+// goff[g] / 16) and their non-ACGT positions (QBAD, list g at [qbad_off[g], qbad_off[g+1]))
+struct QuerySrc {
+	const uint32_t *q2;
+	const uint64_t *goff;
+	const uint32_t *qbad;
+	const uint32_t *qbad_off;
+};
 // hom_rng[2g], hom_rng[2g+1]: genome g's sorted, disjoint list is homs[begin, end).
 // Both take a range — genomes [g0, g1), genome tiles [tg0, tg1) of project_genomes_per_tile()
 // genomes — so that the projection can run for the genomes whose lists are ready.
-void launch_tile_index(const Pileup &P, const DevHom *homs, const uint32_t *hom_rng, uint32_t *first, uint32_t g0,
+void launch_tile_index(const Pileup &P, const QuerySrc &Q, const DevHom *homs, const uint32_t *hom_rng, uint32_t *first, uint32_t g0,
 					   uint32_t g1, hipStream_t st);
 // five_planes = false: V, N0, N1 only; *bang_flag is raised when '!' was projected and D, B are needed after all
-void launch_project(const Pileup &P, bool five_planes, const uint8_t *gbase, const uint64_t *goff, const DevHom *homs,
+void launch_project(const Pileup &P, bool five_planes, const QuerySrc &Q, const DevHom *homs,
 					const uint32_t *hom_rng, const uint32_t *first, uint32_t *bang_flag, uint32_t tg0, uint32_t tg1,
 					hipStream_t st);
 uint32_t project_genomes_per_tile();

@@ -348,6 +348,8 @@ int sync_stream(phylo_ctx *c)
 	return 0;
 }
 
+static QuerySrc query_src(const phylo_ctx *c) { return QuerySrc{c->d_Q2.p, c->d_goff.p, c->d_QBAD.p, c->d_qbad_off.p}; }
+
 WorkerPool &workers(phylo_ctx *c)
 {
 	if (!c->pool) {
@@ -1210,9 +1212,9 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 											c->a_flt.p, c->a_flt.p + 1, c->a_long.p, c->a_misc.p + 7, sg);
 			}
 			if (tail_eager && j1 > j0) {
-				launch_tile_index(TP, c->b_homs.p, c->b_hom_rng.p, c->b_first.p, j0, j1, sg);
+				launch_tile_index(TP, query_src(c), c->b_homs.p, c->b_hom_rng.p, c->b_first.p, j0, j1, sg);
 				KernelSpan s(c, c->eager_five ? "pileup_project5" : "pileup_project", sg);
-				launch_project(TP, c->eager_five, c->d_genomes, c->d_goff.p, c->b_homs.p, c->b_hom_rng.p, c->b_first.p, c->b_flag.p,
+				launch_project(TP, c->eager_five, query_src(c), c->b_homs.p, c->b_hom_rng.p, c->b_first.p, c->b_flag.p,
 							   j0 / tsz_q, g + 1 == tgroups ? TP.Npad / tsz_q : j1 / tsz_q, sg);
 			}
 		}
@@ -1382,9 +1384,9 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 				hipStreamWaitEvent(st, c->copy_events[g], 0) != hipSuccess) {
 				stage_err = 1;
 			} else if (eager) {
-				launch_tile_index(EP, c->b_homs.p, c->b_hom_rng.p, c->b_first.p, (uint32_t)j0, (uint32_t)j1, st);
+				launch_tile_index(EP, query_src(c), c->b_homs.p, c->b_hom_rng.p, c->b_first.p, (uint32_t)j0, (uint32_t)j1, st);
 				KernelSpan s(c, c->eager_five ? "pileup_project5" : "pileup_project");
-				launch_project(EP, c->eager_five, c->d_genomes, c->d_goff.p, c->b_homs.p, c->b_hom_rng.p, c->b_first.p,
+				launch_project(EP, c->eager_five, query_src(c), c->b_homs.p, c->b_hom_rng.p, c->b_first.p,
 							   c->b_flag.p, (uint32_t)(j0 / tsz), g + 1 == ngroups ? EP.Npad / (uint32_t)tsz : (uint32_t)(j1 / tsz), st);
 			}
 		}
@@ -1879,7 +1881,7 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 	const bool projected = c->homs_staged && c->eager_valid && part == 0 && nparts == 1;
 	if (!projected) {
 		HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 16, st));
-		launch_tile_index(P, dev_homs, c->b_hom_rng.p, c->b_first.p, 0, (uint32_t)N, st);
+		launch_tile_index(P, query_src(c), dev_homs, c->b_hom_rng.p, c->b_first.p, 0, (uint32_t)N, st);
 	}
 	// Three planes unless '!' turns up among the projected bytes (the flag says so);
 	// then all five are made.  A context remembers the outcome for its next call.
@@ -1890,7 +1892,7 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		if (pass == 1) HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 16, st));
 		if (pass == 1 || !projected) {
 			KernelSpan s(c, five ? "pileup_project5" : "pileup_project");
-			launch_project(P, five, c->d_genomes, c->d_goff.p, dev_homs, c->b_hom_rng.p, c->b_first.p, c->b_flag.p, 0,
+			launch_project(P, five, query_src(c), dev_homs, c->b_hom_rng.p, c->b_first.p, c->b_flag.p, 0,
 						   P.Npad / project_genomes_per_tile(), st);
 		}
 		HIPOK(c, hipGetLastError());

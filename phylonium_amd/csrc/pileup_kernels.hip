@@ -32,24 +32,19 @@
 
 namespace phy {
 
-// Bit order inside a plane word.  A window is 32 reference positions; position
-// p = 4*i + k (byte k of dword i of the 32 query bytes behind it) is kept at bit
-// 8*k + i.  Every plane of every genome uses the same order and the pair kernel
-// only ANDs, XORs and counts bits, so the order is free to choose — and this one
-// is what eight shift+and_or steps produce straight from the loaded dwords, with no
-// multiplies (v_mul_lo_u32 is quarter rate) and no per-dword movemask.
-static __device__ __forceinline__ uint32_t plane_bit(uint32_t p) { return 8u * (p & 3u) + (p >> 2); }
+// Bit order inside a plane word.  A window is 32 reference positions; the query side arrives as
+// 2-bit codes, 16 bases per dword with the first base in bits 31..30 (lean_core.h: Q2), so the two
+// dwords A (positions 0..15) and B (16..31) of a window interleave into one word with two masks and
+// a shift: position t < 16 sits at bit 31 - 2t, position 16 + t at bit 30 - 2t.  Every plane of every
+// genome uses the same order and the pair kernel only ANDs, XORs and counts bits, so the order is free
+// to choose.  The code's high bit is plane N1, its low bit N0 (A 00, C 01, G 10, T 11: the complement
+// flips both).
+static __device__ __forceinline__ uint32_t plane_bit(uint32_t p) { return p < 16u ? 31u - 2u * p : 30u - 2u * (p - 16u); }
 
-// bit `B` of each of the 32 bytes d[0..7] → one word in plane order
-template <int B> static __device__ __forceinline__ uint32_t gather_plane(const uint32_t (&d)[8])
+// the high (HI) or low bits of the 32 codes in A, B → one word in plane order
+template <bool HI> static __device__ __forceinline__ uint32_t code_plane(uint32_t a, uint32_t b)
 {
-	uint32_t acc = 0;
-#pragma unroll
-	for (int i = 0; i < 8; i++) {
-		const uint32_t t = (B >= i) ? d[i] >> (B - i) : d[i] << (i - B);
-		acc |= t & (0x01010101u << i);
-	}
-	return acc;
+	return HI ? (a & 0xaaaaaaaau) | ((b & 0xaaaaaaaau) >> 1) : ((a & 0x55555555u) << 1) | (b & 0x55555555u);
 }
 
 // an explicitly global load (a pointer selected between LDS and global memory would be FLAT)
@@ -73,8 +68,21 @@ static const uint32_t PROJ_GPW = PROJ_TG / 4; // genomes per wavefront
 // first[g*ntw + tw] = first homology of genome g that ends beyond the first
 // position of window tile tw (lists are sorted and disjoint).  One thread per
 // entry, so the binary searches' latencies overlap instead of serialising inside
-// the projection's wavefronts.
-__global__ __launch_bounds__(256) void tile_index_kernel(Pileup P, const DevHom *__restrict__ homs,
+// the projection's wavefronts.  Bit 31 (TILE_BAD) says that a homology of g carries a
+// non-ACGT query position ('!') into this tile's 2048 reference positions: only there does the
+// projection look positions up in the genome's list (QBAD) to form plane B.
+static const uint32_t TILE_BAD = 0x80000000u;
+static __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *__restrict__ a, uint32_t n, uint32_t key)
+{
+	uint32_t lo = 0, hi = n;
+	while (lo < hi) {
+		const uint32_t mid = lo + ((hi - lo) >> 1);
+		if (a[mid] < key) lo = mid + 1;
+		else hi = mid;
+	}
+	return lo;
+}
+__global__ __launch_bounds__(256) void tile_index_kernel(Pileup P, QuerySrc Q, const DevHom *__restrict__ homs,
 														  const uint32_t *__restrict__ hom_rng,
 														  uint32_t *__restrict__ first, uint32_t g0, uint32_t g1)
 {
@@ -84,13 +92,29 @@ __global__ __launch_bounds__(256) void tile_index_kernel(Pileup P, const DevHom 
 	const uint32_t g = g0 + (uint32_t)(t / ntw), tw = (uint32_t)(t % ntw);
 	const uint64_t tid = (uint64_t)g * ntw + tw;
 	const uint32_t span0 = (P.w0 + tw * PROJ_TW) * 32u;
-	uint32_t lo = hom_rng[2 * g], hi = hom_rng[2 * g + 1]; // genome g's list is homs[lo, hi)
+	const uint32_t h1 = hom_rng[2 * g + 1];
+	uint32_t lo = hom_rng[2 * g], hi = h1; // genome g's list is homs[lo, hi)
 	while (lo < hi) {
 		uint32_t mid = lo + ((hi - lo) >> 1);
 		if (homs[mid].start + homs[mid].len <= span0) lo = mid + 1;
 		else hi = mid;
 	}
-	first[tid] = lo;
+	uint32_t flag = 0;
+	const uint32_t b0 = Q.qbad_off[g], nb = Q.qbad_off[g + 1] - b0;
+	if (nb) {
+		const uint64_t span1 = (uint64_t)span0 + PROJ_TW * 32u;
+		for (uint32_t h = lo; h < h1 && !flag; h++) {
+			const DevHom hm = homs[h];
+			if (hm.start >= span1) break;
+			const uint64_t he = (uint64_t)hm.start + hm.len;
+			const uint64_t xs = hm.start > span0 ? hm.start : span0, xe = he < span1 ? he : span1;
+			// the query positions behind [xs, xe)
+			const uint64_t qa = hm.rev ? hm.iq + (he - xe) : hm.iq + (xs - hm.start), qb = qa + (xe - xs);
+			const uint32_t k = lower_bound_u32(Q.qbad + b0, nb, (uint32_t)qa);
+			if (k < nb && Q.qbad[b0 + k] < qb) flag = TILE_BAD;
+		}
+	}
+	first[tid] = lo | flag;
 }
 
 static const uint32_t PROJ_HM = 8; // homology descriptors cached per genome and tile
@@ -98,8 +122,7 @@ static const uint32_t PROJ_HM = 8; // homology descriptors cached per genome and
 // FIVE = false writes V, N0, N1 only (and still raises bang_flag when a projected
 // position holds '!'): the host then repeats the projection with all five planes.
 template <bool FIVE>
-__global__ __launch_bounds__(256) void project_kernel(Pileup P, const uint8_t *__restrict__ gbase,
-													   const uint64_t *__restrict__ goff,
+__global__ __launch_bounds__(256) void project_kernel(Pileup P, QuerySrc Q,
 													   const DevHom *__restrict__ homs,
 													   const uint32_t *__restrict__ hom_rng,
 													   const uint32_t *__restrict__ first,
@@ -108,7 +131,7 @@ __global__ __launch_bounds__(256) void project_kernel(Pileup P, const uint8_t *_
 	constexpr uint32_t NP = FIVE ? 5u : 3u;
 	__shared__ uint32_t tile[NP][PROJ_TW][PROJ_TG + 1];
 	__shared__ DevHom hcache[PROJ_TG][PROJ_HM];
-	__shared__ uint32_t hlo[PROJ_TG], hend[PROJ_TG];
+	__shared__ uint32_t hlo[PROJ_TG], hend[PROJ_TG], tbad[PROJ_TG];
 	__shared__ uint32_t below[33]; // below[t] = plane-order mask of the positions < t
 	const uint32_t ntw = (P.W + PROJ_TW - 1) / PROJ_TW;
 	const uint32_t tw = blockIdx.x % ntw, tg = tg0 + blockIdx.x / ntw;
@@ -123,9 +146,11 @@ __global__ __launch_bounds__(256) void project_kernel(Pileup P, const uint8_t *_
 		const uint32_t gl = threadIdx.x >> 3, e = threadIdx.x & 7u; // PROJ_TG * PROJ_HM == 256
 		const uint32_t g = tg * PROJ_TG + gl;
 		DevHom hm = {0xffffffffu, 0, 0, 0};
-		uint32_t lo = 0, h1 = 0;
+		uint32_t lo = 0, h1 = 0, bad = 0;
 		if (g < P.N) {
 			lo = first[(size_t)g * ntw + tw];
+			bad = lo & TILE_BAD;
+			lo &= ~TILE_BAD;
 			h1 = hom_rng[2 * g + 1];
 			if (lo + e < h1) hm = homs[lo + e];
 		}
@@ -133,6 +158,7 @@ __global__ __launch_bounds__(256) void project_kernel(Pileup P, const uint8_t *_
 		if (e == 0) {
 			hlo[gl] = lo;
 			hend[gl] = h1;
+			tbad[gl] = bad;
 		}
 	}
 	__syncthreads();
@@ -140,12 +166,12 @@ __global__ __launch_bounds__(256) void project_kernel(Pileup P, const uint8_t *_
 	const uint32_t x0 = (P.w0 + w) * 32u, x1 = x0 + 32u;
 	uint32_t any_bang = 0;
 	// A wavefront owns PROJ_GPW genomes of the tile.  The covering homology of each is
-	// looked up first (LDS only), then the PROJ_GPW 32-byte reads are issued together
-	// — one read per genome in flight at a time left the kernel waiting on HBM latency
-	// three quarters of its cycles — then the planes are formed.  A window that a
-	// second homology also touches (list boundaries) is finished by the loop below.
+	// looked up first (LDS only), then the PROJ_GPW 12-byte reads (32 codes at any 2-bit
+	// offset) are issued together — one read per genome in flight at a time left the kernel
+	// waiting on HBM latency three quarters of its cycles — then the planes are formed.  A
+	// window that a second homology also touches (list boundaries) is finished by the loop below.
 	struct Piece {
-		const uint8_t *src;
+		int64_t pos; // genome-buffer position (in bases, = byte offset of the byte form) of the lowest query index read
 		uint32_t mask, rev, next;
 	};
 	auto load_hom = [&](uint32_t gi, uint32_t h, uint32_t lo) {
@@ -157,14 +183,14 @@ __global__ __launch_bounds__(256) void project_kernel(Pileup P, const uint8_t *_
 		return hm;
 	};
 	// first homology of genome gi at or after h that overlaps the window; next = h1 if none
-	auto find_piece = [&](uint32_t gi, const uint8_t *q, uint32_t h, uint32_t lo, uint32_t h1) {
+	auto find_piece = [&](uint32_t gi, int64_t q, uint32_t h, uint32_t lo, uint32_t h1) {
 		Piece pc = {q, 0u, 0u, h1};
 		for (; h < h1; h++) {
 			const DevHom hm = load_hom(gi, h, lo);
 			if (hm.start >= x1) break;
 			const uint32_t he = hm.start + hm.len;
 			if (he <= x0) continue;
-			// covered part of this window; the 32 bytes are fetched whole (genomes are
+			// covered part of this window; the 32 codes are fetched whole (genomes are
 			// padded on both sides) and the bits outside the homology masked off
 			pc.mask = 0xffffffffu;
 			if (hm.start > x0 || he < x1) {
@@ -173,8 +199,8 @@ __global__ __launch_bounds__(256) void project_kernel(Pileup P, const uint8_t *_
 				pc.mask = below[e] & ~below[s];
 			}
 			// forward: position x ↔ query index iq + (x - start)
-			// reverse: position x ↔ query index iq + (he-1-x): bytes run backwards, complemented
-			pc.src = hm.rev ? q + ((int64_t)hm.iq + (int64_t)he - (int64_t)x1)
+			// reverse: position x ↔ query index iq + (he-1-x): codes run backwards, complemented
+			pc.pos = hm.rev ? q + ((int64_t)hm.iq + (int64_t)he - (int64_t)x1)
 							: q + ((int64_t)hm.iq + (int64_t)x0 - (int64_t)hm.start);
 			pc.rev = hm.rev;
 			pc.next = he < x1 ? h + 1 : h1; // lists are sorted and disjoint: nothing else if this one reaches the end
@@ -182,56 +208,74 @@ __global__ __launch_bounds__(256) void project_kernel(Pileup P, const uint8_t *_
 		}
 		return pc;
 	};
-	auto add_piece = [&](const Piece &pc, uint4 a, uint4 b, uint32_t &V, uint32_t &N0, uint32_t &N1, uint32_t &D,
-						 uint32_t &B) {
-		uint32_t d[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-		uint32_t flip = 0;
+	// the 32 codes at pc.pos: three dwords of Q2, shifted into two
+	auto fetch = [&](const Piece &pc, uint32_t &w0, uint32_t &w1, uint32_t &w2) {
+		const uint32_t *src = Q.q2 + (pc.pos >> 4);
+		struct { uint32_t a, b, c; } v;
+		__builtin_memcpy(&v, (const uint8_t __attribute__((address_space(1))) *)(uintptr_t)src, 12);
+		w0 = v.a;
+		w1 = v.b;
+		w2 = v.c;
+	};
+	auto add_piece = [&](const Piece &pc, uint32_t gi, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t &V, uint32_t &N0,
+						 uint32_t &N1, uint32_t &D, uint32_t &B) {
+		const uint32_t sh = 2u * ((uint32_t)pc.pos & 15u);
+		uint32_t a = (uint32_t)(((((uint64_t)w0 << 32) | w1) << sh) >> 32);
+		uint32_t b = (uint32_t)(((((uint64_t)w1 << 32) | w2) << sh) >> 32);
+		uint32_t hi, lo;
 		if (pc.rev) {
-			const uint32_t r[8] = {__builtin_bswap32(d[7]), __builtin_bswap32(d[6]), __builtin_bswap32(d[5]),
-								   __builtin_bswap32(d[4]), __builtin_bswap32(d[3]), __builtin_bswap32(d[2]),
-								   __builtin_bswap32(d[1]), __builtin_bswap32(d[0])};
-#pragma unroll
-			for (int i = 0; i < 8; i++) d[i] = r[i];
-			flip = 0xffffffffu; // complement: n ^ 2
+			// all 64 bits reversed: the codes run backwards and every code's two bits have changed places;
+			// the complement flips both
+			const uint32_t ra = __builtin_bitreverse32(b), rb = __builtin_bitreverse32(a);
+			hi = ~code_plane<false>(ra, rb);
+			lo = ~code_plane<true>(ra, rb);
 			if (FIVE) D |= pc.mask;
+		} else {
+			hi = code_plane<true>(a, b);
+			lo = code_plane<false>(a, b);
 		}
 		V |= pc.mask;
-		N0 |= gather_plane<1>(d) & pc.mask;
-		N1 |= (gather_plane<2>(d) ^ flip) & pc.mask;
-		// '!' (0x21) is the only byte with bit 6 clear (zero padding aside): look closer
-		// only when some byte of the 32 has it clear
-		const uint32_t all = d[0] & d[1] & d[2] & d[3] & d[4] & d[5] & d[6] & d[7];
-		if ((all & 0x40404040u) != 0x40404040u) B |= gather_plane<5>(d) & ~gather_plane<6>(d) & pc.mask;
+		N0 |= lo & pc.mask;
+		N1 |= hi & pc.mask;
+		if (tbad[gi]) {
+			// '!' among the 32 query positions [pc.pos, pc.pos + 32)?  (the tile index found one in this tile)
+			const uint32_t g = tg * PROJ_TG + gi;
+			const uint32_t b0 = Q.qbad_off[g], nb = Q.qbad_off[g + 1] - b0;
+			const int64_t rel = pc.pos - (int64_t)Q.goff[g]; // query index of the lowest position read (may be < 0)
+			const uint32_t from = rel < 0 ? 0u : (uint32_t)rel;
+			for (uint32_t k = lower_bound_u32(Q.qbad + b0, nb, from); k < nb; k++) {
+				const int64_t u = (int64_t)Q.qbad[b0 + k] - rel;
+				if (u >= 32) break;
+				B |= (1u << plane_bit(pc.rev ? 31u - (uint32_t)u : (uint32_t)u)) & pc.mask;
+			}
+		}
 	};
 	Piece pc[PROJ_GPW];
-	uint4 da[PROJ_GPW], db[PROJ_GPW];
+	uint32_t d0[PROJ_GPW], d1[PROJ_GPW], d2[PROJ_GPW];
 #pragma unroll
 	for (uint32_t u = 0; u < PROJ_GPW; u++) {
 		const uint32_t gi = wave + 4 * u, g = tg * PROJ_TG + gi;
-		pc[u] = Piece{gbase, 0u, 0u, 0u};
-		if (g < P.N && w < P.W) pc[u] = find_piece(gi, gbase + goff[g], hlo[gi], hlo[gi], hend[gi]);
+		pc[u] = Piece{64, 0u, 0u, 0u};
+		if (g < P.N && w < P.W) pc[u] = find_piece(gi, (int64_t)Q.goff[g], hlo[gi], hlo[gi], hend[gi]);
 	}
 #pragma unroll
-	for (uint32_t u = 0; u < PROJ_GPW; u++) { // mask == 0: src is a valid address all the same, the data is ignored
-		__builtin_memcpy(&da[u], pc[u].src, 16);
-		__builtin_memcpy(&db[u], pc[u].src + 16, 16);
-	}
+	for (uint32_t u = 0; u < PROJ_GPW; u++) // mask == 0: pos is a valid position all the same, the data is ignored
+		fetch(pc[u], d0[u], d1[u], d2[u]);
 #pragma unroll
 	for (uint32_t u = 0; u < PROJ_GPW; u++) {
 		const uint32_t gi = wave + 4 * u, g = tg * PROJ_TG + gi;
 		uint32_t V = 0, N0 = 0, N1 = 0, D = 0, B = 0;
 		if (pc[u].mask) {
-			add_piece(pc[u], da[u], db[u], V, N0, N1, D, B);
+			add_piece(pc[u], gi, d0[u], d1[u], d2[u], V, N0, N1, D, B);
 			const uint32_t lo = hlo[gi], h1 = hend[gi];
-			const uint8_t *q = gbase + goff[g];
+			const int64_t q = (int64_t)Q.goff[g];
 			uint32_t h = pc[u].next;
 			while (h < h1) {
 				const Piece more = find_piece(gi, q, h, lo, h1);
 				if (!more.mask) break;
-				uint4 a, b;
-				__builtin_memcpy(&a, more.src, 16);
-				__builtin_memcpy(&b, more.src + 16, 16);
-				add_piece(more, a, b, V, N0, N1, D, B);
+				uint32_t e0, e1, e2;
+				fetch(more, e0, e1, e2);
+				add_piece(more, gi, e0, e1, e2, V, N0, N1, D, B);
 				h = more.next;
 			}
 		}
@@ -383,17 +427,17 @@ void launch_symmetrise(uint32_t N, unsigned long long *a, unsigned long long *b,
 
 // genomes [g0, g1) / genome tiles [tg0, tg1) of PROJ_TG genomes: the whole pileup, or the part
 // of it whose lists are ready (phase A projects eagerly, group by group)
-void launch_tile_index(const Pileup &P, const DevHom *homs, const uint32_t *hom_rng, uint32_t *first, uint32_t g0,
+void launch_tile_index(const Pileup &P, const QuerySrc &Q, const DevHom *homs, const uint32_t *hom_rng, uint32_t *first, uint32_t g0,
 					   uint32_t g1, hipStream_t st)
 {
 	uint32_t ntw = (P.W + PROJ_TW - 1) / PROJ_TW;
 	if (g1 > P.N) g1 = P.N;
 	if (!ntw || g0 >= g1) return;
 	uint64_t entries = (uint64_t)(g1 - g0) * ntw;
-	hipLaunchKernelGGL(tile_index_kernel, dim3((uint32_t)((entries + 255) / 256)), dim3(256), 0, st, P, homs, hom_rng, first,
+	hipLaunchKernelGGL(tile_index_kernel, dim3((uint32_t)((entries + 255) / 256)), dim3(256), 0, st, P, Q, homs, hom_rng, first,
 					   g0, g1);
 }
-void launch_project(const Pileup &P, bool five_planes, const uint8_t *gbase, const uint64_t *goff, const DevHom *homs,
+void launch_project(const Pileup &P, bool five_planes, const QuerySrc &Q, const DevHom *homs,
 					const uint32_t *hom_rng, const uint32_t *first, uint32_t *bang_flag, uint32_t tg0, uint32_t tg1,
 					hipStream_t st)
 {
@@ -402,9 +446,9 @@ void launch_project(const Pileup &P, bool five_planes, const uint8_t *gbase, con
 	if (!ntw || tg0 >= tg1) return;
 	dim3 grid(ntw * (tg1 - tg0));
 	if (five_planes)
-		hipLaunchKernelGGL(project_kernel<true>, grid, dim3(256), 0, st, P, gbase, goff, homs, hom_rng, first, bang_flag, tg0);
+		hipLaunchKernelGGL(project_kernel<true>, grid, dim3(256), 0, st, P, Q, homs, hom_rng, first, bang_flag, tg0);
 	else
-		hipLaunchKernelGGL(project_kernel<false>, grid, dim3(256), 0, st, P, gbase, goff, homs, hom_rng, first, bang_flag, tg0);
+		hipLaunchKernelGGL(project_kernel<false>, grid, dim3(256), 0, st, P, Q, homs, hom_rng, first, bang_flag, tg0);
 }
 uint32_t project_genomes_per_tile() { return PROJ_TG; }
 size_t project_index_entries(const Pileup &P) { return (size_t)P.N * ((P.W + PROJ_TW - 1) / PROJ_TW); }
