@@ -12,9 +12,9 @@
 //     substitutions(i,j) = #those positions where the two projected bases differ
 // (SURVEY §3.4).  So each genome is projected ONCE onto reference coordinates
 // as bit planes (32 positions per word):
-//     V  covered            N0,N1  base on the forward strand (A0 C1 T2 G3; reverse
-//     D  reverse homology          hits store the complement, n^2)
-//     B  raw byte is '!'
+//     V  covered            N0,N1  the 2-bit code of the base on the forward strand (A 00, C 01,
+//     D  reverse homology          G 10, T 11 — the genomes' packed form, lean_core.h; reverse hits
+//     B  raw byte is '!'           store the complement, both bits flipped); '!' has code 00
 // and a pair is  both = Vi&Vj;  diff = (N0i^N0j)|(N1i^N1j);  popcount.  '!' needs
 // the two extra planes because seqcmp compares bytes ('!' != 'A') while
 // revseqcmp's ((c^d)&6)==4 test sees '!' as 'A' (libs/revseqcmp.h:19-23):
@@ -26,6 +26,7 @@
 // load, and genome i's word is wave-uniform (scalar load).  HBM traffic is
 // 3/8 (5/8) byte per genome per reference position, re-used from L2 across the
 // whole pair grid, against 2 bytes per compared site for the reference layout.
+// The projection itself reads the genomes as 2-bit codes: 12 bytes per window and genome.
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
