@@ -228,6 +228,7 @@ def main():
     ap.add_argument("--kmer", type=int, default=0, help="dev: force the bucket k of the reference index")
     ap.add_argument("--anchor-kernel", type=int, default=-1, help="dev: 1 lean 2-bit chains, 0 general byte-wise chains (library default when < 0)")
     ap.add_argument("--tail-groups", type=int, default=0, help="dev: phase A's tail on this many streams (library default when 0)")
+    ap.add_argument("--sa-builder", type=int, default=-1, help="dev: who builds the reference's suffix array: 1 the device, 0 the host cores (library default when < 0)")
     ap.add_argument("--pairs-wchunk", type=int, default=0, help="dev: windows per chunk of the pair kernel (library's choice when 0)")
     ap.add_argument("--d-range", default="", help="dev: lo,hi — override the workload's divergence range")
     ap.add_argument("--emulate-rank", default="", help="dev: R/N — time rank R of N's share of the work on this one GPU "
@@ -299,6 +300,8 @@ def main():
         ctx.set_option("tail_groups", args.tail_groups)
     if args.pairs_wchunk > 0:
         ctx.set_option("pairs_wchunk", args.pairs_wchunk)
+    if args.sa_builder >= 0:
+        ctx.set_option("sa_builder", args.sa_builder)
     if args.host_threads:
         ctx.set_option("host_threads", args.host_threads)
     if args.filter:
@@ -315,8 +318,11 @@ def main():
     t_ref = time.time()
     ctx.set_reference(ref_idx)  # host suffix array + tables: outside the metric
     t_ref = time.time() - t_ref
-    ref_stats = {k: ctx.stat(k) for k in ("ms:ref_suffix_array", "ms:ref_lcp_table", "ms:ref_total")}
-    print(f"# reference index built in {t_ref:.1f} s (suffix array {(ref_stats['ms:ref_suffix_array'] or 0) / 1e3:.1f} s)",
+    ref_stats = {k: ctx.stat(k) for k in ("ms:ref_suffix_array", "ms:ref_lcp_table", "ms:ref_total", "ms:ref_fetch", "ref:sa_on_device", "ref:sa_rounds")}
+    if os.environ.get("BENCH_REF_STATS"):
+        print("# " + json.dumps({k: v for k, v in ctx.stats().items() if "ref" in k}), file=sys.stderr, flush=True)
+    print(f"# reference index built in {t_ref:.3f} s (suffix array {(ref_stats['ms:ref_suffix_array'] or 0) / 1e3:.3f} s, "
+          f"{'device, %d doubling rounds' % ref_stats['ref:sa_rounds'] if ref_stats['ref:sa_on_device'] else 'host cores'})",
           file=sys.stderr, flush=True)
     total_bases = float(sum(lens))
 
@@ -590,7 +596,8 @@ def main():
                                                          "HBM-bound"} if tb > 0 else None)(
                 sum(kern[k] for k in kern if k.startswith("pileup_")) / K, phase_b_traffic),
             "setup_s": {"generate": round(t_gen, 2), "reference_index": round(t_ref, 2),
-                        "suffix_array": round((ref_stats["ms:ref_suffix_array"] or 0) / 1e3, 2)},
+                        "suffix_array": round((ref_stats["ms:ref_suffix_array"] or 0) / 1e3, 3),
+                        "suffix_array_builder": "device" if ref_stats["ref:sa_on_device"] else "host"},
         }
         if args.dump_matrix:
             np.savez(args.dump_matrix, subst=np.asarray(s), homologs=np.asarray(h))

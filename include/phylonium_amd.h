@@ -102,10 +102,15 @@ int phylo_get_genome(phylo_ctx *ctx, size_t i, char *buf);
 /* ── reference: `esa ref(subject)` + threshold, src/process.cxx:413-417 ──
  * sa: suffix array of S = subject + '#' + revcomp(subject), 2L+1 entries,
  * exactly what divsufsort64 returns at src/esa.cxx:74; NULL builds it on the
- * host cores (SA-IS). threshold 0 computes
+ * device (option "sa_builder" = 1, the default: prefix doubling over radix sorts, csrc/sa_kernels.hip) or on the
+ * host cores ("sa_builder" = 0: bucket sort / SA-IS). threshold 0 computes
  * min_anchor_length(0.025, gc, 2L+1) as src/process.cxx:416-417. */
 int phylo_set_reference(phylo_ctx *ctx, size_t ref_idx, const int64_t *sa, size_t threshold);
 size_t phylo_threshold(const phylo_ctx *ctx);
+/* The suffix array the current reference's index was built from (2L+1 entries, as divsufsort64 would return
+ * them at src/esa.cxx:74), copied from the device: with sa == NULL above it was built there (option
+ * "sa_builder": 1, the default, prefix doubling on the device; 0 the host cores). */
+int phylo_reference_suffix_array(phylo_ctx *ctx, int64_t *sa);
 /* 1 when the reference build would NOT give the longest match on this subject: its 6-mer interval cache
  * stores an over-deep interval when a nucleotide string of <= 4 characters occurs at least twice in S and
  * only in front of the same contig join (src/esa.cxx:174-199) — possible for references of a few kbp

@@ -24,7 +24,7 @@ PHOM = np.dtype([("index_reference", "<u8"), ("index_reference_projected", "<u8"
 SYMBOLS = [
     "phylo_ctx_create", "phylo_ctx_destroy", "phylo_last_error", "phylo_set_option", "phylo_get_stat", "phylo_reference_cache_quirk",
     "phylo_reset_stats", "phylo_stat_keys", "phylo_set_genomes", "phylo_set_genomes_device", "phylo_set_genomes_packed", "phylo_get_genome",
-    "phylo_set_reference", "phylo_threshold", "phylo_anchor", "phylo_get_homologies", "phylo_set_homologies",
+    "phylo_set_reference", "phylo_threshold", "phylo_reference_suffix_array", "phylo_anchor", "phylo_get_homologies", "phylo_set_homologies",
     "phylo_export_homologies", "phylo_import_homologies", "phylo_export_packed", "phylo_import_packed",
     "phylo_export_packed_device", "phylo_attach_packed_device", "phylo_compare_device",
     "phylo_complete_delete", "phylo_compare", "phylo_compare_all", "phylo_process", "phylo_seqcmp",
@@ -65,6 +65,7 @@ def load():
     L.phylo_set_genomes_packed.argtypes = [vp, sz, vp, vp, vp, vp]
     L.phylo_get_genome.argtypes = [vp, sz, vp]
     L.phylo_set_reference.argtypes = [vp, sz, vp, sz]
+    L.phylo_reference_suffix_array.argtypes = [vp, vp]
     L.phylo_threshold.restype = sz
     L.phylo_threshold.argtypes = [vp]
     L.phylo_anchor.argtypes = [vp, sz, sz]
@@ -213,6 +214,12 @@ class Context:
             sap = self._sa.ctypes.data_as(C.c_void_p)
         self._chk(self.L.phylo_set_reference(self.h, ref_idx, sap, threshold))
         self.ref_idx = ref_idx
+
+    def reference_suffix_array(self):
+        """The suffix array of S = reference + '#' + revcomp(reference) the index was built from (int64)."""
+        out = np.empty(2 * self.lengths[self.ref_idx] + 1, np.int64)
+        self._chk(self.L.phylo_reference_suffix_array(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
 
     @property
     def threshold(self):

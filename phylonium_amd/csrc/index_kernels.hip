@@ -1,6 +1,9 @@
 // index_kernels.hip — the reference index on the device.  The suffix array comes
-// from the host (north star: "the libdivsufsort ESA build stays on the host
-// cores"); everything derived from it is built here:
+// from the caller, from the host cores (north star: "the libdivsufsort ESA build stays
+// on the host cores") or from sa_kernels.hip; everything else is built here:
+//   S     subject + '#' + reverse complement (esa.cxx:72-75, sequence.cxx:73-103), with the
+//         subject's GC count (sequence.cxx:152-165) and, for the 6-mer cache check, the set of
+//         bytes seen after every nucleotide string of up to 5 letters
 //   LCP   (the reference's init_LCP, /root/reference/src/esa.cxx:305-347) — by direct
 //         comparison of neighbouring suffixes, capped; exact values beyond the cap
 //         are only needed for repeats >= 64 kbp and then come from the host (Kasai)
@@ -9,10 +12,77 @@
 // SLOT is assembled from T and SAX by build_slots_kernel in phylo_abi.hip.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "anchor_core.h"
 #include "kernels.h"
 
 namespace phy {
+
+// S[0..L) = ref, S[L] = '#', S[L+1..2L+1) = reverse complement, zeros behind (total bytes written: ns + 64).
+// *gc += bytes of ref that count for gc_content (hostlogic.hpp: the same predicate).
+__global__ __launch_bounds__(256) void build_subject_kernel(const uint8_t *__restrict__ ref, uint32_t L, uint8_t *__restrict__ S,
+															 unsigned long long *__restrict__ gc)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t ns = 2ull * L + 1;
+	uint32_t is_gc = 0;
+	if (i < ns + 64) {
+		uint8_t out = 0;
+		if (i < L) {
+			out = ref[i];
+			is_gc = (out & 'G' & 'C') == ('G' & 'C');
+		} else if (i == L) {
+			out = '#';
+		} else if (i < ns) {
+			const uint8_t c = ref[2ull * L - i];
+			out = (c < 'A') ? c : (uint8_t)(c ^ ((c & 2) ? 4 : 21));
+		}
+		S[i] = out;
+	}
+	const unsigned long long m = __ballot(is_gc);
+	if ((threadIdx.x & 63u) == 0 && m) atomicAdd(gc, (unsigned long long)__popcll(m));
+}
+void launch_build_subject(const uint8_t *ref, uint32_t L, uint8_t *S, unsigned long long *gc, hipStream_t st)
+{
+	const uint64_t total = 2ull * L + 1 + 64;
+	hipLaunchKernelGGL(build_subject_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, ref, L, S, gc);
+}
+
+// For every nucleotide string w of 1..5 letters (entry: NEXT_BASE[|w|] + code of w) the set of "next bytes" seen
+// behind its occurrences in S: bits 0..3 a nucleotide A C G T, bit 4 anything else or the end of S.  The
+// reference's 6-mer cache can only go wrong (hostlogic.hpp: esa_cache_quirk) below a string all of whose
+// occurrences go on with the same byte; when every string that occurs is followed by at least two different
+// bytes the exact walk over the suffix array is not needed — the case of every genome beyond a few kbp.
+static const uint32_t NEXT_ENTRIES = 4 + 16 + 64 + 256 + 1024;
+__global__ __launch_bounds__(256) void next_bytes_kernel(const uint8_t *__restrict__ S, uint32_t n, uint32_t *__restrict__ masks)
+{
+	__shared__ uint32_t loc[NEXT_ENTRIES];
+	for (uint32_t t = threadIdx.x; t < NEXT_ENTRIES; t += blockDim.x) loc[t] = 0;
+	__syncthreads();
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		uint32_t code = 0, base = 0, span = 4;
+		for (uint32_t k = 1; k <= 5; k++) {
+			const uint32_t v = nuc_code(S[i + k - 1]); // S is followed by zero bytes: 4 past the end
+			if (v > 3) break;
+			code = (code << 2) | v;
+			const uint32_t nx = (i + k < n) ? nuc_code(S[i + k]) : 4u;
+			const uint32_t bit = 1u << nx;
+			if (!(loc[base + code] & bit)) atomicOr(&loc[base + code], bit);
+			base += span;
+			span <<= 2;
+		}
+	}
+	__syncthreads();
+	for (uint32_t t = threadIdx.x; t < NEXT_ENTRIES; t += blockDim.x)
+		if (loc[t]) atomicOr(&masks[t], loc[t]);
+}
+uint32_t next_bytes_entries() { return NEXT_ENTRIES; }
+void launch_next_bytes(const uint8_t *S, uint32_t n, uint32_t *masks, hipStream_t st)
+{
+	const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)n + 255) / 256, 4096);
+	hipLaunchKernelGGL(next_bytes_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, S, n, masks);
+}
 
 // LCP[r] = lcp(suffix SA[r-1], suffix SA[r]) for 1 <= r < n, min'ed with `cap`;
 // LCP[0] = LCP[n] = 0.  *capped counts the ranks that reached the cap.

@@ -48,11 +48,21 @@ void launch_sort_filter_long(const RawHom *raw, const uint64_t *raw_base, const 
 							 uint32_t *slot_counter, hipStream_t st);
 
 // index_kernels.hip
+// S = ref + '#' + revcomp(ref) + 64 zero bytes; *gc += the subject's G/C count (zeroed by the caller)
+void launch_build_subject(const uint8_t *ref, uint32_t L, uint8_t *S, unsigned long long *gc, hipStream_t st);
+// masks[next_bytes_entries()] (zeroed by the caller): the bytes seen after every nucleotide string of 1..5 letters
+uint32_t next_bytes_entries();
+void launch_next_bytes(const uint8_t *S, uint32_t n, uint32_t *masks, hipStream_t st);
 void launch_lcp(const uint8_t *S, const uint32_t *SA, uint32_t n, uint32_t cap, uint32_t *LCP, uint32_t *capped,
 				hipStream_t st);
 void launch_kmer_table(const uint8_t *S, uint32_t n, uint32_t k, uint32_t *T, uint32_t *scratch_sums, hipStream_t st);
 size_t kmer_table_scratch(uint32_t k);
 void launch_sax(const uint8_t *S, const uint32_t *SA, const uint32_t *LCP, uint32_t n, U4 *SAX, hipStream_t st);
+
+// sa_kernels.hip: the suffix array on the device (prefix doubling over rocPRIM's radix sort).  Returns 0, 1 when S
+// holds a byte other than ! # A C G T (build it on the host then), 2 on a HIP error.
+size_t suffix_array_scratch_bytes(uint32_t n);
+int device_suffix_array(const uint8_t *S, uint32_t n, uint32_t *SA, void *scratch, uint32_t *rounds_out, hipStream_t st);
 
 // seqcmp_kernels.hip
 struct Segment {

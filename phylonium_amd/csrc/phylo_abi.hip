@@ -181,6 +181,7 @@ struct phylo_ctx {
 	hipStream_t tail_stream[TAIL_GROUPS - 1] = {nullptr, nullptr};
 	hipEvent_t tail_event[TAIL_GROUPS] = {nullptr, nullptr, nullptr};
 	int opt_filter_kernel = 0; // option "filter_kernel": 0 stretch-wise chain filter (then the general kernel for what it hands over), 1 general only
+	int opt_sa_builder = 1; // option "sa_builder": who builds the suffix array when the caller brings none — 1 the device, 0 the host cores
 	uint32_t opt_pairs_wchunk = 0; // option "pairs_wchunk": windows per chunk of the pair kernel (0: chosen from the L2 size)
 	int opt_tail_groups = 1; // option "tail_groups": streams the tail is spread over (default 1: measured, the groups run in lockstep and nothing is hidden — DESIGN.md)
 	std::string err;
@@ -503,6 +504,9 @@ int phylo_set_option(phylo_ctx *c, const char *key, long value)
 	} else if (k == "tail_groups") {
 		if (value < 1 || value > phylo_ctx::TAIL_GROUPS) return c->fail("tail_groups must be in 1..%d", phylo_ctx::TAIL_GROUPS);
 		c->opt_tail_groups = (int)value;
+	} else if (k == "sa_builder") {
+		if (value != 0 && value != 1) return c->fail("sa_builder must be 1 (device) or 0 (host cores)");
+		c->opt_sa_builder = (int)value;
 	} else if (k == "pairs_wchunk") {
 		if (value < 0 || value > (1 << 20)) return c->fail("pairs_wchunk must be in 0..2^20");
 		c->opt_pairs_wchunk = (uint32_t)value;
@@ -830,37 +834,77 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 	if (2 * L + 1 >= 0x7fffffffull) return c->fail("reference too long: 2L+1 must be < 2^31 (src/esa.cxx:374-375)");
 	if (L == 0) return c->fail("reference genome is empty");
 	uint32_t ns = (uint32_t)(2 * L + 1);
-	std::vector<uint8_t> S((size_t)ns + 64, 0);
-	HIPOK(c, hipMemcpy(S.data(), c->d_genomes + c->goff[ref_idx], L, hipMemcpyDeviceToHost));
-	S[L] = '#';
-	revcomp(S.data(), L, S.data() + L + 1);
-	std::vector<uint32_t> SA((size_t)ns + 4, 0); // +4: tables are read 16 bytes at a time
+	// S = subject + '#' + reverse complement is made where the subject is — on the device — together with the GC
+	// count the threshold needs; the host gets a copy only for the steps that walk it there (its own suffix sorters,
+	// Kasai's LCP for repeats beyond the clip, the exact 6-mer-cache check)
+	std::vector<uint8_t> S;
+	std::vector<uint32_t> SA; // +4: tables are read 16 bytes at a time
+	hipStream_t st = c->stream;
+	HIPOK(c, c->d_S.ensure((size_t)ns + 64));
+	HIPOK(c, c->d_SA.ensure((size_t)ns + 4));
+	HIPOK(c, c->a_misc.ensure(16));
+	DevBuf<uint32_t> d_next;
+	HIPOK(c, d_next.ensure(next_bytes_entries() + 4));
+	HIPOK(c, hipMemsetAsync(c->a_misc.p, 0, 64, st));
+	HIPOK(c, hipMemsetAsync(d_next.p, 0, (next_bytes_entries() + 4) * 4, st));
+	launch_build_subject(c->d_genomes + c->goff[ref_idx], (uint32_t)L, c->d_S.p, (unsigned long long *)(c->a_misc.p + 2), st);
+	launch_next_bytes(c->d_S.p, ns, d_next.p, st);
+	unsigned long long gc_count = 0;
+	std::vector<uint32_t> next_masks(next_bytes_entries());
+	HIPOK(c, hipMemcpyAsync(&gc_count, c->a_misc.p + 2, 8, hipMemcpyDeviceToHost, st));
+	HIPOK(c, hipMemcpyAsync(next_masks.data(), d_next.p, next_masks.size() * 4, hipMemcpyDeviceToHost, st));
+	HIPOK(c, hipStreamSynchronize(st));
+	d_next.release();
+	auto host_S = [&]() -> int {
+		if (!S.empty()) return 0;
+		S.assign((size_t)ns + 64, 0);
+		HIPOK(c, hipMemcpy(S.data(), c->d_S.p, (size_t)ns, hipMemcpyDeviceToHost));
+		return 0;
+	};
 	double t1 = now_ms();
-	if (sa) {
-		for (uint32_t i = 0; i < ns; i++) {
-			if (sa[i] < 0 || sa[i] >= (int64_t)ns) return c->fail("suffix array entry %u out of range", i);
-			SA[i] = (uint32_t)sa[i];
+	bool sa_on_device = false; // the array exists in d_SA only; `SA` is fetched if a host step asks for it
+	uint32_t sa_rounds = 0;
+	if (!sa && c->opt_sa_builder == 1) {
+		// esa.cxx:74's divsufsort64, on the device (sa_kernels.hip)
+		DevBuf<uint8_t> scratch;
+		HIPOK(c, scratch.ensure(suffix_array_scratch_bytes(ns)));
+		HIPOK(c, hipMemsetAsync(c->d_SA.p + ns, 0, 16, st));
+		const int rc = device_suffix_array(c->d_S.p, ns, c->d_SA.p, scratch.p, &sa_rounds, st);
+		HIPOK(c, hipStreamSynchronize(st));
+		scratch.release();
+		if (rc == 2) return c->fail("suffix array on the device: %s", hipGetErrorString(hipGetLastError()));
+		sa_on_device = rc == 0; // rc == 1: a byte outside ! # A C G T — the host builders order any bytes
+	}
+	auto host_sa = [&]() -> int { // the array on the host, for the steps that walk it there
+		if (!SA.empty()) return 0;
+		SA.assign((size_t)ns + 4, 0);
+		HIPOK(c, hipMemcpy(SA.data(), c->d_SA.p, (size_t)ns * 4, hipMemcpyDeviceToHost));
+		return 0;
+	};
+	if (!sa_on_device) {
+		SA.assign((size_t)ns + 4, 0);
+		if (sa) {
+			for (uint32_t i = 0; i < ns; i++) {
+				if (sa[i] < 0 || sa[i] >= (int64_t)ns) return c->fail("suffix array entry %u out of range", i);
+				SA[i] = (uint32_t)sa[i];
+			}
+		} else {
+			// host cores (north star); everything below is on the device
+			if (host_S()) return 1;
+			WorkerPool &pool = workers(c);
+			auto par = [&](size_t nt, const std::function<void(size_t)> &f) { pool.run(nt, f); };
+			suffix_array_u32_par(S.data(), ns, SA.data(), par, std::max<size_t>(1, pool.size()));
 		}
-	} else {
-		// host cores (north star); everything below is on the device
-		WorkerPool &pool = workers(c);
-		auto par = [&](size_t nt, const std::function<void(size_t)> &f) { pool.run(nt, f); };
-		suffix_array_u32_par(S.data(), ns, SA.data(), par, std::max<size_t>(1, pool.size()));
+		HIPOK(c, hipMemcpyAsync(c->d_SA.p, SA.data(), SA.size() * 4, hipMemcpyHostToDevice, st));
 	}
 	double t2 = now_ms();
 	uint32_t k = c->opt_kmer ? c->opt_kmer : choose_k(ns);
-	if (threshold == 0) threshold = min_anchor_length(0.025, gc_content(S.data(), L), ns);
+	if (threshold == 0) threshold = min_anchor_length(0.025, (double)gc_count / (double)L, ns); // gc_content, sequence.cxx:152-165
 	const uint64_t codes = (uint64_t)1 << (2 * k);
-	hipStream_t st = c->stream;
-	HIPOK(c, c->d_S.ensure(S.size()));
-	HIPOK(c, c->d_SA.ensure(SA.size()));
 	HIPOK(c, c->d_SAX.ensure((size_t)ns + 4));
 	HIPOK(c, c->d_LCP.ensure((size_t)ns + 1 + 4));
 	HIPOK(c, c->d_T.ensure(codes + 1 + 4 + kmer_table_scratch(k)));
 	HIPOK(c, c->d_SLOT.ensure(codes * SLOT_RECS));
-	HIPOK(c, c->a_misc.ensure(16));
-	HIPOK(c, hipMemcpyAsync(c->d_S.p, S.data(), S.size(), hipMemcpyHostToDevice, st));
-	HIPOK(c, hipMemcpyAsync(c->d_SA.p, SA.data(), SA.size() * 4, hipMemcpyHostToDevice, st));
 	HIPOK(c, hipMemsetAsync(c->a_misc.p, 0, 64, st));
 	HIPOK(c, hipMemsetAsync(c->d_LCP.p, 0, ((size_t)ns + 1 + 4) * 4, st));
 	// LCP by direct comparison of neighbouring suffixes, capped at the 16-bit clip of the
@@ -871,11 +915,13 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 	HIPOK(c, hipStreamSynchronize(st));
 	if (capped) {
 		std::vector<uint32_t> LCP((size_t)ns + 1 + 4, 0);
+		if (host_sa() || host_S()) return 1;
 		lcp_kasai(S.data(), ns, SA.data(), LCP.data());
 		HIPOK(c, hipMemcpyAsync(c->d_LCP.p, LCP.data(), LCP.size() * 4, hipMemcpyHostToDevice, st));
 		HIPOK(c, hipStreamSynchronize(st));
 		c->stats["ref:lcp_from_host"] = 1;
 	}
+	double t2a = now_ms();
 	launch_kmer_table(c->d_S.p, ns, k, c->d_T.p, c->d_T.p + codes + 1 + 4, st);
 	launch_sax(c->d_S.p, c->d_SA.p, c->d_LCP.p, ns, c->d_SAX.p, st);
 	{
@@ -884,6 +930,7 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 	}
 	HIPOK(c, hipGetLastError());
 	HIPOK(c, hipStreamSynchronize(st));
+	double t2b = now_ms();
 	{ // the lean chain's view of S: 2-bit codes and the sorted non-ACGT positions, then n
 		const size_t swords = ((size_t)ns + 64) / 16; // S's buffer is ns + 64 bytes
 		HIPOK(c, c->d_S2.ensure(swords + 64));
@@ -905,7 +952,18 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 		HIPOK(c, hipMemcpy(&c->sb_first, c->d_SBAD.p, 4, hipMemcpyDeviceToHost));
 		// The reference's 6-mer cache bug (esa.cxx:174-199) needs two contig joins behind the same few
 		// nucleotides: looked for only when S holds a '!' at all (nsb counts '#', the end and the '!'s).
-		c->cache_quirk = c->nsb > 2 && esa_cache_quirk(S.data(), ns, SA.data());
+		c->cache_quirk = false;
+		c->stats["ms:ref_packed_view"] += now_ms() - t2b;
+		// ... and a nucleotide string (up to 5 letters) all of whose occurrences go on with the same byte: when every
+		// string that occurs is followed by two different bytes or more, the cache's walk never fast-forwards
+		// (esa.cxx:150-155 is the only branch taken) and the exact check over the suffix array is not needed
+		bool suspect = false;
+		for (uint32_t m : next_masks) suspect = suspect || (m && !(m & (m - 1)));
+		c->stats["ref:cache_quirk_exact_check"] = (c->nsb > 2 && suspect) ? 1 : 0;
+		if (c->nsb > 2 && suspect) {
+			if (host_sa() || host_S()) return 1;
+			c->cache_quirk = esa_cache_quirk(S.data(), ns, SA.data());
+		}
 		c->stats["ref:cache_quirk"] = c->cache_quirk ? 1 : 0;
 	}
 	double t3 = now_ms();
@@ -922,7 +980,11 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 	c->stats["ms:ref_fetch"] += t1 - t0;
 	c->stats["ms:ref_suffix_array"] += t2 - t1;
 	c->stats["ms:ref_lcp_table"] += t3 - t2;
+	c->stats["ms:ref_lcp"] += t2a - t2;
+	c->stats["ms:ref_slots"] += t2b - t2a;
 	c->stats["ms:ref_total"] += now_ms() - t0;
+	c->stats["ref:sa_on_device"] = sa_on_device ? 1 : 0;
+	c->stats["ref:sa_rounds"] = sa_rounds;
 	c->stats["ref:k"] = k;
 	c->stats["ref:threshold"] = (double)threshold;
 	c->stats["ref:size"] = ns;
@@ -930,6 +992,18 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 }
 
 size_t phylo_threshold(const phylo_ctx *c) { return c ? c->threshold : 0; }
+
+int phylo_reference_suffix_array(phylo_ctx *c, int64_t *sa)
+{
+	if (!c) return 1;
+	if (!c->have_ref) return c->fail("phylo_reference_suffix_array: no reference set");
+	if (!sa) return c->fail("null buffer");
+	HIPOK(c, hipSetDevice(c->device));
+	std::vector<uint32_t> tmp(c->ns);
+	HIPOK(c, hipMemcpy(tmp.data(), c->d_SA.p, (size_t)c->ns * 4, hipMemcpyDeviceToHost));
+	for (uint32_t i = 0; i < c->ns; i++) sa[i] = tmp[i];
+	return 0;
+}
 
 int phylo_reference_cache_quirk(const phylo_ctx *c) { return c && c->have_ref && c->cache_quirk ? 1 : 0; }
 

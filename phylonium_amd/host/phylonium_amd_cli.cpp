@@ -295,6 +295,7 @@ Matrix process(Run &r, size_t ref_idx, const int64_t *sa = nullptr)
 		"    --progress=WHEN    Accepted for compatibility; no progress bar is drawn\n"
 		"  -r FILE              Set the reference genome\n"
 		"  -t, --threads=N      Host threads (FASTA reading, per-genome sort/filter step)\n"
+		"      --sa=WHERE       device (default) or host: who sorts the reference's suffixes\n"
 		"      --ingest=HOW     packed (default: 2-bit codes made while reading, a quarter of the\n"
 		"                       bytes uploaded) or bytes\n"
 		"      --timing         Print where the wall-clock went to stderr\n"
@@ -317,7 +318,7 @@ int main(int argc, char *argv[])
 	const char *seed_env = getenv("PHYLONIUM_AMD_SEED");
 	std::mt19937 prng(seed_env ? (std::mt19937::result_type)strtoul(seed_env, nullptr, 10) : rd());
 	int version_flag = 0, timing = 0, flags = 0, device = 0;
-	bool packed_ingest = true;
+	bool packed_ingest = true, host_sa = false;
 	long threads = 0;
 	bool two_pass = false;
 	unsigned long bootstrap = 0;
@@ -335,6 +336,7 @@ int main(int argc, char *argv[])
 										   {"version", no_argument, &version_flag, 1},
 										   {"timing", no_argument, &timing, 1},
 										   {"ingest", required_argument, NULL, 0},
+										   {"sa", required_argument, NULL, 0},
 										   {0, 0, 0, 0}};
 	for (;;) {
 		int option_index = 0;
@@ -344,6 +346,10 @@ int main(int argc, char *argv[])
 			case 0: {
 				std::string name = long_options[option_index].name;
 				if (name == "complete-deletion") flags |= F_COMPLETE_DELETION;
+				if (name == "sa") {
+					if (strcasecmp(optarg, "host") == 0) host_sa = true;
+					else if (strcasecmp(optarg, "device") != 0) usage(EXIT_FAILURE);
+				}
 				if (name == "ingest") {
 					if (strcasecmp(optarg, "bytes") == 0) packed_ingest = false;
 					else if (strcasecmp(optarg, "packed") != 0) usage(EXIT_FAILURE);
@@ -431,17 +437,22 @@ int main(int argc, char *argv[])
 	size_t ref_idx;
 	if (reference_name.empty()) ref_idx = pick_first_pass(q, pk, flags);
 	else ref_idx = std::find(files.begin(), files.end(), reference_name) - files.begin();
-	// The reference's suffix array (the longest host step, one thread) is built while the device
-	// context finishes starting and the genomes are uploaded.
-	if (packed_ingest) q[ref_idx].nucl = phyfasta::unpack_genome(pk[ref_idx]);
-	std::vector<int64_t> sa(2 * q[ref_idx].nucl.size() + 1);
+	// The reference's suffix array: built by the library on the device (the default), or — `--sa=host`, the north
+	// star's placement — on the host cores, on a thread of its own while the genomes are uploaded.
+	std::vector<int64_t> sa;
 	int sa_rc = 0;
-	std::thread sa_thread([&] { sa_rc = phylo_host_reference_suffix_array(q[ref_idx].nucl.data(), q[ref_idx].nucl.size(), sa.data()); });
+	std::thread sa_thread;
+	if (host_sa) {
+		if (packed_ingest) q[ref_idx].nucl = phyfasta::unpack_genome(pk[ref_idx]);
+		sa.resize(2 * q[ref_idx].nucl.size() + 1);
+		sa_thread = std::thread([&] { sa_rc = phylo_host_reference_suffix_array(q[ref_idx].nucl.data(), q[ref_idx].nucl.size(), sa.data()); });
+	}
 
 	r.q = &q;
 	r.flags = flags;
 	r.refpos_file = refpos_file;
 	if (threads > 0) ok(r, phylo_set_option(r.ctx, "host_threads", threads));
+	ok(r, phylo_set_option(r.ctx, "sa_builder", host_sa ? 0 : 1));
 	if (packed_ingest) {
 		std::vector<const uint32_t *> q2(q.size()), bad(q.size());
 		std::vector<size_t> nbad(q.size());
@@ -462,10 +473,10 @@ int main(int argc, char *argv[])
 		ok(r, phylo_set_genomes(r.ctx, q.size(), seq.data(), GLEN.data()));
 	}
 	t_upload = now_s();
-	sa_thread.join();
+	if (sa_thread.joinable()) sa_thread.join();
 	double t_sa = now_s();
 
-	Matrix m = process(r, ref_idx, sa_rc == 0 ? sa.data() : nullptr);
+	Matrix m = process(r, ref_idx, host_sa && sa_rc == 0 ? sa.data() : nullptr);
 	std::vector<int64_t>().swap(sa);
 	if (two_pass) {
 		ref_idx = pick_second_pass(q.size(), m);
@@ -484,11 +495,11 @@ int main(int argc, char *argv[])
 		fprintf(stderr,
 				"timing: genomes %zu  bases %.0f  total %.3f s | read %.3f (%zu threads, %s)  wait-for-device %.3f  upload %.3f (device memory %.3f  copies %.3f  "
 				"install %.3f)  "
-				"wait-for-suffix-array %.3f (built on a thread since the files were read)  process+print %.3f  "
-				"[suffix array hand-over %.3f  index on device %.3f  anchor %.3f  compare %.3f]\n",
+				"wait-for-suffix-array %.3f (%s)  process+print %.3f  "
+				"[suffix array %.3f  rest of the index %.3f  anchor %.3f  compare %.3f]\n",
 				q.size(), bases, t_done - t_start, t_read - t_start, read_threads, packed_ingest ? "packed" : "bytes", t_ctx - t_read, t_upload - t_ctx, stat("ms:genomes_alloc"), stat("ms:genomes_copy"),
 				stat("ms:genomes_install"),
-				t_sa - t_upload, t_done - t_sa, stat("ms:ref_suffix_array"), stat("ms:ref_total") - stat("ms:ref_suffix_array"),
+				t_sa - t_upload, host_sa ? "built on a host thread since the files were read" : "built on the device with the index", t_done - t_sa, stat("ms:ref_suffix_array"), stat("ms:ref_total") - stat("ms:ref_suffix_array"),
 				stat("ms:anchor_total"), stat("ms:compare_total"));
 	}
 	phylo_ctx_destroy(r.ctx);

@@ -13,7 +13,8 @@ warnings and exit status), laid out for N ranks:
     every GPU
     — the layout of each block is what `phylo_set_genomes_device` wants, so the gathered
     buffer is used as it lands, without a copy;
-  * the rank that read the reference builds its suffix array on the host cores (north star)
+  * every rank's GPU sorts the reference's suffixes for itself (12 ms at 10 M, `csrc/sa_kernels.hip`); with
+    `--sa host` the rank that read the reference builds the suffix array on the host cores (north star)
     while the genomes travel, and broadcasts it;
   * `dist.process_sharded`: phase A on the rank's block of queries, homology lists
     all-gathered device to device, phase B on the rank's pair tiles, matrices all-reduced;
@@ -93,6 +94,9 @@ def main(argv=None):
     ap.add_argument("--ani", action="store_true", help="average nucleotide identity")
     ap.add_argument("-t", "--threads", type=int, default=0, help="host threads per rank")
     ap.add_argument("--timing", action="store_true", help="where the wall-clock went (stderr, rank 0)")
+    ap.add_argument("--sa", default="device", choices=["device", "host"],
+                    help="who sorts the reference's suffixes: every rank's GPU for itself (default), or the host cores of the "
+                         "rank that read the reference, broadcast to the others (the north star's placement)")
     ap.add_argument("--backend", default=os.environ.get("PHYLO_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="gloo: collectives through host memory (tests on a box with fewer GPUs than ranks)")
     args = ap.parse_args(argv)
@@ -210,7 +214,7 @@ def main(argv=None):
     ns = 2 * lens[ref_idx] + 1
     sa_box = {}
     sa_thread = None
-    if rank == owner:
+    if rank == owner and args.sa == "host":
         def build_sa():
             try:
                 sa_box["sa"] = api.host_reference_suffix_array(mine[ref_idx - b0])
@@ -266,17 +270,18 @@ def main(argv=None):
     if sa_thread is not None:
         sa_thread.join()
         sa = sa_box.get("sa")
-    if not all_ok(rank != owner or sa is not None, "the reference's suffix array could not be built"):
+    if not all_ok(args.sa != "host" or rank != owner or sa is not None, "the reference's suffix array could not be built"):
         ctx.close()
         if world > 1:
             td.destroy_process_group()
         return 1
-    if world > 1:
+    if world > 1 and args.sa == "host":
         sa_t = torch.from_numpy(sa.astype(np.int32)).to(cdev) if rank == owner else torch.empty(ns, dtype=torch.int32, device=cdev)
         td.broadcast(sa_t, src=owner)
         if rank != owner:
             sa = sa_t.cpu().numpy().astype(np.int64)
     t_sa = time.perf_counter()
+    ctx.set_option("sa_builder", 0 if args.sa == "host" else 1)
     ctx.set_reference(ref_idx, sa=sa)
     del sa
     t_index = time.perf_counter()
@@ -299,7 +304,7 @@ def main(argv=None):
             print(f"timing: ranks {world}  genomes {n}  bases {sum(lens)}  total {t_done - t_start:.3f} s | "
                   f"imports + process group {t_up - t_start:.3f}  read own block {t_read - t_up:.3f} ({threads} threads, {b1 - b0} files)  "
                   f"lengths + wait-for-device {t_ctx - t_read:.3f}  upload + all-gather {t_upload - t_ctx:.3f}  "
-                  f"wait-for-suffix-array + broadcast {t_sa - t_upload:.3f} (built on rank {owner})  "
+                  f"wait-for-suffix-array + broadcast {t_sa - t_upload:.3f} ({'built on rank %d' % owner if args.sa == 'host' else 'none: every GPU builds its own with the index'})  "
                   f"index on device {t_index - t_sa:.3f}  anchor + exchange + compare {t_path - t_index:.3f}  "
                   f"print {t_done - t_path:.3f}", file=sys.stderr)
     ctx.close()

@@ -101,6 +101,7 @@ def test_packed_and_byte_ingest_print_the_same(tmp_path):
         a = run([*extra, *files], tmp_path)
         b = run(["--ingest=bytes", *extra, *files], tmp_path)
         assert a == b and a[1].startswith("5\n")
+        assert run(["--sa=host", *extra, *files], tmp_path) == a  # the suffix array from the host cores (default: the device)
     a = run(["-p", "pa.txt", *files], tmp_path)
     b = run(["--ingest=bytes", "-p", "pb.txt", *files], tmp_path)
     assert a == b and (tmp_path / "pa.txt").read_bytes() == (tmp_path / "pb.txt").read_bytes()
@@ -240,6 +241,16 @@ def test_mgpu_one_rank_matches_the_driver(tmp_path):
         assert out1 == out0 and rc1 == rc0, err1[-2000:]
     rc, out, err = run_mgpu(["--timing", *files], tmp_path)
     assert "timing: ranks 1" in err
+    rc, out2, err = run_mgpu(["--sa", "host", *files], tmp_path)  # the suffix array from the host cores
+    assert out2 == out
+
+
+def test_mgpu_two_ranks_with_the_host_suffix_array(tmp_path):
+    """--sa host: the rank that read the reference sorts its suffixes on the host cores and broadcasts the array."""
+    gs, names, files = _mgpu_set(tmp_path)
+    rc0, out0, err0 = run(files, tmp_path)
+    rc, out, err = run_mgpu(["--sa", "host", *files], tmp_path, ranks=2, backend="gloo")
+    assert out == out0 and rc == rc0, err[-2000:]
 
 
 def test_mgpu_two_ranks_on_one_gpu(tmp_path):

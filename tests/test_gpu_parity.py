@@ -437,6 +437,43 @@ def test_export_import_roundtrip(ctx):
     assert (s == s2).all() and (h == h2).all()
 
 
+def test_device_suffix_array_equals_the_host_one(ctx):
+    """The suffix array built on the device (prefix doubling over radix sorts, csrc/sa_kernels.hip) is THE suffix array
+    of S — equal, entry by entry, to the host builder's (itself equal to the oracle's, tests/test_abi_cpu.py): random
+    sequence, contigs ('!'), inversions, 70 kbp copies, a run of one letter, two-letter periods, tiny inputs."""
+    rng = np.random.default_rng(11)
+    a = synth.random_base(70000, rng)
+    cases = [synth.random_base(300000, rng),
+             synth.make_genomes(2, 60000, seed=5, d_range=(0.05, 0.1), inv_frac=0.1, contigs=6)[1],
+             np.concatenate([a, synth.random_base(5000, rng), a, synth.random_base(100, rng), a[:30000]]),
+             np.frombuffer(b"A" * 40000, np.uint8), np.frombuffer(b"AC" * 20000 + b"!" + b"CA" * 3000, np.uint8),
+             np.frombuffer(b"ACGT!ACGT!!ACGT", np.uint8), np.frombuffer(b"A", np.uint8), np.frombuffer(b"TTTTTTTTTTTTTTTTTTTTTTTTTTTTTT", np.uint8),
+             np.concatenate([synth.random_base(20, rng)] * 2000)]
+    for k, g in enumerate(cases):
+        ctx.set_genomes([g, synth.random_base(100, rng)])
+        ctx.set_option("sa_builder", 1)
+        ctx.set_reference(0)
+        st = ctx.stats()
+        assert st["ref:sa_on_device"] == 1
+        dev = ctx.reference_suffix_array()
+        refb = bytes(np.asarray(g, np.uint8))
+        want = api.host_suffix_array(refb + b"#" + O.revcomp(refb))
+        assert np.array_equal(dev, want), f"case {k}"
+        if k in (2, 3, 8):
+            assert st["ref:sa_rounds"] >= 5  # the repeats kept the doubling going
+        ctx.set_option("sa_builder", 0)
+        ctx.set_reference(0)
+        assert ctx.stats()["ref:sa_on_device"] == 0 and np.array_equal(ctx.reference_suffix_array(), want)
+    ctx.set_option("sa_builder", 1)
+    # a byte the packing has no code for: the host builders take over, the array is still the array
+    odd = np.frombuffer(b"ACGTNNACGTACGTTTGACA", np.uint8)
+    ctx.set_genomes([odd, synth.random_base(50, rng)])
+    ctx.set_reference(0)
+    ob = bytes(odd)
+    assert ctx.stats()["ref:sa_on_device"] == 0
+    assert np.array_equal(ctx.reference_suffix_array(), api.host_suffix_array(ob + b"#" + O.revcomp(ob)))
+
+
 def test_packed_genomes_are_the_same_genomes(ctx):
     """phylo_set_genomes_packed: Q2 copied into place, the byte arena written by the device.  The genomes read back
     byte for byte and both phases give what they give after phylo_set_genomes — for lengths around the 16-base

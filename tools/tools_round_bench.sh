@@ -1,3 +1,6 @@
+#!/bin/bash
+# The round's bench lines and wall-clock runs, on the GPU box: gpurun -- 'bash tools/tools_round_bench.sh'
+# (files land in gpurun_out/final; the ones kept are copied to profiles/ by hand).
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/final
@@ -12,12 +15,5 @@ python bench.py --gpus 2 --workload small --steps 20 --warmup 3 > gpurun_out/fin
 python bench.py --workload c4 --steps 20 --warmup 3 --cpu-sample 0 --emulate-rank 0/8 --emulate-exchange > gpurun_out/final/emu_c4_rank0of8.json 2> gpurun_out/final/emu.err
 python tools/tools_wallclock.py --workload c3 --out gpurun_out/final/r02_wallclock_c3.json > /dev/null 2>&1
 python tools/tools_wallclock.py --workload c4 --out gpurun_out/final/r02_wallclock_c4.json > /dev/null 2>&1
-for f in gpurun_out/final/*.json; do echo $f; python -c "
-import json,sys
-try:
-    d=json.loads(open('$f').read().strip().splitlines()[-1]) if not '$f'.endswith('wallclock_c3.json') and not '$f'.endswith('wallclock_c4.json') else None
-except Exception as e: d=None; print('ERR',e)
-if d: print(d.get('value'), d.get('ms_per_step'), d.get('ms_per_step_noprofile'), d.get('n_gpus'), d.get('check'), (d.get('roofline') or {}).get('frac'), (d.get('cpu_baseline') or {}).get('value'))
-"; done
+python tools/tools_round_summary.py gpurun_out/final
 grep -h "emulated\|check" gpurun_out/final/*.err | head
-grep -h '"timing"' gpurun_out/final/r02_wallclock_c4.json | cut -c1-330
