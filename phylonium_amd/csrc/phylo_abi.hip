@@ -867,13 +867,16 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 	if (!sa && c->opt_sa_builder == 1) {
 		// esa.cxx:74's divsufsort64, on the device (sa_kernels.hip)
 		DevBuf<uint8_t> scratch;
-		HIPOK(c, scratch.ensure(suffix_array_scratch_bytes(ns)));
-		HIPOK(c, hipMemsetAsync(c->d_SA.p + ns, 0, 16, st));
-		const int rc = device_suffix_array(c->d_S.p, ns, c->d_SA.p, scratch.p, &sa_rounds, st);
-		HIPOK(c, hipStreamSynchronize(st));
-		scratch.release();
-		if (rc == 2) return c->fail("suffix array on the device: %s", hipGetErrorString(hipGetLastError()));
-		sa_on_device = rc == 0; // rc == 1: a byte outside ! # A C G T — the host builders order any bytes
+		if (scratch.ensure(suffix_array_scratch_bytes(ns)) == hipSuccess) { // ~41 bytes per suffix
+			HIPOK(c, hipMemsetAsync(c->d_SA.p + ns, 0, 16, st));
+			const int rc = device_suffix_array(c->d_S.p, ns, c->d_SA.p, scratch.p, &sa_rounds, st);
+			HIPOK(c, hipStreamSynchronize(st));
+			scratch.release();
+			if (rc == 2) return c->fail("suffix array on the device: %s", hipGetErrorString(hipGetLastError()));
+			sa_on_device = rc == 0; // rc == 1: a byte outside ! # A C G T — the host builders order any bytes
+		} else {
+			(void)hipGetLastError(); // no room for the working set next to the genomes: the host cores sort
+		}
 	}
 	auto host_sa = [&]() -> int { // the array on the host, for the steps that walk it there
 		if (!SA.empty()) return 0;
