@@ -492,9 +492,13 @@ def format_phylip(names, subst, homologs, kind="jc"):
     s = np.ascontiguousarray(subst, np.uint64)
     h = np.ascontiguousarray(homologs, np.uint64)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
-    need = load().phylo_format_phylip(n, arr, p(s), p(h), KIND[kind], None, 0)
+    # one pass when the text fits the guess (a number takes 12 bytes at most: "  -1.2345e-123" never occurs, "  nan" is shorter)
+    need = n * (n * 14 + 8) + sum(len(x) for x in enc) + 32
     buf = C.create_string_buffer(need)
-    load().phylo_format_phylip(n, arr, p(s), p(h), KIND[kind], buf, need)
+    got = load().phylo_format_phylip(n, arr, p(s), p(h), KIND[kind], buf, need)
+    if got > need:
+        buf = C.create_string_buffer(got)
+        load().phylo_format_phylip(n, arr, p(s), p(h), KIND[kind], buf, got)
     return buf.value.decode()
 
 

@@ -2408,22 +2408,41 @@ double phylo_estimate(int kind, uint64_t subst, uint64_t homologs, int zero_on_e
 size_t phylo_format_phylip(size_t n, const char *const *names, const uint64_t *subst, const uint64_t *homologs,
 						   int kind, char *out, size_t cap)
 {
-	std::ostringstream o;
-	o << n << std::endl;
-	o.precision(4);
-	if (kind == 2) o << std::dec;
-	else o << std::scientific;
-	for (size_t i = 0; i < n; i++) {
-		o << names[i];
-		for (size_t j = 0; j < n; j++) {
-			double d = (i == j) ? 0.0 : phylo_estimate(kind, subst[i * n + j], homologs[i * n + j], 0);
-			o << "  " << d;
+	// just_print, io.cxx:141-163: precision 4 with std::scientific ("%.4e"), or the default float format for ANI
+	// (std::dec does not touch it: "%.4g").  Row blocks are formatted on the host threads and joined in order.
+	const char *fmt = kind == 2 ? "  %.4g" : "  %.4e";
+	unsigned hw = std::thread::hardware_concurrency();
+	const size_t nt = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(hw ? hw : 1, 16), n / 16 + 1));
+	std::vector<std::string> part(nt);
+	ThreadFan fan{nt};
+	fan(nt, [&](size_t t) {
+		std::string &o = part[t];
+		const size_t i0 = n * t / nt, i1 = n * (t + 1) / nt;
+		o.reserve((i1 - i0) * (n * 12 + 32));
+		char buf[64];
+		for (size_t i = i0; i < i1; i++) {
+			o += names[i];
+			for (size_t j = 0; j < n; j++) {
+				const double d = (i == j) ? 0.0 : phylo_estimate(kind, subst[i * n + j], homologs[i * n + j], 0);
+				o.append(buf, (size_t)snprintf(buf, sizeof buf, fmt, d));
+			}
+			o += '\n';
 		}
-		o << std::endl;
+	});
+	std::string head = std::to_string(n) + "\n";
+	size_t need = head.size() + 1;
+	for (auto &p : part) need += p.size();
+	if (out && cap >= need) {
+		char *w = out;
+		memcpy(w, head.data(), head.size());
+		w += head.size();
+		for (auto &p : part) {
+			memcpy(w, p.data(), p.size());
+			w += p.size();
+		}
+		*w = 0;
 	}
-	std::string s = o.str();
-	if (out && cap >= s.size() + 1) memcpy(out, s.c_str(), s.size() + 1);
-	return s.size() + 1;
+	return need;
 }
 
 } // extern "C"

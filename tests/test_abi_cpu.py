@@ -110,6 +110,15 @@ def test_estimates_and_phylip(lib):
     names = ["a", "bb", "c c"]
     for kind in ("jc", "raw", "ani"):
         assert api.format_phylip(names, S, H, kind) == O.phylip(names, S, H, kind)
+    # a matrix large enough for several row blocks (formatted on several threads, joined in order), with nan cells
+    rng = np.random.default_rng(2)
+    n = 83
+    H = rng.integers(0, 5_000_000, (n, n)).astype(np.uint64)
+    H[rng.random((n, n)) < 0.05] = 0
+    S = (H * rng.random((n, n))).astype(np.uint64)
+    names = [f"genome_{i}" for i in range(n)]
+    for kind in ("jc", "raw", "ani"):
+        assert api.format_phylip(names, S, H, kind) == O.phylip(names, S, H, kind)
 
 
 def test_host_fasta_reader_and_reference_choice(lib, tmp_path):
