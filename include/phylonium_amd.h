@@ -95,6 +95,13 @@ int phylo_set_genomes_device(phylo_ctx *ctx, size_t n, const void *dev_base, con
  * fused with the packing). */
 int phylo_set_genomes_packed(phylo_ctx *ctx, size_t n, const uint32_t *const *q2, const size_t *len,
 							 const uint32_t *const *bad, const size_t *nbad);
+/* The packed form already in device memory (one buffer for all genomes: word w holds the codes of bytes
+ * [16w, 16w + 16) of the layout phylo_set_genomes_device describes — genome j at byte offset offsets[j] — and 0
+ * everywhere else; the buffer must reach 16 bytes' worth of words past the last genome's padding).  Copied; the
+ * byte form is written by the device.  What a rank of a multi-GPU run holds after gathering the other ranks'
+ * packed blocks. */
+int phylo_set_genomes_packed_device(phylo_ctx *ctx, size_t n, const void *dev_q2, const uint64_t *offsets,
+									const uint64_t *lens, const uint32_t *const *bad, const size_t *nbad);
 /* Genome i as bytes (len[i] of them, no terminator), copied from the device: a host that ingested packed
  * genomes needs the reference's bytes for the suffix array, and all of them for -p. */
 int phylo_get_genome(phylo_ctx *ctx, size_t i, char *buf);

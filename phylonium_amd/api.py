@@ -23,7 +23,7 @@ PHOM = np.dtype([("index_reference", "<u8"), ("index_reference_projected", "<u8"
 # every symbol include/phylonium_amd.h declares
 SYMBOLS = [
     "phylo_ctx_create", "phylo_ctx_destroy", "phylo_last_error", "phylo_set_option", "phylo_get_stat", "phylo_reference_cache_quirk",
-    "phylo_reset_stats", "phylo_stat_keys", "phylo_set_genomes", "phylo_set_genomes_device", "phylo_set_genomes_packed", "phylo_get_genome",
+    "phylo_reset_stats", "phylo_stat_keys", "phylo_set_genomes", "phylo_set_genomes_device", "phylo_set_genomes_packed", "phylo_set_genomes_packed_device", "phylo_get_genome",
     "phylo_set_reference", "phylo_threshold", "phylo_reference_suffix_array", "phylo_anchor", "phylo_get_homologies", "phylo_set_homologies",
     "phylo_export_homologies", "phylo_import_homologies", "phylo_export_packed", "phylo_import_packed",
     "phylo_export_packed_device", "phylo_attach_packed_device", "phylo_compare_device",
@@ -63,6 +63,7 @@ def load():
     L.phylo_set_genomes.argtypes = [vp, sz, vp, vp]
     L.phylo_set_genomes_device.argtypes = [vp, sz, vp, vp, vp]
     L.phylo_set_genomes_packed.argtypes = [vp, sz, vp, vp, vp, vp]
+    L.phylo_set_genomes_packed_device.argtypes = [vp, sz, vp, vp, vp, vp, vp]
     L.phylo_get_genome.argtypes = [vp, sz, vp]
     L.phylo_set_reference.argtypes = [vp, sz, vp, sz]
     L.phylo_reference_suffix_array.argtypes = [vp, vp]
@@ -193,6 +194,20 @@ class Context:
         self._chk(self.L.phylo_set_genomes_packed(self.h, n, qp, lens, bp, nb))
         self.n = n
         self.lengths = [int(p[1]) for p in packed]
+
+    def set_genomes_packed_device(self, dev_q2_ptr, offsets, lens, bad):
+        """dev_q2_ptr: device buffer of 2-bit codes laid out as the arena's Q2 (word w = arena bytes [16w, 16w+16));
+        offsets/lens as set_genomes_device; bad: per genome the ascending separator positions."""
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        ln = np.ascontiguousarray(lens, dtype=np.uint64)
+        n = off.size
+        bl = [np.ascontiguousarray(b, np.uint32) for b in bad]
+        bp = (C.c_void_p * n)(*[a.ctypes.data for a in bl])
+        nb = (C.c_size_t * n)(*[a.size for a in bl])
+        self._chk(self.L.phylo_set_genomes_packed_device(self.h, n, C.c_void_p(int(dev_q2_ptr)), off.ctypes.data_as(C.c_void_p),
+                                                         ln.ctypes.data_as(C.c_void_p), bp, nb))
+        self.n = n
+        self.lengths = [int(x) for x in ln]
 
     def get_genome(self, i):
         out = np.empty(self.lengths[i], np.uint8)

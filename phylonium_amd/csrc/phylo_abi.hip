@@ -774,6 +774,59 @@ int phylo_set_genomes_packed(phylo_ctx *c, size_t n, const uint32_t *const *q2, 
 	return 0;
 }
 
+// The packed genomes already in device memory, laid out as the arena's Q2: word w of dev_q2 holds the codes of
+// arena bytes [16w, 16w + 16), genome j at byte offset offsets[j] (the rules of phylo_set_genomes_device), codes
+// outside the genomes and at the separator positions 0.  A rank of a multi-GPU run gathers exactly this.
+int phylo_set_genomes_packed_device(phylo_ctx *c, size_t n, const void *dev_q2, const uint64_t *offsets, const uint64_t *lens,
+									const uint32_t *const *bad, const size_t *nbad)
+{
+	if (!c) return 1;
+	if (n && (!dev_q2 || !offsets || !lens || !bad || !nbad)) return c->fail("null genome arrays");
+	HIPOK(c, hipSetDevice(c->device));
+	double t0 = now_ms();
+	std::vector<uint32_t> boff(n + 1, 0), blist;
+	uint64_t tot = 64;
+	for (size_t j = 0; j < n; j++) {
+		if (offsets[j] % 64 || offsets[j] < 64)
+			return c->fail("genome %zu: device offset must be a multiple of 64 and >= 64", j);
+		if (j && offsets[j] < offsets[j - 1] + (lens[j - 1] + 63) / 64 * 64 + 64)
+			return c->fail("genome %zu: device offsets must ascend, each genome followed by at least 64 bytes of padding", j);
+		if (lens[j] >= 0xfff00000ull) return c->fail("genome %zu is too long (%llu >= 2^32-2^20)", j, (unsigned long long)lens[j]);
+		if (nbad[j] && !bad[j]) return c->fail("genome %zu: null position list", j);
+		for (size_t k = 0; k < nbad[j]; k++)
+			if (bad[j][k] >= lens[j] || (k && bad[j][k] <= bad[j][k - 1]))
+				return c->fail("genome %zu: separator positions must ascend and lie inside the genome", j);
+		if (blist.size() + nbad[j] + 1 >= 0xffffffffull) return c->fail("more than 2^32 non-ACGT positions");
+		blist.insert(blist.end(), bad[j], bad[j] + nbad[j]);
+		boff[j + 1] = (uint32_t)blist.size();
+		tot = offsets[j] + (lens[j] + 63) / 64 * 64 + 64;
+	}
+	tot += 256;
+	if (tot / 16 + 64 >= 0xffffffffull) return c->fail("genome buffer too large for 32-bit word offsets");
+	const size_t words = (size_t)(tot / 16);
+	c->n = n;
+	c->goff.assign(offsets, offsets + n);
+	c->glen.assign(lens, lens + n);
+	HIPOK(c, c->genomes_store.ensure(tot));
+	HIPOK(c, c->d_Q2.ensure(words + 64));
+	HIPOK(c, hipMemsetAsync(c->d_Q2.p + words, 0, 64 * 4, c->stream));
+	HIPOK(c, hipMemcpyAsync(c->d_Q2.p, dev_q2, words * 4, hipMemcpyDeviceToDevice, c->stream));
+	c->d_genomes = c->genomes_store.p;
+	c->own_genomes = true;
+	if (install_layout(c, false)) return 1;
+	HIPOK(c, c->d_QBAD.ensure(blist.size() + 2));
+	HIPOK(c, c->d_qbad_off.ensure(n + 2));
+	if (!blist.empty()) HIPOK(c, hipMemcpyAsync(c->d_QBAD.p, blist.data(), blist.size() * 4, hipMemcpyHostToDevice, c->stream));
+	HIPOK(c, hipMemcpyAsync(c->d_qbad_off.p, boff.data(), (n + 1) * 4, hipMemcpyHostToDevice, c->stream));
+	launch_unpack2(c->d_Q2.p, c->d_goff.p, c->d_glen.p, (uint32_t)n, tot, c->genomes_store.p, c->d_QBAD.p, c->d_qbad_off.p,
+				   (uint32_t)blist.size(), c->stream);
+	HIPOK(c, hipGetLastError());
+	HIPOK(c, hipStreamSynchronize(c->stream));
+	c->stats["ms:genomes_install"] += now_ms() - t0;
+	c->stats["count:genome_non_acgt"] = (double)blist.size();
+	return 0;
+}
+
 int phylo_get_genome(phylo_ctx *c, size_t i, char *buf)
 {
 	if (!c) return 1;

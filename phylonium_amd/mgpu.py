@@ -7,12 +7,12 @@ What phylonium's `main` does around process() (/root/reference/src/phylonium.cxx
 name clean-up, reference choice, one pass, print_matrix of src/io.cxx:106-163 with its
 warnings and exit status), laid out for N ranks:
 
-  * the files are split into contiguous blocks balanced by size; a rank reads and filters
-    only its block (library host helper, several threads) and uploads it into its block of
-    the genome buffer; one in-place all-gather (RCCL over xGMI) makes every genome resident on
-    every GPU
-    — the layout of each block is what `phylo_set_genomes_device` wants, so the gathered
-    buffer is used as it lands, without a copy;
+  * the files are split into contiguous blocks balanced by size; a rank reads only its block —
+    mapped files straight to 2-bit codes (library host helper, several threads) — and uploads the
+    codes into its block of the buffer; one in-place all-gather (RCCL over xGMI) makes every genome
+    resident on every GPU, a quarter of the bytes of the byte form
+    — the layout of each block is what `phylo_set_genomes_packed_device` wants, and the byte form
+    the other kernels read is written by each GPU for itself;
   * every rank's GPU sorts the reference's suffixes for itself (12 ms at 10 M, `csrc/sa_kernels.hip`); with
     `--sa host` the rank that read the reference builds the suffix array on the host cores (north star)
     while the genomes travel, and broadcasts it;
@@ -156,7 +156,8 @@ def main(argv=None):
     failed = n
     message = ""
     try:
-        mine = api.read_fasta(files[b0:b1], threads) if b1 > b0 else []
+        # mapped files -> 2-bit codes + separator positions (a quarter of the bytes to upload and to gather)
+        mine = api.read_fasta_packed(files[b0:b1], threads) if b1 > b0 else []
     except api.PhyloniumError as e:
         mine, message = [], str(e)
         failed = b0 + next((k for k, f in enumerate(files[b0:b1]) if message.startswith(f + ":")), 0)
@@ -164,7 +165,7 @@ def main(argv=None):
     names = [api.genome_name(f) for f in files]
     lens_t = torch.zeros(n + 1, dtype=torch.int64)
     for k, g in enumerate(mine):
-        lens_t[b0 + k] = g.size
+        lens_t[b0 + k] = g[1]
     lens_t[n] = -failed  # the first bad file in command-line order wins, as when they are read in order
     if world > 1:
         fail_t = lens_t[n:].clone().to(cdev)
@@ -217,7 +218,7 @@ def main(argv=None):
     if rank == owner and args.sa == "host":
         def build_sa():
             try:
-                sa_box["sa"] = api.host_reference_suffix_array(mine[ref_idx - b0])
+                sa_box["sa"] = api.host_reference_suffix_array(api.unpack_genome(*mine[ref_idx - b0]))
             except Exception as e:  # reported through all_ok below
                 sa_box["error"] = e
         sa_thread = threading.Thread(target=build_sa)
@@ -232,37 +233,49 @@ def main(argv=None):
         return 1
     ctx = box["ctx"]
     t_ctx = time.perf_counter()
+    capw = cap // 16  # block_layout's offsets are multiples of 64 bytes: words of 16 codes line up with them
     if world == 1 or on_rccl:
-        # the own genomes go straight from the reader's buffers into the own block of the buffer every
+        # the own genomes' codes go straight from the reader's buffers into the own block of the buffer every
         # rank will hold (no staging copy on the host), and the all-gather fills the other blocks in place
-        genomes = torch.zeros(world * cap, dtype=torch.uint8, device=device)
-        for k, g in enumerate(mine):
-            if g.size:
-                o = int(offs[b0 + k])
-                genomes[o:o + g.size].copy_(torch.from_numpy(g))
+        q2_all = torch.zeros(world * capw + 64, dtype=torch.int32, device=device)
+        for k, (q2, ln, bad) in enumerate(mine):
+            if q2.size:
+                o = int(offs[b0 + k]) // 16
+                q2_all[o:o + q2.size].copy_(torch.from_numpy(q2.view(np.int32)))
         if world > 1:
-            td.all_gather_into_tensor(genomes, genomes[rank * cap:(rank + 1) * cap])
+            td.all_gather_into_tensor(q2_all[:world * capw], q2_all[rank * capw:(rank + 1) * capw])
     else:
-        stage = torch.zeros(cap, dtype=torch.uint8)
+        stage = torch.zeros(capw, dtype=torch.int32)
         sv = stage.numpy()
-        for k, g in enumerate(mine):
-            o = int(offs[b0 + k]) - rank * cap
-            sv[o:o + g.size] = g
-        gathered = torch.empty(world * cap, dtype=torch.uint8)
+        for k, (q2, ln, bad) in enumerate(mine):
+            o = (int(offs[b0 + k]) - rank * cap) // 16
+            sv[o:o + q2.size] = q2.view(np.int32)
+        gathered = torch.empty(world * capw, dtype=torch.int32)
         td.all_gather_into_tensor(gathered, stage)
-        genomes = gathered.to(device)
+        q2_all = torch.zeros(world * capw + 64, dtype=torch.int32, device=device)
+        q2_all[:world * capw].copy_(gathered)
+    # the separator positions (a few per genome) travel as objects
+    bad_mine = [g[2] for g in mine]
+    if world > 1:
+        parts = [None] * world
+        td.all_gather_object(parts, bad_mine)
+        bad_all = [b for part in parts for b in part]
+    else:
+        bad_all = bad_mine
     torch.cuda.synchronize(device)
     if args.threads:
         ctx.set_option("host_threads", args.threads)
-    ctx.set_genomes_device(genomes.data_ptr(), [int(x) for x in offs], lens)
+    ctx.set_genomes_packed_device(q2_all.data_ptr(), [int(x) for x in offs], lens, bad_all)
     if not args.reference:
         # "the first genome equal to the chosen one" (phylonium.cxx:372-378): only a same-named copy of the
         # same length can precede it; its suffix array is the same array, so the thread above is not redone
-        at = lambda j: genomes[int(offs[j]):int(offs[j]) + lens[j]]
+        at = lambda j: q2_all[int(offs[j]) // 16:int(offs[j]) // 16 + (lens[j] + 15) // 16]
         for i in range(ref_idx):
-            if names[i] == names[ref_idx] and lens[i] == lens[ref_idx] and torch.equal(at(i), at(ref_idx)):
+            if (names[i] == names[ref_idx] and lens[i] == lens[ref_idx] and np.array_equal(bad_all[i], bad_all[ref_idx])
+                    and torch.equal(at(i), at(ref_idx))):
                 ref_idx = i
                 break
+    del q2_all  # copied by the context
     t_upload = time.perf_counter()
 
     # ── suffix array to every rank ──
