@@ -444,14 +444,23 @@ def read_fasta_packed(paths, threads=16):
     rc = L.phylo_host_read_fasta_packed(n, arr, threads, q2, lens, bad, nbad, C.byref(arena))
     if rc:
         raise PhyloniumError((L.phylo_last_error(None) or b"").decode())
-    out = []
-    for i in range(n):
-        words = (lens[i] + 15) // 16
-        a = np.ctypeslib.as_array(C.cast(q2[i], C.POINTER(C.c_uint32)), shape=(words,)).copy() if words else np.zeros(0, np.uint32)
-        b = np.ctypeslib.as_array(C.cast(bad[i], C.POINTER(C.c_uint32)), shape=(nbad[i],)).copy() if nbad[i] else np.zeros(0, np.uint32)
-        out.append((a, int(lens[i]), b))
-    L.phylo_host_free_packed(arena)
-    return out
+    class _Arena:  # the reader's one allocation: released when the last array that points into it is
+        def __init__(self, handle):
+            self.handle = handle
+
+        def __del__(self):
+            L.phylo_host_free_packed(self.handle)
+
+    keep = _Arena(arena)
+
+    def view(ptr, count):
+        if not count:
+            return np.zeros(0, np.uint32)
+        raw = (C.c_uint32 * count).from_address(ptr)
+        raw._arena = keep  # numpy holds `raw`, `raw` holds the arena
+        return np.ctypeslib.as_array(raw)
+
+    return [(view(q2[i], (lens[i] + 15) // 16), int(lens[i]), view(bad[i], nbad[i])) for i in range(n)]
 
 
 def pack_genome(g):
