@@ -518,8 +518,11 @@ def main():
             roof_valu = {"kernel": pk, "bound": "valu", "achieved": round(inst / (t_ms * 1e-3) / 1e9, 1), "peak": peak,
                          "unit": "G wave-instructions/s", "frac": round(inst / (t_ms * 1e-3) / 1e9 / peak, 4),
                          "wave_instructions_per_launch": inst, "avg_launch_ms": round(t_ms, 4),
-                         "note": "instruction count from the kernel's shape (tiles x windows x instructions per window); "
-                                 "profiles/r02_rocprof_c3_summary.json has the counted SQ_INSTS_VALU for C3"}
+                         "note": "instruction count from the kernel's shape (tiles x windows x instructions per window; the counted "
+                                 "SQ_INSTS_VALU of C3 in profiles/r02_rocprof_c3_summary.json is 2 % below it); peak = one wave64 "
+                                 "instruction per 4 cycles and SIMD at the nominal 2.4 GHz — plain register loops of fma, and_or or "
+                                 "xor+popcount reach 520-600 G/s on this chip, so a fraction around 1 means the kernel issues as fast "
+                                 "as such loops do, not that anything ran beyond the hardware"}
         phase_b_traffic = None
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload, {})

@@ -14,6 +14,8 @@ python bench.py --workload c3 --genomes 64 --steps 100 --warmup 5 --cpu-sample 0
 python bench.py --gpus 2 --workload small --steps 20 --warmup 3 > gpurun_out/final/r02_bench_small_2ranks.json 2> gpurun_out/final/small2.err
 python bench.py --workload c4 --steps 20 --warmup 3 --cpu-sample 0 --emulate-rank 0/8 --emulate-exchange > gpurun_out/final/emu_c4_rank0of8.json 2> gpurun_out/final/emu.err
 python tools/tools_wallclock.py --workload c3 --out gpurun_out/final/r02_wallclock_c3.json > /dev/null 2>&1
-python tools/tools_wallclock.py --workload c4 --out gpurun_out/final/r02_wallclock_c4.json > /dev/null 2>&1
+python tools/tools_wallclock.py --workload c4 --mgpu 1,2 --out gpurun_out/final/r02_wallclock_c4.json > /dev/null 2>&1
+python tools/tools_wallclock.py --workload c5 --out gpurun_out/final/r02_wallclock_c5.json > /dev/null 2>&1
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 python tools/tools_round_summary.py gpurun_out/final
 grep -h "emulated\|check" gpurun_out/final/*.err | head
