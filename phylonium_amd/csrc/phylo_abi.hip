@@ -730,31 +730,10 @@ int phylo_set_genomes_packed(phylo_ctx *c, size_t n, const uint32_t *const *q2, 
 	HIPOK(c, hipMemsetAsync(c->d_Q2.p, 0, (words + 64) * 4, c->stream));
 	HIPOK(c, hipStreamSynchronize(c->stream));
 	double t1 = now_ms();
-	// When the code arrays lie in one allocation (phylo_host_read_fasta_packed's arena), that range is page-locked
-	// once for all the copies: a copy from pageable memory locks and unlocks its own pages, which is what bounds
-	// it on first use (measured, 1.2 GB in 1024 pieces: 57 GB/s after 0.03 s of registering against 12-20 GB/s).
-	void *reg = nullptr;
-	{
-		uintptr_t lo = UINTPTR_MAX, hi = 0;
-		uint64_t sum = 0;
-		for (size_t j = 0; j < n; j++)
-			if (len[j]) {
-				const uintptr_t a = (uintptr_t)q2[j], b = a + (len[j] + 15) / 16 * 4;
-				lo = std::min(lo, a);
-				hi = std::max(hi, b);
-				sum += b - a;
-			}
-		if (sum >= (64u << 20) && hi - lo <= sum + sum / 4) {
-			const uintptr_t page = 4096, a = lo / page * page, b = (hi + page - 1) / page * page;
-			if (hipHostRegister((void *)a, b - a, hipHostRegisterDefault) == hipSuccess) reg = (void *)a;
-			else (void)hipGetLastError();
-		}
-	}
 	for (size_t j = 0; j < n; j++)
 		if (len[j])
 			HIPOK(c, hipMemcpyAsync(c->d_Q2.p + c->goff[j] / 16, q2[j], (len[j] + 15) / 16 * 4, hipMemcpyHostToDevice, c->stream));
 	HIPOK(c, hipStreamSynchronize(c->stream));
-	if (reg) (void)hipHostUnregister(reg);
 	double t2 = now_ms();
 	c->d_genomes = c->genomes_store.p;
 	c->own_genomes = true;
