@@ -936,10 +936,14 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 	uint32_t k = c->opt_kmer ? c->opt_kmer : choose_k(ns);
 	if (threshold == 0) threshold = min_anchor_length(0.025, (double)gc_count / (double)L, ns); // gc_content, sequence.cxx:152-165
 	const uint64_t codes = (uint64_t)1 << (2 * k);
-	HIPOK(c, c->d_SAX.ensure((size_t)ns + 4));
-	HIPOK(c, c->d_LCP.ensure((size_t)ns + 1 + 4));
-	HIPOK(c, c->d_T.ensure(codes + 1 + 4 + kmer_table_scratch(k)));
-	HIPOK(c, c->d_SLOT.ensure(codes * SLOT_RECS));
+	{
+		const double ta = now_ms();
+		HIPOK(c, c->d_SAX.ensure((size_t)ns + 4));
+		HIPOK(c, c->d_LCP.ensure((size_t)ns + 1 + 4));
+		HIPOK(c, c->d_T.ensure(codes + 1 + 4 + kmer_table_scratch(k)));
+		HIPOK(c, c->d_SLOT.ensure(codes * SLOT_RECS));
+		c->stats["ms:ref_alloc"] += now_ms() - ta; // hipMalloc of tens of GB stalls when other processes have just released as much
+	}
 	HIPOK(c, hipMemsetAsync(c->a_misc.p, 0, 64, st));
 	HIPOK(c, hipMemsetAsync(c->d_LCP.p, 0, ((size_t)ns + 1 + 4) * 4, st));
 	// LCP by direct comparison of neighbouring suffixes, capped at the 16-bit clip of the

@@ -496,10 +496,10 @@ int main(int argc, char *argv[])
 				"timing: genomes %zu  bases %.0f  total %.3f s | read %.3f (%zu threads, %s)  wait-for-device %.3f  upload %.3f (device memory %.3f  copies %.3f  "
 				"install %.3f)  "
 				"wait-for-suffix-array %.3f (%s)  process+print %.3f  "
-				"[suffix array %.3f  rest of the index %.3f  anchor %.3f  compare %.3f]\n",
+				"[suffix array %.3f  rest of the index %.3f (device allocations %.3f)  anchor %.3f  compare %.3f]\n",
 				q.size(), bases, t_done - t_start, t_read - t_start, read_threads, packed_ingest ? "packed" : "bytes", t_ctx - t_read, t_upload - t_ctx, stat("ms:genomes_alloc"), stat("ms:genomes_copy"),
 				stat("ms:genomes_install"),
-				t_sa - t_upload, host_sa ? "built on a host thread since the files were read" : "built on the device with the index", t_done - t_sa, stat("ms:ref_suffix_array"), stat("ms:ref_total") - stat("ms:ref_suffix_array"),
+				t_sa - t_upload, host_sa ? "built on a host thread since the files were read" : "built on the device with the index", t_done - t_sa, stat("ms:ref_suffix_array"), stat("ms:ref_total") - stat("ms:ref_suffix_array"), stat("ms:ref_alloc"),
 				stat("ms:anchor_total"), stat("ms:compare_total"));
 	}
 	phylo_ctx_destroy(r.ctx);

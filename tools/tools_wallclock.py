@@ -20,23 +20,35 @@ def main():
     ap.add_argument("--mgpu", default="", help="also run the N-rank driver: comma list of rank counts, e.g. 1,2 "
                     "(more ranks than GPUs: collectives over gloo, all ranks on GPU 0)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "wallclock.json"))
+    ap.add_argument("--prepare", default="", help="internal: write the FASTA files and the expected text, then exit")
     args = ap.parse_args()
-    import torch
-    from phylonium_amd import api
     n, length, d_range, indel, inv, desc = bench.WORKLOADS[args.workload]
     n = args.genomes or n
+    d = f"/tmp/wallclock_{args.workload}_{n}"
+    files = [os.path.join(d, f"g{j:04d}.fasta") for j in range(n)]
+    if not args.prepare:
+        # The files and the expected matrix come from a child process that is gone before the drivers run: a process
+        # that still holds a GPU context makes the drivers' large hipMallocs stall, which is not what
+        # someone running the driver on its own would see.
+        meta_path = os.path.join(d, "meta.json")
+        os.makedirs(d, exist_ok=True)
+        subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--genomes", str(n),
+                        "--prepare", meta_path], check=True)
+        meta = json.load(open(meta_path))
+        want = open(os.path.join(d, "want.txt")).read()
+        return drive(args, n, desc, files, want, meta)
+    import torch
+    from phylonium_amd import api
     dev = torch.device("cuda", 0)
     buf, offs, lens = bench.make_genomes_gpu(torch, n, length, 20260101, dev, d_range, indel, inv,
                                              contigs=bench.CONTIGS.get(args.workload, 1))
-    d = f"/tmp/wallclock_{args.workload}_{n}"
     os.makedirs(d, exist_ok=True)
     t0 = time.time()
-    files, host = [], []
+    host = []
     for j in range(n):
         g = buf[offs[j]:offs[j] + lens[j]].cpu().numpy()
         host.append(g)
-        path = os.path.join(d, f"g{j:04d}.fasta")
-        files.append(path)
+        path = files[j]
         with open(path, "wb") as f:
             for k, contig in enumerate(bytes(g).split(b"!")):
                 f.write(b">contig%d\n" % k)
@@ -54,7 +66,11 @@ def main():
         ctx.set_genomes(host)
         s, h = ctx.process(ref_idx=0)
     names = [f"g{j:04d}" for j in range(n)]
-    want = api.format_phylip(names, s, h)
+    open(os.path.join(d, "want.txt"), "w").write(api.format_phylip(names, s, h))
+    json.dump({"bases": float(sum(lens)), "fasta_write_s": round(t_write, 2), "devices": torch.cuda.device_count()}, open(args.prepare, "w"))
+
+
+def drive(args, n, desc, files, want, meta):
     exe = os.path.join(ROOT, "phylonium_amd", "phylonium-amd")
     runs = []
     for label, extra in (("first run", []), ("files in page cache", []), ("files in page cache, --ingest=bytes", ["--ingest=bytes"]),
@@ -68,7 +84,7 @@ def main():
                      "matrix_identical": p.stdout.decode() == want, "exit": p.returncode})
     for ranks in [int(x) for x in args.mgpu.split(",") if x]:
         env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
-        backend = "nccl" if ranks <= torch.cuda.device_count() else "gloo"
+        backend = "nccl" if ranks <= meta["devices"] else "gloo"
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr",
                "127.0.0.1", "--master-port", "29631", "-m", "phylonium_amd.mgpu", "--backend", backend, "--timing",
                "-r", files[0]] + files
@@ -80,8 +96,8 @@ def main():
         runs.append({"label": f"phylonium_amd.mgpu, {ranks} rank(s), {backend}", "wall_s_including_exec": round(wall, 3),
                      "timing": m.group(1) if m else err[-600:], "matrix_identical": p.stdout.decode() == want,
                      "exit": p.returncode})
-    out = {"workload": f"{args.workload}: {desc}", "genomes": n, "bases": float(sum(lens)),
-           "fasta_bytes": sum(os.path.getsize(f) for f in files), "fasta_write_s": round(t_write, 2), "runs": runs,
+    out = {"workload": f"{args.workload}: {desc}", "genomes": n, "bases": meta["bases"],
+           "fasta_bytes": sum(os.path.getsize(f) for f in files), "fasta_write_s": meta["fasta_write_s"], "runs": runs,
            "note": "exit 1 is the reference's soft-warning status (io.cxx:106-139): this workload has pairs with less than "
                    "20 % homology; the matrix is printed all the same"}
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
