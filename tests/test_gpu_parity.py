@@ -464,6 +464,21 @@ def test_device_suffix_array_equals_the_host_one(ctx):
         ctx.set_option("sa_builder", 0)
         ctx.set_reference(0)
         assert ctx.stats()["ref:sa_on_device"] == 0 and np.array_equal(ctx.reference_suffix_array(), want)
+    # many small strings over two letters (every suffix tied with others for many rounds), with and without contigs
+    for seed in range(120):
+        r = np.random.default_rng(1000 + seed)
+        n = int(r.integers(1, 400))
+        g = np.frombuffer(b"AC", np.uint8)[r.integers(0, 2, n)].copy()
+        if seed % 3 == 0 and n > 4:
+            g[r.integers(0, n, 2)] = ord("!")
+        if seed % 5 == 0:
+            g = np.tile(g, 3)
+        ctx.set_genomes([g, synth.random_base(40, r)])
+        ctx.set_option("sa_builder", 1)
+        ctx.set_reference(0)
+        gb = bytes(g)
+        assert ctx.stats()["ref:sa_on_device"] == 1
+        assert np.array_equal(ctx.reference_suffix_array(), api.host_suffix_array(gb + b"#" + O.revcomp(gb))), f"seed {seed}"
     ctx.set_option("sa_builder", 1)
     # a byte the packing has no code for: the host builders take over, the array is still the array
     odd = np.frombuffer(b"ACGTNNACGTACGTTTGACA", np.uint8)
