@@ -1116,7 +1116,9 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 		// The lean kernels fit more blocks on a CU than the chunk grid should be planned for: with one
 		// chunk per lane, more lanes mean shorter chunks, i.e. more bridges and more chunk starts, and
 		// measured on C3 that costs more than the extra lanes hide (4 blocks per CU: 3.8 ms, 5: 4.1 ms).
-		const int resident = c->anchor_kernel ? std::min(lean_spec_resident_blocks(c->n_cu), 4 * c->n_cu) : spec_resident_blocks(c->n_cu);
+		int per_cu_cap = 4;
+		if (const char *e = getenv("PHY_SPEC_PER_CU")) per_cu_cap = std::max(1, atoi(e)); // experiments
+		const int resident = c->anchor_kernel ? std::min(lean_spec_resident_blocks(c->n_cu), per_cu_cap * c->n_cu) : spec_resident_blocks(c->n_cu);
 		c->plan = plan_chunks(qlen, c->threshold, c->opt_chunk, (uint32_t)resident * 256u, c->opt_chunk_tail);
 		const ChunkPlan &P = c->plan;
 		if (!P.C) return c->fail("phase A: more than 2^32 anchor log slots");
