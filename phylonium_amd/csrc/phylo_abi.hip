@@ -1116,10 +1116,16 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 		// The lean kernels fit more blocks on a CU than the chunk grid should be planned for: with one
 		// chunk per lane, more lanes mean shorter chunks, i.e. more bridges and more chunk starts, and
 		// measured on C3 that costs more than the extra lanes hide (4 blocks per CU: 3.8 ms, 5: 4.1 ms).
-		int per_cu_cap = 4;
+		// speculative-chain blocks per CU the plan counts on: 4 for large inputs, 3 below ~1.2 Gbp of queries — there
+		// the longer chunks of fewer lanes win (a rank's eighth of C4: 1.90 -> 1.79 ms, 64 x 5 Mbp: 1.19 -> 1.06; C3 the
+		// same either way; C4 11.9 -> 12.8 with 3)
+		uint64_t total_q = 0;
+		for (uint32_t l : qlen) total_q += l;
+		int per_cu_cap = total_q < 1200000000ull ? 3 : 4;
 		if (const char *e = getenv("PHY_SPEC_PER_CU")) per_cu_cap = std::max(1, atoi(e)); // experiments
 		const int resident = c->anchor_kernel ? std::min(lean_spec_resident_blocks(c->n_cu), per_cu_cap * c->n_cu) : spec_resident_blocks(c->n_cu);
-		c->plan = plan_chunks(qlen, c->threshold, c->opt_chunk, (uint32_t)resident * 256u, c->opt_chunk_tail);
+		c->plan = plan_chunks(qlen, c->threshold, c->opt_chunk, (uint32_t)resident * 256u, c->opt_chunk_tail,
+							  c->anchor_kernel ? (uint32_t)c->n_cu * 256u : 0u);
 		const ChunkPlan &P = c->plan;
 		if (!P.C) return c->fail("phase A: more than 2^32 anchor log slots");
 		// an emitted homology spans >= 2*threshold query positions
