@@ -2004,27 +2004,13 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 16, st));
 		launch_tile_index(P, query_src(c), dev_homs, c->b_hom_rng.p, c->b_first.p, 0, (uint32_t)N, st);
 	}
-	// Three planes unless '!' turns up among the projected bytes (the flag says so);
-	// then all five are made.  A context remembers the outcome for its next call.
+	// Three planes and the plain pair kernel unless '!' turns up among the projected positions (the projection raises
+	// a flag); then all five planes and the kernel that reads D and B.  The context remembers the outcome of its last
+	// call and goes ahead on that assumption — projection, pairs, mirror image and the copy back are queued without
+	// waiting for the flag, which is read with the result; only when it says '!' and the plain kernel ran is the
+	// work repeated with five planes (once per set of genomes: the next call expects it).  The other way round —
+	// five planes and no '!' after all — the result is right as it stands, since B is empty.
 	uint32_t *flagp = (uint32_t *)(c->h_mat.p + 2 * N * N);
-	uint32_t flag = 0;
-	for (int pass = 0; pass < 2; pass++) {
-		const bool five = pass == 1 || (projected ? c->eager_five : c->pileup_five);
-		if (pass == 1) HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 16, st));
-		if (pass == 1 || !projected) {
-			KernelSpan s(c, five ? "pileup_project5" : "pileup_project");
-			launch_project(P, five, query_src(c), dev_homs, c->b_hom_rng.p, c->b_first.p, c->b_flag.p, 0,
-						   P.Npad / project_genomes_per_tile(), st);
-		}
-		HIPOK(c, hipGetLastError());
-		HIPOK(c, hipMemcpyAsync(flagp, c->b_flag.p, 4, hipMemcpyDeviceToHost, st));
-		if (sync_stream(c)) return 1; // the flag picks the pair kernel
-		flag = *flagp;
-		if (five || !flag) break;
-	}
-	c->pileup_five = flag != 0;
-	double t1 = now_ms();
-
 	// pair tiles (ig, jt) holding at least one pair i<j
 	std::vector<uint32_t> tiles;
 	uint32_t nig = (uint32_t)((N + PAIR_IG - 1) / PAIR_IG), njt = (uint32_t)((N + PAIR_JT - 1) / PAIR_JT);
@@ -2033,13 +2019,16 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 			if ((uint64_t)ig * PAIR_IG >= (uint64_t)jt * PAIR_JT + PAIR_JT - 1) continue; // no i<j inside
 			tiles.push_back((ig << 16) | jt);
 		}
-	if (!tiles.empty() && P.W) {
+	if (!tiles.empty()) {
 		HIPOK(c, c->b_tiles.ensure(tiles.size()));
 		HIPOK(c, hipMemcpyAsync(c->b_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, st));
+	}
+	auto pairs = [&](bool bang) -> int {
+		if (tiles.empty() || !P.W) return 0;
 		// window chunks: small enough that a chunk's plane rows (3 or 5 planes x Npad x 4 B
 		// per window) fit an XCD's 4 MiB L2 with room to spare, and small enough that
 		// tiles x chunks fills the chip several times over; at least 64 windows
-		uint32_t row_bytes = (flag ? 5u : 3u) * P.Npad * 4u;
+		uint32_t row_bytes = (bang ? 5u : 3u) * P.Npad * 4u;
 		uint32_t l2_fit = std::max<uint32_t>(64, (3u << 20) / row_bytes);
 		// (four rounds of the chip's n_cu x 32 wavefront slots: with one round — what n_cu x 32 gave at N = 256 — the
 		// wavefronts all end together and the tail is a whole wavefront long; measured 1.30 -> 1.13 ms on C3)
@@ -2052,23 +2041,50 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		}
 		if (c->opt_pairs_wchunk) wchunk = c->opt_pairs_wchunk;
 		{
-			KernelSpan s(c, flag ? "pileup_pairs_bang" : "pileup_pairs");
-			launch_pairs(P, flag != 0, c->b_tiles.p, (uint32_t)tiles.size(), wchunk, acc_s, acc_h, st);
+			KernelSpan s(c, bang ? "pileup_pairs_bang" : "pileup_pairs");
+			launch_pairs(P, bang, c->b_tiles.p, (uint32_t)tiles.size(), wchunk, acc_s, acc_h, st);
 		}
 		HIPOK(c, hipGetLastError());
+		launch_symmetrise((uint32_t)N, acc_s, acc_h, st);
+		return 0;
+	};
+	auto project = [&](bool five) -> int {
+		KernelSpan s(c, five ? "pileup_project5" : "pileup_project");
+		launch_project(P, five, query_src(c), dev_homs, c->b_hom_rng.p, c->b_first.p, c->b_flag.p, 0, P.Npad / project_genomes_per_tile(), st);
+		return 0;
+	};
+	uint64_t *hs = c->h_mat.p, *hh = c->h_mat.p + N * N;
+	auto fetch = [&]() -> int { // the flag, and the result unless it stays on the device
+		HIPOK(c, hipGetLastError());
+		HIPOK(c, hipMemcpyAsync(flagp, c->b_flag.p, 4, hipMemcpyDeviceToHost, st));
+		if (!dev_out) {
+			HIPOK(c, hipMemcpyAsync(hs, acc_s, N * N * 8, hipMemcpyDeviceToHost, st));
+			HIPOK(c, hipMemcpyAsync(hh, acc_h, N * N * 8, hipMemcpyDeviceToHost, st));
+		}
+		return sync_stream(c);
+	};
+	const bool have_five = projected ? c->eager_five : c->pileup_five; // the planes this attempt works on
+	bool bang = c->pileup_five && have_five;
+	if (!projected && project(have_five)) return 1;
+	double t1 = now_ms();
+	if (pairs(bang) || fetch()) return 1;
+	uint32_t flag = *flagp;
+	if (flag && !bang) { // '!' among the projected positions, and the plain kernel ran: once more with all five planes
+		c->stats["count:compare_repeated_with_five_planes"] += 1;
+		HIPOK(c, hipMemsetAsync(acc_s, 0, N * N * 8, st));
+		HIPOK(c, hipMemsetAsync(acc_h, 0, N * N * 8, st));
+		HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 16, st));
+		bang = true;
+		if (project(true) || pairs(true) || fetch()) return 1;
+		flag = *flagp;
 	}
-	launch_symmetrise((uint32_t)N, acc_s, acc_h, st);
+	c->pileup_five = flag != 0;
 	if (dev_out) {
-		if (sync_stream(c)) return 1;
 		c->stats["ms:compare_project_phase"] += t1 - t0;
 		c->stats["ms:compare_pairs_phase"] += now_ms() - t1;
 		c->stats["pileup:bang"] = flag;
 		return 0;
 	}
-	uint64_t *hs = c->h_mat.p, *hh = c->h_mat.p + N * N;
-	HIPOK(c, hipMemcpyAsync(hs, acc_s, N * N * 8, hipMemcpyDeviceToHost, st));
-	HIPOK(c, hipMemcpyAsync(hh, acc_h, N * N * 8, hipMemcpyDeviceToHost, st));
-	if (sync_stream(c)) return 1;
 	double t2 = now_ms();
 	// out of the pinned buffer into the caller's matrices (16 MB at N = 1024: worth several threads)
 	double sites = 0;
