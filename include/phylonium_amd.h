@@ -89,7 +89,8 @@ int phylo_set_genomes_device(phylo_ctx *ctx, size_t n, const void *dev_base, con
 
 /* Same genomes, handed over as 2-bit codes: q2[j] holds (len[j] + 15) / 16 words, 16 bases per word, the
  * first base in bits 31..30, A0 C1 G2 T3, codes behind the last base 0; bad[j][0..nbad[j]) are the ascending
- * positions of the '!' separators (their code is 0).  This is the form phase A's kernels read, so it is copied
+ * positions of the '!' separators (their code is 0; code bits behind a genome's end or under a separator that are not
+ * 0 are cleared by the device).  This is the form phase A's kernels read, so it is copied
  * into place — a quarter of the bytes of phylo_set_genomes cross PCIe — and the byte form the other kernels
  * read is written by the device.  The FASTA side of it: phylo_host_read_fasta_packed (src/sequence.cxx:109-199
  * fused with the packing). */

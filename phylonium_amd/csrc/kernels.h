@@ -18,8 +18,9 @@ void launch_lean_bridge(const PhaseA &A, const RefIndex &R, const LeanIndex &X, 
 void launch_lean_bridge_range(const PhaseA &A, const RefIndex &R, const LeanIndex &X, uint32_t c_lo, uint32_t c_hi,
 							  uint32_t fetch_slot, int n_cu, hipStream_t st);
 void launch_pack2(const uint8_t *src, uint64_t bytes, uint32_t *dst, hipStream_t st); // bytes: a multiple of 16
-// Q2 → byte arena (bytes: the whole arena, a multiple of 16), then '!' at the nbad listed positions
-void launch_unpack2(const uint32_t *q2, const uint64_t *off, const uint32_t *len, uint32_t n, uint64_t bytes, uint8_t *dst,
+// Q2 → byte arena (bytes: the whole arena, a multiple of 16), then '!' at the nbad listed positions; code bits of Q2
+// outside the genomes or under a separator are cleared on the way
+void launch_unpack2(uint32_t *q2, const uint64_t *off, const uint32_t *len, uint32_t n, uint64_t bytes, uint8_t *dst,
 					const uint32_t *bad, const uint32_t *bad_off, uint32_t nbad, hipStream_t st);
 uint32_t bad_segment_bytes();
 // non-ACGT positions per sequence; out == nullptr: count per segment into seg_cnt, else write from seg_off

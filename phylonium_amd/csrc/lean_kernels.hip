@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256) void pack2_kernel(const uint8_t *__restrict__ 
 // arena from Q2.  One thread per 16-byte piece of the arena; bytes outside every genome are
 // zero (the padding the chain kernels rely on).  off[] ascends; a block looks up the genome
 // of its first piece once (block-uniform → scalar loads) and a thread walks on from there.
-__global__ __launch_bounds__(256) void unpack2_kernel(const uint32_t *__restrict__ q2, const uint64_t *__restrict__ off,
+__global__ __launch_bounds__(256) void unpack2_kernel(uint32_t *__restrict__ q2, const uint64_t *__restrict__ off,
 													   const uint32_t *__restrict__ len, uint32_t n, uint64_t words,
 													   uint8_t *__restrict__ dst)
 {
@@ -593,9 +593,11 @@ __global__ __launch_bounds__(256) void unpack2_kernel(const uint32_t *__restrict
 	const uint64_t p = 16 * w;
 	while (j + 1 < n && off[j + 1] <= p) j++;
 	uint32_t o[4] = {0, 0, 0, 0};
+	const uint32_t c = q2[w];
+	uint32_t keep = 0; // the code bits that belong to a genome: everything else in Q2 is to be 0 whatever the caller sent
 	if (n && p >= off[j] && p < off[j] + len[j]) {
 		const uint64_t left = off[j] + len[j] - p;
-		const uint32_t c = q2[w];
+		keep = left >= 16 ? 0xffffffffu : ~(0xffffffffu >> (2u * (uint32_t)left));
 #pragma unroll
 		for (uint32_t i = 0; i < 16; i++) {
 			const uint32_t code = (c >> (30u - 2u * i)) & 3u;
@@ -603,12 +605,14 @@ __global__ __launch_bounds__(256) void unpack2_kernel(const uint32_t *__restrict
 			o[i >> 2] |= b << (8u * (i & 3u));
 		}
 	}
+	if (c & ~keep) q2[w] = c & keep;
 	*(uint4 *)(dst + p) = uint4{o[0], o[1], o[2], o[3]};
 }
 
 // '!' at the listed positions: entry t of genome j (bad_off[j] <= t < bad_off[j+1])
 __global__ __launch_bounds__(256) void patch_bad_kernel(const uint32_t *__restrict__ bad, const uint32_t *__restrict__ bad_off,
-														 uint32_t n, const uint64_t *__restrict__ off, uint8_t *__restrict__ dst)
+														 uint32_t n, const uint64_t *__restrict__ off, uint8_t *__restrict__ dst,
+														 uint32_t *__restrict__ q2)
 {
 	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= bad_off[n]) return;
@@ -618,7 +622,9 @@ __global__ __launch_bounds__(256) void patch_bad_kernel(const uint32_t *__restri
 		if (bad_off[mid + 1] <= t) lo = mid + 1;
 		else hi = mid;
 	}
-	dst[off[lo] + bad[t]] = (uint8_t)'!';
+	const uint64_t p = off[lo] + bad[t];
+	dst[p] = (uint8_t)'!';
+	atomicAnd(&q2[p >> 4], ~(3u << (30u - 2u * (uint32_t)(p & 15u)))); // a separator's code is 0 (the packed kernels rely on it)
 }
 
 // Non-ACGT positions of sequences (genomes, or S as one sequence), sorted per sequence.
@@ -689,12 +695,12 @@ void launch_pack2(const uint8_t *src, uint64_t bytes, uint32_t *dst, hipStream_t
 	if (!words) return;
 	hipLaunchKernelGGL(pack2_kernel, dim3((uint32_t)((words + 255) / 256)), dim3(256), 0, st, src, words, dst);
 }
-void launch_unpack2(const uint32_t *q2, const uint64_t *off, const uint32_t *len, uint32_t n, uint64_t bytes, uint8_t *dst,
+void launch_unpack2(uint32_t *q2, const uint64_t *off, const uint32_t *len, uint32_t n, uint64_t bytes, uint8_t *dst,
 					const uint32_t *bad, const uint32_t *bad_off, uint32_t nbad, hipStream_t st)
 {
 	const uint64_t words = bytes / 16;
 	if (words) hipLaunchKernelGGL(unpack2_kernel, dim3((uint32_t)((words + 255) / 256)), dim3(256), 0, st, q2, off, len, n, words, dst);
-	if (nbad) hipLaunchKernelGGL(patch_bad_kernel, dim3((nbad + 255) / 256), dim3(256), 0, st, bad, bad_off, n, off, dst);
+	if (nbad) hipLaunchKernelGGL(patch_bad_kernel, dim3((nbad + 255) / 256), dim3(256), 0, st, bad, bad_off, n, off, dst, q2);
 }
 uint32_t bad_segment_bytes() { return BAD_SEG; }
 void launch_bad_positions(const uint8_t *base, const uint64_t *off, const uint32_t *len, const uint32_t *seg_seq,
