@@ -21,6 +21,7 @@ cur[wl] = tot
 cur["detail_" + wl] = det
 cur["method"] = ("HBM-side bytes per launch from rocprofv3 PMC (separate passes): reads = TCC_EA0_RDREQ_128B*128 + _64B*64 "
                  "+ _32B*32 (FETCH_SIZE tallies every request at 64 B, i.e. half the bytes of the 128-B requests, as "
-                 "MI355X_MICROARCH.md warns); writes = WRITE_SIZE KB. Source: " + label)
+                 "MI355X_MICROARCH.md warns); writes = WRITE_SIZE KB. Sources: the source_<workload> entries")
+cur["source_" + wl] = label
 json.dump(cur, open(out, "w"), indent=1)
 print(json.dumps(tot, indent=1))
