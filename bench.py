@@ -156,6 +156,82 @@ def cpu_baseline(torch, buf, offs, lens, ref_idx, sa_ref, sample_queries, thread
                       f"ESA build {t_esa:.1f}s excluded"}
 
 
+def wallclock_leg(torch, holder, offs, lens, contigs_sep, want_text, n_gpus, runs=3):
+    """BASELINE.json's second metric: wall-clock FASTA files -> PHYLIP text, through the C++ host driver
+    (phylonium_amd/phylonium-amd, FASTA in / matrix out as src/phylonium.cxx:89-299) started as a fresh process.
+    The workload's genomes are written as FASTA files (70 columns) to /dev/shm — outside every timed region — the
+    driver runs `runs` times, and the median of the child's wall-clock (start of the process to its exit, as this
+    parent sees it) is reported with the driver's own --timing split of the median run.  The text it prints must be
+    the text made from this bench's result matrices."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "phylonium_amd", "phylonium-amd")
+    if not os.path.exists(exe):
+        return {"wallclock_s": None, "note": "phylonium_amd/phylonium-amd has not been built"}
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    d = tempfile.mkdtemp(prefix="phylonium_amd_bench_", dir=base)
+    buf = holder[0]  # the genome buffer; `holder` is the caller's only reference to it
+    try:
+        t0 = time.time()
+        files = []
+        nl = torch.tensor([10], dtype=torch.uint8, device=buf.device)
+        for j, (o, l) in enumerate(zip(offs, lens)):
+            path = os.path.join(d, f"g{j:04d}.fasta")
+            files.append(path)
+            g = buf[o:o + l]
+            with open(path, "wb") as f:
+                if contigs_sep:
+                    parts = bytes(g.cpu().numpy()).split(b"!")
+                else:
+                    parts = [g]
+                for k, part in enumerate(parts):
+                    f.write(b">contig%d\n" % k)
+                    a = part if torch.is_tensor(part) else torch.frombuffer(bytearray(part), dtype=torch.uint8).to(buf.device)
+                    full = a.numel() // 70 * 70
+                    if full:
+                        lines = torch.empty((full // 70, 71), dtype=torch.uint8, device=buf.device)
+                        lines[:, :70] = a[:full].view(-1, 70)
+                        lines[:, 70] = 10
+                        f.write(lines.cpu().numpy().tobytes())
+                    if full < a.numel():
+                        f.write(torch.cat([a[full:], nl]).cpu().numpy().tobytes())
+        t_write = time.time() - t0
+        fasta_bytes = sum(os.path.getsize(f) for f in files)
+        # this process lets go of its device memory before the driver starts (it keeps only an idle HIP context)
+        del g, buf, a, parts, part
+        holder.clear()
+        torch.cuda.empty_cache()
+        cmd = [exe, "--timing", "-r", files[0]] + (["--gpus", str(n_gpus)] if n_gpus > 1 else []) + files
+        res = []
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            pr = subprocess.run(cmd, capture_output=True)
+            wall = time.perf_counter() - t0
+            err = pr.stderr.decode(errors="replace")
+            m = re.search(r"timing: (genomes .*)", err)
+            res.append({"wall_s": round(wall, 4), "exit": pr.returncode, "timing": m.group(1) if m else err[-300:],
+                        "matrix_identical": pr.stdout.decode(errors="replace") == want_text})
+        med = sorted(res, key=lambda r: r["wall_s"])[len(res) // 2]
+        split = {}
+        for key, pat in (("inside_main", r"total ([0-9.]+) s"), ("read", r"\| read ([0-9.]+)"), ("wait_for_device", r"wait-for-device ([0-9.]+)"),
+                         ("upload", r"upload ([0-9.]+)"), ("process_and_print", r"process\+print ([0-9.]+)"),
+                         ("suffix_array", r"\[suffix array ([0-9.]+)"), ("rest_of_index", r"rest of the index ([0-9.]+)"),
+                         ("anchor", r"anchor ([0-9.]+)"), ("compare", r"compare ([0-9.]+)\]")):
+            mm = re.search(pat, med["timing"])
+            if mm:
+                split[key] = float(mm.group(1))
+        return {"wallclock_s": med["wall_s"], "unit": "s", "n_gpus": n_gpus, "what": "FASTA files in /dev/shm -> PHYLIP text on stdout, "
+                "`phylonium-amd --timing -r g0000.fasta <files>` as a fresh process, start to exit; median of %d runs" % runs,
+                "runs_s": [r["wall_s"] for r in res], "matrix_identical": all(r["matrix_identical"] for r in res),
+                "exit_status": med["exit"], "split_s": split, "fasta_bytes": fasta_bytes, "fasta_write_s": round(t_write, 2),
+                "note": "exit status 1 is the reference's soft-warning status (src/io.cxx:106-139: a pair with < 20 % homology); "
+                        "split_s is the driver's own --timing of the median run: process start-up and exit are the difference to wallclock_s"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def usable_cpus():
     """CPUs this process may actually burn: the cgroup CPU-time quota (cpu.max) when there is
     one — the GPU boxes show 256 CPUs but meter a job to a fraction of them — else cpu_count."""
@@ -196,12 +272,30 @@ def launch_ranks(n_ranks):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         out = None if r == 0 else subprocess.DEVNULL
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
-    rc = 0
+    # all ranks are watched together: one that dies alone (out of memory, an import error) would leave the others
+    # waiting inside a collective until its timeout; the first non-zero exit ends the rest, and so does the deadline
+    rc, deadline = 0, time.time() + float(os.environ.get("BENCH_LAUNCH_TIMEOUT_S", "3000"))
     try:
-        for p in procs:
-            rc = max(rc, abs(p.wait()))
+        live = list(procs)
+        while live:
+            for p in list(live):
+                st = p.poll()
+                if st is not None:
+                    live.remove(p)
+                    rc = max(rc, abs(st))
+            if rc or time.time() > deadline:
+                rc = rc or 124
+                break
+            if live:
+                time.sleep(0.05)
     finally:
         for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + 5
+        for p in procs:
+            while p.poll() is None and time.time() < t_end:
+                time.sleep(0.05)
             if p.poll() is None:
                 p.kill()
     return rc
@@ -221,6 +315,7 @@ def main():
     ap.add_argument("--seed", type=int, default=20260101)
     ap.add_argument("--cpu-sample", type=int, default=63, help="queries in the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernels with HIP events")
+    ap.add_argument("--no-wallclock", action="store_true", help="skip the FASTA -> PHYLIP wall-clock leg (the C++ host driver as a child process)")
     ap.add_argument("--check", action="store_true", help="verify a sample of the result against the oracle")
     ap.add_argument("--chunk", type=int, default=0, help="dev: force the phase-A chunk length")
     ap.add_argument("--filter", type=int, default=0, help="dev: sort + chain filter 1 on the host, 2 on the device (0: the library chooses)")
@@ -470,6 +565,7 @@ def main():
         if kern:
             alg = {"anchor_spec": bytes_a / world, "anchor_bridge": 0.0, "anchor_fold": 0.0, "anchor_compact": 0.0,
                    "pileup_project": total_bases, "pileup_project5": total_bases, "pileup_pairs": bytes_b / world, "pileup_pairs_bang": bytes_b / world,
+                   "pileup_pairs_mfma": bytes_b / world,
                    "seqcmp_batch": bytes_b / world}
             for k in kern:
                 avg_ms = kern[k] / launches[k]
@@ -523,6 +619,24 @@ def main():
                                  "instruction per 4 cycles and SIMD at the nominal 2.4 GHz — plain register loops of fma, and_or or "
                                  "xor+popcount reach 520-600 G/s on this chip, so a fraction around 1 means the kernel issues as fast "
                                  "as such loops do, not that anything ran beyond the hardware"}
+        # the pair kernel on the matrix cores (the default when no projected position holds '!'): four FP4 channels of
+        # {-1, 0, 1} per reference position and pair, one multiply-add each — against the dense FP4 peak
+        roof_mfma = None
+        if "pileup_pairs_mfma" in kern:
+            t_ms = kern["pileup_pairs_mfma"] / launches["pileup_pairs_mfma"]
+            positions = lens[ref_idx] / world
+            flop_alg = 2.0 * 4.0 * P * positions
+            nt = (n + 63) // 64
+            flop_issued = 2.0 * 4.0 * (nt * (nt + 1) // 2 * 4096 - nt * 1024) * ((lens[ref_idx] + 31) // 32 * 32) / world
+            peak = 10000.0  # MI355X_MICROARCH.md: FP4 MFMA ~10 PFLOP/s dense
+            roof_mfma = {"kernel": "pileup_pairs_mfma", "bound": "mfma", "achieved": round(flop_alg / (t_ms * 1e-3) / 1e12, 1), "peak": peak,
+                         "unit": "TFLOP/s", "frac": round(flop_alg / (t_ms * 1e-3) / 1e12 / peak, 4), "avg_launch_ms": round(t_ms, 4),
+                         "issued_TFLOPs": round(flop_issued / (t_ms * 1e-3) / 1e12, 1),
+                         "note": "algorithmic work: pairs x reference positions x 4 channels x 2 (v_mfma_f32_32x32x64_f8f6f4, both operands "
+                                 "FP4, f32 accumulators exact below 2^24); `issued` adds the halves of the diagonal 32 x 32 sub-tiles "
+                                 "and the padding of the last window.  The operands are expanded from the bit planes in registers "
+                                 "(~7 vector instructions per matrix instruction): the kernel runs at the sum of the two, the chip "
+                                 "holding ~1.4-2.1 GHz under it (tools/microbench/mfma_pairs.hip, DESIGN section 12)"}
         phase_b_traffic = None
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload, {})
@@ -569,7 +683,7 @@ def main():
                                    "gloo: %d ranks share %d GPU(s), exchange through the host" % (world, ndev) if shared else
                                    "nccl (RCCL), one rank per GPU, device-resident exchange")},
             "ms_per_step_noprofile": round(dt_plain / K * 1e3, 3) if dt_plain else None,
-            "roofline": roof, "roofline_valu": roof_valu, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_valu": roof_valu, "roofline_mfma": roof_mfma, "cpu_baseline": cpu,
             "phases_ms_per_step": {k[3:]: round(v / K, 3) for k, v in stats.items()
                                    if k in ("ms:anchor_total", "ms:anchor_gpu", "ms:anchor_setup", "ms:anchor_copyback",
                                             "ms:host_sort_filter", "ms:compare_total")},
@@ -606,9 +720,19 @@ def main():
             np.savez(args.dump_matrix, subst=np.asarray(s), homologs=np.asarray(h))
     else:
         out = None
+    want_text = None
+    if out is not None and not args.no_wallclock and not emu and world == 1:
+        want_text = api.format_phylip([f"g{j:04d}" for j in range(n)], np.asarray(s), np.asarray(h))
     ctx.close()
     if world > 1 or args.emulate_exchange:
         td.destroy_process_group()
+    if want_text is not None:
+        try:
+            holder = [buf]
+            del buf
+            out["wallclock"] = wallclock_leg(torch, holder, offs, lens, CONTIGS.get(args.workload, 1) > 1, want_text, world)
+        except Exception as e:  # a report beside the metric, never a reason to lose the bench line
+            out["wallclock"] = {"wallclock_s": None, "note": f"failed: {e!r}"}
     import ctypes
     sys.stdout.flush()
     ctypes.CDLL(None).fflush(None)

@@ -406,8 +406,15 @@ static inline void build_slots(const std::vector<uint32_t> &T, const std::vector
 // nucleotide string of at most 4 characters that occurs at least twice in S and ONLY in front of the same
 // contig join — impossible beyond a few kbp of sequence, so the product computes the true longest match
 // and this walk (the same DFS over the suffix array: at most 4^5 nodes) says when the reference would not.
-static inline bool esa_cache_quirk(const uint8_t *S, uint32_t n, const uint32_t *SA)
+// One over-deep cache entry: every 6-mer key that starts with the `k` nucleotides `prefix` (2 bits each, first
+// nucleotide in the highest of the 2k bits) holds the interval of ranks [lo, hi) with depth `depth` > k — what its
+// suffixes share: the k nucleotides, then a non-nucleotide byte within the next depth - k.
+struct CacheQuirk {
+	uint32_t prefix, k, depth, lo, hi;
+};
+static inline std::vector<CacheQuirk> esa_cache_quirks(const uint8_t *S, uint32_t n, const uint32_t *SA)
 {
+	std::vector<CacheQuirk> found;
 	const uint32_t CACHE_LENGTH = 6;
 	auto at = [&](uint32_t r, uint32_t off) -> int { // byte at offset off of the suffix of rank r; -1 past the end
 		const uint64_t p = (uint64_t)SA[r] + off;
@@ -431,10 +438,10 @@ static inline bool esa_cache_quirk(const uint8_t *S, uint32_t n, const uint32_t 
 		*b = l;
 	};
 	struct Node {
-		uint32_t pos, lo, hi;
+		uint32_t pos, lo, hi, prefix; // prefix: the pos nucleotides on the way here, 2 bits each
 	};
 	std::vector<Node> stack;
-	stack.push_back(Node{0, 0, n});
+	stack.push_back(Node{0, 0, n, 0});
 	while (!stack.empty()) {
 		const Node nd = stack.back();
 		stack.pop_back();
@@ -445,23 +452,31 @@ static inline bool esa_cache_quirk(const uint8_t *S, uint32_t n, const uint32_t 
 			if (b - a < 2) continue; // not found, or a singleton: filled as it is (esa.cxx:136-148)
 			uint32_t l = nd.pos + 1; // the child's lcp value: what its first and last suffix share
 			while (l <= CACHE_LENGTH && at(a, l) >= 0 && at(a, l) == at(b - 1, l)) l++;
+			uint32_t prefix = (nd.prefix << 2) | (uint32_t)code;
 			if (l <= nd.pos + 1) {
-				stack.push_back(Node{nd.pos + 1, a, b}); // the usual case, esa.cxx:150-155
+				stack.push_back(Node{nd.pos + 1, a, b, prefix}); // the usual case, esa.cxx:150-155
 				continue;
 			}
 			if (l >= CACHE_LENGTH) continue; // deeper than the cache: filled with the parent, esa.cxx:159-163
+			// fast forward (esa.cxx:178-192): the nucleotides the interval shares go into the key; a byte that is
+			// none ends it, and the keys below str[0..k) get this interval, whose depth l is beyond k (esa.cxx:195-196)
+			uint32_t k = nd.pos + 1;
 			bool non_acgt = false;
-			for (uint32_t k = nd.pos + 1; k < l; k++)
-				if (nuc_code((uint8_t)at(a, k)) > 3) {
+			for (; k < l; k++) {
+				const uint32_t c = nuc_code((uint8_t)at(a, k));
+				if (c > 3) {
 					non_acgt = true;
 					break;
 				}
-			if (non_acgt) return true; // esa.cxx:195-196: keys below str[0..k) get an interval of depth l > k
-			stack.push_back(Node{l, a, b});
+				prefix = (prefix << 2) | c;
+			}
+			if (non_acgt) found.push_back(CacheQuirk{prefix, k, l, a, b});
+			else stack.push_back(Node{l, a, b, prefix});
 		}
 	}
-	return false;
+	return found;
 }
+static inline bool esa_cache_quirk(const uint8_t *S, uint32_t n, const uint32_t *SA) { return !esa_cache_quirks(S, n, SA).empty(); }
 
 static inline uint32_t choose_k(uint32_t n)
 {

@@ -112,6 +112,13 @@ size_t project_index_entries(const Pileup &P);
 void launch_pairs(const Pileup &P, bool with_bang, const uint32_t *tiles, uint32_t ntiles, uint32_t wchunk,
 				  unsigned long long *subst, unsigned long long *homologs, hipStream_t st);
 
+// the same tallies on the matrix cores (three planes only): tiles of pairs_mfma_tile() x pairs_mfma_tile() genomes,
+// packed as ti << 16 | tj with ti <= tj; wchunk <= pairs_mfma_max_wchunk()
+uint32_t pairs_mfma_tile();
+uint32_t pairs_mfma_max_wchunk();
+void launch_pairs_mfma(const Pileup &P, const uint32_t *tiles, uint32_t ntiles, uint32_t wchunk, unsigned long long *subst,
+					   unsigned long long *homologs, hipStream_t st);
+
 void launch_symmetrise(uint32_t N, unsigned long long *a, unsigned long long *b, hipStream_t st);
 // *bad = 1 unless every genome's list is sorted by projected start, disjoint and inside [0, L)
 void launch_check_lists(const DevHom *homs, const uint32_t *hom_rng, uint32_t N, uint32_t L, uint32_t *bad, hipStream_t st);

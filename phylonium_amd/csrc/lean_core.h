@@ -50,7 +50,32 @@ struct LeanIndex {
 	const uint32_t *qbad_off; // [nq+1]: query j's list is QBAD[qbad_off[j] .. qbad_off[j+1])
 	uint32_t force_slow;      // tests: every step through the slow resolver
 	unsigned long long *dbg;  // builds with PHY_LEAN_TIMING: per-segment cycle sums of the chain kernels (else unused)
+	// The reference's 6-mer interval cache holds over-deep intervals on some tiny multi-contig subjects
+	// (src/esa.cxx:174-199; hostlogic.hpp: esa_cache_quirks): entry e = {prefix, k | depth << 8, lo, hi} — a query
+	// window whose first 6 bytes are nucleotides and start with the k nucleotides `prefix` is matched by the reference
+	// as if its first `depth` bytes were what the suffixes of ranks [lo, hi) share.  With entries present every step
+	// goes through the slow resolver (force_slow is set with them), which reproduces that.
+	const U4 *quirk;
+	uint32_t nquirk;
 };
+
+static const uint32_t LEAN_NO_QUIRK = 0xffffffffu;
+// the cache entry the window Q (n bytes left in the query) falls under: get_match_cached, src/esa.cxx:542-563
+PHY_HD uint32_t lean_quirk_lookup(const LeanIndex &X, const uint8_t *Q, uint32_t n)
+{
+	if (!X.nquirk || n <= 6u) return LEAN_NO_QUIRK; // qlen <= CACHE_LENGTH: the plain search (esa.cxx:544)
+	uint32_t key = 0;
+	for (uint32_t i = 0; i < 6u; i++) {
+		const uint32_t c = nuc_code(Q[i]);
+		if (c > 3u) return LEAN_NO_QUIRK; // no key: the plain search (esa.cxx:552-554)
+		key = (key << 2) | c;
+	}
+	for (uint32_t e = 0; e < X.nquirk; e++) {
+		const uint32_t k = X.quirk[e].y & 0xffu;
+		if ((key >> (2u * (6u - k))) == X.quirk[e].x) return e;
+	}
+	return LEAN_NO_QUIRK;
+}
 
 enum LeanPhase : uint32_t { LP_STEP = 0, LP_SEARCH, LP_SCAN, LP_EXT, LP_REFILL, LP_SLOW, LP_SLOWEXT };
 
@@ -475,12 +500,13 @@ PHY_HD void lean_step(LeanLane &ln, const RefIndex &R, const LeanIndex &X, const
 // insertion point in the suffix array, unique iff the LCP array says the next suffix outward does
 // not share it (anchor_core.h's header).
 #if !defined(__HIP_DEVICE_COMPILE__)
-inline void lean_resolve_scalar(LeanLane &ln, const uint8_t *qbase, const RefIndex &R)
+inline void lean_resolve_scalar(LeanLane &ln, const uint8_t *qbase, const RefIndex &R, const LeanIndex &X)
 {
 	const uint8_t *Q = qbase + ((uint64_t)ln.qw0 << 4) + ln.q;
 	const uint32_t n = ln.qlen - ln.q;
+	uint32_t skip = 0; // bytes the comparisons take as matched (an over-deep cache entry's depth, else 0)
 	auto cmp = [&](uint32_t sa, uint32_t *len, uint32_t *less) {
-		uint32_t i = 0;
+		uint32_t i = skip;
 		while (i < n && Q[i] == R.S[sa + i]) i++; // S ends in zero bytes, query bytes are never zero
 		*len = i;
 		*less = (i < n && R.S[sa + i] < Q[i]) ? 1u : 0u;
@@ -500,7 +526,15 @@ inline void lean_resolve_scalar(LeanLane &ln, const uint8_t *qbase, const RefInd
 			return;
 		}
 	}
-	uint32_t lo = 0, hi = R.n;
+	uint32_t lo = 0, hi = R.n, in_lo = 0, in_hi = R.n;
+	const uint32_t qe = lean_quirk_lookup(X, Q, n);
+	if (qe != LEAN_NO_QUIRK) {
+		// get_match_from(query, qlen, ij.l, ij) with the cache's over-deep ij (esa.cxx:556-562): the search goes on
+		// below the interval from depth ij.l, whatever the query holds before that
+		skip = X.quirk[qe].y >> 8;
+		lo = in_lo = X.quirk[qe].z;
+		hi = in_hi = X.quirk[qe].w;
+	}
 	while (lo < hi) {
 		const uint32_t mid = lo + ((hi - lo) >> 1);
 		cmp(R.SAX[mid].x, &len, &less);
@@ -508,11 +542,11 @@ inline void lean_resolve_scalar(LeanLane &ln, const uint8_t *qbase, const RefInd
 		else hi = mid;
 	}
 	uint32_t lp = 0, pp = 0, lsu = 0, ps = 0;
-	if (lo > 0) {
+	if (lo > in_lo) { // (a rank outside an over-deep interval shares less than its depth: never the better neighbour)
 		pp = R.SAX[lo - 1].x;
 		cmp(pp, &lp, &less);
 	}
-	if (lo < R.n) {
+	if (lo < in_hi) {
 		ps = R.SAX[lo].x;
 		cmp(ps, &lsu, &less);
 	}
@@ -818,7 +852,7 @@ inline void lean_trip_cpu(LeanLane &ln, uint32_t *ring, const uint8_t *qbase, co
 		}
 	}
 	if (ln.ph == LP_SLOW) {
-		lean_resolve_scalar(ln, qbase, R);
+		lean_resolve_scalar(ln, qbase, R, X);
 		(*slow_steps)++;
 		return;
 	}

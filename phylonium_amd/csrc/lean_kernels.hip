@@ -17,6 +17,8 @@
 // reach) + instruction issue; algorithmic bytes per launch as anchor_kernels.hip.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "kernels.h"
 #include "lean_core.h"
 
@@ -145,7 +147,8 @@ static __device__ void lanes_compare(const uint8_t *qp, uint32_t n, const uint8_
 // lean_resolve_scalar is the same in plain loops): lucky_anchor; else the insertion point of the
 // query suffix among the suffixes of S — 64 probes per round — the longer of its two neighbours'
 // matches, unique iff the LCP array says the next suffix outward does not share it.
-static __device__ void coop_resolve(LeanLane &ln, int leader, const PhaseA &A, const RefIndex &R, const uint8_t *s_end)
+static __device__ void coop_resolve(LeanLane &ln, int leader, const PhaseA &A, const RefIndex &R, const LeanIndex &X,
+									const uint8_t *s_end)
 {
 	const uint32_t lane = lane64();
 	const uint32_t qw0 = bcast(ln.qw0, leader), q = bcast(ln.q, leader), qlen = bcast(ln.qlen, leader);
@@ -155,7 +158,19 @@ static __device__ void coop_resolve(LeanLane &ln, int leader, const PhaseA &A, c
 	const uint32_t n = qlen - q;
 	// A speculative chain's comparisons stop at its cap (lean_core.h: q_cap) when the step's outcome no
 	// longer depends on the length: first with the cap; if that leaves anything open, once more without.
-	const uint32_t cap_rel = (q_cap != NO_BAD && q_cap > q && q_cap - q < n) ? q_cap - q : NO_BAD;
+	uint32_t cap_rel = (q_cap != NO_BAD && q_cap > q && q_cap - q < n) ? q_cap - q : NO_BAD;
+	// A window under an over-deep entry of the reference's 6-mer cache (lean_core.h: LeanIndex::quirk): the search
+	// goes on below the entry's interval [in_lo, in_hi) from depth `skip` — get_match_from(query, qlen, ij.l, ij),
+	// src/esa.cxx:556-562 — whatever the query holds before that.  (Tiny subjects only; no cap there.)
+	uint32_t skip = 0, in_lo = 0, in_hi = R.n;
+	const uint32_t qe = X.nquirk ? lean_quirk_lookup(X, Q, n) : LEAN_NO_QUIRK;
+	if (qe != LEAN_NO_QUIRK) {
+		const U4 e = X.quirk[qe];
+		skip = e.y >> 8;
+		in_lo = e.z;
+		in_hi = e.w;
+		cap_rel = NO_BAD;
+	}
 	uint32_t r_pos = 0, r_len = 0;
 	bool r_acc = false, r_cut = false;
 	for (int pass = 0; pass < 2; pass++) {
@@ -174,8 +189,8 @@ static __device__ void coop_resolve(LeanLane &ln, int leader, const PhaseA &A, c
 				break;
 			}
 		}
-		uint32_t lo = 0, hi = R.n;
-		{ // the k-mer's bucket bounds the search when the window starts with k nucleotides
+		uint32_t lo = in_lo, hi = in_hi;
+		if (qe == LEAN_NO_QUIRK) { // the k-mer's bucket bounds the search when the window starts with k nucleotides
 			uint32_t valid;
 			const uint32_t code = window_code(lg16(Q), &valid);
 			const uint32_t qv = valid < n ? valid : n;
@@ -185,12 +200,14 @@ static __device__ void coop_resolve(LeanLane &ln, int leader, const PhaseA &A, c
 				hi = hdr.y;
 			}
 		}
+		const uint8_t *const Qs = Q + skip, *const Ss = R.S + skip; // comparisons start behind the bytes taken as matched
+		const uint32_t ns = neff - skip;
 		while (hi - lo > 62u) {
 			const uint32_t m = hi - lo;
 			const uint32_t r = lo + (uint32_t)(((uint64_t)(lane + 1u) * m) / 65u); // lo <= r < hi, nondecreasing in lane
 			const uint32_t sa = lg16((const uint8_t *)(R.SAX + r)).x;
 			uint32_t len, less;
-			lanes_compare(Q, neff, R.S, sa, true, s_end, &len, &less);
+			lanes_compare(Qs, ns, Ss, sa, true, s_end, &len, &less);
 			if (capped && __ballot(len >= neff)) { // a probe ran into the cap: its order is unknown
 				redo = true;
 				break;
@@ -203,11 +220,14 @@ static __device__ void coop_resolve(LeanLane &ln, int leader, const PhaseA &A, c
 		}
 		if (redo) continue;
 		const uint32_t m = hi - lo; // lanes 0 .. m+1 take ranks lo-1 .. hi
-		const bool on = lane < m + 2u && !(lo == 0 && lane == 0) && lo + lane - 1u < R.n;
+		// (a rank outside an over-deep interval shares less than its depth with the window as the reference reads it:
+		// never the better neighbour, its length stays 0)
+		const bool on = lane < m + 2u && !(lo == 0 && lane == 0) && lo + lane - 1u < R.n && lo + lane - 1u >= in_lo && lo + lane - 1u < in_hi;
 		const uint32_t rank = on ? lo + lane - 1u : 0u;
 		const uint32_t sa = lg16((const uint8_t *)(R.SAX + rank)).x;
 		uint32_t len, less;
-		lanes_compare(Q, neff, R.S, sa, on, s_end, &len, &less);
+		lanes_compare(Qs, ns, Ss, sa, on, s_end, &len, &less);
+		if (on) len += skip;
 		if (capped) {
 			const uint64_t hit = __ballot(on && len >= neff);
 			if (hit) {
@@ -542,7 +562,7 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 #ifdef PHY_LEAN_TIMING
 			tm[5] += lph == LP_SLOW ? 1ull : (1ull << 32);
 #endif
-			if (lph == LP_SLOW) coop_resolve(ln, leader, A, R, s_end);
+			if (lph == LP_SLOW) coop_resolve(ln, leader, A, R, X, s_end);
 			else coop_ext(ln, leader, A, R, s_end);
 			slow &= slow - 1;
 		}
@@ -726,12 +746,13 @@ static int lean_resident(const void *fn, int n_cu)
 }
 int lean_spec_resident_blocks(int n_cu)
 {
-	static int cached_cu = 0, cached = 0;
-	if (cached_cu != n_cu) {
-		cached = lean_resident((const void *)lean_chain_kernel<0>, n_cu);
-		cached_cu = n_cu;
-	}
-	return cached;
+	// (n_cu, blocks) in one atomic word: contexts driven from different host threads may ask at the same time
+	static std::atomic<uint64_t> cache{0};
+	const uint64_t seen = cache.load(std::memory_order_acquire);
+	if ((int)(seen >> 32) == n_cu && (uint32_t)seen) return (int)(uint32_t)seen;
+	const int blocks = lean_resident((const void *)lean_chain_kernel<0>, n_cu);
+	cache.store(((uint64_t)(uint32_t)n_cu << 32) | (uint32_t)blocks, std::memory_order_release);
+	return blocks;
 }
 void launch_lean_spec(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st)
 {

@@ -183,6 +183,7 @@ struct phylo_ctx {
 	int opt_filter_kernel = 0; // option "filter_kernel": 0 stretch-wise chain filter (then the general kernel for what it hands over), 1 general only
 	int opt_sa_builder = 1; // option "sa_builder": who builds the suffix array when the caller brings none — 1 the device, 0 the host cores
 	uint32_t opt_pairs_wchunk = 0; // option "pairs_wchunk": windows per chunk of the pair kernel (0: chosen from the L2 size)
+	int opt_pairs_kernel = 0; // option "pairs_kernel": 0 the matrix-core kernel when no projected position holds '!' (default), 1 the vector-ALU kernel always
 	int opt_tail_groups = 1; // option "tail_groups": streams the tail is spread over (default 1: measured, the groups run in lockstep and nothing is hidden — DESIGN.md)
 	std::string err;
 	int n_cu = 256;
@@ -215,7 +216,10 @@ struct phylo_ctx {
 	DevBuf<uint32_t> d_Q2, d_QBAD, d_qbad_off, d_S2, d_SBAD, d_badscr;
 	DevBuf<uint64_t> d_badoff;
 	uint32_t nsb = 0, sb_first = 0;
-	bool cache_quirk = false; // the reference's 6-mer cache would over-report matches on this subject (hostlogic.hpp: esa_cache_quirk)
+	bool cache_quirk = false; // the reference's 6-mer cache over-reports matches on this subject (hostlogic.hpp: esa_cache_quirks)
+	DevBuf<U4> d_quirk;       // its over-deep entries {prefix, k | depth << 8, lo, hi} for the chains' slow resolver (lean_core.h)
+	uint32_t nquirk = 0;
+	int opt_cache_quirk = 1; // option "cache_quirk": 1 reproduce what the reference answers on such a subject (default), 0 the true longest matches
 	int anchor_kernel = 1; // option "anchor_kernel": 1 lean 2-bit chains (default), 0 the general byte-wise chains
 	int lean_force_slow = 0;
 
@@ -429,6 +433,7 @@ void phylo_ctx_destroy(phylo_ctx *c)
 	c->d_SBAD.release();
 	c->d_badscr.release();
 	c->d_badoff.release();
+	c->d_quirk.release();
 	c->a_flt.release();
 	c->a_long.release();
 	c->a_qoff.release();
@@ -510,6 +515,14 @@ int phylo_set_option(phylo_ctx *c, const char *key, long value)
 	} else if (k == "pairs_wchunk") {
 		if (value < 0 || value > (1 << 20)) return c->fail("pairs_wchunk must be in 0..2^20");
 		c->opt_pairs_wchunk = (uint32_t)value;
+	} else if (k == "cache_quirk") {
+		if (value != 0 && value != 1) return c->fail("cache_quirk must be 1 (as the reference answers) or 0 (true longest matches)");
+		c->opt_cache_quirk = (int)value;
+		c->plan_valid = false;
+		c->homs_staged = false;
+	} else if (k == "pairs_kernel") {
+		if (value != 0 && value != 1) return c->fail("pairs_kernel must be 0 (matrix cores unless '!' is projected) or 1 (vector ALUs)");
+		c->opt_pairs_kernel = (int)value;
 	} else if (k == "lean_force_slow") {
 		c->lean_force_slow = value != 0;
 	} else if (k == "profile") {
@@ -627,6 +640,7 @@ static int pack_genomes(phylo_ctx *c)
 	HIPOK(c, hipMemcpy(c->d_qbad_off.p, off.data(), (n + 1) * 4, hipMemcpyHostToDevice));
 	c->stats["ms:pack_genomes"] += now_ms() - t0;
 	c->stats["count:genome_non_acgt"] = off[n];
+	c->pileup_five = off[n] > 0;
 	return 0;
 }
 
@@ -649,6 +663,11 @@ static int install_layout(phylo_ctx *c, bool pack = true)
 	c->homs_staged = false;
 	c->att_homs = nullptr; // lists that only lived in an attached buffer are gone
 	c->host_stale.clear();
+	// Phase B goes ahead on a guess of whether a projected position will hold '!' (compare_pileup).  Genomes without any
+	// separator cannot project one; genomes in several contigs nearly always do (a homology that ends at a contig join
+	// carries it).  The guess is re-seeded from the new genomes' '!' count where that count becomes known, so the first
+	// call after an install starts with the right kernels instead of repeating the work.
+	c->pileup_five = false;
 	return pack ? pack_genomes(c) : 0;
 }
 
@@ -750,6 +769,7 @@ int phylo_set_genomes_packed(phylo_ctx *c, size_t n, const uint32_t *const *q2, 
 	c->stats["ms:genomes_copy"] += t2 - t1;
 	c->stats["ms:genomes_install"] += now_ms() - t2;
 	c->stats["count:genome_non_acgt"] = (double)blist.size();
+	c->pileup_five = !blist.empty();
 	return 0;
 }
 
@@ -780,6 +800,9 @@ int phylo_set_genomes_packed_device(phylo_ctx *c, size_t n, const void *dev_q2, 
 		boff[j + 1] = (uint32_t)blist.size();
 		tot = offsets[j] + (lens[j] + 63) / 64 * 64 + 64;
 	}
+	// the caller's buffer reaches 16 bytes' worth of words past the last genome's padding (the header's promise): that
+	// much is copied, the rest of this context's Q2 — the 256 bytes the kernels may prefetch behind it — is cleared here
+	const size_t src_words = (size_t)(tot / 16) + 1;
 	tot += 256;
 	if (tot / 16 + 64 >= 0xffffffffull) return c->fail("genome buffer too large for 32-bit word offsets");
 	const size_t words = (size_t)(tot / 16);
@@ -788,8 +811,8 @@ int phylo_set_genomes_packed_device(phylo_ctx *c, size_t n, const void *dev_q2, 
 	c->glen.assign(lens, lens + n);
 	HIPOK(c, c->genomes_store.ensure(tot));
 	HIPOK(c, c->d_Q2.ensure(words + 64));
-	HIPOK(c, hipMemsetAsync(c->d_Q2.p + words, 0, 64 * 4, c->stream));
-	HIPOK(c, hipMemcpyAsync(c->d_Q2.p, dev_q2, words * 4, hipMemcpyDeviceToDevice, c->stream));
+	HIPOK(c, hipMemsetAsync(c->d_Q2.p + src_words, 0, (words + 64 - src_words) * 4, c->stream));
+	HIPOK(c, hipMemcpyAsync(c->d_Q2.p, dev_q2, src_words * 4, hipMemcpyDeviceToDevice, c->stream));
 	c->d_genomes = c->genomes_store.p;
 	c->own_genomes = true;
 	if (install_layout(c, false)) return 1;
@@ -803,6 +826,7 @@ int phylo_set_genomes_packed_device(phylo_ctx *c, size_t n, const void *dev_q2, 
 	HIPOK(c, hipStreamSynchronize(c->stream));
 	c->stats["ms:genomes_install"] += now_ms() - t0;
 	c->stats["count:genome_non_acgt"] = (double)blist.size();
+	c->pileup_five = !blist.empty();
 	return 0;
 }
 
@@ -904,7 +928,10 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 			const int rc = device_suffix_array(c->d_S.p, ns, c->d_SA.p, scratch.p, &sa_rounds, st);
 			HIPOK(c, hipStreamSynchronize(st));
 			scratch.release();
-			if (rc == 2) return c->fail("suffix array on the device: %s", hipGetErrorString(hipGetLastError()));
+			if (rc == 2) { // a library primitive refused (e.g. its scratch requirement): the host builders take over
+				c->stats["ref:sa_device_error"] = (double)hipGetLastError();
+				(void)hipStreamSynchronize(st);
+			}
 			sa_on_device = rc == 0; // rc == 1: a byte outside ! # A C G T — the host builders order any bytes
 		} else {
 			(void)hipGetLastError(); // no room for the working set next to the genomes: the host cores sort
@@ -999,10 +1026,20 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 		bool suspect = false;
 		for (uint32_t m : next_masks) suspect = suspect || (m && !(m & (m - 1)));
 		c->stats["ref:cache_quirk_exact_check"] = (c->nsb > 2 && suspect) ? 1 : 0;
+		c->nquirk = 0;
 		if (c->nsb > 2 && suspect) {
 			if (host_sa() || host_S()) return 1;
-			c->cache_quirk = esa_cache_quirk(S.data(), ns, SA.data());
+			const std::vector<CacheQuirk> qs = esa_cache_quirks(S.data(), ns, SA.data());
+			c->cache_quirk = !qs.empty();
+			if (!qs.empty()) {
+				std::vector<U4> tab;
+				for (const CacheQuirk &e : qs) tab.push_back(U4{e.prefix, e.k | (e.depth << 8), e.lo, e.hi});
+				HIPOK(c, c->d_quirk.ensure(tab.size()));
+				HIPOK(c, hipMemcpy(c->d_quirk.p, tab.data(), tab.size() * sizeof(U4), hipMemcpyHostToDevice));
+				c->nquirk = (uint32_t)tab.size();
+			}
 		}
+		c->stats["ref:cache_quirk_entries"] = c->nquirk;
 		c->stats["ref:cache_quirk"] = c->cache_quirk ? 1 : 0;
 	}
 	double t3 = now_ms();
@@ -1097,6 +1134,8 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 		if (ensure_host_lists(c, 0, q_begin) || ensure_host_lists(c, q_end, c->n)) return 1;
 	}
 	double t0 = now_ms();
+	const bool quirk_mode = c->nquirk > 0 && c->opt_cache_quirk != 0; // (see below, where the chains' tables are set up)
+	const bool lean_chains = c->anchor_kernel != 0 || quirk_mode;
 
 	hipStream_t st = c->stream;
 	if (!c->plan_valid || c->plan_qb != q_begin || c->plan_qe != q_end) {
@@ -1123,9 +1162,9 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 		for (uint32_t l : qlen) total_q += l;
 		int per_cu_cap = total_q < 1200000000ull ? 3 : 4;
 		if (const char *e = getenv("PHY_SPEC_PER_CU")) per_cu_cap = std::max(1, atoi(e)); // experiments
-		const int resident = c->anchor_kernel ? std::min(lean_spec_resident_blocks(c->n_cu), per_cu_cap * c->n_cu) : spec_resident_blocks(c->n_cu);
+		const int resident = lean_chains ? std::min(lean_spec_resident_blocks(c->n_cu), per_cu_cap * c->n_cu) : spec_resident_blocks(c->n_cu);
 		c->plan = plan_chunks(qlen, c->threshold, c->opt_chunk, (uint32_t)resident * 256u, c->opt_chunk_tail,
-							  c->anchor_kernel ? (uint32_t)c->n_cu * 256u : 0u);
+							  lean_chains ? (uint32_t)c->n_cu * 256u : 0u);
 		const ChunkPlan &P = c->plan;
 		if (!P.C) return c->fail("phase A: more than 2^32 anchor log slots");
 		// an emitted homology spans >= 2*threshold query positions
@@ -1213,15 +1252,18 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	A.error = c->a_misc.p + 3;
 	A.overrun = c->a_misc.p + 4;
 	RefIndex R = {c->d_S.p, c->d_SAX.p, c->d_LCP.p, c->d_SLOT.p, c->ns, c->k, c->threshold};
+	// A subject on which the reference's 6-mer cache holds over-deep intervals (esa.cxx:174-199): the reference's
+	// answers there are reproduced by the lean chains' slow resolver, so every step goes through it (such subjects
+	// are a few kbp in several contigs; option "cache_quirk" = 0 computes the true longest matches instead).
 	LeanIndex X = {c->d_S2.p, c->d_SBAD.p, c->nsb, c->ns, c->sb_first, c->d_Q2.p, c->d_QBAD.p, c->d_qbad_off.p + q_begin,
-				   (uint32_t)c->lean_force_slow, nullptr};
+				   (uint32_t)(c->lean_force_slow || quirk_mode), nullptr, quirk_mode ? c->d_quirk.p : nullptr, quirk_mode ? c->nquirk : 0u};
 #ifdef PHY_LEAN_TIMING
 	static unsigned long long *dbg_buf = nullptr;
 	if (!dbg_buf) (void)hipMalloc((void **)&dbg_buf, 16 * 8);
 	(void)hipMemsetAsync(dbg_buf, 0, 16 * 8, st);
 	X.dbg = dbg_buf;
 #endif
-	const bool lean = c->anchor_kernel != 0;
+	const bool lean = lean_chains;
 
 	double t1 = now_ms();
 	const bool dbg = getenv("PHY_DEBUG_SYNC") != nullptr; // name the kernel a hang is in
@@ -2020,11 +2062,43 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 			tiles.push_back((ig << 16) | jt);
 		}
 	if (!tiles.empty()) {
-		HIPOK(c, c->b_tiles.ensure(tiles.size()));
+		HIPOK(c, c->b_tiles.ensure(tiles.size() + (N / 64 + 2) * (N / 64 + 2))); // room for the matrix-core kernel's tiles behind them
 		HIPOK(c, hipMemcpyAsync(c->b_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, st));
+	}
+	// tiles of the matrix-core kernel: 64 x 64 genomes, ti <= tj
+	std::vector<uint32_t> mtiles;
+	if (c->opt_pairs_kernel == 0) {
+		const uint32_t T = pairs_mfma_tile(), nt = (uint32_t)((N + T - 1) / T);
+		for (uint32_t a = 0; a < nt; a++)
+			for (uint32_t b = a; b < nt; b++) mtiles.push_back((a << 16) | b);
+		HIPOK(c, c->b_tiles.ensure(tiles.size() + mtiles.size()));
+		if (!mtiles.empty()) HIPOK(c, hipMemcpyAsync(c->b_tiles.p + tiles.size(), mtiles.data(), mtiles.size() * 4, hipMemcpyHostToDevice, st));
 	}
 	auto pairs = [&](bool bang) -> int {
 		if (tiles.empty() || !P.W) return 0;
+		if (!bang && !mtiles.empty()) {
+			// Without '!' the tallies are a contraction over {-1, 0, 1} channels: the matrix cores take it
+			// (pileup_kernels.hip: pairs_mfma_kernel).  Window chunks: the chunk's rows of three planes in an XCD's L2,
+			// ~16 wavefronts per CU in all (measured best at N = 256; indifferent at N = 1024), a multiple of 8 chunks
+			// (dealt round-robin over the XCDs) of a whole number of steps (2 windows) each.
+			const uint32_t row_bytes = 3u * P.Npad * 4u;
+			const uint32_t l2_fit = std::max<uint32_t>(64, (3u << 20) / row_bytes);
+			const uint32_t want_chunks = std::max<uint32_t>(1, ((uint32_t)c->n_cu * 16u) / (uint32_t)mtiles.size());
+			uint32_t wchunk = std::max<uint32_t>(48, (P.W + want_chunks - 1) / want_chunks);
+			wchunk = std::min(wchunk, l2_fit);
+			const uint32_t groups = (P.W + 8u * wchunk - 1) / (8u * wchunk);
+			wchunk = std::max<uint32_t>(2, (P.W + 8u * groups - 1) / (8u * groups));
+			wchunk = (wchunk + 1u) & ~1u;
+			if (c->opt_pairs_wchunk) wchunk = (c->opt_pairs_wchunk + 1u) & ~1u;
+			wchunk = std::min(wchunk, pairs_mfma_max_wchunk() & ~1u);
+			{
+				KernelSpan s(c, "pileup_pairs_mfma");
+				launch_pairs_mfma(P, c->b_tiles.p + tiles.size(), (uint32_t)mtiles.size(), wchunk, acc_s, acc_h, st);
+			}
+			HIPOK(c, hipGetLastError());
+			launch_symmetrise((uint32_t)N, acc_s, acc_h, st);
+			return 0;
+		}
 		// window chunks: small enough that a chunk's plane rows (3 or 5 planes x Npad x 4 B
 		// per window) fit an XCD's 4 MiB L2 with room to spare, and small enough that
 		// tiles x chunks fills the chip several times over; at least 64 windows

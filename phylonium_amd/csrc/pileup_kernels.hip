@@ -386,6 +386,172 @@ __global__ __launch_bounds__(64) void pairs_kernel(Pileup P, const uint32_t *__r
 	}
 }
 
+// ───────────────── the pair tallies as a matrix-core contraction (the default without '!') ─────────────────
+//
+// Over the projected planes the two tallies are contractions over reference positions:
+//     homologs(i,j) = sum_p V_i V_j
+//     matches(i,j)  = sum_p V_i V_j (1 + a_i a_j)(1 + b_i b_j) / 4,     a = (-1)^N0, b = (-1)^N1
+//                   = (sum_p [V V' + Va Va' + Vb Vb' + Vab Vab']) / 4,   substitutions = homologs - matches
+// — four channels of values in {-1, 0, +1}, which FP4 (E2M1: +1.0 = 0b0010, sign = bit 3) holds exactly, so the
+// densest matrix instruction of gfx950 applies: v_mfma_f32_32x32x64_f8f6f4, 65536 multiply-adds per wavefront in
+// the cycles of the bf16 32x32x16 form.  The f32 accumulators hold integers exactly below 2^24 (a wavefront's
+// window chunk contributes at most 3 x 32 x wchunk to one of them).  (seqcmp counts byte mismatches,
+// libs/seqcmp.c:13-28; on the planes that is this sum.  The north star kept the matrix cores out of the merge-join
+// formulation; with the pileup the work IS a contraction — measured: tools/microbench/mfma_pairs.hip)
+//
+// Operands are made in registers from the plane words.  A plane word holds 32 positions; its position class d
+// (positions = d mod 4) becomes one dword of 8 nibbles by one shift and one mask, V landing on nibble bit 1 and the
+// channel's sign plane on nibble bit 3 (a set sign bit over V = 0 is -0: harmless).  The order of K inside an
+// instruction is free as long as both operands use the same one — they do, the expansion is the same code for the
+// i side and the j side.  Lane l holds genome l & 31 of a group of 32 genomes; lanes 0..31 take window w, lanes
+// 32..63 window w + 1: the instruction's two K blocks of 32.  A wavefront owns a tile of 64 x 64 genomes (2 x 2
+// instructions per channel and step) and a chunk of windows; two wavefronts per SIMD.
+typedef int pm_v8i __attribute__((ext_vector_type(8)));
+typedef float pm_v16f __attribute__((ext_vector_type(16)));
+static const int PM_G = 2;  // groups of 32 genomes per tile side
+static const int PM_NB = 3; // register sets of plane words in flight (a set is refilled right after its step has expanded it)
+
+static __device__ __forceinline__ void pm_expand_v(uint32_t V, uint32_t o[4])
+{
+	o[0] = (V << 1) & 0x22222222u;
+	o[1] = V & 0x22222222u;
+	o[2] = (V >> 1) & 0x22222222u;
+	o[3] = (V >> 2) & 0x22222222u;
+}
+static __device__ __forceinline__ void pm_expand_s(uint32_t S, const uint32_t v[4], uint32_t o[4])
+{
+	o[0] = v[0] | ((S << 3) & 0x88888888u);
+	o[1] = v[1] | ((S << 2) & 0x88888888u);
+	o[2] = v[2] | ((S << 1) & 0x88888888u);
+	o[3] = v[3] | (S & 0x88888888u);
+}
+static __device__ __forceinline__ pm_v16f pm_mfma(const uint32_t a[4], const uint32_t b[4], pm_v16f c)
+{
+	const pm_v8i va = {(int)a[0], (int)a[1], (int)a[2], (int)a[3], 0, 0, 0, 0};
+	const pm_v8i vb = {(int)b[0], (int)b[1], (int)b[2], (int)b[3], 0, 0, 0, 0};
+	return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, vb, c, 4, 4, 0, 0, 0, 0); // both FP4, unscaled
+}
+struct PmWords {
+	uint32_t v, a, b;
+};
+// DIAG: a tile on the diagonal of the pair grid — its sub-tile below the diagonal is left out
+template <bool DIAG>
+static __device__ __forceinline__ void pairs_mfma_body(const Pileup &P, uint32_t ti, uint32_t tj, uint32_t w0, uint32_t w1,
+														unsigned long long *__restrict__ subst, unsigned long long *__restrict__ homologs)
+{
+	constexpr int G = PM_G, NG = 2 * PM_G;
+	const uint32_t lane = threadIdx.x & 63u, gl = lane & 31u, half = lane >> 5;
+	// the chunk's rows as buffers: an offset beyond the chunk reads 0, so the last step's odd window and the
+	// loads issued ahead need no guard (and offsets stay 32-bit whatever the planes' size)
+	const uint32_t chunk_bytes = (w1 - w0) * P.Npad * 4u;
+	const size_t row0 = (size_t)w0 * P.Npad;
+	const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(P.plane[0] + row0), 0, chunk_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)(P.plane[1] + row0), 0, chunk_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(P.plane[2] + row0), 0, chunk_bytes, 0x00020000);
+	const uint32_t so_i = ti * G * 128u, so_j = tj * G * 128u; // byte offset of the tile's first i / j genome in a row
+	uint32_t off = (half * P.Npad + gl) * 4u;                  // this lane's word of its window's row
+	const uint32_t step = 2u * P.Npad * 4u;
+	pm_v16f acc_h[G][G], acc_t[G][G];
+#pragma unroll
+	for (int a = 0; a < G; a++)
+#pragma unroll
+		for (int b = 0; b < G; b++)
+#pragma unroll
+			for (int r = 0; r < 16; r++) acc_h[a][b][r] = acc_t[a][b][r] = 0.f;
+#define PM_NEED(a, b) (!DIAG || (a) <= (b))
+	auto load = [&](PmWords (&x)[NG]) {
+#pragma unroll
+		for (int g = 0; g < NG; g++) {
+			const uint32_t so = g < G ? so_i : so_j, im = (uint32_t)(g < G ? g : g - G) * 128u;
+			x[g].v = __builtin_amdgcn_raw_buffer_load_b32(rv, off + im, so, 0);
+			x[g].a = __builtin_amdgcn_raw_buffer_load_b32(ra, off + im, so, 0);
+			x[g].b = __builtin_amdgcn_raw_buffer_load_b32(rb, off + im, so, 0);
+		}
+		off += step;
+	};
+	constexpr int NMF = DIAG ? (G * (G + 1)) / 2 : G * G; // matrix instructions per channel and step
+	auto compute = [&](PmWords (&x)[NG]) {
+		uint32_t vd[NG][4], op[NG][4];
+#pragma unroll
+		for (int g = 0; g < NG; g++) pm_expand_v(x[g].v, vd[g]);
+#pragma unroll
+		for (int a = 0; a < G; a++)
+#pragma unroll
+			for (int b = 0; b < G; b++)
+				if (PM_NEED(a, b)) acc_h[a][b] = pm_mfma(vd[a], vd[G + b], acc_h[a][b]);
+#pragma unroll
+		for (int c = 0; c < 3; c++) {
+#pragma unroll
+			for (int g = 0; g < NG; g++) pm_expand_s(c == 0 ? x[g].a : c == 1 ? x[g].b : (x[g].a ^ x[g].b), vd[g], op[g]);
+#pragma unroll
+			for (int a = 0; a < G; a++)
+#pragma unroll
+				for (int b = 0; b < G; b++)
+					if (PM_NEED(a, b)) acc_t[a][b] = pm_mfma(op[a], op[G + b], acc_t[a][b]);
+		}
+		load(x); // the set is free again: its words for the step PM_NB from now
+		// ask the scheduler to deal the expansion's vector instructions out between the matrix instructions
+		constexpr int PER = (29 * NG + 4 * NMF - 1) / (4 * NMF);
+#pragma unroll
+		for (int i = 0; i < 4 * NMF; i++) {
+			__builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+			__builtin_amdgcn_sched_group_barrier(0x002, PER, 0);
+			if (i % NMF == 0) __builtin_amdgcn_sched_group_barrier(0x020, 3 * NG / 4, 0);
+		}
+	};
+	PmWords x[PM_NB][NG];
+#pragma unroll
+	for (int k = 0; k < PM_NB; k++) load(x[k]);
+	for (uint32_t w = w0; w < w1; w += 2 * PM_NB) {
+#pragma unroll
+		for (int k = 0; k < PM_NB; k++) compute(x[k]);
+	}
+	// C/D layout of the 32x32 forms: column = lane & 31 (the B operand's row: genome j), row = (r & 3) + 8 (r >> 2)
+	// + 4 (lane >> 5) (the A operand's row: genome i)
+#pragma unroll
+	for (int a = 0; a < G; a++)
+#pragma unroll
+		for (int b = 0; b < G; b++) {
+			if (!PM_NEED(a, b)) continue;
+			const uint32_t j = (tj * G + b) * 32u + gl;
+#pragma unroll
+			for (int r = 0; r < 16; r++) {
+				const uint32_t i = (ti * G + a) * 32u + (r & 3) + 8 * (r >> 2) + 4 * half;
+				const int h = (int)acc_h[a][b][r], t = (int)acc_t[a][b][r];
+				if (i < j && j < P.N && h) {
+					atomicAdd(&homologs[(size_t)i * P.N + j], (unsigned long long)h);
+					const int sb = (3 * h - t) >> 2; // matches = (h + t) / 4
+					if (sb) atomicAdd(&subst[(size_t)i * P.N + j], (unsigned long long)sb);
+				}
+			}
+		}
+#undef PM_NEED
+}
+// One wavefront per (tile of 64 x 64 genomes, window chunk); the same XCD-aware order as pairs_kernel.
+__global__ __launch_bounds__(64, 2) void pairs_mfma_kernel(Pileup P, const uint32_t *__restrict__ tiles, uint32_t ntiles,
+															uint32_t wchunk, uint32_t nwc, unsigned long long *__restrict__ subst,
+															unsigned long long *__restrict__ homologs)
+{
+	const uint32_t xcd = blockIdx.x & 7u, local = blockIdx.x >> 3;
+	const uint32_t tile = local % ntiles;
+	const uint32_t wc = (local / ntiles) * 8u + xcd;
+	if (wc >= nwc) return;
+	const uint32_t ti = tiles[tile] >> 16, tj = tiles[tile] & 0xffffu;
+	const uint32_t w0 = wc * wchunk, w1 = (w0 + wchunk < P.W) ? w0 + wchunk : P.W;
+	if (ti == tj) pairs_mfma_body<true>(P, ti, tj, w0, w1, subst, homologs);
+	else pairs_mfma_body<false>(P, ti, tj, w0, w1, subst, homologs);
+}
+uint32_t pairs_mfma_tile() { return PM_G * 32u; }
+uint32_t pairs_mfma_max_wchunk() { return (1u << 24) / (3u * 32u) - 8u; } // exact integers in the f32 accumulators
+void launch_pairs_mfma(const Pileup &P, const uint32_t *tiles, uint32_t ntiles, uint32_t wchunk, unsigned long long *subst,
+					   unsigned long long *homologs, hipStream_t st)
+{
+	if (!ntiles || !P.W) return;
+	const uint32_t nwc = (P.W + wchunk - 1) / wchunk;
+	dim3 grid(((nwc + 7) / 8) * 8 * ntiles);
+	hipLaunchKernelGGL(pairs_mfma_kernel, grid, dim3(64), 0, st, P, tiles, ntiles, wchunk, nwc, subst, homologs);
+}
+
 // tallies are accumulated for i<j only; mirror them so the matrices leave symmetric
 __global__ __launch_bounds__(256) void symmetrise_kernel(uint32_t N, unsigned long long *__restrict__ a,
 														  unsigned long long *__restrict__ b)

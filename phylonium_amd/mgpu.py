@@ -265,7 +265,18 @@ def main(argv=None):
     torch.cuda.synchronize(device)
     if args.threads:
         ctx.set_option("host_threads", args.threads)
-    ctx.set_genomes_packed_device(q2_all.data_ptr(), [int(x) for x in offs], lens, bad_all)
+    # a failure on one rank (device memory, a refused layout) must end all of them: the others would wait in the
+    # next collective otherwise
+    err = None
+    try:
+        ctx.set_genomes_packed_device(q2_all.data_ptr(), [int(x) for x in offs], lens, bad_all)
+    except api.PhyloniumError as e:
+        err = e
+    if not all_ok(err is None, f"a rank could not install the genomes ({err})"):
+        ctx.close()
+        if world > 1:
+            td.destroy_process_group()
+        return 1
     if not args.reference:
         # "the first genome equal to the chosen one" (phylonium.cxx:372-378): only a same-named copy of the
         # same length can precede it; its suffix array is the same array, so the thread above is not redone
@@ -295,8 +306,17 @@ def main(argv=None):
             sa = sa_t.cpu().numpy().astype(np.int64)
     t_sa = time.perf_counter()
     ctx.set_option("sa_builder", 0 if args.sa == "host" else 1)
-    ctx.set_reference(ref_idx, sa=sa)
+    err = None
+    try:
+        ctx.set_reference(ref_idx, sa=sa)
+    except api.PhyloniumError as e:
+        err = e
     del sa
+    if not all_ok(err is None, f"a rank could not build the reference's index ({err})"):
+        ctx.close()
+        if world > 1:
+            td.destroy_process_group()
+        return 1
     t_index = time.perf_counter()
 
     # ── the path ──

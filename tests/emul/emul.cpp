@@ -171,6 +171,12 @@ void *emul_run2(size_t n, const char *const *seq, const size_t *len, size_t ref_
 
 	if (chatty) fprintf(stderr, "emul: index done (k %u), %u chunks of %u\n", k, P.nchunks, P.C);
 	// the lean chain's packed tables (the product builds them on the device: lean_kernels.hip)
+	// over-deep entries of the reference's 6-mer cache (esa.cxx:174-199): as in the product (phylo_anchor), the lean
+	// chains then run with every step through the slow resolver, which reproduces what the reference answers
+	const std::vector<CacheQuirk> quirks = getenv("EMUL_NO_QUIRK") ? std::vector<CacheQuirk>() : esa_cache_quirks(S.data(), ns, SA.data());
+	std::vector<U4> quirk_tab;
+	for (const CacheQuirk &e : quirks) quirk_tab.push_back(U4{e.prefix, e.k | (e.depth << 8), e.lo, e.hi});
+	if (!quirk_tab.empty()) mode |= 3u;
 	const bool lean = (mode & 1u) != 0;
 	std::vector<uint32_t> S2, SBAD, Q2, QBAD, qbad_off;
 	LeanIndex X = {};
@@ -200,6 +206,8 @@ void *emul_run2(size_t n, const char *const *seq, const size_t *len, size_t ref_
 		X.QBAD = QBAD.data();
 		X.qbad_off = qbad_off.data();
 		X.force_slow = (mode & 2u) ? 1u : 0u;
+		X.quirk = quirk_tab.data();
+		X.nquirk = (uint32_t)quirk_tab.size();
 		LT.slot = (const uint8_t *)SLOT.data();
 		LT.sax = (const uint8_t *)SAX.data();
 		LT.q2 = (const uint8_t *)Q2.data();

@@ -52,7 +52,9 @@ def check_process(ctx, gs, ref, chunk=0, kmer=0, backend=0, complete_deletion=Fa
     ctx.set_reference(ref, threshold=threshold)
     r = O.Run(gs, ref, threshold=threshold).process(complete_deletion=complete_deletion)
     assert ctx.threshold == r.threshold
-    assert not ctx.reference_cache_quirk  # (callers check quirk_case() first: with the bug present the reference over-reports)
+    # a subject on which the reference's 6-mer cache holds an over-deep interval (esa.cxx:174-199) is flagged, and
+    # the reference's answers on it are reproduced all the same (option "cache_quirk", default on)
+    assert ctx.reference_cache_quirk == bool(O.Esa(gs[ref]).cache_quirks())
     ctx.anchor()
     if complete_deletion:
         ctx.complete_delete()
@@ -92,15 +94,9 @@ def check_process(ctx, gs, ref, chunk=0, kmer=0, backend=0, complete_deletion=Fa
 
 
 def quirk_case(ctx, gs, ref):
-    """True when the reference's 6-mer cache bug (esa.cxx:174-199) bites on this subject — then the product must
-    say so (phylo_reference_cache_quirk) and the bit-exact comparison does not apply: the reference
-    over-reports matches there, the product returns the true longest ones."""
-    if not O.Esa(gs[ref]).cache_quirks():
-        return False
-    ctx.set_genomes(gs)
-    ctx.set_reference(ref)
-    assert ctx.reference_cache_quirk, "the reference's cache bug is present but phylo_reference_cache_quirk does not report it"
-    return True
+    """Kept for the callers' sake: False — a subject on which the reference's 6-mer cache bug bites (esa.cxx:174-199)
+    is compared bit for bit like any other since round 3 (check_process asserts that it is flagged)."""
+    return False
 
 
 # ── B0: seqcmp / revseqcmp ──
@@ -326,6 +322,22 @@ def test_reference_cache_quirk_is_reported(ctx):
     ctx.set_genomes([bad, bad.copy()])
     ctx.set_reference(0)
     assert ctx.reference_cache_quirk
+    # ... and what the reference answers there is reproduced: queries that walk into the over-deep keys
+    q1 = np.frombuffer(b"CCGTAAAAAGTACCCCGTCAAAGTTCCCC" * 3, np.uint8)
+    q2 = np.frombuffer(b"GTAGTCGTGGTTGTAAGTACGTCC" * 4, np.uint8)
+    for thr in (0, 4, 6):
+        check_process(ctx, [bad, q1, q2, synth.revcomp(q1)], 0, threshold=thr)
+    # with the option off the product gives the true longest matches: the raw lists differ from the reference's
+    gs = [bad, q1, q2, synth.revcomp(q1)]
+    r = O.Run(gs, 0, threshold=4).process()
+    ctx.set_option("cache_quirk", 0)
+    try:
+        ctx.set_genomes(gs)
+        ctx.set_reference(0, threshold=4)
+        ctx.anchor()
+        assert any(hom_tuples_gpu(ctx.homologies(j)) != hom_tuples_orc(r.homologies(j)) for j in range(4))
+    finally:
+        ctx.set_option("cache_quirk", 1)
     good = synth.split_contigs(synth.random_base(30000, rng), 4, rng)
     assert O.Esa(good).cache_quirks() == 0
     ctx.set_genomes([good, synth.mutate(good, 0.05, rng)])
@@ -646,7 +658,7 @@ def test_two_process_sharded_run_on_gpu(tmp_path):
     assert (np.load(out + ".h.npy") == ho).all()
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("PHY_FUZZ_SEEDS", "12"))))  # a long sweep: PHY_FUZZ_SEEDS=300
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PHY_FUZZ_SEEDS", "48"))))  # a long sweep: PHY_FUZZ_SEEDS=300
 def test_fuzz_small_random_sets(ctx, seed):
     """Randomised shapes: genome count, lengths, divergence, structure, contigs, chunk
     and k-mer sizes all drawn per seed; every tally and homology list must match."""
@@ -773,7 +785,7 @@ def test_long_head_and_short_tail_chunks(ctx, chunk, tail):
     check_process(ctx, gs, 4, chunk=chunk, tail=tail, backend=1, threshold=17)
 
 
-@pytest.mark.timeout(600)
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize("workload", ["c3", "c3tree", "c5s", "c4", "c2like", "c3dup", "c5"])
 def test_full_size_properties_and_reference_row(workload):
     """BASELINE configs[2] and [3] at full size (256 and 1024 x 5 Mbp), the tree-shaped variant, the stand-in for
@@ -785,8 +797,8 @@ def test_full_size_properties_and_reference_row(workload):
     diagonal, substitutions <= homologs <= the shorter genome; every filtered list is sorted and
     non-overlapping on the reference; and the reference's row is recomputed by another route — the B0
     kernels (seqcmp / revseqcmp semantics over the resident genomes) summed over each query's list — which
-    shares nothing with the pileup kernels that made the matrix.  (bench.py --check compares the first six
-    genomes with the oracle at this size.)"""
+    shares nothing with the pileup kernels that made the matrix; and a sub-matrix of three or four genomes,
+    at full length, against the oracle.  (bench.py --check compares the first six genomes with the oracle at this size.)"""
     import sys
     import torch
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -817,8 +829,11 @@ def test_full_size_properties_and_reference_row(workload):
             assert int(sub.sum()) == int(s[0, j])
         # a handful of genomes through the oracle at full length: a pair's tallies depend on the reference
         # and the two genomes only, so the small run must reproduce the sub-matrix
-        if workload in ("c3", "c5s", "c2like", "c3dup"):
-            idx = {"c2like": [0, 1, n - 1], "c3dup": [0, 2, 10, n - 1]}.get(workload, [0, 1, n // 2, n - 1])
+        # (every workload: c4 checks a pair kernel tile table of 1024 genomes, c5 — three genomes of 100 Mbp in 100
+        # contigs, 10 % inverted — the five-plane kernels and the long-list filter at full length)
+        if True:
+            idx = {"c2like": [0, 1, n - 1], "c3dup": [0, 2, 10, n - 1], "c5": [0, 1, n - 1],
+                   "c4": [0, 1, n // 2 + 1, n - 1]}.get(workload, [0, 1, n // 2, n - 1])
             gs = [buf[offs[j]:offs[j] + lens[j]].cpu().numpy() for j in idx]
             refb = bytes(gs[0])
             sa = api.host_suffix_array(refb + b"#" + O.revcomp(refb))  # unique: spares the oracle's slow sorter

@@ -163,6 +163,252 @@ __global__ __launch_bounds__(64) void pairs_mfma(Planes P, const uint32_t *__res
 	else pairs_mfma_body<GI, GJ, false>(P, ti, tj, wc, wchunk, subst, homologs);
 }
 
+// ── second version: what the product would run ──
+// Two waves per SIMD (one wave's expansion issues while the other's matrix instructions run), plane words fetched by
+// buffer loads (one 32-bit offset per lane, the tile's genome columns in the scalar offset and the immediate), the
+// loop unrolled by two steps so that no register moves separate them.  Window chunks are even (host), so a step's
+// two windows lie in the chunk or — at the end of the planes — outside the buffer, where a buffer load returns 0.
+struct PlaneWords {
+	uint32_t v, a, b;
+};
+#ifdef CLOCK_DIAG
+__device__ unsigned long long g_clk[4]; // sum of shader cycles, of 100 MHz ticks, waves, steps
+#endif
+template <int GI, int GJ, bool DIAG>
+static __device__ __forceinline__ void pairs_mfma2_body(const Planes &P, uint32_t ti, uint32_t tj, uint32_t wc, uint32_t wchunk,
+														 unsigned long long *__restrict__ subst, unsigned long long *__restrict__ homologs)
+{
+	const uint32_t lane = threadIdx.x & 63u, gl = lane & 31u, half = lane >> 5;
+	const uint32_t w0 = wc * wchunk, w1 = (w0 + wchunk < P.W) ? w0 + wchunk : P.W;
+	constexpr int NG = GI + GJ;
+	const uint32_t plane_bytes = P.W * P.Npad * 4u;
+	const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)P.V, 0, plane_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)P.N0, 0, plane_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)P.N1, 0, plane_bytes, 0x00020000);
+	const uint32_t so_i = ti * GI * 128u, so_j = tj * GJ * 128u; // byte offset of the tile's first i / j genome in a row
+	uint32_t off = ((w0 + half) * P.Npad + gl) * 4u;             // this lane's word of its window's row
+	const uint32_t step = 2u * P.Npad * 4u;
+	v16f acc_h[GI][GJ], acc_t[GI][GJ];
+#pragma unroll
+	for (int a = 0; a < GI; a++)
+#pragma unroll
+		for (int b = 0; b < GJ; b++)
+#pragma unroll
+			for (int r = 0; r < 16; r++) acc_h[a][b][r] = acc_t[a][b][r] = 0.f;
+#define NEED(a, b) (!DIAG || (a) <= (b))
+	auto load = [&](PlaneWords (&x)[NG]) {
+#pragma unroll
+		for (int g = 0; g < NG; g++) {
+			const uint32_t so = g < GI ? so_i : so_j, im = (uint32_t)(g < GI ? g : g - GI) * 128u;
+			x[g].v = __builtin_amdgcn_raw_buffer_load_b32(rv, off + im, so, 0);
+			x[g].a = __builtin_amdgcn_raw_buffer_load_b32(ra, off + im, so, 0);
+			x[g].b = __builtin_amdgcn_raw_buffer_load_b32(rb, off + im, so, 0);
+		}
+		off += step;
+	};
+	auto compute = [&](const PlaneWords (&x)[NG]) {
+		uint32_t vd[NG][4], op[NG][4];
+#pragma unroll
+		for (int g = 0; g < NG; g++) expand_v(x[g].v, vd[g]);
+#pragma unroll
+		for (int a = 0; a < GI; a++)
+#pragma unroll
+			for (int b = 0; b < GJ; b++)
+				if (NEED(a, b)) acc_h[a][b] = mfma_fp4(vd[a], vd[GI + b], acc_h[a][b]);
+#pragma unroll
+		for (int c = 0; c < 3; c++) {
+#pragma unroll
+			for (int g = 0; g < NG; g++) expand_s(c == 0 ? x[g].a : c == 1 ? x[g].b : (x[g].a ^ x[g].b), vd[g], op[g]);
+#pragma unroll
+			for (int a = 0; a < GI; a++)
+#pragma unroll
+				for (int b = 0; b < GJ; b++)
+					if (NEED(a, b)) acc_t[a][b] = mfma_fp4(op[a], op[GI + b], acc_t[a][b]);
+		}
+	};
+	PlaneWords x0[NG], x1[NG];
+	load(x0);
+	for (uint32_t w = w0; w < w1; w += 4) {
+		load(x1);
+		compute(x0);
+		load(x0);
+		if (w + 2 < w1) compute(x1);
+	}
+#pragma unroll
+	for (int a = 0; a < GI; a++)
+#pragma unroll
+		for (int b = 0; b < GJ; b++) {
+			if (!NEED(a, b)) continue;
+			const uint32_t j = (tj * GJ + b) * 32u + gl;
+#pragma unroll
+			for (int r = 0; r < 16; r++) {
+				const uint32_t i = (ti * GI + a) * 32u + (r & 3) + 8 * (r >> 2) + 4 * half;
+				const int h = (int)acc_h[a][b][r], t = (int)acc_t[a][b][r];
+				if (i < j && j < P.N && h) {
+					atomicAdd(&homologs[(size_t)i * P.N + j], (unsigned long long)h);
+					const int s = (3 * h - t) >> 2; // matches = (h + t) / 4
+					if (s) atomicAdd(&subst[(size_t)i * P.N + j], (unsigned long long)s);
+				}
+			}
+		}
+#undef NEED
+}
+template <int GI, int GJ>
+__global__ __launch_bounds__(64, 2) void pairs_mfma2(Planes P, const uint32_t *__restrict__ tiles, uint32_t ntiles, uint32_t wchunk,
+													  uint32_t nwc, unsigned long long *__restrict__ subst,
+													  unsigned long long *__restrict__ homologs)
+{
+	const uint32_t xcd = blockIdx.x & 7u, local = blockIdx.x >> 3;
+	const uint32_t tile = local % ntiles;
+	const uint32_t wc = (local / ntiles) * 8u + xcd;
+	if (wc >= nwc) return;
+	const uint32_t ti = tiles[tile] >> 16, tj = tiles[tile] & 0xffffu;
+	if (GI == GJ && ti == tj) pairs_mfma2_body<GI, GJ, true>(P, ti, tj, wc, wchunk, subst, homologs);
+	else pairs_mfma2_body<GI, GJ, false>(P, ti, tj, wc, wchunk, subst, homologs);
+}
+
+// ── third version: NB register sets of plane words in flight (a set is refilled as soon as its step has expanded it and
+// is used NB steps later), no branch in the loop (chunks are multiples of 2 NB windows; beyond the planes' end the
+// buffer loads return 0), and — SCHED — the request to the compiler's scheduler to deal the expansion's vector
+// instructions out between the matrix instructions instead of bunching each kind.
+template <int GI, int GJ, bool DIAG, int NB, int SCHED>
+static __device__ __forceinline__ void pairs_mfma3_body(const Planes &P, uint32_t ti, uint32_t tj, uint32_t wc, uint32_t wchunk,
+														 unsigned long long *__restrict__ subst, unsigned long long *__restrict__ homologs)
+{
+	const uint32_t lane = threadIdx.x & 63u, gl = lane & 31u, half = lane >> 5;
+	const uint32_t w0 = wc * wchunk, w1 = (w0 + wchunk < P.W) ? w0 + wchunk : P.W;
+	constexpr int NG = GI + GJ;
+	const uint32_t plane_bytes = P.W * P.Npad * 4u;
+	const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)P.V, 0, plane_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)P.N0, 0, plane_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)P.N1, 0, plane_bytes, 0x00020000);
+	const uint32_t so_i = ti * GI * 128u, so_j = tj * GJ * 128u;
+	uint32_t off = ((w0 + half) * P.Npad + gl) * 4u;
+	const uint32_t step = 2u * P.Npad * 4u;
+	v16f acc_h[GI][GJ], acc_t[GI][GJ];
+#pragma unroll
+	for (int a = 0; a < GI; a++)
+#pragma unroll
+		for (int b = 0; b < GJ; b++)
+#pragma unroll
+			for (int r = 0; r < 16; r++) acc_h[a][b][r] = acc_t[a][b][r] = 0.f;
+#define NEED(a, b) (!DIAG || (a) <= (b))
+	auto load = [&](PlaneWords (&x)[NG]) {
+#pragma unroll
+		for (int g = 0; g < NG; g++) {
+			const uint32_t so = g < GI ? so_i : so_j, im = (uint32_t)(g < GI ? g : g - GI) * 128u;
+			x[g].v = __builtin_amdgcn_raw_buffer_load_b32(rv, off + im, so, 0);
+			x[g].a = __builtin_amdgcn_raw_buffer_load_b32(ra, off + im, so, 0);
+			x[g].b = __builtin_amdgcn_raw_buffer_load_b32(rb, off + im, so, 0);
+		}
+		off += step;
+	};
+	constexpr int NMF = (DIAG ? (GI * (GI + 1)) / 2 : GI * GJ); // matrix instructions per channel
+	uint32_t sink = 0; // (experiments: SCHED 2 = the expansion alone, 3 = the matrix instructions alone)
+	auto compute = [&](PlaneWords (&x)[NG]) {
+		uint32_t vd[NG][4], op[NG][4];
+		if (SCHED == 3) {
+#pragma unroll
+			for (int g = 0; g < NG; g++)
+#pragma unroll
+				for (int d = 0; d < 4; d++) vd[g][d] = op[g][d] = x[g].v & 0x2a2a2a2au;
+#pragma unroll
+			for (int c = 0; c < 4; c++)
+#pragma unroll
+				for (int a = 0; a < GI; a++)
+#pragma unroll
+					for (int b = 0; b < GJ; b++)
+						if (NEED(a, b)) acc_t[a][b] = mfma_fp4(op[a], op[GI + b], acc_t[a][b]);
+			load(x);
+			return;
+		}
+#pragma unroll
+		for (int g = 0; g < NG; g++) expand_v(x[g].v, vd[g]);
+#pragma unroll
+		for (int a = 0; a < GI; a++)
+#pragma unroll
+			for (int b = 0; b < GJ; b++)
+				if (NEED(a, b)) {
+					if (SCHED == 2) sink ^= vd[a][0] ^ vd[a][1] ^ vd[a][2] ^ vd[a][3] ^ vd[GI + b][0] ^ vd[GI + b][1] ^ vd[GI + b][2] ^ vd[GI + b][3];
+					else acc_h[a][b] = mfma_fp4(vd[a], vd[GI + b], acc_h[a][b]);
+				}
+#pragma unroll
+		for (int c = 0; c < 3; c++) {
+#pragma unroll
+			for (int g = 0; g < NG; g++) expand_s(c == 0 ? x[g].a : c == 1 ? x[g].b : (x[g].a ^ x[g].b), vd[g], op[g]);
+#pragma unroll
+			for (int a = 0; a < GI; a++)
+#pragma unroll
+				for (int b = 0; b < GJ; b++)
+					if (NEED(a, b)) {
+						if (SCHED == 2) sink ^= op[a][0] ^ op[a][1] ^ op[a][2] ^ op[a][3] ^ op[GI + b][0] ^ op[GI + b][1] ^ op[GI + b][2] ^ op[GI + b][3];
+						else acc_t[a][b] = mfma_fp4(op[a], op[GI + b], acc_t[a][b]);
+					}
+		}
+		load(x); // the set is free again: its words for the step NB from now
+		if (SCHED == 1) {
+			// per matrix instruction its share of the step's vector instructions (~29 per group and step)
+			constexpr int PER = (29 * NG + 4 * NMF - 1) / (4 * NMF);
+#pragma unroll
+			for (int i = 0; i < 4 * NMF; i++) {
+				__builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+				__builtin_amdgcn_sched_group_barrier(0x002, PER, 0); // PER VALU
+				if (i % (4 * NMF / 4) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 3 * NG / 4, 0); // a quarter of the loads
+			}
+		}
+	};
+	PlaneWords x[NB][NG];
+#ifdef CLOCK_DIAG
+	const uint64_t c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+#pragma unroll
+	for (int k = 0; k < NB; k++) load(x[k]);
+	for (uint32_t w = w0; w < w1; w += 2 * NB) {
+#pragma unroll
+		for (int k = 0; k < NB; k++) compute(x[k]);
+	}
+	if (SCHED == 2 && sink == 0x12345u) acc_h[0][0][0] = 1.f; // keeps the expansion alive
+#ifdef CLOCK_DIAG
+	if (lane == 0) {
+		atomicAdd(&g_clk[0], __builtin_amdgcn_s_memtime() - c0);
+		atomicAdd(&g_clk[1], __builtin_amdgcn_s_memrealtime() - r0);
+		atomicAdd(&g_clk[2], 1ull);
+		atomicAdd(&g_clk[3], (unsigned long long)((w1 - w0 + 2 * NB - 1) / (2 * NB) * NB));
+	}
+#endif
+#pragma unroll
+	for (int a = 0; a < GI; a++)
+#pragma unroll
+		for (int b = 0; b < GJ; b++) {
+			if (!NEED(a, b)) continue;
+			const uint32_t j = (tj * GJ + b) * 32u + gl;
+#pragma unroll
+			for (int r = 0; r < 16; r++) {
+				const uint32_t i = (ti * GI + a) * 32u + (r & 3) + 8 * (r >> 2) + 4 * half;
+				const int h = (int)acc_h[a][b][r], t = (int)acc_t[a][b][r];
+				if (i < j && j < P.N && h) {
+					atomicAdd(&homologs[(size_t)i * P.N + j], (unsigned long long)h);
+					const int s = (3 * h - t) >> 2; // matches = (h + t) / 4
+					if (s) atomicAdd(&subst[(size_t)i * P.N + j], (unsigned long long)s);
+				}
+			}
+		}
+#undef NEED
+}
+template <int GI, int GJ, int NB, int SCHED>
+__global__ __launch_bounds__(64, 2) void pairs_mfma3(Planes P, const uint32_t *__restrict__ tiles, uint32_t ntiles, uint32_t wchunk,
+													  uint32_t nwc, unsigned long long *__restrict__ subst,
+													  unsigned long long *__restrict__ homologs)
+{
+	const uint32_t xcd = blockIdx.x & 7u, local = blockIdx.x >> 3;
+	const uint32_t tile = local % ntiles;
+	const uint32_t wc = (local / ntiles) * 8u + xcd;
+	if (wc >= nwc) return;
+	const uint32_t ti = tiles[tile] >> 16, tj = tiles[tile] & 0xffffu;
+	if (GI == GJ && ti == tj) pairs_mfma3_body<GI, GJ, true, NB, SCHED>(P, ti, tj, wc, wchunk, subst, homologs);
+	else pairs_mfma3_body<GI, GJ, false, NB, SCHED>(P, ti, tj, wc, wchunk, subst, homologs);
+}
+
 // the product's kernel (csrc/pileup_kernels.hip: pairs_kernel<false>), for the same-box comparison
 static const uint32_t PAIR_IG = 16, PAIR_JT = 64;
 __global__ __launch_bounds__(64) void pairs_valu(Planes P, const uint32_t *__restrict__ tiles, uint32_t ntiles, uint32_t wchunk,
@@ -255,7 +501,7 @@ static uint32_t choose_wchunk(const Run &R, uint32_t ntiles, uint32_t slots_per_
 	wchunk = std::min(wchunk, l2_fit);
 	const uint32_t groups = (R.W + 8u * wchunk - 1) / (8u * wchunk);
 	wchunk = std::max<uint32_t>(1, (R.W + 8u * groups - 1) / (8u * groups));
-	wchunk = (wchunk + 1) & ~1u; // the matrix-core kernel takes two windows per step
+	wchunk = (wchunk + 11) / 12 * 12; // the matrix-core kernels take two windows per step, two or three steps per trip
 	return wchunk;
 }
 
@@ -286,6 +532,15 @@ template <class K> static float time_kernel(const Run &R, K kern, const std::vec
 	CK(hipGetLastError());
 	printf("    grid %u waves, %zu tiles x %u chunks of %u windows: avg %.3f ms, best %.3f ms\n", grid.x, tiles.size(), nwc, wchunk,
 		   sum / reps, best);
+#ifdef CLOCK_DIAG
+	{
+		unsigned long long h[4];
+		CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_clk), sizeof h));
+		if (h[2]) printf("    in-kernel: %.0f MHz, %.0f shader cycles per step and wave (%llu waves, %llu steps)\n", 100.0 * h[0] / h[1], (double)h[0] / h[3], h[2], h[3]);
+		unsigned long long z[4] = {0, 0, 0, 0};
+		CK(hipMemcpyToSymbol(HIP_SYMBOL(g_clk), z, sizeof z));
+	}
+#endif
 	return sum / reps;
 }
 
@@ -371,6 +626,14 @@ int main(int argc, char **argv)
 		ok &= check_kernel(R, pairs_mfma<2, 2>, make_tiles(R.N, 64, 64), 126, rs, rh, "MFMA fp4 64x64 c126");
 		ok &= check_kernel(R, pairs_mfma<2, 4>, make_tiles(R.N, 64, 128), 64, rs, rh, "MFMA fp4 64x128");
 		ok &= check_kernel(R, pairs_mfma<1, 2>, make_tiles(R.N, 32, 64), 64, rs, rh, "MFMA fp4 32x64");
+		ok &= check_kernel(R, pairs_mfma2<2, 2>, make_tiles(R.N, 64, 64), 64, rs, rh, "MFMA v2 64x64");
+		ok &= check_kernel(R, pairs_mfma2<2, 2>, make_tiles(R.N, 64, 64), 126, rs, rh, "MFMA v2 64x64 c126");
+		ok &= check_kernel(R, pairs_mfma2<2, 2>, make_tiles(R.N, 64, 64), 1002, rs, rh, "MFMA v2 64x64 c1002");
+		ok &= check_kernel(R, pairs_mfma2<1, 2>, make_tiles(R.N, 32, 64), 62, rs, rh, "MFMA v2 32x64 c62");
+		ok &= check_kernel(R, pairs_mfma3<2, 2, 2, 0>, make_tiles(R.N, 64, 64), 60, rs, rh, "MFMA v3 nb2 c60");
+		ok &= check_kernel(R, pairs_mfma3<2, 2, 3, 0>, make_tiles(R.N, 64, 64), 126, rs, rh, "MFMA v3 nb3 c126");
+		ok &= check_kernel(R, pairs_mfma3<2, 2, 3, 1>, make_tiles(R.N, 64, 64), 1008, rs, rh, "MFMA v3 nb3 sched c1008");
+		ok &= check_kernel(R, pairs_mfma3<2, 2, 2, 1>, make_tiles(R.N, 64, 64), 1008, rs, rh, "MFMA v3 nb2 sched c1008");
 		CK(hipFree(R.dV));
 		CK(hipFree(R.d0));
 		CK(hipFree(R.d1));
@@ -417,6 +680,31 @@ int main(int argc, char **argv)
 			auto t = make_tiles(R.N, 64, 128);
 			printf("  MFMA fp4 64x128, %u wave slots per CU\n", slots);
 			float ms = time_kernel(R, pairs_mfma<2, 4>, t, choose_wchunk(R, (uint32_t)t.size(), slots), reps);
+			printf("    -> %.1f T pair-positions/s\n", pairpos / (ms * 1e-3) / 1e12);
+		}
+		for (uint32_t slots : {8u, 16u, 32u, 64u}) {
+			auto t = make_tiles(R.N, 64, 64);
+			printf("  MFMA v2 64x64 (2 waves per SIMD, buffer loads), %u wave slots per CU\n", slots);
+			float ms = time_kernel(R, pairs_mfma2<2, 2>, t, choose_wchunk(R, (uint32_t)t.size(), slots), reps);
+			printf("    -> %.1f T pair-positions/s\n", pairpos / (ms * 1e-3) / 1e12);
+		}
+		for (uint32_t slots : {8u, 16u, 32u}) {
+			auto t = make_tiles(R.N, 64, 64);
+			const uint32_t wch = choose_wchunk(R, (uint32_t)t.size(), slots);
+			printf("  MFMA v3 64x64, %u wave slots per CU: nb2 / nb3 / nb2 sched / nb3 sched\n", slots);
+			float m1 = time_kernel(R, pairs_mfma3<2, 2, 2, 0>, t, wch, reps);
+			float m2 = time_kernel(R, pairs_mfma3<2, 2, 3, 0>, t, wch, reps);
+			float m3 = time_kernel(R, pairs_mfma3<2, 2, 2, 1>, t, wch, reps);
+			float m4 = time_kernel(R, pairs_mfma3<2, 2, 3, 1>, t, wch, reps);
+			printf("    -> %.3f / %.3f / %.3f / %.3f ms\n", m1, m2, m3, m4);
+			printf("  the same shape, expansion alone / matrix instructions alone (nb3; results meaningless)\n");
+			time_kernel(R, pairs_mfma3<2, 2, 3, 2>, t, wch, reps);
+			time_kernel(R, pairs_mfma3<2, 2, 3, 3>, t, wch, reps);
+		}
+		for (uint32_t slots : {16u, 32u}) {
+			auto t = make_tiles(R.N, 32, 64);
+			printf("  MFMA v2 32x64, %u wave slots per CU\n", slots);
+			float ms = time_kernel(R, pairs_mfma2<1, 2>, t, choose_wchunk(R, (uint32_t)t.size(), slots), reps);
 			printf("    -> %.1f T pair-positions/s\n", pairpos / (ms * 1e-3) / 1e12);
 		}
 		{
