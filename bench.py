@@ -428,7 +428,7 @@ def main():
 
     emu_state = {}
     # one rank: the host keeps its two N x N result matrices across steps (the N-rank path has its own pinned pair)
-    out_mats = (np.empty((n, n), np.uint64), np.empty((n, n), np.uint64)) if world == 1 else None
+    out_mats = (np.empty((n, n), np.uint64), np.empty((n, n), np.uint64))
 
     seg = {}
     def lap(name, t_prev):
@@ -444,65 +444,50 @@ def main():
             ctx.anchor(qb, qe)
             tl = lap("anchor", tl)
             if args.emulate_exchange:
-                # what rank emu[0] of emu[1] does around its kernels, with a one-rank RCCL group standing
-                # in for the collectives and the other ranks' records copied in from a prepared buffer
-                W, item = emu[1], 16
-                call = np.zeros(n, np.int64)
-                call[qb:qe] = ctx.hom_counts(qb, qe).astype(np.int64)
-                ct = torch.from_numpy(call).to(device)
-                td.all_reduce(ct)
-                ct.cpu()
-                tl = lap("counts all_reduce", tl)
-                call = emu_state["counts"]
-                sizes = [int(call[bounds[r]:bounds[r + 1]].sum()) for r in range(W)]
-                cap = max(max(sizes), 1)
-                mine = torch.empty(cap * item, dtype=torch.uint8, device=device)
-                gathered = torch.empty(W * cap * item, dtype=torch.uint8, device=device)
-                torch.cuda.current_stream(device).synchronize()
-                ctx.export_packed_device(qb, qe, mine.data_ptr(), cap)
-                tl = lap("export", tl)
-                td.all_gather_into_tensor(gathered[emu[0] * cap * item:(emu[0] + 1) * cap * item], mine)
-                begin = np.zeros(n, np.uint64)
-                src_off = np.concatenate(([0], np.cumsum(call)))
-                for r in range(W):
-                    b0, b1 = bounds[r], bounds[r + 1]
-                    if b1 > b0:
-                        begin[b0:b1] = r * cap + (src_off[b0:b1] - src_off[b0])
-                        if r != emu[0]:
-                            gathered[r * cap * item:r * cap * item + sizes[r] * item] = \
-                                emu_state["all"][int(src_off[b0]) * item:int(src_off[b1]) * item]
-                torch.cuda.current_stream(device).synchronize()
-                tl = lap("all_gather + stand-in copies", tl)
-                ctx.attach_packed_device(gathered.data_ptr(), begin, call.astype(np.uint64), qb, qe)
-                t = torch.empty(2 * n * n, dtype=torch.int64, device=device)
-                torch.cuda.current_stream(device).synchronize()
-                tl = lap("attach", tl)
-                ctx.compare_device(emu[0], W, t.data_ptr(), t.data_ptr() + n * n * 8)
-                tl = lap("compare_device", tl)
-                ctx._attached_records = gathered
-                td.all_reduce(t)
-                pin = emu_state.get("pin")
-                if pin is None:
-                    pin = emu_state["pin"] = torch.empty(t.numel(), dtype=torch.int64, pin_memory=True)
-                pin.copy_(t, non_blocking=True)
-                torch.cuda.current_stream(device).synchronize()
-                m = pin.numpy().view(np.uint64).reshape(2, n, n)  # views of the pinned buffer: valid until the next call
-                tl = lap("matrix all_reduce + D2H", tl)
-                return m[0], m[1]
+                # what rank emu[0] of emu[1] does around its kernels (dist.process_sharded_device), with a one-rank RCCL
+                # group standing in for the collectives and the other ranks' blocks prepared beforehand
+                W = emu[1]
+                pl = emu_state["plan"]
+                own = pl["all"][emu[0] * pl["nbytes"]:(emu[0] + 1) * pl["nbytes"]]
+                ctx.export_block_device(qb, qe, pl["block"].data_ptr(), pl["maxq"], pl["cap"])
+                tl = lap("export (queued)", tl)
+                td.all_gather_into_tensor(own, pl["block"])
+                tl = lap("all_gather (queued)", tl)
+                ctx.attach_blocks_device(pl["all"].data_ptr(), bounds, pl["maxq"], pl["cap"], qb, qe)
+                tl = lap("attach (queued)", tl)
+                ctx.compare_triangle_device(emu[0], W, pl["tri"].data_ptr())
+                tl = lap("compare (waits for the flag)", tl)
+                td.all_reduce(pl["tri"])
+                r = ctx.triangle_to_matrices(pl["tri"].data_ptr(), out_mats)
+                tl = lap("all_reduce + triangle to matrices", tl)
+                return r
             return ctx.compare(emu[0], emu[1])
         return dist.process_sharded(ctx, ref_idx, rank, world, device=None if shared else device, lengths=lens,
                                     set_reference=False, out=out_mats, copy=False)
 
     if emu:  # the other ranks' lists must exist for the projection: compute them once, untimed
-        ctx.anchor(0, n)
         if args.emulate_exchange:
-            cnt_all = ctx.hom_counts(0, n).astype(np.int64)
-            tot = int(cnt_all.sum())
-            allrec = torch.empty(max(tot, 1) * 16, dtype=torch.uint8, device=device)
+            W = emu[1]
+            ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
+            bounds = [dist.query_shard(n, r, W, lens)[0] for r in range(W)] + [n]
+            tot = []
+            for r in range(W):
+                ctx.anchor(bounds[r], bounds[r + 1])
+                tot.append(int(ctx.hom_counts(bounds[r], bounds[r + 1]).sum()))
+            cap = max(tot) + max(tot) // 4 + 64
+            maxq = (max(bounds[r + 1] - bounds[r] for r in range(W)) + 3) // 4 * 4
+            nbytes = ctx.exchange_block_bytes(maxq, cap)
+            allb = torch.zeros(W * nbytes, dtype=torch.uint8, device=device)
+            for r in range(W):
+                ctx.anchor(bounds[r], bounds[r + 1])
+                ctx.export_block_device(bounds[r], bounds[r + 1], allb.data_ptr() + r * nbytes, maxq, cap)
             torch.cuda.synchronize()
-            ctx.export_packed_device(0, n, allrec.data_ptr(), max(tot, 1))
-            emu_state["counts"] = cnt_all
-            emu_state["all"] = allrec
+            emu_state["plan"] = {"maxq": maxq, "cap": cap, "nbytes": nbytes, "all": allb,
+                                 "block": torch.empty(nbytes, dtype=torch.uint8, device=device),
+                                 "tri": torch.empty(n * (n - 1), dtype=torch.int32, device=device)}
+            print(f"# emulated exchange: blocks of {nbytes / 1e6:.2f} MB x {W} ranks, triangle {n * (n - 1) * 4 / 1e6:.2f} MB", file=sys.stderr)
+        else:
+            ctx.anchor(0, n)
 
     for _ in range(args.warmup):
         s, h = step()
@@ -558,15 +543,16 @@ def main():
         sites = float(np.triu(h.astype(np.float64), 1).sum())
         bytes_a = total_bases + 26.0 * ns          # each query byte once + one pass over the reference-layout ESA
         bytes_b = 2.0 * sites + 16.0 * P           # two 1-byte nucleotides per compared site + one 16 B tally per pair
+        shard = emu[1] if emu else world  # the fraction of the work one rank's kernels carry
         kern = {k[3:]: v for k, v in stats.items() if k.startswith("ms:") and ("n:" + k[3:]) in stats}
         launches = {k: stats["n:" + k] for k in kern}
         roof = None
         kernels = {}
         if kern:
-            alg = {"anchor_spec": bytes_a / world, "anchor_bridge": 0.0, "anchor_fold": 0.0, "anchor_compact": 0.0,
-                   "pileup_project": total_bases, "pileup_project5": total_bases, "pileup_pairs": bytes_b / world, "pileup_pairs_bang": bytes_b / world,
-                   "pileup_pairs_mfma": bytes_b / world,
-                   "seqcmp_batch": bytes_b / world}
+            alg = {"anchor_spec": bytes_a / shard, "anchor_bridge": 0.0, "anchor_fold": 0.0, "anchor_compact": 0.0,
+                   "pileup_project": total_bases, "pileup_project5": total_bases, "pileup_pairs": bytes_b / shard, "pileup_pairs_bang": bytes_b / shard,
+                   "pileup_pairs_mfma": bytes_b / shard,
+                   "seqcmp_batch": bytes_b / shard}
             for k in kern:
                 avg_ms = kern[k] / launches[k]
                 kernels[k] = {"avg_ms": round(avg_ms, 4), "launches_per_step": launches[k] / K,
@@ -606,7 +592,7 @@ def main():
         pk = next((k for k in ("pileup_pairs", "pileup_pairs_bang") if k in kern), None)
         if pk:
             ntiles = sum(1 for ig in range((n + 15) // 16) for jt in range((n + 63) // 64) if ig * 16 < jt * 64 + 63)
-            windows = (lens[ref_idx] + 31) // 32 / world
+            windows = (lens[ref_idx] + 31) // 32 / shard
             per_win = 104 if pk == "pileup_pairs" else 135  # VALU instructions of the loop body in the ISA (hipcc -S)
             inst = ntiles * windows * per_win
             t_ms = kern[pk] / launches[pk]
@@ -624,10 +610,10 @@ def main():
         roof_mfma = None
         if "pileup_pairs_mfma" in kern:
             t_ms = kern["pileup_pairs_mfma"] / launches["pileup_pairs_mfma"]
-            positions = lens[ref_idx] / world
+            positions = lens[ref_idx] / shard
             flop_alg = 2.0 * 4.0 * P * positions
             nt = (n + 63) // 64
-            flop_issued = 2.0 * 4.0 * (nt * (nt + 1) // 2 * 4096 - nt * 1024) * ((lens[ref_idx] + 31) // 32 * 32) / world
+            flop_issued = 2.0 * 4.0 * (nt * (nt + 1) // 2 * 4096 - nt * 1024) * ((lens[ref_idx] + 31) // 32 * 32) / shard
             peak = 10000.0  # MI355X_MICROARCH.md: FP4 MFMA ~10 PFLOP/s dense
             roof_mfma = {"kernel": "pileup_pairs_mfma", "bound": "mfma", "achieved": round(flop_alg / (t_ms * 1e-3) / 1e12, 1), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(flop_alg / (t_ms * 1e-3) / 1e12 / peak, 4), "avg_launch_ms": round(t_ms, 4),
@@ -701,8 +687,8 @@ def main():
                               "note": "algorithmic bytes of the reference's layout over this run's time: above 1 because the "
                                       "bit-plane pileup moves far fewer bytes than 2 B per compared site, not because HBM "
                                       "ran beyond its peak"},
-            "roofline_phase_b": (lambda tb, tr: {"achieved": round(bytes_b / world / (tb * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
-                                                 "unit": "GB/s", "frac": round(bytes_b / world / (tb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "roofline_phase_b": (lambda tb, tr: {"achieved": round(bytes_b / shard / (tb * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                                                 "unit": "GB/s", "frac": round(bytes_b / shard / (tb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                                  "ms": round(tb, 3), "kernels": "pileup_project* + pileup_pairs*",
                                                  "traffic": tr,
                                                  "traffic_GBps": round(tr / (tb * 1e-3) / 1e9, 1) if tr else None,

@@ -53,6 +53,11 @@ typedef struct phylo_homology {
 /* ── context ── */
 int phylo_ctx_create(phylo_ctx **out, int device);
 void phylo_ctx_destroy(phylo_ctx *ctx);
+/* Run this context's work on the caller's HIP stream (a hipStream_t of the context's device; NULL: back to the
+ * context's own): a host that issues collectives on a stream of its own (RCCL, torch.distributed) then needs no
+ * synchronisation between its calls and the library's.  The context waits for its current work first. */
+int phylo_ctx_set_stream(phylo_ctx *ctx, void *hip_stream);
+int phylo_ctx_device(const phylo_ctx *ctx);
 /* ctx may be NULL: last error of a failed phylo_ctx_create on this thread. */
 const char *phylo_last_error(const phylo_ctx *ctx);
 /* Tunables, mostly for tests: "chunk" (phase-A chunk length, a multiple of 64), "chunk_tail"
@@ -175,6 +180,21 @@ int phylo_export_packed_device(phylo_ctx *ctx, size_t q_begin, size_t q_end, voi
 							   uint64_t *counts, size_t *total);
 int phylo_attach_packed_device(phylo_ctx *ctx, const void *dev_records, const uint64_t *begin,
 							   const uint64_t *count, size_t keep_begin, size_t keep_end);
+/* The same exchange without the host in it (one process per GPU, or one host thread per GPU): every rank writes a
+ * block of fixed shape — 4 header words {records, overflow, queries, 0}, max_queries list lengths (u32, a multiple
+ * of 4 of them), cap_records records of 16 bytes; phylo_exchange_block_bytes gives its size — one all-gather of the
+ * blocks assembles the lists of all ranks on every GPU, and the receiving side works the per-genome ranges out on
+ * the device.  Neither call waits for the device: they queue work on the context's stream (phylo_ctx_set_stream).
+ * Export needs the lists where phase A's device filter left them (phylo_anchor(q_begin, q_end) was this context's
+ * last list-changing call; nonzero otherwise: use phylo_export_packed_device).  Attach: bounds[r] .. bounds[r+1] are
+ * rank r's genomes (bounds[0] = 0, bounds[world] = n); a block that overflowed cap_records, or a list that is not
+ * sorted, disjoint and inside the reference, makes the NEXT call that looks at the lists fail (phylo_compare*,
+ * phylo_get_homologies) — size cap_records from an earlier step's counts and repeat with the host forms then. */
+size_t phylo_exchange_block_bytes(size_t max_queries, size_t cap_records);
+int phylo_export_block_device(phylo_ctx *ctx, size_t q_begin, size_t q_end, void *dev_block, size_t max_queries,
+							  size_t cap_records);
+int phylo_attach_blocks_device(phylo_ctx *ctx, const void *dev_all, size_t world, const size_t *bounds, size_t max_queries,
+							   size_t cap_records, size_t keep_begin, size_t keep_end);
 /* complete_delete over all genomes' lists, src/process.cxx:467-469,725-776 (host). */
 int phylo_complete_delete(phylo_ctx *ctx);
 
@@ -188,6 +208,14 @@ int phylo_compare(phylo_ctx *ctx, size_t part, size_t nparts, uint64_t *subst, u
 int phylo_compare_all(phylo_ctx *ctx, uint64_t *subst, uint64_t *homologs);
 /* phylo_compare with the two N*N tallies left in device memory (for a device-side all-reduce). */
 int phylo_compare_device(phylo_ctx *ctx, size_t part, size_t nparts, uint64_t *dev_subst, uint64_t *dev_homologs);
+
+/* The tallies of a part as a u32 upper triangle in device memory — what crosses the wire between ranks: tri[k]
+ * substitutions and tri[P + k] homologs of pair i < j, k = i (2n - i - 1) / 2 + (j - i - 1), P = n (n - 1) / 2 (a tally
+ * is at most the reference's length, < 2^31; a quarter of the bytes of the two u64 matrices).  The parts' triangles add
+ * up (one all-reduce); phylo_triangle_to_matrices copies a triangle to the host and writes the two symmetric n x n
+ * matrices process() returns. */
+int phylo_compare_triangle_device(phylo_ctx *ctx, size_t part, size_t nparts, uint32_t *dev_tri);
+int phylo_triangle_to_matrices(phylo_ctx *ctx, const uint32_t *dev_tri, uint64_t *subst, uint64_t *homologs);
 
 /* ── B2 in one call ── */
 int phylo_process(phylo_ctx *ctx, size_t ref_idx, int flags, uint64_t *subst, uint64_t *homologs);

@@ -27,6 +27,8 @@ SYMBOLS = [
     "phylo_set_reference", "phylo_threshold", "phylo_reference_suffix_array", "phylo_anchor", "phylo_get_homologies", "phylo_set_homologies",
     "phylo_export_homologies", "phylo_import_homologies", "phylo_export_packed", "phylo_import_packed",
     "phylo_export_packed_device", "phylo_attach_packed_device", "phylo_compare_device",
+    "phylo_ctx_set_stream", "phylo_ctx_device", "phylo_exchange_block_bytes", "phylo_export_block_device", "phylo_attach_blocks_device",
+    "phylo_compare_triangle_device", "phylo_triangle_to_matrices",
     "phylo_complete_delete", "phylo_compare", "phylo_compare_all", "phylo_process", "phylo_seqcmp",
     "phylo_revseqcmp", "phylo_seqcmp_batch", "phylo_host_suffix_array", "phylo_host_reference_suffix_array", "phylo_host_min_anchor_length",
     "phylo_host_read_fasta", "phylo_host_read_fasta_packed", "phylo_host_free_packed", "phylo_host_free", "phylo_host_median_length_index",
@@ -82,6 +84,14 @@ def load():
     L.phylo_compare_device.argtypes = [vp, sz, sz, vp, vp]
     L.phylo_export_packed_device.argtypes = [vp, sz, sz, vp, sz, vp, C.POINTER(sz)]
     L.phylo_attach_packed_device.argtypes = [vp, vp, vp, vp, sz, sz]
+    L.phylo_ctx_set_stream.argtypes = [vp, vp]
+    L.phylo_ctx_device.argtypes = [vp]
+    L.phylo_exchange_block_bytes.restype = sz
+    L.phylo_exchange_block_bytes.argtypes = [sz, sz]
+    L.phylo_export_block_device.argtypes = [vp, sz, sz, vp, sz, sz]
+    L.phylo_attach_blocks_device.argtypes = [vp, vp, sz, vp, sz, sz, sz, sz]
+    L.phylo_compare_triangle_device.argtypes = [vp, sz, sz, vp]
+    L.phylo_triangle_to_matrices.argtypes = [vp, vp, vp, vp]
     L.phylo_process.argtypes = [vp, sz, C.c_int, vp, vp]
     L.phylo_seqcmp.restype = sz
     L.phylo_seqcmp.argtypes = [vp, vp, sz]
@@ -307,6 +317,36 @@ class Context:
         assert begin.size == self.n and count.size == self.n
         self._chk(self.L.phylo_attach_packed_device(self.h, C.c_void_p(dev_ptr), begin.ctypes.data_as(C.c_void_p),
                                                     count.ctypes.data_as(C.c_void_p), keep_begin, keep_end))
+
+    def set_stream(self, hip_stream):
+        """Run the context's work on the caller's HIP stream (an integer handle, e.g. torch's
+        `torch.cuda.current_stream().cuda_stream`; 0 / None: the context's own stream again)."""
+        self._chk(self.L.phylo_ctx_set_stream(self.h, C.c_void_p(hip_stream or None)))
+
+    def exchange_block_bytes(self, max_queries, cap_records):
+        return int(self.L.phylo_exchange_block_bytes(max_queries, cap_records))
+
+    def export_block_device(self, q_begin, q_end, dev_ptr, max_queries, cap_records):
+        """This rank's lists as an exchange block (header + list lengths + 16-byte records) in device memory; queued on
+        the context's stream, nothing is waited for."""
+        self._chk(self.L.phylo_export_block_device(self.h, q_begin, q_end, C.c_void_p(dev_ptr), max_queries, cap_records))
+
+    def attach_blocks_device(self, dev_ptr, bounds, max_queries, cap_records, keep_begin, keep_end):
+        """The gathered blocks of all ranks (rank r's genomes: bounds[r] .. bounds[r+1]) become the lists phase B reads."""
+        b = (C.c_size_t * len(bounds))(*[int(x) for x in bounds])
+        self._chk(self.L.phylo_attach_blocks_device(self.h, C.c_void_p(dev_ptr), len(bounds) - 1, b, max_queries, cap_records,
+                                                    keep_begin, keep_end))
+
+    def compare_triangle_device(self, part, nparts, dev_tri_ptr):
+        """compare() with the part's tallies as a u32 upper triangle (2 x n (n - 1) / 2 words) in device memory."""
+        self._chk(self.L.phylo_compare_triangle_device(self.h, part, nparts, C.c_void_p(dev_tri_ptr)))
+
+    def triangle_to_matrices(self, dev_tri_ptr, out=None):
+        n = self.n
+        s, h = out if out is not None else (np.empty((n, n), np.uint64), np.empty((n, n), np.uint64))
+        self._chk(self.L.phylo_triangle_to_matrices(self.h, C.c_void_p(dev_tri_ptr), s.ctypes.data_as(C.c_void_p),
+                                                    h.ctypes.data_as(C.c_void_p)))
+        return s, h
 
     def compare_device(self, part, nparts, dev_subst_ptr, dev_homologs_ptr):
         """compare() with the two N*N uint64 tallies written to device memory."""

@@ -251,6 +251,9 @@ struct phylo_ctx {
 	const DevHom *att_homs = nullptr;
 	std::vector<uint64_t> att_begin, att_count;
 	std::vector<uint8_t> host_stale; // [n] 1: the host list of this genome must be fetched from att_homs first
+	bool att_rng_on_device = false;  // att_begin / att_count have not been read back yet: they are b_hom_rng (phylo_attach_blocks_device)
+	bool att_unchecked = false;      // ... and their validity flags (b_flag[1..2]) have not been looked at yet
+	hipStream_t own_stream = nullptr; // the stream this context created (phylo_ctx_set_stream may lend it another)
 	bool pileup_five = false; // the last projection met '!': start with five planes next time
 	DevBuf<DevHom> b_homs;
 	DevBuf<unsigned long long> b_subst, b_homologs;
@@ -400,11 +403,24 @@ int phylo_ctx_create(phylo_ctx **out, int device)
 		delete c;
 		return 4;
 	}
+	c->own_stream = c->stream;
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
 	*out = c;
 	return 0;
 }
+
+int phylo_ctx_set_stream(phylo_ctx *c, void *stream)
+{
+	if (!c) return 1;
+	HIPOK(c, hipSetDevice(c->device));
+	HIPOK(c, hipStreamSynchronize(c->stream));
+	harvest_spans(c);
+	c->stream = stream ? (hipStream_t)stream : c->own_stream;
+	return 0;
+}
+
+int phylo_ctx_device(const phylo_ctx *c) { return c ? c->device : -1; }
 
 void phylo_ctx_destroy(phylo_ctx *c)
 {
@@ -477,7 +493,7 @@ void phylo_ctx_destroy(phylo_ctx *c)
 	for (hipEvent_t e : c->tail_event)
 		if (e) (void)hipEventDestroy(e);
 	if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-	(void)hipStreamDestroy(c->stream);
+	(void)hipStreamDestroy(c->own_stream);
 	delete c;
 }
 
@@ -662,6 +678,7 @@ static int install_layout(phylo_ctx *c, bool pack = true)
 	c->plan_valid = false;
 	c->homs_staged = false;
 	c->att_homs = nullptr; // lists that only lived in an attached buffer are gone
+	c->att_rng_on_device = false;
 	c->host_stale.clear();
 	// Phase B goes ahead on a guess of whether a projected position will hold '!' (compare_pileup).  Genomes without any
 	// separator cannot project one; genomes in several contigs nearly always do (a homology that ends at a contig join
@@ -1052,6 +1069,7 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 	c->plan_valid = false;
 	c->homs_staged = false;
 	c->att_homs = nullptr; // lists that only lived in an attached buffer are gone
+	c->att_rng_on_device = false;
 	c->host_stale.clear();
 	c->stats["ms:ref_fetch"] += t1 - t0;
 	c->stats["ms:ref_suffix_array"] += t2 - t1;
@@ -1402,6 +1420,7 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	c->homs_staged = false;
 	c->eager_valid = false;
 	c->att_homs = nullptr; // an attached buffer is only borrowed until the next phase A
+	c->att_rng_on_device = false;
 	c->host_stale.clear();
 	if (device_filter) {
 		uint32_t *hr = c->h_rng.p; // [0, 2nq) ranges, [2nq, 3nq) flags, then total and the four misc words
@@ -1419,6 +1438,7 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 		if (!flagged) {
 			const size_t N = c->n;
 			c->att_homs = c->b_homs.p;
+			c->att_rng_on_device = false;
 			if (c->att_begin.size() != N) {
 				c->att_begin.assign(N, 0);
 				c->att_count.assign(N, 0);
@@ -1489,6 +1509,7 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	const bool stage = q_begin == 0 && q_end == c->n && nq > 0;
 	c->homs_staged = false;
 	c->att_homs = nullptr; // an attached buffer is only borrowed until the next phase A
+	c->att_rng_on_device = false;
 	c->host_stale.clear();
 	// genomes per group: a whole number of projection tiles — three, or an eighth of all of them
 	// (measured on C3 and C4: every group pays ~30 us of hand-over between the copy engine and
@@ -1618,9 +1639,11 @@ static int unpack_lists(phylo_ctx *c, size_t q_begin, size_t q_end, const uint64
 						const phylo_packed_homology *buf);
 
 // Host lists of genomes [g0, g1) that only exist as attached device records: fetch them.
+static int fetch_att_ranges(phylo_ctx *c);
 static int ensure_host_lists(phylo_ctx *c, size_t g0, size_t g1)
 {
 	if (c->host_stale.empty()) return 0;
+	if (fetch_att_ranges(c)) return 1;
 	for (size_t g = g0; g < g1; g++) {
 		if (!c->host_stale[g]) continue;
 		const size_t m = c->att_count[g];
@@ -1781,6 +1804,7 @@ int phylo_export_packed_device(phylo_ctx *c, size_t q_begin, size_t q_end, void 
 	// phase A may have left these lists on the device only (device sort + filter): copy from there
 	bool on_device = !c->host_stale.empty() && c->att_homs && q_end > q_begin;
 	for (size_t j = q_begin; j < q_end && on_device; j++) on_device = c->host_stale[j] != 0;
+	if (on_device && fetch_att_ranges(c)) return 1;
 	if (on_device) {
 		const size_t m = q_end - q_begin;
 		size_t tot = 0;
@@ -1857,10 +1881,185 @@ int phylo_attach_packed_device(phylo_ctx *c, const void *dev_records, const uint
 	if (sync_stream(c)) return 1;
 	if (bad_lists) return c->fail("phylo_attach_packed_device: a genome's list is not sorted by projected start, disjoint and inside the reference");
 	c->att_homs = (const DevHom *)dev_records;
+	c->att_rng_on_device = false;
 	c->att_begin.assign(begin, begin + N);
 	c->att_count.assign(count, count + N);
 	// lists of the kept range that this context has only on the device so far (device sort +
 	// filter) stay to be fetched — from the new buffer, which holds them too
+	std::vector<uint8_t> was = c->host_stale;
+	c->host_stale.assign(N, 1);
+	for (size_t g = keep_begin; g < keep_end; g++) c->host_stale[g] = was.size() == N ? was[g] : 0;
+	c->homs_staged = true;
+	c->eager_valid = false;
+	return 0;
+}
+
+// ── the exchange between ranks without the host in it ──
+// A rank's block: 4 header words {records in the block, overflow, queries, 0}, max_queries list lengths, then cap
+// records of 16 bytes.  Every rank's block has the same size, so one all-gather assembles all of them; the receiving
+// side works the per-genome ranges out on the device.
+static const uint32_t XB_HDR = 4;
+__global__ __launch_bounds__(256) void block_export_kernel(const DevHom *__restrict__ src, const uint32_t *__restrict__ rng, uint32_t nq,
+															 uint32_t maxq, uint32_t cap, uint32_t *__restrict__ block)
+{
+	const uint32_t j = blockIdx.x; // a slot of the header: the block's query j, or padding
+	__shared__ uint32_t part[256];
+	uint32_t acc = 0;
+	for (uint32_t t = threadIdx.x; t < j && t < nq; t += blockDim.x) acc += rng[2 * t + 1] - rng[2 * t];
+	part[threadIdx.x] = acc;
+	__syncthreads();
+	for (uint32_t s2 = 128; s2 > 0; s2 >>= 1) {
+		if (threadIdx.x < s2) part[threadIdx.x] += part[threadIdx.x + s2];
+		__syncthreads();
+	}
+	const uint32_t off = part[0];
+	const uint32_t cnt = j < nq ? rng[2 * j + 1] - rng[2 * j] : 0u;
+	if (threadIdx.x == 0) {
+		block[XB_HDR + j] = cnt;
+		if (j + 1 == maxq) {
+			block[0] = off + cnt;
+			block[2] = nq;
+			block[3] = 0;
+		}
+		if (off + cnt > cap) block[1] = 1; // (cleared by the caller's memset of the header)
+	}
+	if (off + cnt > cap) return;
+	DevHom *dst = (DevHom *)(block + XB_HDR + maxq) + off;
+	const DevHom *from = src + (j < nq ? rng[2 * j] : 0u);
+	for (uint32_t t = threadIdx.x; t < cnt; t += blockDim.x) dst[t] = from[t];
+}
+// one thread block per rank: the ranges of its genomes in the gathered buffer (in records from the buffer's start)
+__global__ __launch_bounds__(256) void block_attach_kernel(const uint32_t *__restrict__ all, const uint32_t *__restrict__ bounds,
+															 uint32_t maxq, uint32_t cap, uint32_t *__restrict__ rng, uint32_t *__restrict__ flags)
+{
+	const uint32_t r = blockIdx.x;
+	const uint32_t words = XB_HDR + maxq + 4u * cap;
+	const uint32_t *blk = all + (size_t)r * words;
+	const uint32_t g0 = bounds[r], nq = bounds[r + 1] - g0;
+	if (threadIdx.x == 0 && (blk[1] || blk[2] != nq || blk[0] > cap)) flags[2] = 1; // an overflowed or mismatched block
+	__shared__ uint32_t carry;
+	__shared__ uint32_t scan[256];
+	if (threadIdx.x == 0) carry = 0;
+	__syncthreads();
+	const uint32_t base = (uint32_t)(((size_t)r * words + XB_HDR + maxq) / 4u);
+	for (uint32_t t0 = 0; t0 < nq; t0 += 256) {
+		const uint32_t t = t0 + threadIdx.x;
+		const uint32_t cnt = t < nq ? blk[XB_HDR + t] : 0u;
+		scan[threadIdx.x] = cnt;
+		__syncthreads();
+		for (uint32_t d = 1; d < 256; d <<= 1) {
+			const uint32_t v = threadIdx.x >= d ? scan[threadIdx.x - d] : 0u;
+			__syncthreads();
+			scan[threadIdx.x] += v;
+			__syncthreads();
+		}
+		const uint32_t begin = carry + scan[threadIdx.x] - cnt;
+		if (t < nq) {
+			rng[2 * (g0 + t)] = base + begin;
+			rng[2 * (g0 + t) + 1] = base + begin + cnt;
+		}
+		__syncthreads();
+		if (threadIdx.x == 255) carry += scan[255];
+		__syncthreads();
+	}
+}
+
+size_t phylo_exchange_block_bytes(size_t max_queries, size_t cap_records) { return (XB_HDR + max_queries + 4 * cap_records) * 4; }
+
+int phylo_export_block_device(phylo_ctx *c, size_t q_begin, size_t q_end, void *dev_block, size_t max_queries, size_t cap_records)
+{
+	if (!c) return 1;
+	if (q_begin > q_end || q_end > c->n || !dev_block) return c->fail("phylo_export_block_device: bad arguments");
+	const size_t nq = q_end - q_begin;
+	if (max_queries < nq || max_queries % 4 || max_queries == 0) return c->fail("phylo_export_block_device: max_queries must be a multiple of 4 and hold the block's queries");
+	if (XB_HDR + max_queries + 4 * cap_records >= 0xffffffffull) return c->fail("phylo_export_block_device: block too large");
+	// the lists must be where phase A's device filter left them: this context's buffer, ranges by local query index
+	bool on_device = !c->host_stale.empty() && c->att_homs == c->b_homs.p && c->plan_valid && c->plan_qb == q_begin && c->plan_qe == q_end;
+	for (size_t j = q_begin; j < q_end && on_device; j++) on_device = c->host_stale[j] != 0;
+	HIPOK(c, hipSetDevice(c->device));
+	if (!on_device) {
+		// the lists live on the host (a query with tied starts went through std::sort, the host filter was asked for,
+		// lists were installed by the caller): the block is put together here and uploaded — the other ranks' blocks
+		// do not care how this one was made
+		if (ensure_host_lists(c, q_begin, q_end)) return 1;
+		size_t tot = 0;
+		for (size_t j = q_begin; j < q_end; j++) tot += c->homs[j].size();
+		const bool over = tot > cap_records;
+		const size_t words = XB_HDR + max_queries + (over ? 0 : 4 * tot);
+		HIPOK(c, c->h_devhom.ensure(words / 4 + 2));
+		uint32_t *blk = (uint32_t *)c->h_devhom.p;
+		blk[0] = (uint32_t)tot;
+		blk[1] = over ? 1u : 0u;
+		blk[2] = (uint32_t)nq;
+		blk[3] = 0;
+		for (size_t t = 0; t < max_queries; t++) blk[XB_HDR + t] = t < nq ? (uint32_t)c->homs[q_begin + t].size() : 0u;
+		if (!over) {
+			DevHom *rec = (DevHom *)(blk + XB_HDR + max_queries);
+			for (size_t j = q_begin; j < q_end; j++)
+				for (const phylo_homology &h : c->homs[j])
+					*rec++ = DevHom{(uint32_t)h.index_reference_projected, (uint32_t)h.index_query, (uint32_t)h.length, (uint32_t)h.direction};
+		}
+		HIPOK(c, hipMemcpyAsync(dev_block, blk, words * 4, hipMemcpyHostToDevice, c->stream));
+		return sync_stream(c); // (the staging buffer is reused by other calls)
+	}
+	HIPOK(c, hipMemsetAsync(dev_block, 0, XB_HDR * 4, c->stream));
+	hipLaunchKernelGGL(block_export_kernel, dim3((uint32_t)max_queries), dim3(256), 0, c->stream, (const DevHom *)c->b_homs.p,
+					   (const uint32_t *)c->b_hom_rng.p, (uint32_t)nq, (uint32_t)max_queries, (uint32_t)cap_records, (uint32_t *)dev_block);
+	HIPOK(c, hipGetLastError());
+	return 0;
+}
+
+static int fetch_att_ranges(phylo_ctx *c)
+{
+	if (!c->att_rng_on_device) return 0;
+	const size_t N = c->n;
+	std::vector<uint32_t> r(2 * N);
+	uint32_t fl[2] = {0, 0};
+	HIPOK(c, hipSetDevice(c->device));
+	HIPOK(c, hipMemcpyAsync(r.data(), c->b_hom_rng.p, 2 * N * 4, hipMemcpyDeviceToHost, c->stream));
+	if (c->att_unchecked) HIPOK(c, hipMemcpyAsync(fl, c->b_flag.p + 1, 8, hipMemcpyDeviceToHost, c->stream));
+	HIPOK(c, hipStreamSynchronize(c->stream));
+	if (c->att_unchecked && (fl[0] || fl[1])) return c->fail("the lists gathered from the ranks are not usable (overflowed block or unsorted list)");
+	c->att_begin.assign(N, 0);
+	c->att_count.assign(N, 0);
+	for (size_t g = 0; g < N; g++) {
+		c->att_begin[g] = r[2 * g];
+		c->att_count[g] = r[2 * g + 1] - r[2 * g];
+	}
+	c->att_rng_on_device = false;
+	return 0;
+}
+
+int phylo_attach_blocks_device(phylo_ctx *c, const void *dev_all, size_t world, const size_t *bounds, size_t max_queries,
+							   size_t cap_records, size_t keep_begin, size_t keep_end)
+{
+	if (!c) return 1;
+	if (!dev_all || !world || !bounds || keep_begin > keep_end || keep_end > c->n) return c->fail("phylo_attach_blocks_device: bad arguments");
+	if (!c->have_ref) return c->fail("phylo_attach_blocks_device: no reference set");
+	if (bounds[0] != 0 || bounds[world] != c->n) return c->fail("phylo_attach_blocks_device: the blocks must cover all genomes");
+	const size_t words = XB_HDR + max_queries + 4 * cap_records;
+	if (max_queries % 4 || world * words >= 0xffffffffull) return c->fail("phylo_attach_blocks_device: bad block shape");
+	for (size_t r = 0; r < world; r++)
+		if (bounds[r + 1] < bounds[r] || bounds[r + 1] - bounds[r] > max_queries) return c->fail("phylo_attach_blocks_device: bad bounds");
+	HIPOK(c, hipSetDevice(c->device));
+	const size_t N = c->n;
+	HIPOK(c, c->b_hom_rng.ensure(2 * N + world + 2));
+	HIPOK(c, c->b_flag.ensure(4));
+	HIPOK(c, c->h_rng.ensure(3 * N + world + 16));
+	uint32_t *hb = c->h_rng.p; // pinned: the copy below must not wait for pageable staging
+	for (size_t r = 0; r <= world; r++) hb[r] = (uint32_t)bounds[r];
+	uint32_t *d_bounds = c->b_hom_rng.p + 2 * N;
+	HIPOK(c, hipMemcpyAsync(d_bounds, hb, (world + 1) * 4, hipMemcpyHostToDevice, c->stream));
+	HIPOK(c, hipMemsetAsync(c->b_flag.p + 1, 0, 8, c->stream));
+	hipLaunchKernelGGL(block_attach_kernel, dim3((uint32_t)world), dim3(256), 0, c->stream, (const uint32_t *)dev_all, d_bounds,
+					   (uint32_t)max_queries, (uint32_t)cap_records, c->b_hom_rng.p, c->b_flag.p);
+	launch_check_lists((const DevHom *)dev_all, c->b_hom_rng.p, (uint32_t)N, c->L, c->b_flag.p + 1, c->stream);
+	HIPOK(c, hipGetLastError());
+	// nothing is waited for: b_flag[1] (a list that is not sorted and disjoint) and b_flag[2] (a block that overflowed
+	// its capacity) are read with the result of the comparison that follows
+	c->att_homs = (const DevHom *)dev_all;
+	c->att_rng_on_device = true;
+	c->att_unchecked = true;
 	std::vector<uint8_t> was = c->host_stale;
 	c->host_stale.assign(N, 1);
 	for (size_t g = keep_begin; g < keep_end; g++) c->host_stale[g] = was.size() == N ? was[g] : 0;
@@ -1965,8 +2164,25 @@ static int compare_segments(phylo_ctx *c, size_t part, size_t nparts, uint64_t *
 }
 
 // dev_out: leave the tallies in the caller's device buffers (subst / homologs are device pointers)
-static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *subst, uint64_t *homologs, bool dev_out = false)
+// u32 upper triangle: tri[k] = substitutions, tri[P + k] = homologs of pair (i < j), k = i (2N - i - 1) / 2 + (j - i - 1):
+// what crosses the wire between ranks (a tally is at most the reference's length, which is below 2^31)
+__global__ __launch_bounds__(256) void pack_triangle_kernel(uint32_t N, const unsigned long long *__restrict__ s,
+															 const unsigned long long *__restrict__ h, uint32_t *__restrict__ tri)
 {
+	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= (uint64_t)N * N) return;
+	const uint32_t i = (uint32_t)(t / N), j = (uint32_t)(t % N);
+	if (i >= j) return;
+	const uint64_t P = (uint64_t)N * (N - 1) / 2, k = (uint64_t)i * (2ull * N - i - 1) / 2 + (j - i - 1);
+	tri[k] = (uint32_t)s[t];
+	tri[P + k] = (uint32_t)h[t];
+}
+
+// out_mode 0: the caller's host matrices; 1: the caller's device matrices (subst / homologs are device pointers);
+// 2: the caller's device u32 triangle (subst is the device pointer, homologs unused)
+static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *subst, uint64_t *homologs, int out_mode = 0)
+{
+	const bool dev_out = out_mode != 0;
 	size_t N = c->n;
 	hipStream_t st = c->stream;
 	Pileup P;
@@ -1978,6 +2194,7 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		if (ensure_host_lists(c, 0, N)) return 1;
 		c->host_stale.clear();
 		c->att_homs = nullptr;
+		c->att_rng_on_device = false;
 		std::vector<uint32_t> hom_rng(2 * N);
 		size_t tot = 0;
 		for (size_t g = 0; g < N; g++) {
@@ -2027,7 +2244,7 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 	HIPOK(c, c->b_flag.ensure(4));
 	HIPOK(c, c->b_first.ensure(project_index_entries(P) + 1));
 	unsigned long long *acc_s, *acc_h; // where the pair kernel accumulates
-	if (dev_out) {
+	if (out_mode == 1) {
 		acc_s = (unsigned long long *)subst;
 		acc_h = (unsigned long long *)homologs;
 	} else {
@@ -2043,7 +2260,7 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 	// phase A may have projected the lists already (whole reference, i.e. part 0 of 1)
 	const bool projected = c->homs_staged && c->eager_valid && part == 0 && nparts == 1;
 	if (!projected) {
-		HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 16, st));
+		HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 4, st)); // (words 1 and 2 belong to phylo_attach_blocks_device)
 		launch_tile_index(P, query_src(c), dev_homs, c->b_hom_rng.p, c->b_first.p, 0, (uint32_t)N, st);
 	}
 	// Three planes and the plain pair kernel unless '!' turns up among the projected positions (the projection raises
@@ -2074,8 +2291,17 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		HIPOK(c, c->b_tiles.ensure(tiles.size() + mtiles.size()));
 		if (!mtiles.empty()) HIPOK(c, hipMemcpyAsync(c->b_tiles.p + tiles.size(), mtiles.data(), mtiles.size() * 4, hipMemcpyHostToDevice, st));
 	}
+	auto finish_tallies = [&]() { // mirror image for the matrices; the packed triangle for the wire
+		if (out_mode == 2)
+			hipLaunchKernelGGL(pack_triangle_kernel, dim3((uint32_t)((N * N + 255) / 256)), dim3(256), 0, st, (uint32_t)N, acc_s, acc_h, (uint32_t *)subst);
+		else
+			launch_symmetrise((uint32_t)N, acc_s, acc_h, st);
+	};
 	auto pairs = [&](bool bang) -> int {
-		if (tiles.empty() || !P.W) return 0;
+		if (tiles.empty() || !P.W) {
+			finish_tallies();
+			return 0;
+		}
 		if (!bang && !mtiles.empty()) {
 			// Without '!' the tallies are a contraction over {-1, 0, 1} channels: the matrix cores take it
 			// (pileup_kernels.hip: pairs_mfma_kernel).  Window chunks: the chunk's rows of three planes in an XCD's L2,
@@ -2096,7 +2322,7 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 				launch_pairs_mfma(P, c->b_tiles.p + tiles.size(), (uint32_t)mtiles.size(), wchunk, acc_s, acc_h, st);
 			}
 			HIPOK(c, hipGetLastError());
-			launch_symmetrise((uint32_t)N, acc_s, acc_h, st);
+			finish_tallies();
 			return 0;
 		}
 		// window chunks: small enough that a chunk's plane rows (3 or 5 planes x Npad x 4 B
@@ -2119,7 +2345,7 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 			launch_pairs(P, bang, c->b_tiles.p, (uint32_t)tiles.size(), wchunk, acc_s, acc_h, st);
 		}
 		HIPOK(c, hipGetLastError());
-		launch_symmetrise((uint32_t)N, acc_s, acc_h, st);
+		finish_tallies();
 		return 0;
 	};
 	auto project = [&](bool five) -> int {
@@ -2130,7 +2356,7 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 	uint64_t *hs = c->h_mat.p, *hh = c->h_mat.p + N * N;
 	auto fetch = [&]() -> int { // the flag, and the result unless it stays on the device
 		HIPOK(c, hipGetLastError());
-		HIPOK(c, hipMemcpyAsync(flagp, c->b_flag.p, 4, hipMemcpyDeviceToHost, st));
+		HIPOK(c, hipMemcpyAsync(flagp, c->b_flag.p, 12, hipMemcpyDeviceToHost, st));
 		if (!dev_out) {
 			HIPOK(c, hipMemcpyAsync(hs, acc_s, N * N * 8, hipMemcpyDeviceToHost, st));
 			HIPOK(c, hipMemcpyAsync(hh, acc_h, N * N * 8, hipMemcpyDeviceToHost, st));
@@ -2142,12 +2368,17 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 	if (!projected && project(have_five)) return 1;
 	double t1 = now_ms();
 	if (pairs(bang) || fetch()) return 1;
+	const bool att_bad = c->att_unchecked && (flagp[1] || flagp[2]);
+	c->att_unchecked = false;
+	if (att_bad)
+		return c->fail(flagp[2] ? "the lists gathered from the ranks overflowed their blocks' capacity (phylo_attach_blocks_device)"
+								: "a gathered list is not sorted by projected start, disjoint and inside the reference");
 	uint32_t flag = *flagp;
 	if (flag && !bang) { // '!' among the projected positions, and the plain kernel ran: once more with all five planes
 		c->stats["count:compare_repeated_with_five_planes"] += 1;
 		HIPOK(c, hipMemsetAsync(acc_s, 0, N * N * 8, st));
 		HIPOK(c, hipMemsetAsync(acc_h, 0, N * N * 8, st));
-		HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 16, st));
+		HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 4, st));
 		bang = true;
 		if (project(true) || pairs(true) || fetch()) return 1;
 		flag = *flagp;
@@ -2226,11 +2457,56 @@ int phylo_compare_device(phylo_ctx *c, size_t part, size_t nparts, uint64_t *dev
 			HIPOK(c, hipMemcpy(dev_homologs, h.data(), N * N * 8, hipMemcpyHostToDevice));
 		}
 	} else {
-		rc = compare_pileup(c, part, nparts, dev_subst, dev_homologs, true);
+		rc = compare_pileup(c, part, nparts, dev_subst, dev_homologs, 1);
 	}
 	c->stats["ms:compare_total"] += now_ms() - t0;
 	c->stats["n:compare_calls"] += 1;
 	return rc;
+}
+
+int phylo_compare_triangle_device(phylo_ctx *c, size_t part, size_t nparts, uint32_t *dev_tri)
+{
+	if (!c) return 1;
+	if (!dev_tri) return c->fail("null output triangle");
+	if (nparts == 0 || part >= nparts) return c->fail("bad part %zu of %zu", part, nparts);
+	if (!c->have_ref) return c->fail("phylo_compare_triangle_device: no reference set");
+	if (c->backend == 1) return c->fail("phylo_compare_triangle_device: the segment backend tallies on the host (use phylo_compare)");
+	HIPOK(c, hipSetDevice(c->device));
+	double t0 = now_ms();
+	const int rc = compare_pileup(c, part, nparts, (uint64_t *)dev_tri, nullptr, 2);
+	c->stats["ms:compare_total"] += now_ms() - t0;
+	c->stats["n:compare_calls"] += 1;
+	return rc;
+}
+
+int phylo_triangle_to_matrices(phylo_ctx *c, const uint32_t *dev_tri, uint64_t *subst, uint64_t *homologs)
+{
+	if (!c) return 1;
+	if (!dev_tri || !subst || !homologs) return c->fail("phylo_triangle_to_matrices: null argument");
+	HIPOK(c, hipSetDevice(c->device));
+	const size_t N = c->n, P = N * (N - 1) / 2;
+	HIPOK(c, c->h_mat.ensure(2 * N * N + 8)); // (2 P u32 fit the front of it)
+	uint32_t *tri = (uint32_t *)c->h_mat.p;
+	if (P) HIPOK(c, hipMemcpyAsync(tri, dev_tri, 2 * P * 4, hipMemcpyDeviceToHost, c->stream));
+	if (sync_stream(c)) return 1;
+	auto row = [&](size_t i) {
+		uint64_t *so = subst + i * N, *ho = homologs + i * N;
+		for (size_t j = 0; j < i; j++) { // pair (j, i)
+			const size_t k = j * (2 * N - j - 1) / 2 + (i - j - 1);
+			so[j] = tri[k];
+			ho[j] = tri[P + k];
+		}
+		so[i] = ho[i] = 0;
+		const size_t k0 = i * (2 * N - i - 1) / 2;
+		for (size_t j = i + 1; j < N; j++) {
+			so[j] = tri[k0 + (j - i - 1)];
+			ho[j] = tri[P + k0 + (j - i - 1)];
+		}
+	};
+	if (N >= 256) workers(c).run(N, row);
+	else
+		for (size_t i = 0; i < N; i++) row(i);
+	return 0;
 }
 
 int phylo_compare_all(phylo_ctx *c, uint64_t *subst, uint64_t *homologs)

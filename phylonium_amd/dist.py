@@ -16,6 +16,8 @@ from .api import PACKED
 
 # tests: run the collectives even in a one-rank group (exercises the RCCL code path on a single GPU)
 _FORCE_COLLECTIVES = False
+# tests: round 2's exchange (counts through the host, u64 matrices on the wire) instead of the block exchange
+_LEGACY_DEVICE_EXCHANGE = False
 
 
 def query_shard(n, rank, world, lengths=None):
@@ -106,6 +108,58 @@ def exchange_homologies_device(ctx, n, rank, world, bounds, device):
     return gathered  # borrowed by the context: the caller keeps it alive until the comparison is done
 
 
+def _exchange_plan(ctx, n, rank, world, bounds, device):
+    """Shape of the exchange blocks (list lengths per rank, record capacity), from this step's counts: the one
+    place where the ranks wait for each other's numbers on the host.  Kept on the context and reused while the
+    lists fit (their sizes repeat from step to step; an overflow is detected on the device and re-plans)."""
+    qb, qe = bounds[rank], bounds[rank + 1]
+    own = int(ctx.hom_counts(qb, qe).sum())
+    t = torch.tensor([own], dtype=torch.int64, device=device)
+    td.all_reduce(t, op=td.ReduceOp.MAX)
+    cap = int(t.item())
+    cap = cap + cap // 4 + 64
+    maxq = max(bounds[r + 1] - bounds[r] for r in range(world))
+    maxq = (maxq + 3) // 4 * 4 or 4
+    nbytes = ctx.exchange_block_bytes(maxq, cap)
+    P = n * (n - 1) // 2
+    return {"maxq": maxq, "cap": cap, "bounds": tuple(bounds),
+            "block": torch.empty(nbytes, dtype=torch.uint8, device=device),
+            "all": torch.empty(world * nbytes, dtype=torch.uint8, device=device),
+            "tri": torch.empty(max(2 * P, 1), dtype=torch.int32, device=device)}
+
+
+def process_sharded_device(ctx, rank, world, bounds, device, out=None):
+    """One step with the exchange left to the device: the context works on torch's current stream, so the library's
+    kernels and the collectives are ordered by the stream and the host waits twice — at the end of phase A (its
+    error and tie flags) and for the result.  Lists travel as fixed-shape blocks (one all-gather), tallies as a u32
+    upper triangle (one all-reduce, a quarter of the bytes of the two u64 matrices)."""
+    n = ctx.n
+    qb, qe = bounds[rank], bounds[rank + 1]
+    stream = torch.cuda.current_stream(device).cuda_stream
+    if getattr(ctx, "_on_stream", None) != stream:
+        ctx.set_stream(stream)
+        ctx._on_stream = stream
+    for attempt in range(2):
+        ctx.anchor(qb, qe)
+        plan = getattr(ctx, "_xplan", None)
+        if plan is None or plan["bounds"] != tuple(bounds) or plan["tri"].numel() != max(n * (n - 1), 1):
+            plan = ctx._xplan = _exchange_plan(ctx, n, rank, world, bounds, device)
+        try:
+            ctx.export_block_device(qb, qe, plan["block"].data_ptr(), plan["maxq"], plan["cap"])
+            td.all_gather_into_tensor(plan["all"], plan["block"])
+            ctx.attach_blocks_device(plan["all"].data_ptr(), bounds, plan["maxq"], plan["cap"], qb, qe)
+            ctx.compare_triangle_device(rank, world, plan["tri"].data_ptr())
+        except Exception as e:  # a block overflowed its capacity (every rank sees every block's flag): plan again
+            if attempt == 0 and "overflow" in str(e):
+                ctx._xplan = None
+                continue
+            raise
+        td.all_reduce(plan["tri"], op=td.ReduceOp.SUM)
+        ctx._attached_records = plan["all"]  # still the source of the other ranks' lists should the caller ask for them
+        return ctx.triangle_to_matrices(plan["tri"].data_ptr(), out)
+    raise RuntimeError("process_sharded_device: the exchange blocks overflowed twice")
+
+
 def process_sharded(ctx, ref_idx, rank, world, device=None, lengths=None, set_reference=True, out=None, copy=True):
     """process() with queries and pair tiles sharded over `world` ranks.
     ctx: an api.Context (or any object with the same methods) holding all genomes.
@@ -121,6 +175,8 @@ def process_sharded(ctx, ref_idx, rank, world, device=None, lengths=None, set_re
     qb, qe = bounds[rank], bounds[rank + 1]
     ctx.anchor(qb, qe)
     on_gpu = device is not None and torch.device(device).type == "cuda" and hasattr(ctx, "attach_packed_device")
+    if on_gpu and (world > 1 or _FORCE_COLLECTIVES) and hasattr(ctx, "export_block_device") and not _LEGACY_DEVICE_EXCHANGE:
+        return process_sharded_device(ctx, rank, world, bounds, device, out=out)
     if on_gpu and (world > 1 or _FORCE_COLLECTIVES):
         # device-resident: records and tallies never visit the host between the ranks
         keep = exchange_homologies_device(ctx, ctx.n, rank, world, bounds, device)

@@ -624,6 +624,64 @@ def test_device_resident_exchange_between_two_contexts():
             c.close()
 
 
+def test_block_exchange_between_three_contexts():
+    """The exchange without the host in it (phylo_export_block_device / phylo_attach_blocks_device /
+    phylo_compare_triangle_device): three contexts stand for three ranks on torch's current stream; each anchors its
+    block of queries and writes its exchange block straight into its slot of the buffer an all-gather would fill, all
+    attach that buffer, the three u32 triangles add up to the oracle's matrices (one all-reduce), and lists a context
+    did not compute come out of the gathered buffer.  Rank 0 filters on the host (its block is put together there),
+    a capacity that is too small is reported by every rank, and round 2's exchange still works beside it."""
+    import torch
+    gs = synth.make_genomes(13, 25000, seed=85, d_range=(0.01, 0.25), indel_per_mbp=300, inv_frac=0.08, contigs=2)
+    n, ref = len(gs), 5
+    r_orc = O.Run(gs, ref).process()
+    so, ho = r_orc.matrix()
+    dev = torch.device("cuda", 0)
+    bounds = [0, 3, 9, n]
+    world = 3
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ctxs = [api.Context(0) for _ in range(world)]
+    try:
+        for r, c in enumerate(ctxs):
+            c.set_stream(stream)
+            c.set_option("filter", 1 if r == 0 else 0)
+            c.set_genomes(gs)
+            c.set_reference(ref)
+        maxq = 8
+        for cap, fits in ((200000, True), (40, False), (200000, True)):
+            nbytes = ctxs[0].exchange_block_bytes(maxq, cap)
+            gathered = torch.zeros(world * nbytes, dtype=torch.uint8, device=dev)
+            P = n * (n - 1) // 2
+            total = torch.zeros(2 * P, dtype=torch.int32, device=dev)
+            for r, c in enumerate(ctxs):
+                c.anchor(bounds[r], bounds[r + 1])
+                c.export_block_device(bounds[r], bounds[r + 1], gathered.data_ptr() + r * nbytes, maxq, cap)
+            failed = 0
+            for r, c in enumerate(ctxs):
+                c.attach_blocks_device(gathered.data_ptr(), bounds, maxq, cap, bounds[r], bounds[r + 1])
+                t = torch.empty(2 * P, dtype=torch.int32, device=dev)
+                try:
+                    c.compare_triangle_device(r, world, t.data_ptr())
+                    total += t
+                except api.PhyloniumError as e:
+                    assert "overflow" in str(e)
+                    failed += 1
+            assert failed == (0 if fits else world)
+            if not fits:
+                continue
+            s, h = ctxs[1].triangle_to_matrices(total.data_ptr())
+            assert (s == so).all() and (h == ho).all()
+            for j in range(n):
+                want = hom_tuples_orc(r_orc.homologies(j))
+                for c in ctxs:
+                    assert hom_tuples_gpu(c.homologies(j)) == want, j
+        s2, h2 = ctxs[2].compare()
+        assert (s2 == so).all() and (h2 == ho).all()
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def _two_rank_worker(rank, world, port, out):
     import torch.distributed as td
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -697,7 +755,13 @@ def _nccl_one_rank_worker(rank, world, port, out):
     gs = synth.make_genomes(6, 20000, seed=91, d_range=(0.01, 0.2), inv_frac=0.05)
     c = api.Context(0)
     c.set_genomes(gs)
-    s, h = dist.process_sharded(c, 1, rank, world, device=dev)
+    s, h = dist.process_sharded(c, 1, rank, world, device=dev)  # block exchange on torch's stream, u32 triangle on the wire
+    s, h = s.copy(), h.copy()
+    s3, h3 = dist.process_sharded(c, 1, rank, world, device=dev)  # once more: the planned capacity is reused
+    assert (s3 == s).all() and (h3 == h).all()
+    dist._LEGACY_DEVICE_EXCHANGE = True  # round 2's exchange: counts through the host, u64 matrices on the wire
+    s2, h2 = dist.process_sharded(c, 1, rank, world, device=dev)
+    assert (s2 == s).all() and (h2 == h).all()
     np.save(out + ".s.npy", s)
     np.save(out + ".h.npy", h)
     c.close()
