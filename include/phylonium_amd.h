@@ -220,6 +220,34 @@ int phylo_triangle_to_matrices(phylo_ctx *ctx, const uint32_t *dev_tri, uint64_t
 /* ── B2 in one call ── */
 int phylo_process(phylo_ctx *ctx, size_t ref_idx, int flags, uint64_t *subst, uint64_t *homologs);
 
+/* ── several GPUs of one node behind one host (csrc/group.hip) ──
+ * process() shards without a data-path collective inside either phase: phase A by query block (the loop at
+ * src/process.cxx:433-434), phase B by range of reference windows (the pair loop at src/process.cxx:524-529 re-cut so
+ * that projection and pair kernel both shrink with the ranks).  A group is one context and one host thread per rank;
+ * the ranks meet three times per pass — the packed genomes (an all-gather of the blocks each rank uploaded), the
+ * filtered lists after phase A (an all-gather of fixed-shape device blocks), the tallies after phase B (a reduce of
+ * u32 triangles to rank 0) — over RCCL / xGMI when every rank has a GPU of its own (the library is loaded when a
+ * group is made), by device-to-device copies when ranks share a GPU.  devices: n_ranks ordinals (NULL: rank r on
+ * device r modulo the device count).  Results are identical to one context's for any number of ranks. */
+typedef struct phylo_group phylo_group;
+int phylo_group_create(phylo_group **out, size_t n_ranks, const int *devices);
+void phylo_group_destroy(phylo_group *g);
+const char *phylo_group_last_error(const phylo_group *g); /* g may be NULL: a failed phylo_group_create on this thread */
+size_t phylo_group_size(const phylo_group *g);
+phylo_ctx *phylo_group_ctx(phylo_group *g, size_t rank);   /* rank 0 holds every list after phylo_group_anchor */
+const char *phylo_group_backend(const phylo_group *g);     /* "rccl", "device-to-device copies" or "one rank" */
+int phylo_group_set_option(phylo_group *g, const char *key, long value); /* phylo_set_option on every rank */
+/* phylo_get_stat of a rank, plus "group:ms_anchor", "group:ms_exchange", "group:ms_compare", "group:ms_reduce" (the
+ * rank's host-side milliseconds in the last pass) */
+int phylo_group_get_stat(phylo_group *g, size_t rank, const char *key, double *out);
+/* the arguments of phylo_set_genomes_packed: rank r uploads its block of the genomes, one all-gather does the rest */
+int phylo_group_set_genomes_packed(phylo_group *g, size_t n, const uint32_t *const *q2, const size_t *len,
+								   const uint32_t *const *bad, const size_t *nbad);
+int phylo_group_set_reference(phylo_group *g, size_t ref_idx, const int64_t *sa, size_t threshold);
+int phylo_group_anchor(phylo_group *g);                                    /* phase A + the lists to every rank */
+int phylo_group_compare(phylo_group *g, uint64_t *subst, uint64_t *homologs); /* phase B + the sum on rank 0 */
+int phylo_group_process(phylo_group *g, uint64_t *subst, uint64_t *homologs); /* both */
+
 /* ── B0 ── */
 size_t phylo_seqcmp(const char *begin, const char *other, size_t length);
 size_t phylo_revseqcmp(const char *begin, const char *other, size_t length);
@@ -231,7 +259,8 @@ int phylo_seqcmp_batch(phylo_ctx *ctx, size_t n, const uint32_t *ga, const uint6
 					   const uint32_t *gb, const uint64_t *offb, const uint64_t *len, const uint8_t *rev,
 					   uint64_t *out);
 
-/* ── host-side helpers (no GPU) ── */
+/* ── host-side helpers (no GPU, except the first) ── */
+int phylo_host_device_count(int *count); /* HIP devices this process sees; nonzero when the runtime cannot say */
 int phylo_host_suffix_array(const char *s, size_t n, int64_t *sa);
 /* Suffix array of S = ref + '#' + revcomp(ref) (2*len + 1 entries, src/esa.cxx:72-75), the `sa`
  * argument of phylo_set_reference: lets a host build it on another thread while genomes are

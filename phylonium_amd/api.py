@@ -28,7 +28,10 @@ SYMBOLS = [
     "phylo_export_homologies", "phylo_import_homologies", "phylo_export_packed", "phylo_import_packed",
     "phylo_export_packed_device", "phylo_attach_packed_device", "phylo_compare_device",
     "phylo_ctx_set_stream", "phylo_ctx_device", "phylo_exchange_block_bytes", "phylo_export_block_device", "phylo_attach_blocks_device",
-    "phylo_compare_triangle_device", "phylo_triangle_to_matrices",
+    "phylo_compare_triangle_device", "phylo_triangle_to_matrices", "phylo_host_device_count",
+    "phylo_group_create", "phylo_group_destroy", "phylo_group_last_error", "phylo_group_size", "phylo_group_ctx", "phylo_group_backend",
+    "phylo_group_set_option", "phylo_group_get_stat", "phylo_group_set_genomes_packed", "phylo_group_set_reference", "phylo_group_anchor",
+    "phylo_group_compare", "phylo_group_process",
     "phylo_complete_delete", "phylo_compare", "phylo_compare_all", "phylo_process", "phylo_seqcmp",
     "phylo_revseqcmp", "phylo_seqcmp_batch", "phylo_host_suffix_array", "phylo_host_reference_suffix_array", "phylo_host_min_anchor_length",
     "phylo_host_read_fasta", "phylo_host_read_fasta_packed", "phylo_host_free_packed", "phylo_host_free", "phylo_host_median_length_index",
@@ -92,6 +95,25 @@ def load():
     L.phylo_attach_blocks_device.argtypes = [vp, vp, sz, vp, sz, sz, sz, sz]
     L.phylo_compare_triangle_device.argtypes = [vp, sz, sz, vp]
     L.phylo_triangle_to_matrices.argtypes = [vp, vp, vp, vp]
+    L.phylo_host_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.phylo_group_create.argtypes = [C.POINTER(vp), sz, vp]
+    L.phylo_group_destroy.argtypes = [vp]
+    L.phylo_group_destroy.restype = None
+    L.phylo_group_last_error.restype = C.c_char_p
+    L.phylo_group_last_error.argtypes = [vp]
+    L.phylo_group_size.restype = sz
+    L.phylo_group_size.argtypes = [vp]
+    L.phylo_group_ctx.restype = vp
+    L.phylo_group_ctx.argtypes = [vp, sz]
+    L.phylo_group_backend.restype = C.c_char_p
+    L.phylo_group_backend.argtypes = [vp]
+    L.phylo_group_set_option.argtypes = [vp, C.c_char_p, C.c_long]
+    L.phylo_group_get_stat.argtypes = [vp, sz, C.c_char_p, C.POINTER(C.c_double)]
+    L.phylo_group_set_genomes_packed.argtypes = [vp, sz, vp, vp, vp, vp]
+    L.phylo_group_set_reference.argtypes = [vp, sz, vp, sz]
+    L.phylo_group_anchor.argtypes = [vp]
+    L.phylo_group_compare.argtypes = [vp, vp, vp]
+    L.phylo_group_process.argtypes = [vp, vp, vp]
     L.phylo_process.argtypes = [vp, sz, C.c_int, vp, vp]
     L.phylo_seqcmp.restype = sz
     L.phylo_seqcmp.argtypes = [vp, vp, sz]
@@ -501,6 +523,105 @@ def read_fasta_packed(paths, threads=16):
         return np.ctypeslib.as_array(raw)
 
     return [(view(q2[i], (lens[i] + 15) // 16), int(lens[i]), view(bad[i], nbad[i])) for i in range(n)]
+
+
+class Group:
+    """Several GPUs of one node behind one host (phylo_group_*, csrc/group.hip): one context and one host thread per
+    rank inside the library; results are those of one Context.  devices: one ordinal per rank (None: rank r on device
+    r modulo the device count — ranks then share GPUs when there are fewer)."""
+
+    def __init__(self, n_ranks, devices=None):
+        self.L = load()
+        h = C.c_void_p()
+        dv = (C.c_int * n_ranks)(*devices) if devices is not None else None
+        if self.L.phylo_group_create(C.byref(h), n_ranks, dv):
+            raise PhyloniumError(self.L.phylo_group_last_error(None).decode())
+        self.h = h
+        self.n = 0
+        self.world = n_ranks
+
+    def _chk(self, rc):
+        if rc:
+            raise PhyloniumError(self.L.phylo_group_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.phylo_group_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def backend(self):
+        return self.L.phylo_group_backend(self.h).decode()
+
+    def set_option(self, key, value):
+        self._chk(self.L.phylo_group_set_option(self.h, key.encode(), int(value)))
+
+    def stat(self, rank, key):
+        v = C.c_double()
+        return v.value if self.L.phylo_group_get_stat(self.h, rank, key.encode(), C.byref(v)) == 0 else None
+
+    def set_genomes(self, genomes):
+        """genomes: bytes / uint8 arrays over A, C, G, T, '!' (packed here; a FASTA host packs while it reads)."""
+        self.set_genomes_packed([pack_genome(g) for g in genomes])
+
+    def set_genomes_packed(self, packed):
+        n = len(packed)
+        q2 = [np.ascontiguousarray(p[0], np.uint32) for p in packed]
+        bad = [np.ascontiguousarray(p[2], np.uint32) for p in packed]
+        qp = (C.c_void_p * n)(*[a.ctypes.data for a in q2])
+        bp = (C.c_void_p * n)(*[a.ctypes.data for a in bad])
+        lens = (C.c_size_t * n)(*[int(p[1]) for p in packed])
+        nb = (C.c_size_t * n)(*[a.size for a in bad])
+        self._chk(self.L.phylo_group_set_genomes_packed(self.h, n, qp, lens, bp, nb))
+        self.n = n
+        self.lengths = [int(p[1]) for p in packed]
+
+    def set_reference(self, ref_idx, sa=None, threshold=0):
+        sap = None
+        if sa is not None:
+            self._sa = np.ascontiguousarray(sa, dtype=np.int64)
+            sap = self._sa.ctypes.data_as(C.c_void_p)
+        self._chk(self.L.phylo_group_set_reference(self.h, ref_idx, sap, threshold))
+
+    def anchor(self):
+        self._chk(self.L.phylo_group_anchor(self.h))
+
+    def compare(self, out=None):
+        n = self.n
+        s, h = out if out is not None else (np.zeros((n, n), np.uint64), np.zeros((n, n), np.uint64))
+        self._chk(self.L.phylo_group_compare(self.h, s.ctypes.data_as(C.c_void_p), h.ctypes.data_as(C.c_void_p)))
+        return s, h
+
+    def process(self, ref_idx=None, out=None):
+        if ref_idx is not None:
+            self.set_reference(ref_idx)
+        n = self.n
+        s, h = out if out is not None else (np.zeros((n, n), np.uint64), np.zeros((n, n), np.uint64))
+        self._chk(self.L.phylo_group_process(self.h, s.ctypes.data_as(C.c_void_p), h.ctypes.data_as(C.c_void_p)))
+        return s, h
+
+    def rank_context(self, rank):
+        """A borrowed Context view of a rank's phylo_ctx (rank 0 holds every list after anchor())."""
+        c = Context.__new__(Context)
+        c.L = self.L
+        c.h = C.c_void_p(self.L.phylo_group_ctx(self.h, rank))
+        c.n = self.n
+        c.lengths = getattr(self, "lengths", [])
+        c.close = lambda: None  # owned by the group
+        return c
+
+
+def device_count():
+    n = C.c_int()
+    if load().phylo_host_device_count(C.byref(n)):
+        return 0
+    return n.value
 
 
 def pack_genome(g):

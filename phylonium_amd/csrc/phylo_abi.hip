@@ -2487,14 +2487,17 @@ int phylo_triangle_to_matrices(phylo_ctx *c, const uint32_t *dev_tri, uint64_t *
 	const size_t N = c->n, P = N * (N - 1) / 2;
 	HIPOK(c, c->h_mat.ensure(2 * N * N + 8)); // (2 P u32 fit the front of it)
 	uint32_t *tri = (uint32_t *)c->h_mat.p;
+	const double t0 = now_ms();
 	if (P) HIPOK(c, hipMemcpyAsync(tri, dev_tri, 2 * P * 4, hipMemcpyDeviceToHost, c->stream));
 	if (sync_stream(c)) return 1;
+	const double t1 = now_ms();
 	auto row = [&](size_t i) {
 		uint64_t *so = subst + i * N, *ho = homologs + i * N;
-		for (size_t j = 0; j < i; j++) { // pair (j, i)
-			const size_t k = j * (2 * N - j - 1) / 2 + (i - j - 1);
+		size_t k = i ? i - 1 : 0; // pair (j, i): k(j, i) = j (2N - j - 1) / 2 + (i - j - 1), stepping by N - j - 2 from j to j + 1
+		for (size_t j = 0; j < i; j++) {
 			so[j] = tri[k];
 			ho[j] = tri[P + k];
+			k += N - j - 2;
 		}
 		so[i] = ho[i] = 0;
 		const size_t k0 = i * (2 * N - i - 1) / 2;
@@ -2503,9 +2506,15 @@ int phylo_triangle_to_matrices(phylo_ctx *c, const uint32_t *dev_tri, uint64_t *
 			ho[j] = tri[P + k0 + (j - i - 1)];
 		}
 	};
-	if (N >= 256) workers(c).run(N, row);
-	else
-		for (size_t i = 0; i < N; i++) row(i);
+	// bands of rows, a few per worker (a task per row would cost more in hand-outs than in copying)
+	const size_t bands = N >= 256 ? std::min<size_t>(64, N / 8) : 1;
+	auto band = [&](size_t b) {
+		for (size_t i = N * b / bands, e = N * (b + 1) / bands; i < e; i++) row(i);
+	};
+	if (bands > 1) workers(c).run(bands, band);
+	else band(0);
+	c->stats["ms:triangle_copy"] += t1 - t0;
+	c->stats["ms:triangle_widen"] += now_ms() - t1;
 	return 0;
 }
 
@@ -2664,6 +2673,13 @@ int phylo_host_reference_suffix_array(const char *ref, size_t len, int64_t *sa)
 }
 
 size_t phylo_host_min_anchor_length(double p, double gc, size_t l) { return min_anchor_length(p, gc, l); }
+
+int phylo_host_device_count(int *count)
+{
+	if (!count) return 1;
+	*count = 0;
+	return hipGetDeviceCount(count) == hipSuccess ? 0 : 1;
+}
 
 int phylo_host_read_fasta(size_t n, const char *const *paths, size_t threads, char **out, size_t *len)
 {

@@ -204,7 +204,8 @@ size_t pick_second_pass(size_t N, const Matrix &m)
 }
 
 struct Run {
-	phylo_ctx *ctx = nullptr;
+	phylo_ctx *ctx = nullptr;      // the context (rank 0's, with several GPUs)
+	phylo_group *grp = nullptr;    // --gpus N: one context and one host thread per GPU (csrc/group.hip)
 	std::vector<Genome> *q = nullptr;
 	int flags = 0;
 	std::string refpos_file;
@@ -213,6 +214,10 @@ struct Run {
 void ok(Run &r, int rc)
 {
 	if (rc) die(phylo_last_error(r.ctx));
+}
+void gok(Run &r, int rc)
+{
+	if (rc) die(phylo_group_last_error(r.grp));
 }
 
 // -p FILE: reference positions of the core alignment with the segregating
@@ -267,16 +272,23 @@ Matrix process(Run &r, size_t ref_idx, const int64_t *sa = nullptr)
 {
 	auto &q = *r.q;
 	size_t N = q.size();
-	ok(r, phylo_set_reference(r.ctx, ref_idx, sa, 0));
+	if (r.grp) gok(r, phylo_group_set_reference(r.grp, ref_idx, sa, 0));
+	else ok(r, phylo_set_reference(r.ctx, ref_idx, sa, 0));
 	if (r.flags & F_VERBOSE) std::cerr << "ref: " << q[ref_idx].name << std::endl;
 	if ((r.flags & F_VERBOSE) && phylo_reference_cache_quirk(r.ctx))
-		std::cerr << "note: phylonium's 6-mer cache would over-report some matches on this reference (src/esa.cxx:174-199); "
-					 "distances computed here use the true longest matches and may differ from phylonium's" << std::endl;
-	ok(r, phylo_anchor(r.ctx, 0, N));
+		std::cerr << "note: phylonium's 6-mer cache over-reports some matches on this reference (src/esa.cxx:174-199); "
+					 "its answers are reproduced here, so the distances are phylonium's, not those of the true longest matches" << std::endl;
+	// phase A: every GPU anchors its block of the queries, then every GPU holds all lists (rank 0's context
+	// hands out any of them)
+	if (r.grp) gok(r, phylo_group_anchor(r.grp));
+	else ok(r, phylo_anchor(r.ctx, 0, N));
 	if (r.flags & F_COMPLETE_DELETION) ok(r, phylo_complete_delete(r.ctx));
 	if (r.flags & F_POSITIONS) write_positions(r, ref_idx);
 	std::vector<uint64_t> s(N * N), h(N * N);
-	ok(r, phylo_compare_all(r.ctx, s.data(), h.data()));
+	// phase B: by range of reference windows over the GPUs — or, after the N-way intersection of the lists on the
+	// host (complete deletion, src/process.cxx:467-469), on rank 0's GPU, which holds the result of it
+	if (r.grp && !(r.flags & F_COMPLETE_DELETION)) gok(r, phylo_group_compare(r.grp, s.data(), h.data()));
+	else ok(r, phylo_compare_all(r.ctx, s.data(), h.data()));
 	Matrix m(N * N);
 	for (size_t k = 0; k < N * N; k++) m[k] = Tally{s[k], h[k]};
 	return m;
@@ -299,7 +311,10 @@ Matrix process(Run &r, size_t ref_idx, const int64_t *sa = nullptr)
 		"      --ingest=HOW     packed (default: 2-bit codes made while reading, a quarter of the\n"
 		"                       bytes uploaded) or bytes\n"
 		"      --timing         Print where the wall-clock went to stderr\n"
-		"  -d, --device=N       GPU ordinal (default 0)\n"
+		"  -d, --device=N       GPU ordinal (default 0; with --gpus: the first of them)\n"
+		"      --gpus=N         Shard the queries (phase A) and the reference's windows (phase B) over N\n"
+		"                       GPUs: one host thread and one context per GPU, RCCL between them\n"
+		"                       (ranks share GPUs when the machine has fewer)\n"
 		"  -v, --verbose        Print additional information\n"
 		"      --distance=OPT   Choose between raw, jc corrected and ANI\n"
 		"  -h, --help           Display this help and exit\n"
@@ -317,7 +332,7 @@ int main(int argc, char *argv[])
 	std::random_device rd;
 	const char *seed_env = getenv("PHYLONIUM_AMD_SEED");
 	std::mt19937 prng(seed_env ? (std::mt19937::result_type)strtoul(seed_env, nullptr, 10) : rd());
-	int version_flag = 0, timing = 0, flags = 0, device = 0;
+	int version_flag = 0, timing = 0, flags = 0, device = 0, gpus = 0;
 	bool packed_ingest = true, host_sa = false;
 	long threads = 0;
 	bool two_pass = false;
@@ -337,6 +352,7 @@ int main(int argc, char *argv[])
 										   {"timing", no_argument, &timing, 1},
 										   {"ingest", required_argument, NULL, 0},
 										   {"sa", required_argument, NULL, 0},
+										   {"gpus", required_argument, NULL, 0},
 										   {0, 0, 0, 0}};
 	for (;;) {
 		int option_index = 0;
@@ -349,6 +365,10 @@ int main(int argc, char *argv[])
 				if (name == "sa") {
 					if (strcasecmp(optarg, "host") == 0) host_sa = true;
 					else if (strcasecmp(optarg, "device") != 0) usage(EXIT_FAILURE);
+				}
+				if (name == "gpus") {
+					gpus = atoi(optarg);
+					if (gpus < 1 || gpus > 64) usage(EXIT_FAILURE);
 				}
 				if (name == "ingest") {
 					if (strcasecmp(optarg, "bytes") == 0) packed_ingest = false;
@@ -410,8 +430,22 @@ int main(int argc, char *argv[])
 	// The device context (HIP start-up, ~0.3 s) is created while the files are being read.
 	Run r;
 	std::string ctx_error;
+	if (gpus > 0) packed_ingest = true; // the ranks exchange the packed form
 	std::thread ctx_thread([&] {
-		if (phylo_ctx_create(&r.ctx, device)) ctx_error = phylo_last_error(nullptr);
+		if (gpus > 0) {
+			// rank k on GPU (device + k) modulo the machine's GPUs: with fewer GPUs than ranks they share them
+			int count = 0;
+			std::vector<int> devs;
+			if (phylo_host_device_count(&count) || count < 1) {
+				ctx_error = "no usable HIP device";
+				return;
+			}
+			for (int k = 0; k < gpus; k++) devs.push_back((device + k) % count);
+			if (phylo_group_create(&r.grp, (size_t)gpus, devs.data())) ctx_error = phylo_group_last_error(nullptr);
+			else r.ctx = phylo_group_ctx(r.grp, 0);
+		} else if (phylo_ctx_create(&r.ctx, device)) {
+			ctx_error = phylo_last_error(nullptr);
+		}
 	});
 	size_t read_threads = threads > 0 ? (size_t)threads : std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));
 	PRINT_THREADS = read_threads;
@@ -451,8 +485,13 @@ int main(int argc, char *argv[])
 	r.q = &q;
 	r.flags = flags;
 	r.refpos_file = refpos_file;
-	if (threads > 0) ok(r, phylo_set_option(r.ctx, "host_threads", threads));
-	ok(r, phylo_set_option(r.ctx, "sa_builder", host_sa ? 0 : 1));
+	if (r.grp) {
+		if (threads > 0) gok(r, phylo_group_set_option(r.grp, "host_threads", threads));
+		gok(r, phylo_group_set_option(r.grp, "sa_builder", host_sa ? 0 : 1));
+	} else {
+		if (threads > 0) ok(r, phylo_set_option(r.ctx, "host_threads", threads));
+		ok(r, phylo_set_option(r.ctx, "sa_builder", host_sa ? 0 : 1));
+	}
 	if (packed_ingest) {
 		std::vector<const uint32_t *> q2(q.size()), bad(q.size());
 		std::vector<size_t> nbad(q.size());
@@ -461,7 +500,8 @@ int main(int argc, char *argv[])
 			bad[i] = pk[i].bad.data();
 			nbad[i] = pk[i].bad.size();
 		}
-		ok(r, phylo_set_genomes_packed(r.ctx, q.size(), q2.data(), GLEN.data(), bad.data(), nbad.data()));
+		if (r.grp) gok(r, phylo_group_set_genomes_packed(r.grp, q.size(), q2.data(), GLEN.data(), bad.data(), nbad.data()));
+		else ok(r, phylo_set_genomes_packed(r.ctx, q.size(), q2.data(), GLEN.data(), bad.data(), nbad.data()));
 		// pk_arena stays mapped until the process ends: unmapping 1.3 GB that has just been the source of
 		// device copies costs 0.3 s here (measured at 1024 genomes; the GPU driver's MMU notifier walks the
 		// range), the process's exit does not
@@ -502,7 +542,21 @@ int main(int argc, char *argv[])
 				t_sa - t_upload, host_sa ? "built on a host thread since the files were read" : "built on the device with the index", t_done - t_sa, stat("ms:ref_suffix_array"), stat("ms:ref_total") - stat("ms:ref_suffix_array"), stat("ms:ref_alloc"),
 				stat("ms:anchor_total"), stat("ms:compare_total"));
 	}
-	phylo_ctx_destroy(r.ctx);
-	if (timing) fprintf(stderr, "timing: releasing the device context %.3f s\n", now_s() - t_done);
+	if (timing && r.grp) {
+		fprintf(stderr, "timing: %zu ranks over %s; last pass per rank (ms) anchor / exchange / compare / reduce:", phylo_group_size(r.grp),
+				phylo_group_backend(r.grp));
+		for (size_t k = 0; k < phylo_group_size(r.grp); k++) {
+			double a = 0, e = 0, c2 = 0, d2 = 0;
+			phylo_group_get_stat(r.grp, k, "group:ms_anchor", &a);
+			phylo_group_get_stat(r.grp, k, "group:ms_exchange", &e);
+			phylo_group_get_stat(r.grp, k, "group:ms_compare", &c2);
+			phylo_group_get_stat(r.grp, k, "group:ms_reduce", &d2);
+			fprintf(stderr, "  [%zu] %.2f / %.2f / %.2f / %.2f", k, a, e, c2, d2);
+		}
+		fprintf(stderr, "\n");
+	}
+	if (r.grp) phylo_group_destroy(r.grp);
+	else phylo_ctx_destroy(r.ctx);
+	if (timing) fprintf(stderr, "timing: releasing the device context%s %.3f s\n", r.grp ? "s" : "", now_s() - t_done);
 	return RETURN_CODE;
 }

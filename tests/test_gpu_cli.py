@@ -281,3 +281,41 @@ def test_mgpu_warnings_and_bad_files(tmp_path):
     assert "bad.fasta: File is not in FASTA format." in err1 and "bad.fasta: File is not in FASTA format." in err0
     rc1, out1, err1 = run_mgpu(["a.fasta", "missing.fasta", "b.fasta"], tmp_path)
     assert rc1 == 1 and "missing.fasta" in err1
+
+
+@pytest.mark.parametrize("backend", ["auto", "copies"])
+def test_several_gpus_print_the_same(tmp_path, backend):
+    """`phylonium-amd --gpus N` (one host thread and one context per rank, csrc/group.hip: the genomes' blocks
+    all-gathered, phase A by query block, the lists exchanged as device blocks, phase B by window range, the u32
+    triangles reduced to rank 0) prints what one GPU prints — stdout, warnings and exit status — for N = 1, 2, 3, 5,
+    with a reference given or chosen, complete deletion, -p and the two-pass mode; on a box with fewer GPUs than
+    ranks the ranks share them and the exchange is device-to-device copies."""
+    env = dict(os.environ)
+    if backend == "copies":
+        env["PHYLONIUM_AMD_GROUP_BACKEND"] = "copies"
+
+    def run_env(args):
+        p = subprocess.run([CLI, *args], cwd=tmp_path, capture_output=True, text=True, env=env)
+        return p.returncode, p.stdout, p.stderr
+
+    gs = synth.make_genomes(11, 30000, seed=83, d_range=(0.01, 0.25), indel_per_mbp=300, inv_frac=0.08, contigs=3,
+                            inv_len=(200, 1500))
+    gs.append(synth.random_base(2000, np.random.default_rng(5)))  # unrelated: nan distances, a warning, exit status 1
+    names = [f"m{i:02d}" for i in range(len(gs))]
+    for n, g in zip(names, gs):
+        write_fasta(tmp_path / f"{n}.fa", g)
+    files = [f"{n}.fa" for n in names]
+    so, ho = O.Run(gs, 4).process().matrix()
+    want = O.phylip(names, so, ho)
+    for extra in (["-r", files[4]], [], ["--complete-deletion", "-r", files[2]], ["-2"], ["--sa=host", "-r", files[7]]):
+        one = run([*extra, *files], tmp_path)
+        if extra == ["-r", files[4]]:
+            assert one[1] == want and one[0] == 1
+        for n in (1, 2, 3, 5):
+            got = run_env(["--gpus", str(n), *extra, *files])
+            assert got == one, (extra, n, got[2][-300:])
+    one = run(["-p", "p1.txt", "-r", files[2], *files], tmp_path)
+    got = run_env(["--gpus", "3", "-p", "p3.txt", "-r", files[2], *files])
+    assert got == one and (tmp_path / "p1.txt").read_bytes() == (tmp_path / "p3.txt").read_bytes()
+    rc, out, err = run_env(["--gpus", "3", "--timing", "-r", files[4], *files])
+    assert out == want and "3 ranks over" in err

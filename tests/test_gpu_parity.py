@@ -682,6 +682,43 @@ def test_block_exchange_between_three_contexts():
             c.close()
 
 
+@pytest.mark.parametrize("world", [1, 2, 4, 7])
+def test_group_of_ranks_gives_one_contexts_result(world):
+    """phylo_group_* (csrc/group.hip): one context and one host thread per rank; the genomes' blocks all-gathered,
+    phase A by query block, lists exchanged as device blocks, phase B by window range, triangles reduced to rank 0.
+    Matrices and every list equal the oracle's for any number of ranks — more ranks than GPUs share them (device
+    copies instead of RCCL) — over repeated passes (the planned block capacity is reused), after a change of
+    reference, and when a later pass outgrows the plan."""
+    gs = synth.make_genomes(13, 25000, seed=87, d_range=(0.01, 0.25), indel_per_mbp=300, inv_frac=0.08, contigs=2)
+    gs.append(gs[3].copy())
+    n = len(gs)
+    with api.Group(world) as g:
+        assert g.backend in ("one rank", "rccl", "device-to-device copies")
+        g.set_genomes(gs)
+        for ref in (5, 0):
+            r = O.Run(gs, ref).process()
+            so, ho = r.matrix()
+            g.set_reference(ref)
+            for rep in range(2):
+                s, h = g.process()
+                assert (s == so).all() and (h == ho).all(), (world, ref, rep)
+            c0 = g.rank_context(0)
+            for j in range(n):
+                assert hom_tuples_gpu(c0.homologies(j)) == hom_tuples_orc(r.homologies(j)), j
+        # lists that outgrow the plan: against an unrelated reference the lists are all but empty and so is the plan;
+        # back on a related one the blocks overflow, every rank sees it, and the pass is repeated with a new plan
+        rng = np.random.default_rng(3)
+        big = [synth.random_base(90000, rng)]
+        big += [synth.mutate(big[0], 0.2, rng) for _ in range(n - 2)] + [synth.random_base(90000, rng)]
+        g.set_genomes(big)
+        for ref in (n - 1, 0, n - 1, 0):
+            s, h = g.process(ref_idx=ref)
+            so, ho = O.Run(big, ref).process(threads=4).matrix()
+            assert (s == so).all() and (h == ho).all(), ref
+        if world > 1:
+            assert g.stat(0, "group:replans") >= 1
+
+
 def _two_rank_worker(rank, world, port, out):
     import torch.distributed as td
     os.environ["MASTER_ADDR"] = "127.0.0.1"
