@@ -16,6 +16,9 @@
 #include <rccl/rccl.h>
 
 #include <dlfcn.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -151,6 +154,18 @@ double now_ms()
 }
 
 thread_local std::string g_group_error;
+
+// PHY_DEBUG_ABORT=1 (experiments): the native stack of the thread that aborts, on stderr
+void abort_trace(int sig)
+{
+	void *frames[64];
+	const int n = backtrace(frames, 64);
+	const char msg[] = "[phylonium_amd] fatal signal, native stack:\n";
+	(void)!write(2, msg, sizeof msg - 1);
+	backtrace_symbols_fd(frames, n, 2);
+	signal(sig, SIG_DFL);
+	raise(sig);
+}
 
 } // namespace
 
@@ -324,6 +339,10 @@ int phylo_group_create(phylo_group **out, size_t n_ranks, const int *devices)
 		g_group_error = "no usable HIP device";
 		return 2;
 	}
+	if (getenv("PHY_DEBUG_ABORT")) {
+		signal(SIGABRT, abort_trace);
+		signal(SIGSEGV, abort_trace);
+	}
 	phylo_group *g = new phylo_group();
 	g->world = n_ranks;
 	for (size_t r = 0; r < n_ranks; r++) g->dev.push_back(devices ? devices[r] : (int)(r % (size_t)count));
@@ -364,6 +383,11 @@ int phylo_group_create(phylo_group **out, size_t n_ranks, const int *devices)
 			phylo_ctx_set_stream(g->ctx[r], g->stream[r])) {
 			g->fail("rank %zu: cannot create its stream", r);
 			return;
+		}
+		// the contexts' host worker pools (sort + chain filter of tie lists, result copies) share the host's cores
+		{
+			const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+			(void)phylo_set_option(g->ctx[r], "host_threads", (long)std::max<size_t>(2, std::min<size_t>(48, hw) / g->world));
 		}
 		if (!g->use_rccl) // copies between the ranks' devices
 			for (size_t o = 0; o < g->world; o++)

@@ -1936,7 +1936,10 @@ __global__ __launch_bounds__(256) void block_attach_kernel(const uint32_t *__res
 	const uint32_t words = XB_HDR + maxq + 4u * cap;
 	const uint32_t *blk = all + (size_t)r * words;
 	const uint32_t g0 = bounds[r], nq = bounds[r + 1] - g0;
-	if (threadIdx.x == 0 && (blk[1] || blk[2] != nq || blk[0] > cap)) flags[2] = 1; // an overflowed or mismatched block
+	// an overflowed or mismatched block: reported (flags[2]), and its genomes' lists are left empty — the lengths in
+	// its header reach beyond the records it holds, and the kernels that follow must not read there
+	const bool usable = !(blk[1] || blk[2] != nq || blk[0] > cap);
+	if (threadIdx.x == 0 && !usable) flags[2] = 1;
 	__shared__ uint32_t carry;
 	__shared__ uint32_t scan[256];
 	if (threadIdx.x == 0) carry = 0;
@@ -1944,7 +1947,7 @@ __global__ __launch_bounds__(256) void block_attach_kernel(const uint32_t *__res
 	const uint32_t base = (uint32_t)(((size_t)r * words + XB_HDR + maxq) / 4u);
 	for (uint32_t t0 = 0; t0 < nq; t0 += 256) {
 		const uint32_t t = t0 + threadIdx.x;
-		const uint32_t cnt = t < nq ? blk[XB_HDR + t] : 0u;
+		const uint32_t cnt = (usable && t < nq) ? blk[XB_HDR + t] : 0u;
 		scan[threadIdx.x] = cnt;
 		__syncthreads();
 		for (uint32_t d = 1; d < 256; d <<= 1) {
@@ -1955,8 +1958,10 @@ __global__ __launch_bounds__(256) void block_attach_kernel(const uint32_t *__res
 		}
 		const uint32_t begin = carry + scan[threadIdx.x] - cnt;
 		if (t < nq) {
-			rng[2 * (g0 + t)] = base + begin;
-			rng[2 * (g0 + t) + 1] = base + begin + cnt;
+			const bool inside = begin + cnt <= cap; // (lengths that do not add up to the header's total)
+			if (!inside) flags[2] = 1;
+			rng[2 * (g0 + t)] = base + (inside ? begin : 0u);
+			rng[2 * (g0 + t) + 1] = base + (inside ? begin + cnt : 0u);
 		}
 		__syncthreads();
 		if (threadIdx.x == 255) carry += scan[255];
