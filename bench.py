@@ -156,7 +156,7 @@ def cpu_baseline(torch, buf, offs, lens, ref_idx, sa_ref, sample_queries, thread
                       f"ESA build {t_esa:.1f}s excluded"}
 
 
-def wallclock_leg(torch, holder, offs, lens, contigs_sep, want_text, n_gpus, runs=3):
+def wallclock_leg(torch, holder, offs, lens, contigs_sep, want_text, n_gpus, runs=3, before_run=None):
     """BASELINE.json's second metric: wall-clock FASTA files -> PHYLIP text, through the C++ host driver
     (phylonium_amd/phylonium-amd, FASTA in / matrix out as src/phylonium.cxx:89-299) started as a fresh process.
     The workload's genomes are written as FASTA files (70 columns) to /dev/shm — outside every timed region — the
@@ -203,6 +203,8 @@ def wallclock_leg(torch, holder, offs, lens, contigs_sep, want_text, n_gpus, run
         del g, buf, a, parts, part
         holder.clear()
         torch.cuda.empty_cache()
+        if before_run:  # several ranks: the others have let go of their device memory too
+            before_run()
         cmd = [exe, "--timing", "-r", files[0]] + (["--gpus", str(n_gpus)] if n_gpus > 1 else []) + files
         res = []
         for _ in range(runs):
@@ -706,19 +708,31 @@ def main():
             np.savez(args.dump_matrix, subst=np.asarray(s), homologs=np.asarray(h))
     else:
         out = None
+    # BASELINE.json's second metric, wall-clock FASTA -> PHYLIP: the C++ host driver as a fresh process on the same
+    # genomes (with N ranks: `phylonium-amd --gpus N`, one host thread and one context per GPU, RCCL between them)
+    do_wall = not args.no_wallclock and not emu
     want_text = None
-    if out is not None and not args.no_wallclock and not emu and world == 1:
+    if out is not None and do_wall:
         want_text = api.format_phylip([f"g{j:04d}" for j in range(n)], np.asarray(s), np.asarray(h))
     ctx.close()
+    if do_wall:
+        holder = [buf]
+        del buf
+        sync = (lambda: td.barrier()) if world > 1 else None
+        if rank == 0:
+            try:
+                out["wallclock"] = wallclock_leg(torch, holder, offs, lens, CONTIGS.get(args.workload, 1) > 1, want_text,
+                                                 world if not shared else 1, before_run=sync)
+            except Exception as e:  # a report beside the metric, never a reason to lose the bench line
+                out["wallclock"] = {"wallclock_s": None, "note": f"failed: {e!r}"}
+                if sync and not holder == []:
+                    sync()
+        else:
+            holder.clear()
+            torch.cuda.empty_cache()
+            sync()
     if world > 1 or args.emulate_exchange:
         td.destroy_process_group()
-    if want_text is not None:
-        try:
-            holder = [buf]
-            del buf
-            out["wallclock"] = wallclock_leg(torch, holder, offs, lens, CONTIGS.get(args.workload, 1) > 1, want_text, world)
-        except Exception as e:  # a report beside the metric, never a reason to lose the bench line
-            out["wallclock"] = {"wallclock_s": None, "note": f"failed: {e!r}"}
     import ctypes
     sys.stdout.flush()
     ctypes.CDLL(None).fflush(None)

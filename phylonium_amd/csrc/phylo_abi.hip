@@ -257,6 +257,7 @@ struct phylo_ctx {
 	bool pileup_five = false; // the last projection met '!': start with five planes next time
 	DevBuf<DevHom> b_homs;
 	DevBuf<unsigned long long> b_subst, b_homologs;
+	DevBuf<uint32_t> b_sym32; // both result matrices as symmetric u32, on their way to the host
 	DevBuf<Segment> s_segs;
 	DevBuf<uint64_t> s_out;
 
@@ -480,6 +481,7 @@ void phylo_ctx_destroy(phylo_ctx *c)
 	c->b_homs.release();
 	c->b_subst.release();
 	c->b_homologs.release();
+	c->b_sym32.release();
 	c->s_segs.release();
 	c->s_out.release();
 	for (TimedSpan &s : c->spans) {
@@ -2169,6 +2171,52 @@ static int compare_segments(phylo_ctx *c, size_t part, size_t nparts, uint64_t *
 }
 
 // dev_out: leave the tallies in the caller's device buffers (subst / homologs are device pointers)
+// The result on its way to the host: both matrices as symmetric u32 (a tally is at most the reference's length,
+// below 2^31) — half the bytes of the u64 matrices across PCIe; the host widens them row by row, which is a streaming
+// pass.  (Mirroring on the host instead is a strided walk over 16 MB: measured 0.5-2 ms at N = 1024)
+__global__ __launch_bounds__(256) void sym32_from_matrices_kernel(uint32_t N, const unsigned long long *__restrict__ s,
+																   const unsigned long long *__restrict__ h, uint32_t *__restrict__ out)
+{
+	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, NN = (uint64_t)N * N;
+	if (t >= NN) return;
+	const uint32_t i = (uint32_t)(t / N), j = (uint32_t)(t % N);
+	const uint64_t src = i < j ? t : (uint64_t)j * N + i;
+	out[t] = i == j ? 0u : (uint32_t)s[src];
+	out[NN + t] = i == j ? 0u : (uint32_t)h[src];
+}
+__global__ __launch_bounds__(256) void sym32_from_triangle_kernel(uint32_t N, const uint32_t *__restrict__ tri, uint32_t *__restrict__ out)
+{
+	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, NN = (uint64_t)N * N;
+	if (t >= NN) return;
+	const uint32_t i = (uint32_t)(t / N), j = (uint32_t)(t % N);
+	const uint32_t a = i < j ? i : j, b = i < j ? j : i;
+	const uint64_t P = (uint64_t)N * (N - 1) / 2, k = (uint64_t)a * (2ull * N - a - 1) / 2 + (b - a - 1);
+	out[t] = i == j ? 0u : tri[k];
+	out[NN + t] = i == j ? 0u : tri[P + k];
+}
+// sym (2 N^2 u32 in pinned memory) -> the caller's two N x N u64 matrices; returns the sum of the homologs matrix
+static double widen_result(phylo_ctx *c, const uint32_t *sym, uint64_t *subst, uint64_t *homologs)
+{
+	const size_t N = c->n, NN = N * N, parts = NN >= ((size_t)1 << 18) ? 32 : 1;
+	std::vector<double> part_sites(parts, 0.0);
+	auto widen = [&](size_t t) {
+		const size_t a = NN * t / parts, b = NN * (t + 1) / parts;
+		for (size_t k = a; k < b; k++) subst[k] = sym[k];
+		uint64_t acc = 0;
+		for (size_t k = a; k < b; k++) {
+			const uint32_t v = sym[NN + k];
+			homologs[k] = v;
+			acc += v;
+		}
+		part_sites[t] = (double)acc;
+	};
+	if (parts > 1) workers(c).run(parts, widen);
+	else widen(0);
+	double sites = 0;
+	for (double v : part_sites) sites += v;
+	return sites;
+}
+
 // u32 upper triangle: tri[k] = substitutions, tri[P + k] = homologs of pair (i < j), k = i (2N - i - 1) / 2 + (j - i - 1):
 // what crosses the wire between ranks (a tally is at most the reference's length, which is below 2^31)
 __global__ __launch_bounds__(256) void pack_triangle_kernel(uint32_t N, const unsigned long long *__restrict__ s,
@@ -2259,6 +2307,7 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		acc_h = c->b_homologs.p;
 	}
 	HIPOK(c, c->h_mat.ensure(2 * N * N + 8));
+	if (out_mode == 0) HIPOK(c, c->b_sym32.ensure(2 * N * N + 4));
 	HIPOK(c, hipMemsetAsync(acc_s, 0, N * N * 8, st));
 	HIPOK(c, hipMemsetAsync(acc_h, 0, N * N * 8, st));
 	const DevHom *dev_homs = c->att_homs ? c->att_homs : c->b_homs.p;
@@ -2296,11 +2345,13 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		HIPOK(c, c->b_tiles.ensure(tiles.size() + mtiles.size()));
 		if (!mtiles.empty()) HIPOK(c, hipMemcpyAsync(c->b_tiles.p + tiles.size(), mtiles.data(), mtiles.size() * 4, hipMemcpyHostToDevice, st));
 	}
-	auto finish_tallies = [&]() { // mirror image for the matrices; the packed triangle for the wire
+	auto finish_tallies = [&]() { // the packed triangle for the wire; mirror images for the matrices (u32 on the way to the host)
 		if (out_mode == 2)
 			hipLaunchKernelGGL(pack_triangle_kernel, dim3((uint32_t)((N * N + 255) / 256)), dim3(256), 0, st, (uint32_t)N, acc_s, acc_h, (uint32_t *)subst);
-		else
+		else if (out_mode == 1)
 			launch_symmetrise((uint32_t)N, acc_s, acc_h, st);
+		else
+			hipLaunchKernelGGL(sym32_from_matrices_kernel, dim3((uint32_t)((N * N + 255) / 256)), dim3(256), 0, st, (uint32_t)N, acc_s, acc_h, c->b_sym32.p);
 	};
 	auto pairs = [&](bool bang) -> int {
 		if (tiles.empty() || !P.W) {
@@ -2358,14 +2409,11 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		launch_project(P, five, query_src(c), dev_homs, c->b_hom_rng.p, c->b_first.p, c->b_flag.p, 0, P.Npad / project_genomes_per_tile(), st);
 		return 0;
 	};
-	uint64_t *hs = c->h_mat.p, *hh = c->h_mat.p + N * N;
+	uint64_t *hs = c->h_mat.p;
 	auto fetch = [&]() -> int { // the flag, and the result unless it stays on the device
 		HIPOK(c, hipGetLastError());
 		HIPOK(c, hipMemcpyAsync(flagp, c->b_flag.p, 12, hipMemcpyDeviceToHost, st));
-		if (!dev_out) {
-			HIPOK(c, hipMemcpyAsync(hs, acc_s, N * N * 8, hipMemcpyDeviceToHost, st));
-			HIPOK(c, hipMemcpyAsync(hh, acc_h, N * N * 8, hipMemcpyDeviceToHost, st));
-		}
+		if (!dev_out) HIPOK(c, hipMemcpyAsync(hs, c->b_sym32.p, 2 * N * N * 4, hipMemcpyDeviceToHost, st));
 		return sync_stream(c);
 	};
 	const bool have_five = projected ? c->eager_five : c->pileup_five; // the planes this attempt works on
@@ -2396,23 +2444,8 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		return 0;
 	}
 	double t2 = now_ms();
-	// out of the pinned buffer into the caller's matrices (16 MB at N = 1024: worth several threads)
-	double sites = 0;
-	{
-		const size_t NN = N * N, parts = NN >= ((size_t)1 << 18) ? 32 : 1;
-		std::vector<double> part_sites(parts, 0.0);
-		auto copy_part = [&](size_t t) {
-			const size_t a = NN * t / parts, b = NN * (t + 1) / parts;
-			memcpy(subst + a, hs + a, (b - a) * 8);
-			memcpy(homologs + a, hh + a, (b - a) * 8);
-			double acc = 0;
-			for (size_t k = a; k < b; k++) acc += (double)hh[k];
-			part_sites[t] = acc;
-		};
-		if (parts > 1) workers(c).run(parts, copy_part);
-		else copy_part(0);
-		for (double v : part_sites) sites += v;
-	}
+	// out of the pinned buffer into the caller's matrices, widened (16 MB at N = 1024: worth several threads)
+	double sites = widen_result(c, (const uint32_t *)hs, subst, homologs);
 	sites *= 0.5;
 	c->stats["ms:compare_project_phase"] += t1 - t0;
 	c->stats["ms:compare_pairs_phase"] += t2 - t1;
@@ -2489,37 +2522,20 @@ int phylo_triangle_to_matrices(phylo_ctx *c, const uint32_t *dev_tri, uint64_t *
 	if (!c) return 1;
 	if (!dev_tri || !subst || !homologs) return c->fail("phylo_triangle_to_matrices: null argument");
 	HIPOK(c, hipSetDevice(c->device));
-	const size_t N = c->n, P = N * (N - 1) / 2;
-	HIPOK(c, c->h_mat.ensure(2 * N * N + 8)); // (2 P u32 fit the front of it)
-	uint32_t *tri = (uint32_t *)c->h_mat.p;
+	const size_t N = c->n;
+	if (!N) return 0;
+	HIPOK(c, c->h_mat.ensure(2 * N * N + 8));
+	HIPOK(c, c->b_sym32.ensure(2 * N * N + 4));
 	const double t0 = now_ms();
-	if (P) HIPOK(c, hipMemcpyAsync(tri, dev_tri, 2 * P * 4, hipMemcpyDeviceToHost, c->stream));
+	hipLaunchKernelGGL(sym32_from_triangle_kernel, dim3((uint32_t)((N * N + 255) / 256)), dim3(256), 0, c->stream, (uint32_t)N, dev_tri, c->b_sym32.p);
+	HIPOK(c, hipGetLastError());
+	HIPOK(c, hipMemcpyAsync(c->h_mat.p, c->b_sym32.p, 2 * N * N * 4, hipMemcpyDeviceToHost, c->stream));
 	if (sync_stream(c)) return 1;
 	const double t1 = now_ms();
-	auto row = [&](size_t i) {
-		uint64_t *so = subst + i * N, *ho = homologs + i * N;
-		size_t k = i ? i - 1 : 0; // pair (j, i): k(j, i) = j (2N - j - 1) / 2 + (i - j - 1), stepping by N - j - 2 from j to j + 1
-		for (size_t j = 0; j < i; j++) {
-			so[j] = tri[k];
-			ho[j] = tri[P + k];
-			k += N - j - 2;
-		}
-		so[i] = ho[i] = 0;
-		const size_t k0 = i * (2 * N - i - 1) / 2;
-		for (size_t j = i + 1; j < N; j++) {
-			so[j] = tri[k0 + (j - i - 1)];
-			ho[j] = tri[P + k0 + (j - i - 1)];
-		}
-	};
-	// bands of rows, a few per worker (a task per row would cost more in hand-outs than in copying)
-	const size_t bands = N >= 256 ? std::min<size_t>(64, N / 8) : 1;
-	auto band = [&](size_t b) {
-		for (size_t i = N * b / bands, e = N * (b + 1) / bands; i < e; i++) row(i);
-	};
-	if (bands > 1) workers(c).run(bands, band);
-	else band(0);
+	const double sites = widen_result(c, (const uint32_t *)c->h_mat.p, subst, homologs);
 	c->stats["ms:triangle_copy"] += t1 - t0;
 	c->stats["ms:triangle_widen"] += now_ms() - t1;
+	c->stats["count:compare_sites"] += 0.5 * sites;
 	return 0;
 }
 

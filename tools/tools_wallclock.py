@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--genomes", type=int, default=0)
     ap.add_argument("--mgpu", default="", help="also run the N-rank driver: comma list of rank counts, e.g. 1,2 "
                     "(more ranks than GPUs: collectives over gloo, all ranks on GPU 0)")
+    ap.add_argument("--gpus", default="", help="also run `phylonium-amd --gpus N` (the C++ host with one thread and one context per "
+                    "rank, csrc/group.hip): comma list of rank counts, e.g. 1,2,8 (more ranks than GPUs: they share them)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "wallclock.json"))
     ap.add_argument("--prepare", default="", help="internal: write the FASTA files and the expected text, then exit")
     args = ap.parse_args()
@@ -82,6 +84,17 @@ def drive(args, n, desc, files, want, meta):
         m = re.search(r"timing: (.*)", err)
         runs.append({"label": label, "wall_s_including_exec": round(wall, 3), "timing": m.group(1) if m else err[-400:],
                      "matrix_identical": p.stdout.decode() == want, "exit": p.returncode})
+    for ranks in [int(x) for x in args.gpus.split(",") if x]:
+        for rep in range(2):
+            t0 = time.time()
+            p = subprocess.run([exe, "--timing", "--gpus", str(ranks), "-r", files[0]] + files, capture_output=True)
+            wall = time.time() - t0
+            err = p.stderr.decode()
+            m = re.search(r"timing: (genomes .*)", err)
+            m2 = re.search(r"timing: (\d+ ranks over .*)", err)
+            runs.append({"label": f"phylonium-amd --gpus {ranks} ({meta['devices']} GPU(s) in the box), run {rep + 1}",
+                         "wall_s_including_exec": round(wall, 3), "timing": m.group(1) if m else err[-400:],
+                         "ranks": m2.group(1) if m2 else None, "matrix_identical": p.stdout.decode() == want, "exit": p.returncode})
     for ranks in [int(x) for x in args.mgpu.split(",") if x]:
         env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
         backend = "nccl" if ranks <= meta["devices"] else "gloo"
