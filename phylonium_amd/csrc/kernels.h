@@ -103,9 +103,14 @@ struct QuerySrc {
 void launch_tile_index(const Pileup &P, const QuerySrc &Q, const DevHom *homs, const uint32_t *hom_rng, uint32_t *first, uint32_t g0,
 					   uint32_t g1, hipStream_t st);
 // five_planes = false: V, N0, N1 only; *bang_flag is raised when '!' was projected and D, B are needed after all
+// bang_list / bang_cap (three planes only; may be null / 0): the projected '!' are listed there — {genome | reverse << 31,
+// position} each, counted in bang_flag[3], bit 1 of bang_flag[0] on overflow — for launch_bang_correct
 void launch_project(const Pileup &P, bool five_planes, const QuerySrc &Q, const DevHom *homs,
 					const uint32_t *hom_rng, const uint32_t *first, uint32_t *bang_flag, uint32_t tg0, uint32_t tg1,
-					hipStream_t st);
+					hipStream_t st, uint32_t *bang_list = nullptr, uint32_t bang_cap = 0);
+// the substitutions the three planes miss: '!' against 'A' in the same direction (one block per listed '!')
+void launch_bang_correct(const Pileup &P, const QuerySrc &Q, const DevHom *homs, const uint32_t *hom_rng, const uint32_t *list,
+						 const uint32_t *count, uint32_t cap, unsigned long long *subst, hipStream_t st);
 uint32_t project_genomes_per_tile();
 size_t project_index_entries(const Pileup &P);
 // tiles: list of (ig, jt) pairs packed as ig<<16|jt

@@ -258,6 +258,8 @@ struct phylo_ctx {
 	DevBuf<DevHom> b_homs;
 	DevBuf<unsigned long long> b_subst, b_homologs;
 	DevBuf<uint32_t> b_sym32; // both result matrices as symmetric u32, on their way to the host
+	DevBuf<uint32_t> b_bang;  // the projected '!' of the three-plane projection: {genome | reverse << 31, position} each
+	uint32_t bang_cap = 0;    // as many as the genomes hold separators (a separator is projected at most once)
 	DevBuf<Segment> s_segs;
 	DevBuf<uint64_t> s_out;
 
@@ -482,6 +484,7 @@ void phylo_ctx_destroy(phylo_ctx *c)
 	c->b_subst.release();
 	c->b_homologs.release();
 	c->b_sym32.release();
+	c->b_bang.release();
 	c->s_segs.release();
 	c->s_out.release();
 	for (TimedSpan &s : c->spans) {
@@ -659,6 +662,7 @@ static int pack_genomes(phylo_ctx *c)
 	c->stats["ms:pack_genomes"] += now_ms() - t0;
 	c->stats["count:genome_non_acgt"] = off[n];
 	c->pileup_five = off[n] > 0;
+	c->bang_cap = off[n];
 	return 0;
 }
 
@@ -789,6 +793,7 @@ int phylo_set_genomes_packed(phylo_ctx *c, size_t n, const uint32_t *const *q2, 
 	c->stats["ms:genomes_install"] += now_ms() - t2;
 	c->stats["count:genome_non_acgt"] = (double)blist.size();
 	c->pileup_five = !blist.empty();
+	c->bang_cap = (uint32_t)blist.size();
 	return 0;
 }
 
@@ -846,6 +851,7 @@ int phylo_set_genomes_packed_device(phylo_ctx *c, size_t n, const void *dev_q2, 
 	c->stats["ms:genomes_install"] += now_ms() - t0;
 	c->stats["count:genome_non_acgt"] = (double)blist.size();
 	c->pileup_five = !blist.empty();
+	c->bang_cap = (uint32_t)blist.size();
 	return 0;
 }
 
@@ -1355,7 +1361,8 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 			HIPOK(c, c->b_flag.ensure(4));
 			HIPOK(c, c->b_first.ensure(project_index_entries(TP) + 1));
 			HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 16, st));
-			c->eager_five = c->pileup_five;
+			c->eager_five = c->pileup_five && c->opt_pairs_kernel != 0; // (the matrix-core path lists the '!' instead: compare_pileup)
+			HIPOK(c, c->b_bang.ensure(2 * (size_t)c->bang_cap + 2));
 		}
 	}
 	if (tgroups > 1) {
@@ -1398,7 +1405,7 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 				launch_tile_index(TP, query_src(c), c->b_homs.p, c->b_hom_rng.p, c->b_first.p, j0, j1, sg);
 				KernelSpan s(c, c->eager_five ? "pileup_project5" : "pileup_project", sg);
 				launch_project(TP, c->eager_five, query_src(c), c->b_homs.p, c->b_hom_rng.p, c->b_first.p, c->b_flag.p,
-							   j0 / tsz_q, g + 1 == tgroups ? TP.Npad / tsz_q : j1 / tsz_q, sg);
+							   j0 / tsz_q, g + 1 == tgroups ? TP.Npad / tsz_q : j1 / tsz_q, sg, c->b_bang.p, c->bang_cap);
 			}
 		}
 		if (g) {
@@ -1544,7 +1551,8 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 			HIPOK(c, c->b_flag.ensure(4));
 			HIPOK(c, c->b_first.ensure(project_index_entries(EP) + 1));
 			HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 16, st));
-			c->eager_five = c->pileup_five;
+			c->eager_five = c->pileup_five && c->opt_pairs_kernel != 0; // (the matrix-core path lists the '!' instead: compare_pileup)
+			HIPOK(c, c->b_bang.ensure(2 * (size_t)c->bang_cap + 2));
 		}
 	}
 	auto stage_list = [&](size_t j, const std::vector<phylo_homology> &list) {
@@ -1573,7 +1581,7 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 				launch_tile_index(EP, query_src(c), c->b_homs.p, c->b_hom_rng.p, c->b_first.p, (uint32_t)j0, (uint32_t)j1, st);
 				KernelSpan s(c, c->eager_five ? "pileup_project5" : "pileup_project");
 				launch_project(EP, c->eager_five, query_src(c), c->b_homs.p, c->b_hom_rng.p, c->b_first.p,
-							   c->b_flag.p, (uint32_t)(j0 / tsz), g + 1 == ngroups ? EP.Npad / (uint32_t)tsz : (uint32_t)(j1 / tsz), st);
+							   c->b_flag.p, (uint32_t)(j0 / tsz), g + 1 == ngroups ? EP.Npad / (uint32_t)tsz : (uint32_t)(j1 / tsz), st, c->b_bang.p, c->bang_cap);
 			}
 		}
 		t_send_done = now_ms();
@@ -2313,8 +2321,10 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 	const DevHom *dev_homs = c->att_homs ? c->att_homs : c->b_homs.p;
 	// phase A may have projected the lists already (whole reference, i.e. part 0 of 1)
 	const bool projected = c->homs_staged && c->eager_valid && part == 0 && nparts == 1;
+	HIPOK(c, c->b_bang.ensure(2 * (size_t)c->bang_cap + 2));
 	if (!projected) {
 		HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 4, st)); // (words 1 and 2 belong to phylo_attach_blocks_device)
+		HIPOK(c, hipMemsetAsync(c->b_flag.p + 3, 0, 4, st)); // the count of listed '!'
 		launch_tile_index(P, query_src(c), dev_homs, c->b_hom_rng.p, c->b_first.p, 0, (uint32_t)N, st);
 	}
 	// Three planes and the plain pair kernel unless '!' turns up among the projected positions (the projection raises
@@ -2345,7 +2355,12 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		HIPOK(c, c->b_tiles.ensure(tiles.size() + mtiles.size()));
 		if (!mtiles.empty()) HIPOK(c, hipMemcpyAsync(c->b_tiles.p + tiles.size(), mtiles.data(), mtiles.size() * 4, hipMemcpyHostToDevice, st));
 	}
+	bool do_correct = false; // three planes under the matrix-core kernel: the listed '!' are settled before the tallies leave
 	auto finish_tallies = [&]() { // the packed triangle for the wire; mirror images for the matrices (u32 on the way to the host)
+		if (do_correct && c->bang_cap) {
+			KernelSpan s(c, "pileup_bang_correct");
+			launch_bang_correct(P, query_src(c), dev_homs, c->b_hom_rng.p, c->b_bang.p, c->b_flag.p + 3, c->bang_cap, acc_s, st);
+		}
 		if (out_mode == 2)
 			hipLaunchKernelGGL(pack_triangle_kernel, dim3((uint32_t)((N * N + 255) / 256)), dim3(256), 0, st, (uint32_t)N, acc_s, acc_h, (uint32_t *)subst);
 		else if (out_mode == 1)
@@ -2406,7 +2421,8 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 	};
 	auto project = [&](bool five) -> int {
 		KernelSpan s(c, five ? "pileup_project5" : "pileup_project");
-		launch_project(P, five, query_src(c), dev_homs, c->b_hom_rng.p, c->b_first.p, c->b_flag.p, 0, P.Npad / project_genomes_per_tile(), st);
+		launch_project(P, five, query_src(c), dev_homs, c->b_hom_rng.p, c->b_first.p, c->b_flag.p, 0, P.Npad / project_genomes_per_tile(), st,
+					   c->b_bang.p, c->bang_cap);
 		return 0;
 	};
 	uint64_t *hs = c->h_mat.p;
@@ -2416,10 +2432,16 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		if (!dev_out) HIPOK(c, hipMemcpyAsync(hs, c->b_sym32.p, 2 * N * N * 4, hipMemcpyDeviceToHost, st));
 		return sync_stream(c);
 	};
-	const bool have_five = projected ? c->eager_five : c->pileup_five; // the planes this attempt works on
-	bool bang = c->pileup_five && have_five;
+	// The matrix-core path (option "pairs_kernel" = 0) works on three planes whatever the genomes hold: the projection
+	// lists the '!' it meets — a handful: contig joins inside homologies — and launch_bang_correct settles them after the
+	// pair kernel.  (Only a list beyond its capacity — lists installed by a caller that overlap on the query — falls
+	// back to the five planes below.)
+	const bool sparse = !mtiles.empty() && !(projected && c->eager_five);
+	const bool have_five = sparse ? false : (projected ? c->eager_five : c->pileup_five); // the planes this attempt works on
+	bool bang = !sparse && c->pileup_five && have_five;
 	if (!projected && project(have_five)) return 1;
 	double t1 = now_ms();
+	do_correct = sparse;
 	if (pairs(bang) || fetch()) return 1;
 	const bool att_bad = c->att_unchecked && (flagp[1] || flagp[2]);
 	c->att_unchecked = false;
@@ -2427,6 +2449,8 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		return c->fail(flagp[2] ? "the lists gathered from the ranks overflowed their blocks' capacity (phylo_attach_blocks_device)"
 								: "a gathered list is not sorted by projected start, disjoint and inside the reference");
 	uint32_t flag = *flagp;
+	if (sparse) flag = (flag & 2u) ? 1u : 0u; // only a '!' list beyond its capacity sends this path to the five planes
+	do_correct = false;
 	if (flag && !bang) { // '!' among the projected positions, and the plain kernel ran: once more with all five planes
 		c->stats["count:compare_repeated_with_five_planes"] += 1;
 		HIPOK(c, hipMemsetAsync(acc_s, 0, N * N * 8, st));
@@ -2436,7 +2460,7 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		if (project(true) || pairs(true) || fetch()) return 1;
 		flag = *flagp;
 	}
-	c->pileup_five = flag != 0;
+	if (!sparse) c->pileup_five = flag != 0;
 	if (dev_out) {
 		c->stats["ms:compare_project_phase"] += t1 - t0;
 		c->stats["ms:compare_pairs_phase"] += now_ms() - t1;

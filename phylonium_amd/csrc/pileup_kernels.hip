@@ -122,12 +122,15 @@ static const uint32_t PROJ_HM = 8; // homology descriptors cached per genome and
 
 // FIVE = false writes V, N0, N1 only (and still raises bang_flag when a projected
 // position holds '!'): the host then repeats the projection with all five planes.
+// bang_list (FIVE = false only, may be null): every projected '!' as {genome | reverse << 31, reference position},
+// appended through the counter bang_flag[3]; more than bang_cap of them raise bit 1 of bang_flag[0].
 template <bool FIVE>
 __global__ __launch_bounds__(256) void project_kernel(Pileup P, QuerySrc Q,
 													   const DevHom *__restrict__ homs,
 													   const uint32_t *__restrict__ hom_rng,
 													   const uint32_t *__restrict__ first,
-													   uint32_t *__restrict__ bang_flag, uint32_t tg0)
+													   uint32_t *__restrict__ bang_flag, uint32_t tg0,
+													   uint32_t *__restrict__ bang_list, uint32_t bang_cap)
 {
 	constexpr uint32_t NP = FIVE ? 5u : 3u;
 	__shared__ uint32_t tile[NP][PROJ_TW][PROJ_TG + 1];
@@ -247,7 +250,18 @@ __global__ __launch_bounds__(256) void project_kernel(Pileup P, QuerySrc Q,
 			for (uint32_t k = lower_bound_u32(Q.qbad + b0, nb, from); k < nb; k++) {
 				const int64_t u = (int64_t)Q.qbad[b0 + k] - rel;
 				if (u >= 32) break;
-				B |= (1u << plane_bit(pc.rev ? 31u - (uint32_t)u : (uint32_t)u)) & pc.mask;
+				const uint32_t wp = pc.rev ? 31u - (uint32_t)u : (uint32_t)u; // position inside the window
+				const uint32_t bit = (1u << plane_bit(wp)) & pc.mask;
+				B |= bit;
+				if (!FIVE && bit && bang_list) {
+					const uint32_t idx = atomicAdd(bang_flag + 3, 1u);
+					if (idx < bang_cap) {
+						bang_list[2 * idx] = g | (pc.rev ? 0x80000000u : 0u);
+						bang_list[2 * idx + 1] = x0 + wp;
+					} else {
+						atomicOr(bang_flag, 2u);
+					}
+				}
 			}
 		}
 	};
@@ -552,6 +566,51 @@ void launch_pairs_mfma(const Pileup &P, const uint32_t *tiles, uint32_t ntiles, 
 	hipLaunchKernelGGL(pairs_mfma_kernel, grid, dim3(64), 0, st, P, tiles, ntiles, wchunk, nwc, subst, homologs);
 }
 
+// The three planes carry '!' as 'A' (code 00), which is what revseqcmp's ((c ^ d) & 6) == 4 test sees
+// (libs/revseqcmp.h:19-23) — but seqcmp compares bytes ('!' != 'A', libs/seqcmp.c:13-28): where two genomes are
+// projected in the same direction, one holds '!' and the other 'A', the plane tallies miss one substitution.  Such
+// positions are a handful (a genome's contig joins that lie inside homologies), so instead of two more planes
+// through the whole pair grid they are listed by the projection and settled here: one block per listed '!', its
+// threads the other genomes — covering homology by binary search in the genome's list, direction, the base at the
+// query position behind it from the 2-bit codes, the genome's own '!' list.
+__global__ __launch_bounds__(256) void bang_correct_kernel(Pileup P, QuerySrc Q, const DevHom *__restrict__ homs,
+															const uint32_t *__restrict__ hom_rng, const uint32_t *__restrict__ list,
+															const uint32_t *__restrict__ count, uint32_t cap,
+															unsigned long long *__restrict__ subst)
+{
+	const uint32_t e = blockIdx.x;
+	const uint32_t n = *count < cap ? *count : cap;
+	if (e >= n) return;
+	const uint32_t i = list[2 * e] & 0x7fffffffu, di = list[2 * e] >> 31, p = list[2 * e + 1];
+	for (uint32_t j = threadIdx.x; j < P.N; j += blockDim.x) {
+		if (j == i) continue;
+		uint32_t lo = hom_rng[2 * j], hi = hom_rng[2 * j + 1];
+		const uint32_t h0 = lo;
+		while (lo < hi) { // first homology that starts beyond p
+			const uint32_t mid = lo + ((hi - lo) >> 1);
+			if (homs[mid].start <= p) lo = mid + 1;
+			else hi = mid;
+		}
+		if (lo == h0) continue;
+		const DevHom hm = homs[lo - 1];
+		if (p - hm.start >= hm.len || (hm.rev ? 1u : 0u) != di) continue; // not covered, or the other strand: revseqcmp's view holds
+		const uint32_t qpos = hm.rev ? hm.iq + (hm.len - 1u - (p - hm.start)) : hm.iq + (p - hm.start);
+		const uint32_t b0 = Q.qbad_off[j], nb = Q.qbad_off[j + 1] - b0;
+		const uint32_t k = lower_bound_u32(Q.qbad + b0, nb, qpos);
+		if (k < nb && Q.qbad[b0 + k] == qpos) continue; // '!' against '!': equal bytes
+		const uint64_t at = Q.goff[j] + qpos;
+		const uint32_t code = (Q.q2[at >> 4] >> (30u - 2u * (uint32_t)(at & 15u))) & 3u;
+		if (code != 0u) continue; // not 'A': the planes counted the substitution already
+		const uint32_t a = i < j ? i : j, b = i < j ? j : i;
+		atomicAdd(&subst[(size_t)a * P.N + b], 1ull);
+	}
+}
+void launch_bang_correct(const Pileup &P, const QuerySrc &Q, const DevHom *homs, const uint32_t *hom_rng, const uint32_t *list,
+						 const uint32_t *count, uint32_t cap, unsigned long long *subst, hipStream_t st)
+{
+	if (cap) hipLaunchKernelGGL(bang_correct_kernel, dim3(cap), dim3(256), 0, st, P, Q, homs, hom_rng, list, count, cap, subst);
+}
+
 // tallies are accumulated for i<j only; mirror them so the matrices leave symmetric
 __global__ __launch_bounds__(256) void symmetrise_kernel(uint32_t N, unsigned long long *__restrict__ a,
 														  unsigned long long *__restrict__ b)
@@ -606,16 +665,16 @@ void launch_tile_index(const Pileup &P, const QuerySrc &Q, const DevHom *homs, c
 }
 void launch_project(const Pileup &P, bool five_planes, const QuerySrc &Q, const DevHom *homs,
 					const uint32_t *hom_rng, const uint32_t *first, uint32_t *bang_flag, uint32_t tg0, uint32_t tg1,
-					hipStream_t st)
+					hipStream_t st, uint32_t *bang_list, uint32_t bang_cap)
 {
 	uint32_t ntw = (P.W + PROJ_TW - 1) / PROJ_TW, ntg = P.Npad / PROJ_TG;
 	if (tg1 > ntg) tg1 = ntg;
 	if (!ntw || tg0 >= tg1) return;
 	dim3 grid(ntw * (tg1 - tg0));
 	if (five_planes)
-		hipLaunchKernelGGL(project_kernel<true>, grid, dim3(256), 0, st, P, Q, homs, hom_rng, first, bang_flag, tg0);
+		hipLaunchKernelGGL(project_kernel<true>, grid, dim3(256), 0, st, P, Q, homs, hom_rng, first, bang_flag, tg0, (uint32_t *)nullptr, 0u);
 	else
-		hipLaunchKernelGGL(project_kernel<false>, grid, dim3(256), 0, st, P, Q, homs, hom_rng, first, bang_flag, tg0);
+		hipLaunchKernelGGL(project_kernel<false>, grid, dim3(256), 0, st, P, Q, homs, hom_rng, first, bang_flag, tg0, bang_list, bang_cap);
 }
 uint32_t project_genomes_per_tile() { return PROJ_TG; }
 size_t project_index_entries(const Pileup &P) { return (size_t)P.N * ((P.W + PROJ_TW - 1) / PROJ_TW); }

@@ -43,6 +43,10 @@ def check_process(ctx, gs, ref, chunk=0, kmer=0, backend=0, complete_deletion=Fa
     ctx.set_option("chunk_tail", tail)
     ctx.set_option("kmer", kmer)
     ctx.set_option("compare_backend", backend)
+    # the pair kernels, alternating: the matrix cores on three planes with the '!' settled from a list (default) /
+    # the vector ALUs on three or five planes
+    check_process.pkern = (getattr(check_process, "pkern", 0) + 1) % 3
+    ctx.set_option("pairs_kernel", 1 if check_process.pkern == 2 else 0)
     # genomes arrive as bytes or as 2-bit codes + separator positions (phylo_set_genomes_packed), alternating
     check_process.pk = 1 - getattr(check_process, "pk", 0)
     if check_process.pk:
@@ -90,6 +94,7 @@ def check_process(ctx, gs, ref, chunk=0, kmer=0, backend=0, complete_deletion=Fa
     ctx.set_option("compare_backend", 0)
     ctx.set_option("filter", 0)
     ctx.set_option("filter_kernel", 0)
+    ctx.set_option("pairs_kernel", 0)
     return s, h
 
 
