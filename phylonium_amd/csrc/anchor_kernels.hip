@@ -266,7 +266,10 @@ template <int MODE> __global__ __launch_bounds__(256) void chain_kernel(PhaseA A
 
 static const uint32_t FOLD_WCH = 1024;  // chunks of metadata per window
 static const uint32_t FOLD_SEGS = 5120; // anchor segments per window (a chunk contributes 1-3; 5 per chunk on average would overflow, reported as error 4)
-static const uint32_t FOLD_APT = 4;     // anchors per thread and iteration
+#ifndef PHY_FOLD_APT
+#define PHY_FOLD_APT 4
+#endif
+static const uint32_t FOLD_APT = PHY_FOLD_APT; // anchors per thread and iteration
 static const uint32_t FOLD_THREADS = 1024; // per block (= per query)
 static const uint32_t FOLD_WAVES = FOLD_THREADS / 64;
 static const uint32_t FOLD_PPT = FOLD_WCH / FOLD_THREADS; // chain positions per thread when segments are laid out
