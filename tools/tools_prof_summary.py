@@ -8,21 +8,25 @@ from collections import defaultdict
 d = sys.argv[1]
 out = {}
 
+NAMES = [  # substring of the kernel's name -> the name bench.py and the library's stats use; first match wins
+    ("chain_kernel<0>", "anchor_spec"), ("chain_kernel<1>", "anchor_bridge"), ("fold_kernel", "anchor_fold"),
+    ("sort_filter_seg_kernel", "anchor_filter"), ("sort_filter_long_kernel", "anchor_filter_long"), ("sort_filter_kernel", "anchor_filter_general"),
+    ("lean_overrun_direct_kernel", "anchor_overruns_direct"), ("lean_overrun_chain_kernel", "anchor_overruns_chain"),
+    ("gather_lists_kernel", "export_gather"), ("block_export_kernel", "exchange_block_export"), ("block_attach_kernel", "exchange_block_attach"),
+    ("check_lists_kernel", "exchange_check_lists"), ("compact_raw_kernel", "anchor_compact"),
+    ("project_kernel<true>", "pileup_project5"), ("project_kernel", "pileup_project"), ("tile_index_kernel", "pileup_tile_index"),
+    ("pairs_mfma_kernel", "pileup_pairs_mfma"), ("bang_correct_kernel", "pileup_bang_correct"),
+    ("pairs_kernel<true>", "pileup_pairs_bang"), ("pairs_kernel<false>", "pileup_pairs"), ("pack_triangle_kernel", "result_pack_triangle"),
+    ("sym32_from", "result_sym32"), ("symmetrise_kernel", "result_symmetrise"), ("seqcmp_batch_kernel", "seqcmp_batch"),
+]
+
+
 def short(name):
-    n = name
-    for key in ("chain_kernel<0>", "chain_kernel<1>", "fold_kernel", "sort_filter_seg_kernel", "sort_filter_kernel", "lean_overrun_direct_kernel",
-                "lean_overrun_chain_kernel", "gather_lists_kernel", "compact_raw_kernel",
-                "project_kernel<true>", "project_kernel",
-                "tile_index_kernel", "pairs_kernel<true>", "pairs_kernel<false>", "seqcmp_batch_kernel"):
-        if key in n:
-            return {"chain_kernel<0>": "anchor_spec", "chain_kernel<1>": "anchor_bridge", "fold_kernel": "anchor_fold",
-                    "sort_filter_kernel": "anchor_filter_general", "sort_filter_seg_kernel": "anchor_filter",
-                    "lean_overrun_direct_kernel": "anchor_overruns_direct", "lean_overrun_chain_kernel": "anchor_overruns_chain",
-                    "gather_lists_kernel": "export_gather",
-                    "compact_raw_kernel": "anchor_compact", "project_kernel": "pileup_project", "project_kernel<false>": "pileup_project", "project_kernel<true>": "pileup_project5",
-                    "tile_index_kernel": "pileup_tile_index", "pairs_kernel<true>": "pileup_pairs_bang",
-                    "pairs_kernel<false>": "pileup_pairs", "seqcmp_batch_kernel": "seqcmp_batch"}[key]
+    for key, val in NAMES:
+        if key in name:
+            return val
     return None
+
 
 # kernel trace
 for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_trace.csv"), recursive=True):
