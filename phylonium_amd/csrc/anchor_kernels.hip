@@ -301,20 +301,28 @@ struct FoldShared {
 	uint32_t ecnt[FOLD_WAVES];
 };
 
-__global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j0, uint32_t nq, uint32_t border, uint32_t thr,
+// Several blocks per query (nb of them; blockIdx = query * nb + part): every block walks the windows itself — the
+// walk is a latency chain, the same for all — and folds a contiguous part of each window's iterations.  What a part
+// needs from the anchors before it (the last anchor, whether that was a right anchor, the latest non-right anchor =
+// the start of the run that is open) is data, not state: it is read back from the logs (carry_at).  Homologies leave
+// through slots handed out by an atomic counter per query: with one block per query they come out in query order as
+// they always did; with several, a query's list is in the order its parts got their slots — the sort + chain filter
+// behind the fold orders by projected start anyway, and the host path re-orders by query position first (the
+// reference's std::sort sees the homologies in query order, process.cxx:438).
+__global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j0, uint32_t nq, uint32_t nb, uint32_t border, uint32_t thr,
 												   RawHom *out, const uint64_t *out_base, const uint32_t *out_cap,
 												   uint32_t *out_cnt)
 {
 	__shared__ FoldShared sh;
-	const uint32_t j = j0 + blockIdx.x;
+	const uint32_t j = j0 + blockIdx.x / nb, part = blockIdx.x % nb;
 	if (j >= nq) return;
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	RawHom *dst = out + out_base[j];
 	const uint32_t cap = out_cap[j];
 	const uint32_t qlen = A.qlen[j];
 	const uint32_t c_begin = A.qchunk0[j], c_end = A.qchunk0[j + 1];
-	// carry (identical in every thread)
-	uint32_t lq = 0, ls = 0, ll = 0, lr = 0, cs = 0, cq = 0, cnt = 0;
+	// carry (identical in every thread): the last anchor, whether it was a right anchor, the latest non-right anchor
+	uint32_t lq = 0, ls = 0, ll = 0, lr = 0, cs = 0, cq = 0, cnt = 0; // (cnt: homologies so far, one block per query only)
 	uint32_t gc = c_begin, idx = 0;
 	bool more = c_begin < c_end;
 
@@ -477,6 +485,69 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j
 		// iteration are a fixed latency chain, so it pays to put many anchors behind each).
 		// The next iteration's anchors are requested before this one's are folded: the
 		// barriers below wait for LDS only (lds_barrier), so the loads stay in flight.
+		// anchor k of the window (k < total), wherever its segment is
+		auto anchor_at = [&](uint32_t k) {
+			uint32_t lo = 0, hi = nseg;
+			while (hi - lo > 1) {
+				const uint32_t mid = (lo + hi) >> 1;
+				if (sh.seg_off[mid] <= k) lo = mid;
+				else hi = mid;
+			}
+			return gload_anchor(sh.seg_ptr[lo] + (k - sh.seg_off[lo]));
+		};
+		// The carry in front of anchor a0 of this window, from the data: (lq, ls, ll) = anchor a0 - 1, lr = was it a right
+		// anchor, (cs, cq) = the latest non-right anchor before a0 — looked for backwards, FOLD_THREADS anchors per round;
+		// what lies before the window is the carry the window started with (wq .. wcq).  All threads take part and get
+		// the same values.
+		const uint32_t wq = lq, ws = ls, wl = ll, wr = lr, wcs = cs, wcq = cq;
+		auto carry_at = [&](uint32_t a0) {
+			if (a0 == 0) {
+				lq = wq, ls = ws, ll = wl, lr = wr, cs = wcs, cq = wcq;
+				return;
+			}
+			const Anchor window_last = {wq, ws, wl};
+			const Anchor a1 = anchor_at(a0 - 1), p1 = a0 >= 2 ? anchor_at(a0 - 2) : window_last;
+			lq = a1.q, ls = a1.s, ll = a1.len;
+			lr = is_right_anchor(p1, a1, border) ? 1u : 0u;
+			cs = wcs, cq = wcq;
+			for (uint32_t top = a0; top > 0;) { // anchors [top - FOLD_THREADS, top), thread t looks at top - 1 - t
+				const bool in = tid < top;
+				const uint32_t k = in ? top - 1u - tid : 0u;
+				bool nonright = false;
+				Anchor ak = {0, 0, 0};
+				if (in) {
+					ak = anchor_at(k);
+					const Anchor pk = k ? anchor_at(k - 1) : window_last;
+					nonright = !is_right_anchor(pk, ak, border);
+				}
+				const uint64_t m = __ballot(nonright);
+				if (lane == 0) sh.scan_s[wave] = m ? (uint32_t)(__ffsll((unsigned long long)m) - 1) : 64u;
+				__syncthreads();
+				uint32_t fw = FOLD_WAVES, fl = 0; // the first wave (highest anchors) that found one, and its lane
+				for (uint32_t w2 = 0; w2 < FOLD_WAVES; w2++)
+					if (fw == FOLD_WAVES && sh.scan_s[w2] < 64u) {
+						fw = w2;
+						fl = sh.scan_s[w2];
+					}
+				if (fw < FOLD_WAVES && wave == fw && lane == fl) {
+					sh.st_s[0] = ak.s;
+					sh.st_q[0] = ak.q;
+				}
+				__syncthreads();
+				if (fw < FOLD_WAVES) {
+					cs = sh.st_s[0];
+					cq = sh.st_q[0];
+					__syncthreads();
+					break;
+				}
+				top = top > FOLD_THREADS ? top - FOLD_THREADS : 0u;
+			}
+		};
+		// this block's part of the window's iterations
+		const uint32_t n_it = (total + FOLD_ITER - 1) / FOLD_ITER;
+		const uint32_t it0 = (uint32_t)((uint64_t)n_it * part / nb), it1 = (uint32_t)((uint64_t)n_it * (part + 1) / nb);
+		const uint32_t base0 = it0 * FOLD_ITER, base1 = it1 * FOLD_ITER < total ? it1 * FOLD_ITER : total;
+		if (nb > 1 && it0 < it1) carry_at(base0);
 		uint32_t cur = 0; // segment cursor of this thread (anchor indices only grow)
 		Anchor an[FOLD_APT];
 		uint32_t evn = 0;
@@ -512,14 +583,14 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j
 					}
 			}
 		};
-		if (total) fetch(0);
-		for (uint32_t base = 0; base < total; base += FOLD_ITER) {
+		if (base0 < base1) fetch(base0);
+		for (uint32_t base = base0; base < base1; base += FOLD_ITER) {
 			const uint32_t k0 = base + tid * FOLD_APT;
 			Anchor a[FOLD_APT];
 #pragma unroll
 			for (uint32_t e = 0; e < FOLD_APT; e++) a[e] = an[e];
 			const uint32_t ev = evn; // valid anchors of this thread (the invalid ones are at the very end)
-			if (base + FOLD_ITER < total) fetch(base + FOLD_ITER);
+			if (base + FOLD_ITER < base1) fetch(base + FOLD_ITER);
 			const uint32_t m = total - base < FOLD_ITER ? total - base : FOLD_ITER; // valid anchors this iteration
 			Anchor tl = a[0]; // this thread's last valid anchor
 #pragma unroll
@@ -604,8 +675,18 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j
 					}
 			}
 			lds_barrier();
-			uint32_t slot = cnt + pe - ne;
-			for (uint32_t w2 = 0; w2 < wave; w2++) slot += sh.ecnt[w2];
+			// slots of the query's list: one block per query counts them itself (query order); several blocks take them
+			// from the query's counter, a wavefront at a time
+			uint32_t slot;
+			if (nb == 1) {
+				slot = cnt + pe - ne;
+				for (uint32_t w2 = 0; w2 < wave; w2++) slot += sh.ecnt[w2];
+				for (uint32_t w2 = 0; w2 < FOLD_WAVES; w2++) cnt += sh.ecnt[w2];
+			} else {
+				uint32_t wbase = 0;
+				if (lane == 63 && pe) wbase = atomicAdd(&out_cnt[j], pe);
+				slot = (uint32_t)__shfl((int)wbase, 63, 64) + pe - ne;
+			}
 #pragma unroll
 			for (uint32_t e = 0; e < FOLD_APT; e++) {
 				if ((em >> e) & 1u) {
@@ -625,7 +706,6 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j
 			}
 			// carry out (same values in every thread)
 			const uint32_t lw = ((m - 1) / FOLD_APT) >> 6;
-			for (uint32_t w2 = 0; w2 < FOLD_WAVES; w2++) cnt += sh.ecnt[w2];
 			lq = sh.wl_q[lw];
 			ls = sh.wl_s[lw];
 			ll = sh.wl_len[lw];
@@ -638,29 +718,32 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j
 				}
 			lds_barrier(); // the exchange arrays are rewritten next iteration
 		}
+		// the carry behind the window's last anchor: every block needs it for the next window (and block 0 for the
+		// query's last homology); the block that folded the window's end has it already
+		if (nb > 1 && !(it0 < it1 && base1 == total)) carry_at(total);
 		more = !sh.finished;
 		gc = sh.next_gc;
 		idx = sh.next_idx;
 		__syncthreads();
 	}
 	// fold_finish (process.cxx:285-292)
-	if (tid == 0) {
+	if (tid == 0 && part == 0) {
 		uint32_t fs = cs, fq = cq, flen = lq + ll - cq;
 		if (ll >= qlen) {
 			fs = ls;
 			fq = 0;
 			flen = qlen;
 		}
+		if (nb == 1) out_cnt[j] = cnt;
 		if (lr || ll / 2 >= thr) {
-			if (cnt < cap) {
+			const uint32_t slot = atomicAdd(&out_cnt[j], 1u);
+			if (slot < cap) {
 				RawHom h = {fs, fq, flen};
-				dst[cnt] = h;
+				dst[slot] = h;
 			} else {
 				*A.error = 3;
 			}
-			cnt++;
 		}
-		out_cnt[j] = cnt;
 	}
 }
 
@@ -700,10 +783,12 @@ void launch_bridge(const PhaseA &A, const RefIndex &R, int n_cu, hipStream_t st)
 }
 // queries [j0, j1)
 void launch_fold(const PhaseA &A, uint32_t j0, uint32_t j1, uint32_t border, uint32_t thr, RawHom *out,
-				 const uint64_t *out_base, const uint32_t *out_cap, uint32_t *out_cnt, hipStream_t st)
+				 const uint64_t *out_base, const uint32_t *out_cap, uint32_t *out_cnt, hipStream_t st, uint32_t blocks_per_query)
 {
 	if (j1 <= j0) return;
-	hipLaunchKernelGGL(fold_kernel, dim3(j1 - j0), dim3(FOLD_THREADS), 0, st, A, j0, j1, border, thr, out, out_base, out_cap, out_cnt);
+	const uint32_t nb = blocks_per_query ? blocks_per_query : 1u;
+	(void)hipMemsetAsync(out_cnt + j0, 0, (size_t)(j1 - j0) * 4, st); // the list lengths are counted up by the blocks
+	hipLaunchKernelGGL(fold_kernel, dim3((j1 - j0) * nb), dim3(FOLD_THREADS), 0, st, A, j0, j1, nb, border, thr, out, out_base, out_cap, out_cnt);
 }
 
 } // namespace phy

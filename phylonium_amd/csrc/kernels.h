@@ -32,8 +32,10 @@ void launch_bad_positions(const uint8_t *base, const uint64_t *off, const uint32
 int spec_resident_blocks(int n_cu); // blocks of the speculative-chain kernel the device holds at once
 void launch_spec(const PhaseA &A, const RefIndex &R, int n_cu, hipStream_t st);
 void launch_bridge(const PhaseA &A, const RefIndex &R, int n_cu, hipStream_t st);
+// queries [j0, j1), blocks_per_query blocks each (with more than one a query's homologies leave in the order its
+// blocks got their slots, not in query order)
 void launch_fold(const PhaseA &A, uint32_t j0, uint32_t j1, uint32_t border, uint32_t thr, RawHom *out,
-				 const uint64_t *out_base, const uint32_t *out_cap, uint32_t *out_cnt, hipStream_t st); // queries [j0, j1)
+				 const uint64_t *out_base, const uint32_t *out_cap, uint32_t *out_cnt, hipStream_t st, uint32_t blocks_per_query = 1);
 
 // filter_kernels.hip: reverseEh + sort + filter_overlaps_max per query on the device; flag[j] = 1
 // leaves query j to the host (two entries share a projected start, or the list is too long)

@@ -183,6 +183,7 @@ struct phylo_ctx {
 	int opt_filter_kernel = 0; // option "filter_kernel": 0 stretch-wise chain filter (then the general kernel for what it hands over), 1 general only
 	int opt_sa_builder = 1; // option "sa_builder": who builds the suffix array when the caller brings none — 1 the device, 0 the host cores
 	uint32_t opt_pairs_wchunk = 0; // option "pairs_wchunk": windows per chunk of the pair kernel (0: chosen from the L2 size)
+	uint32_t opt_fold_blocks = 0; // option "fold_blocks": blocks per query of the fold kernel (0: chosen from the number of queries)
 	int opt_pairs_kernel = 0; // option "pairs_kernel": 0 the matrix-core kernel when no projected position holds '!' (default), 1 the vector-ALU kernel always
 	int opt_tail_groups = 1; // option "tail_groups": streams the tail is spread over (default 1: measured, the groups run in lockstep and nothing is hidden — DESIGN.md)
 	std::string err;
@@ -541,6 +542,9 @@ int phylo_set_option(phylo_ctx *c, const char *key, long value)
 		c->opt_cache_quirk = (int)value;
 		c->plan_valid = false;
 		c->homs_staged = false;
+	} else if (k == "fold_blocks") {
+		if (value < 0 || value > 64) return c->fail("fold_blocks must be in 0..64");
+		c->opt_fold_blocks = (uint32_t)value;
 	} else if (k == "pairs_kernel") {
 		if (value != 0 && value != 1) return c->fail("pairs_kernel must be 0 (matrix cores unless '!' is projected) or 1 (vector ALUs)");
 		c->opt_pairs_kernel = (int)value;
@@ -1384,7 +1388,13 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 		}
 		{
 			KernelSpan s(c, "anchor_fold", sg);
-			launch_fold(A, j0, j1, c->L, c->threshold, c->a_raw.p, c->a_out_base.p, c->a_out_cap.p, c->a_out_cnt.p, sg);
+			// Blocks per query.  A block's time is its windows' walks (a latency chain every block of the query
+			// repeats) plus its share of the anchors; with a block per CU or more there is nothing to gain from
+			// splitting (measured, C3's 256 queries with two blocks each: 0.17 -> 0.21 ms), with a handful of queries
+			// the idle CUs take a part each (c2like's 29 queries: 0.167 -> 0.100 ms; C5's 64: 2.65 -> 2.28 ms)
+			uint32_t fold_nb = c->opt_fold_blocks;
+			if (!fold_nb) fold_nb = 2 * (j1 - j0) <= (uint32_t)c->n_cu ? (uint32_t)std::min<size_t>(8, (size_t)c->n_cu / (j1 - j0)) : 1u;
+			launch_fold(A, j0, j1, c->L, c->threshold, c->a_raw.p, c->a_out_base.p, c->a_out_cap.p, c->a_out_cnt.p, sg, fold_nb);
 		}
 		if (device_filter) {
 			// reverseEh + sort + filter_overlaps_max on the device (filter_kernels.hip).  The lists stay
@@ -1491,7 +1501,7 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	}
 	cbase[nq] = ctot;
 	HIPOK(c, c->h_raw.ensure(ctot + 1));
-	const RawHom *raw = c->h_raw.p;
+	// (the workers read and, for lists that arrive out of query order, reorder c->h_raw in place)
 	if (ctot) {
 		HIPOK(c, c->a_raw_compact.ensure(ctot));
 		HIPOK(c, hipMemcpyAsync(c->a_cmp_base.p, cbase.data(), (nq + 1) * 8, hipMemcpyHostToDevice, st));
@@ -1600,8 +1610,12 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 		}
 		static thread_local SortFilterScratch scratch;
 		static thread_local std::vector<uint32_t> kept;
-		const RawHom *r = raw + cbase[j];
+		RawHom *r = c->h_raw.p + cbase[j];
 		const size_t m = cnt[j];
+		// several fold blocks per query hand a list over in the order they got their slots: back to query order,
+		// which is what the reference's std::sort is given (process.cxx:438; query positions ascend along a chain)
+		if (!std::is_sorted(r, r + m, [](const RawHom &a, const RawHom &b) { return a.iq < b.iq; }))
+			std::sort(r, r + m, [](const RawHom &a, const RawHom &b) { return a.iq < b.iq; });
 		auto get = [&](size_t i, uint64_t *start, uint64_t *len) {
 			*len = r[i].len;
 			*start = r[i].iref >= border ? 2 * border + 1 - r[i].len - r[i].iref : r[i].iref;

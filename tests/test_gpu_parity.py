@@ -47,6 +47,9 @@ def check_process(ctx, gs, ref, chunk=0, kmer=0, backend=0, complete_deletion=Fa
     # the vector ALUs on three or five planes
     check_process.pkern = (getattr(check_process, "pkern", 0) + 1) % 3
     ctx.set_option("pairs_kernel", 1 if check_process.pkern == 2 else 0)
+    # blocks per query of the fold kernel: the library's choice, three, eight (lists then arrive out of query order)
+    check_process.fb = (getattr(check_process, "fb", 0) + 1) % 4
+    ctx.set_option("fold_blocks", (0, 3, 8, 1)[check_process.fb])
     # genomes arrive as bytes or as 2-bit codes + separator positions (phylo_set_genomes_packed), alternating
     check_process.pk = 1 - getattr(check_process, "pk", 0)
     if check_process.pk:
@@ -95,6 +98,7 @@ def check_process(ctx, gs, ref, chunk=0, kmer=0, backend=0, complete_deletion=Fa
     ctx.set_option("filter", 0)
     ctx.set_option("filter_kernel", 0)
     ctx.set_option("pairs_kernel", 0)
+    ctx.set_option("fold_blocks", 0)
     return s, h
 
 
@@ -627,6 +631,33 @@ def test_device_resident_exchange_between_two_contexts():
     finally:
         for c in ctxs:
             c.close()
+
+
+@pytest.mark.parametrize("blocks", [1, 2, 5, 8])
+def test_fold_with_several_blocks_per_query(ctx, blocks):
+    """Queries of 1.2 Mbp at low divergence leave tens of thousands of anchors in one window of chunks: the fold's
+    iterations are split over `blocks` blocks per query, each finding the carry in front of its part (last anchor, its
+    right flag, the open run's start) in the logs; homologies leave through an atomic counter.  Long runs of right
+    anchors (indel-free stretches of tens of kbp) make the backward search for a run's start cross several rounds.
+    Lists and tallies equal the oracle's, with the device filter and with the host's (which restores query order)."""
+    gs = synth.make_genomes(4, 1200000, seed=311, d_range=(0.005, 0.08), indel_per_mbp=15, inv_frac=0.03, contigs=2)
+    ctx.set_genomes(gs)
+    ctx.set_reference(0)
+    r = O.Run(gs, 0).process(threads=4)
+    so, ho = r.matrix()
+    for filt in (2, 1):
+        ctx.set_option("filter", filt)
+        ctx.set_option("fold_blocks", blocks)
+        for chunk in (0, 2048):
+            ctx.set_option("chunk", chunk)
+            ctx.anchor()
+            for j in range(len(gs)):
+                assert hom_tuples_gpu(ctx.homologies(j)) == hom_tuples_orc(r.homologies(j)), (filt, chunk, j)
+            s, h = ctx.compare()
+            assert (s == so).all() and (h == ho).all()
+    ctx.set_option("filter", 0)
+    ctx.set_option("fold_blocks", 0)
+    ctx.set_option("chunk", 0)
 
 
 def test_block_exchange_between_three_contexts():
