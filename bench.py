@@ -598,7 +598,8 @@ def main():
             per_win = 104 if pk == "pileup_pairs" else 135  # VALU instructions of the loop body in the ISA (hipcc -S)
             inst = ntiles * windows * per_win
             t_ms = kern[pk] / launches[pk]
-            peak = 256 * 4 * 2.4 / 4
+            peak = 650.0  # wave64 integer instructions per ns the chip issues in register loops (tools/microbench/valu.hip: 520-650 G/s; the
+            # nominal 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles = 614 is exceeded by the counted SQ_INSTS_VALU of this kernel at C4: 635 G/s)
             roof_valu = {"kernel": pk, "bound": "valu", "achieved": round(inst / (t_ms * 1e-3) / 1e9, 1), "peak": peak,
                          "unit": "G wave-instructions/s", "frac": round(inst / (t_ms * 1e-3) / 1e9 / peak, 4),
                          "wave_instructions_per_launch": inst, "avg_launch_ms": round(t_ms, 4),

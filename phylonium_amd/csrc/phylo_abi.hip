@@ -1537,6 +1537,8 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	const size_t gsz = tsz * std::max<size_t>(3, ((nq + tsz - 1) / tsz) / 8);
 	const size_t ngroups = stage ? (nq + gsz - 1) / gsz : 0;
 	std::vector<std::atomic<uint32_t>> group_left(ngroups);
+	std::mutex group_m; // the calling thread sleeps until a group is complete (it used to spin: under the boxes' CPU-time
+	std::condition_variable group_cv; // quota a spinning thread takes time from the workers it is waiting for)
 	const bool eager = stage && c->backend == 0;
 	c->eager_valid = false;
 	Pileup EP;
@@ -1572,12 +1574,18 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 							   (uint32_t)list[t].length, (uint32_t)list[t].direction};
 		rng[2 * j] = (uint32_t)o;
 		rng[2 * j + 1] = (uint32_t)(o + list.size());
-		group_left[j / gsz].fetch_sub(1, std::memory_order_acq_rel);
+		if (group_left[j / gsz].fetch_sub(1, std::memory_order_acq_rel) == 1) {
+			std::lock_guard<std::mutex> lk(group_m);
+			group_cv.notify_all();
+		}
 	};
 	double t_send_done = 0;
 	auto send_groups = [&]() {
 		for (size_t g = 0; g < ngroups; g++) {
-			while (group_left[g].load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+			if (group_left[g].load(std::memory_order_acquire) != 0) {
+				std::unique_lock<std::mutex> lk(group_m);
+				group_cv.wait(lk, [&] { return group_left[g].load(std::memory_order_acquire) == 0; });
+			}
 			const size_t j0 = g * gsz, j1 = std::min(nq, (g + 1) * gsz);
 			const size_t o0 = cbase[j0] + j0, o1 = cbase[j1] + j1;
 			// the upload goes through the copy stream (DMA engine), so group g+1 travels while
