@@ -324,6 +324,7 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0, help="dev: size of the library's host worker pool")
     ap.add_argument("--kmer", type=int, default=0, help="dev: force the bucket k of the reference index")
     ap.add_argument("--anchor-kernel", type=int, default=-1, help="dev: 1 lean 2-bit chains, 0 general byte-wise chains (library default when < 0)")
+    ap.add_argument("--lean-batch", type=int, default=-1, help="dev: the chain kernels' rarer phases on every n-th trip only")
     ap.add_argument("--tail-groups", type=int, default=0, help="dev: phase A's tail on this many streams (library default when 0)")
     ap.add_argument("--sa-builder", type=int, default=-1, help="dev: who builds the reference's suffix array: 1 the device, 0 the host cores (library default when < 0)")
     ap.add_argument("--pairs-wchunk", type=int, default=0, help="dev: windows per chunk of the pair kernel (library's choice when 0)")
@@ -393,6 +394,8 @@ def main():
         ctx.set_option("kmer", args.kmer)
     if args.anchor_kernel >= 0:
         ctx.set_option("anchor_kernel", args.anchor_kernel)
+    if args.lean_batch >= 0:
+        ctx.set_option("lean_batch", args.lean_batch)
     if args.tail_groups > 0:
         ctx.set_option("tail_groups", args.tail_groups)
     if args.pairs_wchunk > 0:

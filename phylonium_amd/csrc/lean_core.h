@@ -57,6 +57,7 @@ struct LeanIndex {
 	// goes through the slow resolver (force_slow is set with them), which reproduces that.
 	const U4 *quirk;
 	uint32_t nquirk;
+	uint32_t batch; // the chain kernels run the rarer phases on every batch-th trip only (0, 1: every trip)
 };
 
 static const uint32_t LEAN_NO_QUIRK = 0xffffffffu;

@@ -443,6 +443,7 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 		for (int i = 0; i < 16; i++) visbuf[i][tid] = 0;
 	}
 	bool active = false, done = false;
+	uint32_t trip = 0;
 	LeanAlloc alloc = {&A};
 	ln.fin = false;
 	ln.ph = LP_STEP;
@@ -497,6 +498,12 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 				ln.qcode = code_window(ring[w & 15u][tid], ring[(w + 1u) & 15u][tid], ln.q & 15u);
 			}
 		}
+		// Phase batching (X.batch = M > 1): a wavefront pays for the code of every phase one of its lanes is in, and with
+		// 64 lanes nearly every trip has a lane or two in each of the rarer ones (EXT, SCAN, REFILL, SEARCH, the slow
+		// resolver).  Those phases are run on every M-th trip only; in between their lanes sit the trip out and the
+		// wavefront runs the STEP path alone.
+		trip++;
+		if (X.batch > 1 && ph != LP_STEP && (trip % X.batch) != 0) ph = (uint32_t)LP_SLOW + 8u;
 		// one batch of loads for every phase
 		const uint8_t *pA = s2_b, *pB = s2_b, *pY = s2_b;
 		if (ph == LP_STEP || ph == LP_SEARCH) {
@@ -555,7 +562,7 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 		}
 		LEAN_TICK(3)
 		// what the packed path could not answer: the wavefront resolves it, one lane at a time
-		uint64_t slow = __ballot(active && (ln.ph == LP_SLOW || ln.ph == LP_SLOWEXT));
+		uint64_t slow = __ballot(active && (ln.ph == LP_SLOW || ln.ph == LP_SLOWEXT) && (X.batch <= 1 || (trip % X.batch) == 0));
 		while (slow) {
 			const int leader = __ffsll((unsigned long long)slow) - 1;
 			const uint32_t lph = bcast(ln.ph, leader);

@@ -183,6 +183,7 @@ struct phylo_ctx {
 	int opt_filter_kernel = 0; // option "filter_kernel": 0 stretch-wise chain filter (then the general kernel for what it hands over), 1 general only
 	int opt_sa_builder = 1; // option "sa_builder": who builds the suffix array when the caller brings none — 1 the device, 0 the host cores
 	uint32_t opt_pairs_wchunk = 0; // option "pairs_wchunk": windows per chunk of the pair kernel (0: chosen from the L2 size)
+	uint32_t opt_lean_batch = 0; // option "lean_batch": the chain kernels' rarer phases on every n-th trip only (0, 1: every trip)
 	uint32_t opt_fold_blocks = 0; // option "fold_blocks": blocks per query of the fold kernel (0: chosen from the number of queries)
 	int opt_pairs_kernel = 0; // option "pairs_kernel": 0 the matrix-core kernel when no projected position holds '!' (default), 1 the vector-ALU kernel always
 	int opt_tail_groups = 1; // option "tail_groups": streams the tail is spread over (default 1: measured, the groups run in lockstep and nothing is hidden — DESIGN.md)
@@ -542,6 +543,9 @@ int phylo_set_option(phylo_ctx *c, const char *key, long value)
 		c->opt_cache_quirk = (int)value;
 		c->plan_valid = false;
 		c->homs_staged = false;
+	} else if (k == "lean_batch") {
+		if (value < 0 || value > 16) return c->fail("lean_batch must be in 0..16");
+		c->opt_lean_batch = (uint32_t)value;
 	} else if (k == "fold_blocks") {
 		if (value < 0 || value > 64) return c->fail("fold_blocks must be in 0..64");
 		c->opt_fold_blocks = (uint32_t)value;
@@ -1286,7 +1290,8 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	// answers there are reproduced by the lean chains' slow resolver, so every step goes through it (such subjects
 	// are a few kbp in several contigs; option "cache_quirk" = 0 computes the true longest matches instead).
 	LeanIndex X = {c->d_S2.p, c->d_SBAD.p, c->nsb, c->ns, c->sb_first, c->d_Q2.p, c->d_QBAD.p, c->d_qbad_off.p + q_begin,
-				   (uint32_t)(c->lean_force_slow || quirk_mode), nullptr, quirk_mode ? c->d_quirk.p : nullptr, quirk_mode ? c->nquirk : 0u};
+				   (uint32_t)(c->lean_force_slow || quirk_mode), nullptr, quirk_mode ? c->d_quirk.p : nullptr, quirk_mode ? c->nquirk : 0u,
+				   c->opt_lean_batch};
 #ifdef PHY_LEAN_TIMING
 	static unsigned long long *dbg_buf = nullptr;
 	if (!dbg_buf) (void)hipMalloc((void **)&dbg_buf, 16 * 8);

@@ -306,6 +306,34 @@ static __device__ __forceinline__ void pairs_mfma3_body(const Planes &P, uint32_
 	constexpr int NMF = (DIAG ? (GI * (GI + 1)) / 2 : GI * GJ); // matrix instructions per channel
 	uint32_t sink = 0; // (experiments: SCHED 2 = the expansion alone, 3 = the matrix instructions alone)
 	auto compute = [&](PlaneWords (&x)[NG]) {
+		if (SCHED == 4 || SCHED == 5) {
+			// two phases per step — all operands first, then all matrix instructions, at raised priority — so that one
+			// wavefront's expansion can issue under the other's matrix instructions
+			uint32_t opa[4][NG][4];
+#pragma unroll
+			for (int g = 0; g < NG; g++) {
+				expand_v(x[g].v, opa[0][g]);
+				expand_s(x[g].a, opa[0][g], opa[1][g]);
+				expand_s(x[g].b, opa[0][g], opa[2][g]);
+				expand_s(x[g].a ^ x[g].b, opa[0][g], opa[3][g]);
+			}
+			load(x);
+			if (SCHED == 5) __builtin_amdgcn_sched_barrier(0);
+			__builtin_amdgcn_s_setprio(2);
+#pragma unroll
+			for (int c = 0; c < 4; c++)
+#pragma unroll
+				for (int a = 0; a < GI; a++)
+#pragma unroll
+					for (int b = 0; b < GJ; b++)
+						if (NEED(a, b)) {
+							if (c == 0) acc_h[a][b] = mfma_fp4(opa[0][a], opa[0][GI + b], acc_h[a][b]);
+							else acc_t[a][b] = mfma_fp4(opa[c][a], opa[c][GI + b], acc_t[a][b]);
+						}
+			__builtin_amdgcn_s_setprio(0);
+			if (SCHED == 5) __builtin_amdgcn_sched_barrier(0);
+			return;
+		}
 		uint32_t vd[NG][4], op[NG][4];
 		if (SCHED == 3) {
 #pragma unroll
@@ -634,6 +662,8 @@ int main(int argc, char **argv)
 		ok &= check_kernel(R, pairs_mfma3<2, 2, 3, 0>, make_tiles(R.N, 64, 64), 126, rs, rh, "MFMA v3 nb3 c126");
 		ok &= check_kernel(R, pairs_mfma3<2, 2, 3, 1>, make_tiles(R.N, 64, 64), 1008, rs, rh, "MFMA v3 nb3 sched c1008");
 		ok &= check_kernel(R, pairs_mfma3<2, 2, 2, 1>, make_tiles(R.N, 64, 64), 1008, rs, rh, "MFMA v3 nb2 sched c1008");
+		ok &= check_kernel(R, pairs_mfma3<2, 2, 3, 4>, make_tiles(R.N, 64, 64), 252, rs, rh, "MFMA v3 nb3 phases c252");
+		ok &= check_kernel(R, pairs_mfma3<2, 2, 2, 5>, make_tiles(R.N, 64, 64), 252, rs, rh, "MFMA v3 nb2 phases+ c252");
 		CK(hipFree(R.dV));
 		CK(hipFree(R.d0));
 		CK(hipFree(R.d1));
@@ -697,6 +727,11 @@ int main(int argc, char **argv)
 			float m3 = time_kernel(R, pairs_mfma3<2, 2, 2, 1>, t, wch, reps);
 			float m4 = time_kernel(R, pairs_mfma3<2, 2, 3, 1>, t, wch, reps);
 			printf("    -> %.3f / %.3f / %.3f / %.3f ms\n", m1, m2, m3, m4);
+			printf("  two phases per step with priorities: nb2 / nb3 / nb2 + sched_barrier / nb3 + sched_barrier\n");
+			time_kernel(R, pairs_mfma3<2, 2, 2, 4>, t, wch, reps);
+			time_kernel(R, pairs_mfma3<2, 2, 3, 4>, t, wch, reps);
+			time_kernel(R, pairs_mfma3<2, 2, 2, 5>, t, wch, reps);
+			time_kernel(R, pairs_mfma3<2, 2, 3, 5>, t, wch, reps);
 			printf("  the same shape, expansion alone / matrix instructions alone (nb3; results meaningless)\n");
 			time_kernel(R, pairs_mfma3<2, 2, 3, 2>, t, wch, reps);
 			time_kernel(R, pairs_mfma3<2, 2, 3, 3>, t, wch, reps);
