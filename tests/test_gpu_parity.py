@@ -50,6 +50,7 @@ def check_process(ctx, gs, ref, chunk=0, kmer=0, backend=0, complete_deletion=Fa
     # blocks per query of the fold kernel: the library's choice, three, eight (lists then arrive out of query order)
     check_process.fb = (getattr(check_process, "fb", 0) + 1) % 4
     ctx.set_option("fold_blocks", (0, 3, 8, 1)[check_process.fb])
+    ctx.set_option("lean_batch", (0, 0, 2, 3)[check_process.fb])  # the chains' rarer phases on every n-th trip only
     # genomes arrive as bytes or as 2-bit codes + separator positions (phylo_set_genomes_packed), alternating
     check_process.pk = 1 - getattr(check_process, "pk", 0)
     if check_process.pk:
@@ -99,6 +100,7 @@ def check_process(ctx, gs, ref, chunk=0, kmer=0, backend=0, complete_deletion=Fa
     ctx.set_option("filter_kernel", 0)
     ctx.set_option("pairs_kernel", 0)
     ctx.set_option("fold_blocks", 0)
+    ctx.set_option("lean_batch", 0)
     return s, h
 
 
