@@ -188,7 +188,10 @@ def wallclock_leg(torch, holder, offs, lens, contigs_sep, want_text, n_gpus, run
                     parts = [g]
                 for k, part in enumerate(parts):
                     f.write(b">contig%d\n" % k)
-                    a = part if torch.is_tensor(part) else torch.frombuffer(bytearray(part), dtype=torch.uint8).to(buf.device)
+                    if not torch.is_tensor(part):  # a contig cut out on the host: plain bytes, 70 to a line
+                        f.write(b"".join(part[i:i + 70] + b"\n" for i in range(0, len(part), 70)))
+                        continue
+                    a = part
                     full = a.numel() // 70 * 70
                     if full:
                         lines = torch.empty((full // 70, 71), dtype=torch.uint8, device=buf.device)
@@ -200,7 +203,8 @@ def wallclock_leg(torch, holder, offs, lens, contigs_sep, want_text, n_gpus, run
         t_write = time.time() - t0
         fasta_bytes = sum(os.path.getsize(f) for f in files)
         # this process lets go of its device memory before the driver starts (it keeps only an idle HIP context)
-        del g, buf, a, parts, part
+        del g, buf, parts, part
+        a = None
         holder.clear()
         torch.cuda.empty_cache()
         if before_run:  # several ranks: the others have let go of their device memory too
