@@ -328,6 +328,7 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0, help="dev: size of the library's host worker pool")
     ap.add_argument("--kmer", type=int, default=0, help="dev: force the bucket k of the reference index")
     ap.add_argument("--anchor-kernel", type=int, default=-1, help="dev: 1 lean 2-bit chains, 0 general byte-wise chains (library default when < 0)")
+    ap.add_argument("--absent-table", type=int, default=-1, help="dev: 1 steps of k-mers that do not occur in the reference from the absence table, 0 every step fetches its slot")
     ap.add_argument("--lean-batch", type=int, default=-1, help="dev: the chain kernels' rarer phases on every n-th trip only")
     ap.add_argument("--tail-groups", type=int, default=0, help="dev: phase A's tail on this many streams (library default when 0)")
     ap.add_argument("--sa-builder", type=int, default=-1, help="dev: who builds the reference's suffix array: 1 the device, 0 the host cores (library default when < 0)")
@@ -400,6 +401,8 @@ def main():
         ctx.set_option("anchor_kernel", args.anchor_kernel)
     if args.lean_batch >= 0:
         ctx.set_option("lean_batch", args.lean_batch)
+    if args.absent_table >= 0:
+        ctx.set_option("absent_table", args.absent_table)
     if args.tail_groups > 0:
         ctx.set_option("tail_groups", args.tail_groups)
     if args.pairs_wchunk > 0:
@@ -586,8 +589,8 @@ def main():
                     # this run's launch time): the request-granular view of the same kernel
                     "traffic_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic else None,
                     "traffic_frac": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-                    "traffic_source": "profiles/pmc_traffic.json (rocprofv3 PMC passes of this workload on the build of "
-                                      "profiles/r02_rocprof_c3_summary.json; regenerate with tools/tools_prof.sh + tools/tools_pmc_traffic.py "
+                    "traffic_source": "profiles/pmc_traffic.json (rocprofv3 PMC passes of this workload; its source_<workload> "
+                                      "entry names the profile; regenerate with tools/tools_prof.sh + tools/tools_pmc_traffic.py "
                                       "when the kernels change)",
                     "note": "anchor_spec fetches one random 64-B k-mer slot (a 128-B line at the memory) per chain step: its time "
                             "is its line transactions (~122 M per launch at ~48 G lines/s, the rate of uniformly random line "
@@ -705,8 +708,8 @@ def main():
                                                  "traffic_frac": round(tr / (tb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tr else None,
                                                  "note": "achieved/frac price the reference layout's 2 B per compared site (above 1: "
                                                          "see roofline_path); traffic = HBM-side bytes of these kernels from the "
-                                                         "PMC profile: the pair kernel is VALU-bound (DESIGN.md, section 10), not "
-                                                         "HBM-bound"} if tb > 0 else None)(
+                                                         "PMC profile: the pair kernel is bound by its matrix and vector instructions "
+                                                         "(roofline_mfma; DESIGN.md, section 12.1), not by HBM"} if tb > 0 else None)(
                 sum(kern[k] for k in kern if k.startswith("pileup_")) / K, phase_b_traffic),
             "setup_s": {"generate": round(t_gen, 2), "reference_index": round(t_ref, 2),
                         "suffix_array": round((ref_stats["ms:ref_suffix_array"] or 0) / 1e3, 3),

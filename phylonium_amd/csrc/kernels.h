@@ -17,6 +17,8 @@ void launch_lean_bridge(const PhaseA &A, const RefIndex &R, const LeanIndex &X, 
 // the bridges of chunks [c_lo, c_hi) only (a group of queries), work counter A.fetch[fetch_slot]
 void launch_lean_bridge_range(const PhaseA &A, const RefIndex &R, const LeanIndex &X, uint32_t c_lo, uint32_t c_hi,
 							  uint32_t fetch_slot, int n_cu, hipStream_t st);
+// the absence table of the index in R (4^k bytes; lean_core.h: LeanIndex::absent) — after the slots, for R.threshold
+void launch_build_absent(const RefIndex &R, uint8_t *absent, hipStream_t st);
 void launch_pack2(const uint8_t *src, uint64_t bytes, uint32_t *dst, hipStream_t st); // bytes: a multiple of 16
 // Q2 → byte arena (bytes: the whole arena, a multiple of 16), then '!' at the nbad listed positions; code bits of Q2
 // outside the genomes or under a separator are cleared on the way

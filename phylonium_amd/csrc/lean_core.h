@@ -58,7 +58,17 @@ struct LeanIndex {
 	const U4 *quirk;
 	uint32_t nquirk;
 	uint32_t batch; // the chain kernels run the rarer phases on every batch-th trip only (0, 1: every trip)
+	// One byte per k-mer of the index (4^k; null: not in use): 0 when the k-mer occurs in S (or its step needs the
+	// full path for another reason), else 1 + the length of the longest match of any query window that starts with
+	// it.  A k-mer that does not occur in S matches less than k bases, which its own letters decide — and less than
+	// the threshold, so the step accepts no anchor: position + length + 1 is all there is to it (process.cxx:281),
+	// without the k-mer's 64-byte slot out of a table a hundred times this one's size.
+	const uint8_t *absent;
 };
+#ifndef PHY_QUICK_MAX
+#define PHY_QUICK_MAX 6
+#endif
+static const int LEAN_QUICK_MAX = PHY_QUICK_MAX; // such steps a lane may take in one trip before the wavefront moves on
 
 static const uint32_t LEAN_NO_QUIRK = 0xffffffffu;
 // the cache entry the window Q (n bytes left in the query) falls under: get_match_cached, src/esa.cxx:542-563

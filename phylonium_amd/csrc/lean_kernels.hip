@@ -498,6 +498,34 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 				ln.qcode = code_window(ring[w & 15u][tid], ring[(w + 1u) & 15u][tid], ln.q & 15u);
 			}
 		}
+		// Quick steps.  More than half of the windows of diverged sequence start with a k-mer that does not occur in S:
+		// their step is "advance by the table's byte" (lean_core.h: LeanIndex::absent) — no slot, no candidates, no
+		// anchor — unless the last anchor is near enough for the lucky check (process.cxx:227-242), which reads S.  A
+		// lane takes up to LEAN_QUICK_MAX of them here, while the wavefront's other lanes wait for the trip's one slot
+		// fetch anyway; what is left in STEP afterwards has a k-mer that occurs.
+		if (X.absent) {
+			for (int it = 0; it < LEAN_QUICK_MAX; it++) {
+				const bool ask = active && ph == LP_STEP && !ln.lucky_ok(R);
+				uint32_t e = 0;
+				if (ask) e = X.absent[ln.qcode >> (2u * (16u - R.k))];
+				if (!__any(e != 0u)) break;
+				if (e) {
+					ln.finish(0u, e - 1u, false); // no anchor: nothing for step_done to log
+					ln.fin = false;
+					if constexpr (MODE == 0) active = L.begin_step(A, X, vis);
+					else active = L.begin_step(A, X, R);
+					ph = (uint32_t)LP_SLOW + 8u;
+					if (active) {
+						ph = lean_step_phase(ln, X);
+						ln.ph = ph;
+						if (ph == LP_STEP) {
+							const uint32_t w = ln.q >> 4;
+							ln.qcode = code_window(ring[w & 15u][tid], ring[(w + 1u) & 15u][tid], ln.q & 15u);
+						}
+					}
+				}
+			}
+		}
 		// Phase batching (X.batch = M > 1): a wavefront pays for the code of every phase one of its lanes is in, and with
 		// 64 lanes nearly every trip has a lane or two in each of the rarer ones (EXT, SCAN, REFILL, SEARCH, the slow
 		// resolver).  Those phases are run on every M-th trip only; in between their lanes sit the trip out and the
@@ -580,6 +608,37 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 		atomicAdd(&X.dbg[MODE * 8 + 6], 1ull);
 	}
 #endif
+}
+
+// The absence table (lean_core.h: LeanIndex::absent): one thread per k-mer runs the full path's own digest
+// (lean_search on the k-mer's slot) with the k-mer as the window, and keeps the outcome when it is the plain one —
+// the bucket is empty and the step ends without an anchor.  The window's bases behind the k-mer cannot matter then:
+// every suffix differs from it inside the k-mer.
+__global__ __launch_bounds__(256) void build_absent_kernel(RefIndex R, uint64_t codes, uint8_t *__restrict__ absent)
+{
+	const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= codes) return;
+	uint32_t w[16];
+	const U4 *slot = R.SLOT + c * SLOT_RECS;
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		const U4 v = slot[i];
+		w[4 * i] = v.x, w[4 * i + 1] = v.y, w[4 * i + 2] = v.z, w[4 * i + 3] = v.w;
+	}
+	uint8_t out = 0;
+	if (w[0] == w[1]) { // T[c] == T[c + 1]: no suffix starts with this k-mer
+		LeanLane ln;
+		ln.reset(0u, 0x7fffffffu, 0u, 0u, 0u, 0u);
+		ln.qcode = (uint32_t)(c << (2u * (16u - R.k)));
+		lean_search(ln, R, w);
+		if (ln.fin && ln.ph == LP_STEP && !ln.r_accepted && ln.r_len < R.k && ln.r_len < 255u) out = (uint8_t)(ln.r_len + 1u);
+	}
+	absent[c] = out;
+}
+void launch_build_absent(const RefIndex &R, uint8_t *absent, hipStream_t st)
+{
+	const uint64_t codes = (uint64_t)1 << (2u * R.k);
+	hipLaunchKernelGGL(build_absent_kernel, dim3((uint32_t)((codes + 255) / 256)), dim3(256), 0, st, R, codes, absent);
 }
 
 // ───────────────────────── packed tables ─────────────────────────

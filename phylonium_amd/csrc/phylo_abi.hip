@@ -219,6 +219,9 @@ struct phylo_ctx {
 	DevBuf<uint64_t> d_badoff;
 	uint32_t nsb = 0, sb_first = 0;
 	bool cache_quirk = false; // the reference's 6-mer cache over-reports matches on this subject (hostlogic.hpp: esa_cache_quirks)
+	DevBuf<uint8_t> d_ABS;    // one byte per k-mer: the step of a window whose k-mer does not occur in S (lean_core.h: LeanIndex::absent)
+	int opt_absent_table = 0; // option "absent_table": 1 the chain kernels take such steps from the table, 0 every step fetches its slot (default: measured faster)
+	bool abs_built = false;   // d_ABS holds the table of the installed subject
 	DevBuf<U4> d_quirk;       // its over-deep entries {prefix, k | depth << 8, lo, hi} for the chains' slow resolver (lean_core.h)
 	uint32_t nquirk = 0;
 	int opt_cache_quirk = 1; // option "cache_quirk": 1 reproduce what the reference answers on such a subject (default), 0 the true longest matches
@@ -455,6 +458,7 @@ void phylo_ctx_destroy(phylo_ctx *c)
 	c->d_badscr.release();
 	c->d_badoff.release();
 	c->d_quirk.release();
+	c->d_ABS.release();
 	c->a_flt.release();
 	c->a_long.release();
 	c->a_qoff.release();
@@ -543,6 +547,9 @@ int phylo_set_option(phylo_ctx *c, const char *key, long value)
 		c->opt_cache_quirk = (int)value;
 		c->plan_valid = false;
 		c->homs_staged = false;
+	} else if (k == "absent_table") {
+		if (value != 0 && value != 1) return c->fail("absent_table must be 1 (steps of absent k-mers from the table) or 0 (every step fetches its slot)");
+		c->opt_absent_table = (int)value;
 	} else if (k == "lean_batch") {
 		if (value < 0 || value > 16) return c->fail("lean_batch must be in 0..16");
 		c->opt_lean_batch = (uint32_t)value;
@@ -1027,6 +1034,7 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 		hipLaunchKernelGGL(build_slots_kernel, dim3((uint32_t)((codes + 255) / 256)), dim3(256), 0, st, c->d_T.p,
 						   c->d_SAX.p, ns, codes, c->d_SLOT.p);
 	}
+	c->abs_built = false; // the absence table is built when a call first asks for it (option "absent_table")
 	HIPOK(c, hipGetLastError());
 	HIPOK(c, hipStreamSynchronize(st));
 	double t2b = now_ms();
@@ -1289,9 +1297,15 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	// A subject on which the reference's 6-mer cache holds over-deep intervals (esa.cxx:174-199): the reference's
 	// answers there are reproduced by the lean chains' slow resolver, so every step goes through it (such subjects
 	// are a few kbp in several contigs; option "cache_quirk" = 0 computes the true longest matches instead).
+	if (c->opt_absent_table && !c->abs_built) { // the digest of every empty bucket, once per subject (it depends on the threshold: a match that long is an anchor)
+		HIPOK(c, c->d_ABS.ensure(((size_t)1 << (2 * c->k)) + 16));
+		launch_build_absent(R, c->d_ABS.p, st);
+		HIPOK(c, hipGetLastError());
+		c->abs_built = true;
+	}
 	LeanIndex X = {c->d_S2.p, c->d_SBAD.p, c->nsb, c->ns, c->sb_first, c->d_Q2.p, c->d_QBAD.p, c->d_qbad_off.p + q_begin,
 				   (uint32_t)(c->lean_force_slow || quirk_mode), nullptr, quirk_mode ? c->d_quirk.p : nullptr, quirk_mode ? c->nquirk : 0u,
-				   c->opt_lean_batch};
+				   c->opt_lean_batch, c->opt_absent_table ? c->d_ABS.p : (const uint8_t *)nullptr};
 #ifdef PHY_LEAN_TIMING
 	static unsigned long long *dbg_buf = nullptr;
 	if (!dbg_buf) (void)hipMalloc((void **)&dbg_buf, 16 * 8);

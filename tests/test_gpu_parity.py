@@ -51,6 +51,9 @@ def check_process(ctx, gs, ref, chunk=0, kmer=0, backend=0, complete_deletion=Fa
     check_process.fb = (getattr(check_process, "fb", 0) + 1) % 4
     ctx.set_option("fold_blocks", (0, 3, 8, 1)[check_process.fb])
     ctx.set_option("lean_batch", (0, 0, 2, 3)[check_process.fb])  # the chains' rarer phases on every n-th trip only
+    # steps of k-mers that do not occur in the reference from the absence table (default) / every step through its slot
+    check_process.ab = (getattr(check_process, "ab", 0) + 1) % 5
+    ctx.set_option("absent_table", 0 if check_process.ab == 4 else 1)
     # genomes arrive as bytes or as 2-bit codes + separator positions (phylo_set_genomes_packed), alternating
     check_process.pk = 1 - getattr(check_process, "pk", 0)
     if check_process.pk:
@@ -101,6 +104,7 @@ def check_process(ctx, gs, ref, chunk=0, kmer=0, backend=0, complete_deletion=Fa
     ctx.set_option("pairs_kernel", 0)
     ctx.set_option("fold_blocks", 0)
     ctx.set_option("lean_batch", 0)
+    ctx.set_option("absent_table", 1)
     return s, h
 
 
