@@ -332,6 +332,7 @@ def main():
     ap.add_argument("--lean-batch", type=int, default=-1, help="dev: the chain kernels' rarer phases on every n-th trip only")
     ap.add_argument("--tail-groups", type=int, default=0, help="dev: phase A's tail on this many streams (library default when 0)")
     ap.add_argument("--sa-builder", type=int, default=-1, help="dev: who builds the reference's suffix array: 1 the device, 0 the host cores (library default when < 0)")
+    ap.add_argument("--chunk-tail", type=int, default=0, help="dev: chunk length of the second half of every query (phase A)")
     ap.add_argument("--pairs-wchunk", type=int, default=0, help="dev: windows per chunk of the pair kernel (library's choice when 0)")
     ap.add_argument("--d-range", default="", help="dev: lo,hi — override the workload's divergence range")
     ap.add_argument("--emulate-rank", default="", help="dev: R/N — time rank R of N's share of the work on this one GPU "
@@ -395,6 +396,8 @@ def main():
     ctx.set_option("profile", 0 if args.no_profile else 1)
     if args.chunk:
         ctx.set_option("chunk", args.chunk)
+    if args.chunk_tail:
+        ctx.set_option("chunk_tail", args.chunk_tail)
     if args.kmer:
         ctx.set_option("kmer", args.kmer)
     if args.anchor_kernel >= 0:
@@ -711,6 +714,7 @@ def main():
                                                          "PMC profile: the pair kernel is bound by its matrix and vector instructions "
                                                          "(roofline_mfma; DESIGN.md, section 12.1), not by HBM"} if tb > 0 else None)(
                 sum(kern[k] for k in kern if k.startswith("pileup_")) / K, phase_b_traffic),
+            "phase_a_plan": {"chunk": stats.get("anchor:chunk"), "chunks": (stats.get("count:chunks") or 0) / max(1.0, stats.get("n:anchor_calls") or 1.0)},
             "setup_s": {"generate": round(t_gen, 2), "reference_index": round(t_ref, 2),
                         "suffix_array": round((ref_stats["ms:ref_suffix_array"] or 0) / 1e3, 3),
                         "suffix_array_builder": "device" if ref_stats["ref:sa_on_device"] else "host"},

@@ -11,7 +11,7 @@ namespace phy {
 
 // lean_kernels.hip: the chain kernels on 2-bit packed operands (default), and the packed tables
 int lean_spec_resident_blocks(int n_cu);
-void launch_lean_spec(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st);
+void launch_lean_spec(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st, int max_blocks = 0); // max_blocks > 0: no more blocks than that
 void launch_lean_overruns(const PhaseA &A, const RefIndex &R, uint32_t nq, hipStream_t st); // between spec and bridge
 void launch_lean_bridge(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st);
 // the bridges of chunks [c_lo, c_hi) only (a group of queries), work counter A.fetch[fetch_slot]

@@ -421,6 +421,9 @@ struct LeanAlloc {
 	}
 };
 
+#ifndef PHY_PRIO_ROT
+#define PHY_PRIO_ROT 16u // trips between two turns of the wavefronts' issue priorities (0: no rotation)
+#endif
 // MODE 0: speculative chunk chains.  MODE 1: bridges.  Persistent lanes with dynamic work fetch.
 // it_count != 0: the work items are the chunks it_base .. it_base + it_count - 1 themselves (the bridges of a group of
 // queries), counted through A.fetch[fetch_slot]; else A.items[0 .. nchunks) through A.fetch[MODE].
@@ -444,10 +447,16 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 	}
 	bool active = false, done = false;
 	uint32_t trip = 0;
+#if PHY_PRIO_ROT
+	const uint32_t prio_pass = (uint32_t)(((uint64_t)blockIdx.x * 4u) / gridDim.x);
+#endif
 	LeanAlloc alloc = {&A};
 	ln.fin = false;
 	ln.ph = LP_STEP;
 #ifdef PHY_LEAN_TIMING
+	const unsigned long long t_wave0 = __builtin_amdgcn_s_memrealtime();
+	unsigned long long first_query = ~0ull;
+	unsigned long long phase_trips[8] = {0, 0, 0, 0, 0, 0, 0, 0}, phase_lanes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	unsigned long long tm[6] = {0, 0, 0, 0, 0, 0}, t_prev = clock64();
 #define LEAN_TICK(i)                                                                                                    \
 	{                                                                                                                   \
@@ -477,6 +486,9 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 			done = it >= (it_count ? it_count : A.nchunks);
 			if (!done) {
 				L.start(A, X, it_count ? it_base + it : A.items[it]);
+#ifdef PHY_LEAN_TIMING
+				if (first_query == ~0ull) first_query = A.chunk_query[it_count ? it_base + it : A.items[it]];
+#endif
 				if constexpr (MODE == 0) {
 					vis.lo = L.vis_idx; // the chunk's words: from its first position to its end (chunks are multiples of 64 positions)
 					vis.hi = lean_visited_word(ln, L.q_end_full);
@@ -531,6 +543,18 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 		// resolver).  Those phases are run on every M-th trip only; in between their lanes sit the trip out and the
 		// wavefront runs the STEP path alone.
 		trip++;
+#if PHY_PRIO_ROT
+		// The SIMD's arbiter breaks ties between ready wavefronts by age: of the three or four chain wavefronts a SIMD holds,
+		// the one dispatched first issues first, trip after trip, and the last one is left the gaps — same trips, 20 % longer
+		// (measured per wavefront).  Rotating priorities even that out.
+		if ((trip & (PHY_PRIO_ROT - 1u)) == 0u) {
+			const uint32_t pr = ((trip / PHY_PRIO_ROT) + prio_pass) & 3u;
+			if (pr == 0u) __builtin_amdgcn_s_setprio(0);
+			else if (pr == 1u) __builtin_amdgcn_s_setprio(1);
+			else if (pr == 2u) __builtin_amdgcn_s_setprio(2);
+			else __builtin_amdgcn_s_setprio(3);
+		}
+#endif
 		if (X.batch > 1 && ph != LP_STEP && (trip % X.batch) != 0) ph = (uint32_t)LP_SLOW + 8u;
 		// one batch of loads for every phase
 		const uint8_t *pA = s2_b, *pB = s2_b, *pY = s2_b;
@@ -551,6 +575,14 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 			pB = pA + 32;
 		}
 		LEAN_TICK(1)
+#ifdef PHY_LEAN_TIMING
+		for (uint32_t p = 0; p < 7; p++) {
+			const unsigned long long m = __ballot(ph == p);
+			if (m) phase_trips[p]++;
+			phase_lanes[p] += (unsigned long long)__popcll(m);
+		}
+		if (__ballot(active && ph == LP_STEP && ln.lucky_ok(R))) phase_trips[7]++;
+#endif
 		uint32_t d[16], y[2];
 		{
 			const U4 x0 = lg16(pA), x1 = lg16(pA + 16), x2 = lg16(pB), x3 = lg16(pB + 16);
@@ -606,6 +638,18 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 	if (X.dbg && lane64() == 0) {
 		for (int i = 0; i < 6; i++) atomicAdd(&X.dbg[MODE * 8 + i], tm[i]);
 		atomicAdd(&X.dbg[MODE * 8 + 6], 1ull);
+		for (int i = 0; i < 8; i++) {
+			atomicAdd(&X.dbg[16 + 4 * 8192 + MODE * 16 + i], phase_trips[i]);
+			atomicAdd(&X.dbg[16 + 4 * 8192 + MODE * 16 + 8 + i], phase_lanes[i]);
+		}
+		atomicAdd(&X.dbg[16 + 4 * 8192 + 32 + MODE], (unsigned long long)trip);
+		if (MODE == 0) { // per wavefront: start, end (100 MHz counter), trips, the first chunk's query
+			unsigned long long *w = X.dbg + 16 + 4 * (size_t)(blockIdx.x * 4 + (tid >> 6));
+			w[0] = t_wave0;
+			w[1] = __builtin_amdgcn_s_memrealtime();
+			w[2] = trip;
+			w[3] = first_query;
+		}
 	}
 #endif
 }
@@ -820,9 +864,10 @@ int lean_spec_resident_blocks(int n_cu)
 	cache.store(((uint64_t)(uint32_t)n_cu << 32) | (uint32_t)blocks, std::memory_order_release);
 	return blocks;
 }
-void launch_lean_spec(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st)
+void launch_lean_spec(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st, int max_blocks)
 {
 	int blocks = lean_spec_resident_blocks(n_cu);
+	if (max_blocks > 0 && max_blocks < blocks) blocks = max_blocks;
 	const int need = (int)((A.nchunks + 255) / 256);
 	if (need < blocks) blocks = need > 0 ? need : 1;
 	hipLaunchKernelGGL(lean_chain_kernel<0>, dim3(blocks), dim3(256), 0, st, A, R, X, 0u, 0u, 0u);

@@ -192,6 +192,7 @@ struct phylo_ctx {
 
 	// options
 	uint32_t opt_chunk = 0, opt_chunk_tail = 0, opt_kmer = 0;
+	int plan_spec_per_cu = 4; // blocks of the speculative chain kernel per CU the plan was made for
 	bool profile = false;
 	int backend = 0;
 	int host_threads = 0;
@@ -1194,16 +1195,15 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 			// speculative chunk compare to the end of the genome.
 			if (q_begin + j == c->ref_idx) qlen[j] = 0;
 		}
-		// The lean kernels fit more blocks on a CU than the chunk grid should be planned for: with one
-		// chunk per lane, more lanes mean shorter chunks, i.e. more bridges and more chunk starts, and
-		// measured on C3 that costs more than the extra lanes hide (4 blocks per CU: 3.8 ms, 5: 4.1 ms).
-		// speculative-chain blocks per CU the plan counts on: 4 for large inputs, 3 below ~1.2 Gbp of queries — there
-		// the longer chunks of fewer lanes win (a rank's eighth of C4: 1.90 -> 1.79 ms, 64 x 5 Mbp: 1.19 -> 1.06; C3 the
-		// same either way; C4 11.9 -> 12.8 with 3)
-		uint64_t total_q = 0;
-		for (uint32_t l : qlen) total_q += l;
-		int per_cu_cap = total_q < 1200000000ull ? 3 : 4;
+		// Blocks of the chain kernels per CU, for the plan and for the launch alike.  The kernels are bound by the
+		// instructions they issue, not by waiting, as long as the k-mer slot table is the 1-4 GB of k <= 13: a fourth
+		// wavefront on a SIMD then only makes every trip of the other three longer, and since the speculative kernel
+		// ends with its slowest chain, three blocks with longer chunks finish earlier than four with shorter ones
+		// (C3: 3.51 -> 3.29 ms, C4: 13.06 -> 12.38, 128 x 20 Mbp: 8.49 -> 7.64, close or distant genomes alike).
+		// The 17 GB table of k = 14 (C5's 100 Mbp subject) answers slowly enough for the fourth to pay: 21.9 against 24.1 ms.
+		int per_cu_cap = c->k >= 14 ? 4 : 3;
 		if (const char *e = getenv("PHY_SPEC_PER_CU")) per_cu_cap = std::max(1, atoi(e)); // experiments
+		c->plan_spec_per_cu = per_cu_cap;
 		const int resident = lean_chains ? std::min(lean_spec_resident_blocks(c->n_cu), per_cu_cap * c->n_cu) : spec_resident_blocks(c->n_cu);
 		c->plan = plan_chunks(qlen, c->threshold, c->opt_chunk, (uint32_t)resident * 256u, c->opt_chunk_tail,
 							  lean_chains ? (uint32_t)c->n_cu * 256u : 0u);
@@ -1308,8 +1308,9 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 				   c->opt_lean_batch, c->opt_absent_table ? c->d_ABS.p : (const uint8_t *)nullptr};
 #ifdef PHY_LEAN_TIMING
 	static unsigned long long *dbg_buf = nullptr;
-	if (!dbg_buf) (void)hipMalloc((void **)&dbg_buf, 16 * 8);
-	(void)hipMemsetAsync(dbg_buf, 0, 16 * 8, st);
+	const size_t dbg_words = 16 + 4 * 8192 + 48;
+	if (!dbg_buf) (void)hipMalloc((void **)&dbg_buf, dbg_words * 8);
+	(void)hipMemsetAsync(dbg_buf, 0, dbg_words * 8, st);
 	X.dbg = dbg_buf;
 #endif
 	const bool lean = lean_chains;
@@ -1330,7 +1331,7 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	if (nch) {
 		{
 			KernelSpan s(c, "anchor_spec");
-			if (lean) launch_lean_spec(A, R, X, c->n_cu, st);
+			if (lean) launch_lean_spec(A, R, X, c->n_cu, st, c->plan_spec_per_cu * c->n_cu);
 			else launch_spec(A, R, c->n_cu, st);
 		}
 		dbg_sync("anchor_spec");
@@ -1445,9 +1446,24 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	dbg_sync("anchor tail (bridge, fold, filter, projection)");
 #ifdef PHY_LEAN_TIMING
 	{
-		unsigned long long h[16];
+		std::vector<unsigned long long> hv(dbg_words);
+		unsigned long long *h = hv.data();
 		(void)hipStreamSynchronize(st);
-		(void)hipMemcpy(h, X.dbg, sizeof h, hipMemcpyDeviceToHost);
+		(void)hipMemcpy(h, X.dbg, dbg_words * 8, hipMemcpyDeviceToHost);
+		for (int m = 0; m < 2; m++) {
+			const unsigned long long *pt = h + 16 + 4 * 8192 + m * 16, trips = h[16 + 4 * 8192 + 32 + m];
+			fprintf(stderr, "[lean timing] mode %d trips %llu; share of trips with a lane in STEP %.3f SEARCH %.3f SCAN %.3f EXT %.3f REFILL %.3f SLOW %.3f SLOWEXT %.3f, lucky STEP %.3f; lanes per trip: STEP %.1f SEARCH %.2f SCAN %.2f EXT %.1f REFILL %.2f SLOW %.3f\n",
+					m, trips, (double)pt[0] / trips, (double)pt[1] / trips, (double)pt[2] / trips, (double)pt[3] / trips, (double)pt[4] / trips,
+					(double)pt[5] / trips, (double)pt[6] / trips, (double)pt[7] / trips, (double)pt[8] / trips, (double)pt[9] / trips,
+					(double)pt[10] / trips, (double)pt[11] / trips, (double)pt[12] / trips, (double)pt[13] / trips);
+		}
+		if (const char *wf = getenv("PHY_LEAN_WAVES_OUT")) {
+			if (FILE *f = fopen(wf, "w")) { // the last call's speculative wavefronts: start, end (10 ns), trips, query
+				for (size_t w = 0; w < 8192; w++)
+					if (h[16 + 4 * w + 1]) fprintf(f, "%llu %llu %llu %llu\n", h[16 + 4 * w], h[16 + 4 * w + 1], h[16 + 4 * w + 2], h[16 + 4 * w + 3]);
+				fclose(f);
+			}
+		}
 		for (int m = 0; m < 2; m++)
 			fprintf(stderr, "[lean timing] mode %d waves %llu  Mcycles: bookkeeping %.1f  phase+address %.1f  loads %.1f  digest %.1f  slow %.1f; resolves %llu, long compares %llu\n",
 					m, h[m * 8 + 6], h[m * 8 + 0] / 1e6, h[m * 8 + 1] / 1e6, h[m * 8 + 2] / 1e6, h[m * 8 + 3] / 1e6, h[m * 8 + 4] / 1e6,
