@@ -456,6 +456,7 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 #ifdef PHY_LEAN_TIMING
 	const unsigned long long t_wave0 = __builtin_amdgcn_s_memrealtime();
 	unsigned long long first_query = ~0ull;
+	unsigned long long ext_cnt[6] = {0, 0, 0, 0, 0, 0};
 	unsigned long long phase_trips[8] = {0, 0, 0, 0, 0, 0, 0, 0}, phase_lanes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	unsigned long long tm[6] = {0, 0, 0, 0, 0, 0}, t_prev = clock64();
 #define LEAN_TICK(i)                                                                                                    \
@@ -609,7 +610,22 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 				ring[(ln.wb + (uint32_t)i) & 15u][tid] = d[i]; // the query words double as the ring's new content
 			}
 			sw[8] = y[0];
+#ifdef PHY_LEAN_TIMING
+			const uint32_t ext_first = ln.e_pos == 16u ? 1u : 0u, ext_kind = ln.e_kind == EXT_LUCKY ? 1u : 0u;
+#endif
 			lean_ext(ln, R, X, d, sw);
+#ifdef PHY_LEAN_TIMING
+			{
+				const bool over = ln.ph != LP_EXT; // the comparison ended in this trip
+				const uint32_t len = ln.fin ? ln.r_len : 0xffffu;
+				ext_cnt[0] += ext_first && ext_kind;          // first EXT trip of a lucky check
+				ext_cnt[1] += ext_first && !ext_kind;         // ... of a candidate
+				ext_cnt[2] += !ext_first;                     // a later one
+				ext_cnt[3] += ext_first && over && ln.fin && len < 32u;
+				ext_cnt[4] += ext_first && over && ln.fin && len < 48u;
+				ext_cnt[5] += ext_first && over && !ln.fin;   // went on to SEARCH / SLOW
+			}
+#endif
 		} else if (ph == LP_SCAN) {
 			lean_scan(ln, R, U4{d[0], d[1], d[2], d[3]}, U4{d[4], d[5], d[6], d[7]}, U4{d[8], d[9], d[10], d[11]},
 					  U4{d[12], d[13], d[14], d[15]});
@@ -643,6 +659,13 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 			atomicAdd(&X.dbg[16 + 4 * 8192 + MODE * 16 + 8 + i], phase_lanes[i]);
 		}
 		atomicAdd(&X.dbg[16 + 4 * 8192 + 32 + MODE], (unsigned long long)trip);
+		}
+		for (int i = 0; i < 6; i++) { // (per lane)
+			unsigned long long v = ext_cnt[i];
+			for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+			if (lane64() == 0) atomicAdd(&X.dbg[16 + 4 * 8192 + 34 + MODE * 6 + i], v);
+		}
+		if (X.dbg && lane64() == 0) {
 		if (MODE == 0) { // per wavefront: start, end (100 MHz counter), trips, the first chunk's query
 			unsigned long long *w = X.dbg + 16 + 4 * (size_t)(blockIdx.x * 4 + (tid >> 6));
 			w[0] = t_wave0;

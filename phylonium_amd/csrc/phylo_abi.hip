@@ -1308,7 +1308,7 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 				   c->opt_lean_batch, c->opt_absent_table ? c->d_ABS.p : (const uint8_t *)nullptr};
 #ifdef PHY_LEAN_TIMING
 	static unsigned long long *dbg_buf = nullptr;
-	const size_t dbg_words = 16 + 4 * 8192 + 48;
+	const size_t dbg_words = 16 + 4 * 8192 + 64;
 	if (!dbg_buf) (void)hipMalloc((void **)&dbg_buf, dbg_words * 8);
 	(void)hipMemsetAsync(dbg_buf, 0, dbg_words * 8, st);
 	X.dbg = dbg_buf;
@@ -1456,6 +1456,11 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 					m, trips, (double)pt[0] / trips, (double)pt[1] / trips, (double)pt[2] / trips, (double)pt[3] / trips, (double)pt[4] / trips,
 					(double)pt[5] / trips, (double)pt[6] / trips, (double)pt[7] / trips, (double)pt[8] / trips, (double)pt[9] / trips,
 					(double)pt[10] / trips, (double)pt[11] / trips, (double)pt[12] / trips, (double)pt[13] / trips);
+		}
+		for (int m = 0; m < 2; m++) {
+			const unsigned long long *e = h + 16 + 4 * 8192 + 34 + m * 6;
+			fprintf(stderr, "[lean timing] mode %d EXT lane-trips: first of a lucky check %llu, first of a candidate %llu, later %llu; of the first ones: match < 32 bases %llu, < 48 bases %llu, on to SEARCH/SLOW %llu\n",
+					m, e[0], e[1], e[2], e[3], e[4], e[5]);
 		}
 		if (const char *wf = getenv("PHY_LEAN_WAVES_OUT")) {
 			if (FILE *f = fopen(wf, "w")) { // the last call's speculative wavefronts: start, end (10 ns), trips, query
