@@ -803,12 +803,15 @@ static const uint32_t ITEM_RUN = 256; // consecutive chunks of one query in the 
 // `quantum` (0: not used) = lanes of one block on every CU: below one chunk per lane the chunk count aims at a whole
 // number of blocks per CU — 3.2 blocks per CU means a fifth of the CUs works a third longer than the rest (64 x 5 Mbp:
 // 2.46 -> 2.24 ms per pass with 3.0).
+// `groups` > 1: the queries go through the kernels in that many groups one behind the other (group_items below), so
+// the chunk length is what a group's share of the bases asks for.
 static inline ChunkPlan plan_chunks(const std::vector<uint32_t> &qlen, uint32_t threshold, uint32_t forced_C,
-									uint32_t lanes = 256u * 4u * 256u, uint32_t forced_Cs = 0, uint32_t quantum = 0)
+									uint32_t lanes = 256u * 4u * 256u, uint32_t forced_Cs = 0, uint32_t quantum = 0, uint32_t groups = 1)
 {
 	ChunkPlan P;
 	uint64_t total = 0;
 	for (uint32_t l : qlen) total += l;
+	if (groups > 1) total = (total + groups - 1) / groups;
 	uint32_t C = forced_C, Cs = forced_Cs;
 	double tail_frac = forced_Cs ? 0.5 : 0.0;
 	if (C == 0) {
@@ -884,6 +887,35 @@ static inline ChunkPlan plan_chunks(const std::vector<uint32_t> &qlen, uint32_t 
 			for (uint32_t e = 0; e < ITEM_RUN; e++)
 				if (P.qchunk0[j] + P.qnb[j] + r + e < P.qchunk0[j + 1]) P.items.push_back(P.qchunk0[j] + P.qnb[j] + r + e);
 	return P;
+}
+
+// The work order for groups of queries that go through phase A one behind the other (group g = queries
+// [gb[g], gb[g+1])): each group's chunks in plan_chunks' order among themselves, the groups back to back.
+// Returns the groups' first items (and the total at the end).
+static inline std::vector<uint32_t> group_items(ChunkPlan &P, const std::vector<uint32_t> &gb)
+{
+	std::vector<uint32_t> first;
+	std::vector<uint32_t> items;
+	items.reserve(P.nchunks);
+	for (size_t g = 0; g + 1 < gb.size(); g++) {
+		first.push_back((uint32_t)items.size());
+		uint32_t maxb = 0, maxs = 0;
+		for (uint32_t j = gb[g]; j < gb[g + 1]; j++) {
+			maxb = std::max(maxb, P.qnb[j]);
+			maxs = std::max(maxs, P.qchunk0[j + 1] - P.qchunk0[j] - P.qnb[j]);
+		}
+		for (uint32_t r = 0; r < maxb; r += ITEM_RUN)
+			for (uint32_t j = gb[g]; j < gb[g + 1]; j++)
+				for (uint32_t e = 0; e < ITEM_RUN; e++)
+					if (r + e < P.qnb[j]) items.push_back(P.qchunk0[j] + r + e);
+		for (uint32_t r = 0; r < maxs; r += ITEM_RUN)
+			for (uint32_t j = gb[g]; j < gb[g + 1]; j++)
+				for (uint32_t e = 0; e < ITEM_RUN; e++)
+					if (P.qchunk0[j] + P.qnb[j] + r + e < P.qchunk0[j + 1]) items.push_back(P.qchunk0[j] + P.qnb[j] + r + e);
+	}
+	first.push_back((uint32_t)items.size());
+	P.items.swap(items);
+	return first;
 }
 
 } // namespace phy

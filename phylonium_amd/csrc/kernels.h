@@ -12,7 +12,12 @@ namespace phy {
 // lean_kernels.hip: the chain kernels on 2-bit packed operands (default), and the packed tables
 int lean_spec_resident_blocks(int n_cu);
 void launch_lean_spec(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st, int max_blocks = 0); // max_blocks > 0: no more blocks than that
+// the speculative chunks A.items[item_lo .. item_lo + item_count) only (a group of queries), work counter A.fetch[fetch_slot]
+void launch_lean_spec_range(const PhaseA &A, const RefIndex &R, const LeanIndex &X, uint32_t item_lo, uint32_t item_count,
+							uint32_t fetch_slot, int n_cu, hipStream_t st, int max_blocks = 0);
 void launch_lean_overruns(const PhaseA &A, const RefIndex &R, uint32_t nq, hipStream_t st); // between spec and bridge
+// ... of the queries [j0, j1), whose chunks are [c_lo, c_hi)
+void launch_lean_overruns_range(const PhaseA &A, const RefIndex &R, uint32_t c_lo, uint32_t c_hi, uint32_t j0, uint32_t j1, hipStream_t st);
 void launch_lean_bridge(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st);
 // the bridges of chunks [c_lo, c_hi) only (a group of queries), work counter A.fetch[fetch_slot]
 void launch_lean_bridge_range(const PhaseA &A, const RefIndex &R, const LeanIndex &X, uint32_t c_lo, uint32_t c_hi,

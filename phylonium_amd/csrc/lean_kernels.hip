@@ -290,12 +290,12 @@ static __device__ void coop_ext(LeanLane &ln, int leader, const PhaseA &A, const
 // chunk's end: LINK bit), or is this the last chunk of such a run — then the match is compared on, by
 // the whole wavefront, at most two chunk lengths, and the chunk is closed except for its flag bits
 // (neighbouring lanes still read them).
-__global__ __launch_bounds__(64) void lean_overrun_direct_kernel(PhaseA A, RefIndex R)
+__global__ __launch_bounds__(64) void lean_overrun_direct_kernel(PhaseA A, RefIndex R, uint32_t c_lo, uint32_t c_hi)
 {
 	if (*A.overrun == 0) return;
 	const uint32_t lane = lane64();
-	const uint32_t gc0 = blockIdx.x * 64u + lane;
-	const bool on = gc0 < A.nchunks;
+	const uint32_t gc0 = c_lo + blockIdx.x * 64u + lane; // chunks [c_lo, c_hi): whole queries
+	const bool on = gc0 < c_hi;
 	const uint32_t gc = on ? gc0 : 0u;
 	const uint8_t *s_end = R.S + R.n + 64;
 	const uint32_t j = A.chunk_query[gc];
@@ -325,11 +325,11 @@ __global__ __launch_bounds__(64) void lean_overrun_direct_kernel(PhaseA A, RefIn
 // Pass 2, one wavefront per query, its chunks from the last to the first, 64 at a time: a linked chunk
 // takes the end of the nearest closed chunk above it (pointer doubling inside the group, a carry between
 // groups); all flag bits are cleared.
-__global__ __launch_bounds__(64) void lean_overrun_chain_kernel(PhaseA A, uint32_t nq)
+__global__ __launch_bounds__(64) void lean_overrun_chain_kernel(PhaseA A, uint32_t j0, uint32_t j1)
 {
 	if (*A.overrun == 0) return;
-	const uint32_t j = blockIdx.x;
-	if (j >= nq) return;
+	const uint32_t j = j0 + blockIdx.x; // queries [j0, j1)
+	if (j >= j1) return;
 	const uint32_t c0 = A.qchunk0[j], c1 = A.qchunk0[j + 1];
 	const uint32_t lane = lane64();
 	uint32_t car_end = 0;
@@ -426,7 +426,8 @@ struct LeanAlloc {
 #endif
 // MODE 0: speculative chunk chains.  MODE 1: bridges.  Persistent lanes with dynamic work fetch.
 // it_count != 0: the work items are the chunks it_base .. it_base + it_count - 1 themselves (the bridges of a group of
-// queries), counted through A.fetch[fetch_slot]; else A.items[0 .. nchunks) through A.fetch[MODE].
+// queries) or, with bit 31 of fetch_slot set, A.items[it_base .. it_base + it_count) (a group's speculative chunks in
+// their work order), counted through A.fetch[fetch_slot & 0xff]; else A.items[0 .. nchunks) through A.fetch[MODE].
 template <int MODE>
 __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, LeanIndex X, uint32_t it_base, uint32_t it_count,
 														 uint32_t fetch_slot)
@@ -483,12 +484,13 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 			else active = L.begin_step(A, X, R);
 		}
 		if (!active && !done) {
-			const uint32_t it = atomicAdd(&A.fetch[it_count ? fetch_slot : (uint32_t)MODE], 1u);
+			const uint32_t it = atomicAdd(&A.fetch[it_count ? (fetch_slot & 0xffu) : (uint32_t)MODE], 1u);
 			done = it >= (it_count ? it_count : A.nchunks);
 			if (!done) {
-				L.start(A, X, it_count ? it_base + it : A.items[it]);
+				const uint32_t item = !it_count ? A.items[it] : (fetch_slot >> 31) ? A.items[it_base + it] : it_base + it;
+				L.start(A, X, item);
 #ifdef PHY_LEAN_TIMING
-				if (first_query == ~0ull) first_query = A.chunk_query[it_count ? it_base + it : A.items[it]];
+				if (first_query == ~0ull) first_query = A.chunk_query[item];
 #endif
 				if constexpr (MODE == 0) {
 					vis.lo = L.vis_idx; // the chunk's words: from its first position to its end (chunks are multiples of 64 positions)
@@ -866,9 +868,13 @@ void launch_bad_positions(const uint8_t *base, const uint64_t *off, const uint32
 
 void launch_lean_overruns(const PhaseA &A, const RefIndex &R, uint32_t nq, hipStream_t st)
 {
-	if (!nq || !A.nchunks) return;
-	hipLaunchKernelGGL(lean_overrun_direct_kernel, dim3((A.nchunks + 63u) / 64u), dim3(64), 0, st, A, R);
-	hipLaunchKernelGGL(lean_overrun_chain_kernel, dim3(nq), dim3(64), 0, st, A, nq);
+	launch_lean_overruns_range(A, R, 0u, A.nchunks, 0u, nq, st);
+}
+void launch_lean_overruns_range(const PhaseA &A, const RefIndex &R, uint32_t c_lo, uint32_t c_hi, uint32_t j0, uint32_t j1, hipStream_t st)
+{
+	if (j1 <= j0 || c_hi <= c_lo) return;
+	hipLaunchKernelGGL(lean_overrun_direct_kernel, dim3((c_hi - c_lo + 63u) / 64u), dim3(64), 0, st, A, R, c_lo, c_hi);
+	hipLaunchKernelGGL(lean_overrun_chain_kernel, dim3(j1 - j0), dim3(64), 0, st, A, j0, j1);
 }
 
 static int lean_resident(const void *fn, int n_cu)
@@ -886,6 +892,16 @@ int lean_spec_resident_blocks(int n_cu)
 	const int blocks = lean_resident((const void *)lean_chain_kernel<0>, n_cu);
 	cache.store(((uint64_t)(uint32_t)n_cu << 32) | (uint32_t)blocks, std::memory_order_release);
 	return blocks;
+}
+void launch_lean_spec_range(const PhaseA &A, const RefIndex &R, const LeanIndex &X, uint32_t item_lo, uint32_t item_count,
+							uint32_t fetch_slot, int n_cu, hipStream_t st, int max_blocks)
+{
+	if (!item_count) return;
+	int blocks = lean_spec_resident_blocks(n_cu);
+	if (max_blocks > 0 && max_blocks < blocks) blocks = max_blocks;
+	const int need = (int)((item_count + 255) / 256);
+	if (need < blocks) blocks = need;
+	hipLaunchKernelGGL(lean_chain_kernel<0>, dim3(blocks), dim3(256), 0, st, A, R, X, item_lo, item_count, fetch_slot | 0x80000000u);
 }
 void launch_lean_spec(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st, int max_blocks)
 {

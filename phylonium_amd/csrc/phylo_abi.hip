@@ -180,6 +180,13 @@ struct phylo_ctx {
 	static const int TAIL_GROUPS = 3;
 	hipStream_t tail_stream[TAIL_GROUPS - 1] = {nullptr, nullptr};
 	hipEvent_t tail_event[TAIL_GROUPS] = {nullptr, nullptr, nullptr};
+	// Phase A in groups of queries, one behind the other (option "pipeline_groups"): a group's bridges, fold, filter and
+	// projection run on tail_stream[0] while the next group's speculative chains run on the context's stream.
+	static const int PIPE_GROUPS = 8;
+	int opt_pipeline_groups = 1;           // 0: the library chooses, n: that many (as far as the queries allow)
+	hipEvent_t pipe_event[PIPE_GROUPS + 1] = {}; // group g's speculative chains are done; [PIPE_GROUPS]: the last tail is
+	std::vector<uint32_t> plan_gb;         // the plan's groups: queries [plan_gb[g], plan_gb[g+1]) ...
+	std::vector<uint32_t> plan_item0;      // ... and their items [plan_item0[g], plan_item0[g+1]) of the work order
 	int opt_filter_kernel = 0; // option "filter_kernel": 0 stretch-wise chain filter (then the general kernel for what it hands over), 1 general only
 	int opt_sa_builder = 1; // option "sa_builder": who builds the suffix array when the caller brings none — 1 the device, 0 the host cores
 	uint32_t opt_pairs_wchunk = 0; // option "pairs_wchunk": windows per chunk of the pair kernel (0: chosen from the L2 size)
@@ -502,6 +509,8 @@ void phylo_ctx_destroy(phylo_ctx *c)
 	for (hipEvent_t e : c->copy_events) (void)hipEventDestroy(e);
 	for (hipStream_t ts : c->tail_stream)
 		if (ts) (void)hipStreamDestroy(ts);
+	for (hipEvent_t e : c->pipe_event)
+		if (e) (void)hipEventDestroy(e);
 	for (hipEvent_t e : c->tail_event)
 		if (e) (void)hipEventDestroy(e);
 	if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -534,6 +543,10 @@ int phylo_set_option(phylo_ctx *c, const char *key, long value)
 	} else if (k == "filter_kernel") {
 		if (value != 0 && value != 1) return c->fail("filter_kernel must be 0 (stretch-wise) or 1 (general)");
 		c->opt_filter_kernel = (int)value;
+	} else if (k == "pipeline_groups") {
+		if (value < 0 || value > phylo_ctx::PIPE_GROUPS) return c->fail("pipeline_groups must be in 0..%d", phylo_ctx::PIPE_GROUPS);
+		c->opt_pipeline_groups = (int)value;
+		c->plan_valid = false;
 	} else if (k == "tail_groups") {
 		if (value < 1 || value > phylo_ctx::TAIL_GROUPS) return c->fail("tail_groups must be in 1..%d", phylo_ctx::TAIL_GROUPS);
 		c->opt_tail_groups = (int)value;
@@ -1205,10 +1218,28 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 		if (const char *e = getenv("PHY_SPEC_PER_CU")) per_cu_cap = std::max(1, atoi(e)); // experiments
 		c->plan_spec_per_cu = per_cu_cap;
 		const int resident = lean_chains ? std::min(lean_spec_resident_blocks(c->n_cu), per_cu_cap * c->n_cu) : spec_resident_blocks(c->n_cu);
+		// groups of queries that go through phase A one behind the other: whole projection tiles, balanced by chunks
+		const uint32_t tile_q = project_genomes_per_tile();
+		int pg = c->opt_pipeline_groups;
+		if (pg == 0) pg = 1;
+		pg = (int)std::min<size_t>((size_t)pg, nq / (2 * tile_q));
+		if (!lean_chains || c->filter_mode == 1 || pg < 1) pg = 1;
 		c->plan = plan_chunks(qlen, c->threshold, c->opt_chunk, (uint32_t)resident * 256u, c->opt_chunk_tail,
-							  lean_chains ? (uint32_t)c->n_cu * 256u : 0u);
+							  lean_chains ? (uint32_t)c->n_cu * 256u : 0u, (uint32_t)pg);
+		if (!c->plan.C) return c->fail("phase A: more than 2^32 anchor log slots");
+		{
+			c->plan_gb.assign(pg + 1, 0);
+			c->plan_gb[pg] = (uint32_t)nq;
+			for (int g = 1; g < pg; g++) {
+				const uint32_t want = (uint32_t)((uint64_t)c->plan.nchunks * g / pg);
+				uint32_t j = (uint32_t)(std::lower_bound(c->plan.qchunk0.begin(), c->plan.qchunk0.begin() + nq, want) - c->plan.qchunk0.begin());
+				j = (j + tile_q / 2) / tile_q * tile_q;
+				c->plan_gb[g] = std::min<uint32_t>(std::max(j, c->plan_gb[g - 1]), (uint32_t)nq);
+			}
+			c->plan_item0.clear();
+			if (pg > 1) c->plan_item0 = group_items(c->plan, c->plan_gb);
+		}
 		const ChunkPlan &P = c->plan;
-		if (!P.C) return c->fail("phase A: more than 2^32 anchor log slots");
 		// an emitted homology spans >= 2*threshold query positions
 		c->plan_out_base.assign(nq + 1, 0);
 		std::vector<uint32_t> out_cap(nq);
@@ -1229,7 +1260,7 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 		HIPOK(c, c->a_spec_cnt.ensure(nchp + 1));
 		// one visited bit per byte of the genome buffer (chains address it by buffer offset)
 		HIPOK(c, c->a_visited.ensure((c->goff[c->n - 1] + c->glen[c->n - 1]) / 32 + 8));
-		HIPOK(c, c->a_misc.ensure(16));
+		HIPOK(c, c->a_misc.ensure(32)); // [0..8): counters and flags, [8..16): the groups' bridge counters, [16..24): their chain counters
 		HIPOK(c, c->a_spec_anchors.ensure(P.anchor_slots + 1));
 		HIPOK(c, c->a_qnb.ensure(nq));
 		HIPOK(c, c->a_qanc0.ensure(nq));
@@ -1262,7 +1293,7 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	const uint32_t pool_blocks = nch / 4 + 4096;
 	uint64_t total = 0;
 	for (size_t j = 0; j < nq; j++) total += c->glen[q_begin + j];
-	HIPOK(c, hipMemsetAsync(c->a_misc.p, 0, 16 * 4, st));
+	HIPOK(c, hipMemsetAsync(c->a_misc.p, 0, 32 * 4, st));
 	if (nch) { // the words of this call's queries (their genomes lie back to back in the buffer)
 		const uint64_t w0 = c->goff[q_begin] / 32, w1 = (c->goff[q_end - 1] + c->glen[q_end - 1]) / 32 + 1;
 		HIPOK(c, hipMemsetAsync(c->a_visited.p + w0, 0, (size_t)(w1 - w0) * 4, st));
@@ -1328,7 +1359,8 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 		fprintf(stderr, "[phylonium_amd] %s finished at +%.1f ms (%s), chunks %u of %u positions\n", what, now_ms() - t1,
 				hipGetErrorString(e), nch, P.C);
 	};
-	if (nch) {
+	const bool pipelined = lean && nch && c->plan_gb.size() > 2 && c->filter_mode != 1;
+	if (nch && !pipelined) {
 		{
 			KernelSpan s(c, "anchor_spec");
 			if (lean) launch_lean_spec(A, R, X, c->n_cu, st, c->plan_spec_per_cu * c->n_cu);
@@ -1350,14 +1382,17 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 	// groups of queries for the tail: whole projection tiles, balanced by chunks
 	const uint32_t tsz_q = project_genomes_per_tile();
 	int tgroups = 1;
-	if (lean && device_filter && nch && c->opt_tail_groups > 1) {
+	if (pipelined) {
+		tgroups = (int)c->plan_gb.size() - 1;
+	} else if (lean && device_filter && nch && c->opt_tail_groups > 1) {
 		tgroups = c->opt_tail_groups;
 		tgroups = (int)std::min<size_t>((size_t)tgroups, nq / (2 * tsz_q));
 		if (tgroups < 1) tgroups = 1;
 	}
 	std::vector<uint32_t> gb(tgroups + 1, 0); // group g: queries [gb[g], gb[g+1])
 	gb[tgroups] = (uint32_t)nq;
-	for (int g = 1; g < tgroups; g++) {
+	if (pipelined) gb = c->plan_gb;
+	for (int g = 1; g < tgroups && !pipelined; g++) {
 		const uint32_t want = (uint32_t)((uint64_t)nch * g / tgroups);
 		uint32_t j = (uint32_t)(std::lower_bound(P.qchunk0.begin(), P.qchunk0.begin() + nq, want) - P.qchunk0.begin());
 		j = (j + tsz_q / 2) / tsz_q * tsz_q;
@@ -1389,7 +1424,11 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 			HIPOK(c, c->b_bang.ensure(2 * (size_t)c->bang_cap + 2));
 		}
 	}
-	if (tgroups > 1) {
+	if (pipelined) {
+		if (!c->tail_stream[0]) HIPOK(c, hipStreamCreateWithFlags(&c->tail_stream[0], hipStreamNonBlocking));
+		for (int g = 0; g <= phylo_ctx::PIPE_GROUPS; g++)
+			if (!c->pipe_event[g]) HIPOK(c, hipEventCreateWithFlags(&c->pipe_event[g], hipEventDisableTiming));
+	} else if (tgroups > 1) {
 		for (int g = 0; g < tgroups; g++) {
 			if (g && !c->tail_stream[g - 1]) HIPOK(c, hipStreamCreateWithFlags(&c->tail_stream[g - 1], hipStreamNonBlocking));
 			if (!c->tail_event[g]) HIPOK(c, hipEventCreateWithFlags(&c->tail_event[g], hipEventDisableTiming));
@@ -1397,9 +1436,23 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 		HIPOK(c, hipEventRecord(c->tail_event[0], st)); // the speculative chains (and their overruns) are done
 	}
 	for (int g = 0; g < tgroups; g++) {
-		hipStream_t sg = g ? c->tail_stream[g - 1] : st;
+		hipStream_t sg = pipelined ? c->tail_stream[0] : g ? c->tail_stream[g - 1] : st;
 		const uint32_t j0 = gb[g], j1 = gb[g + 1];
-		if (g) HIPOK(c, hipStreamWaitEvent(sg, c->tail_event[0], 0));
+		if (pipelined) { // this group's speculative chains on the context's stream; its tail follows on the other one
+			{
+				KernelSpan s(c, "anchor_spec");
+				launch_lean_spec_range(A, R, X, c->plan_item0[g], c->plan_item0[g + 1] - c->plan_item0[g], 16u + (uint32_t)g, c->n_cu, st,
+									   c->plan_spec_per_cu * c->n_cu);
+			}
+			{
+				KernelSpan s(c, "anchor_overruns");
+				launch_lean_overruns_range(A, R, P.qchunk0[j0], P.qchunk0[j1], j0, j1, st);
+			}
+			HIPOK(c, hipEventRecord(c->pipe_event[g], st));
+			HIPOK(c, hipStreamWaitEvent(sg, c->pipe_event[g], 0));
+		} else if (g) {
+			HIPOK(c, hipStreamWaitEvent(sg, c->tail_event[0], 0));
+		}
 		if (nch) {
 			KernelSpan s(c, "anchor_bridge", sg);
 			if (!lean) launch_bridge(A, R, c->n_cu, st);
@@ -1438,7 +1491,12 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 							   j0 / tsz_q, g + 1 == tgroups ? TP.Npad / tsz_q : j1 / tsz_q, sg, c->b_bang.p, c->bang_cap);
 			}
 		}
-		if (g) {
+		if (pipelined) {
+			if (g + 1 == tgroups) { // everything behind this call on the context's stream waits for the last tail
+				HIPOK(c, hipEventRecord(c->pipe_event[phylo_ctx::PIPE_GROUPS], sg));
+				HIPOK(c, hipStreamWaitEvent(st, c->pipe_event[phylo_ctx::PIPE_GROUPS], 0));
+			}
+		} else if (g) {
 			HIPOK(c, hipEventRecord(c->tail_event[g], sg));
 			HIPOK(c, hipStreamWaitEvent(st, c->tail_event[g], 0));
 		}

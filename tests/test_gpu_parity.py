@@ -51,9 +51,9 @@ def check_process(ctx, gs, ref, chunk=0, kmer=0, backend=0, complete_deletion=Fa
     check_process.fb = (getattr(check_process, "fb", 0) + 1) % 4
     ctx.set_option("fold_blocks", (0, 3, 8, 1)[check_process.fb])
     ctx.set_option("lean_batch", (0, 0, 2, 3)[check_process.fb])  # the chains' rarer phases on every n-th trip only
-    # steps of k-mers that do not occur in the reference from the absence table (default) / every step through its slot
+    # every step through its k-mer's slot (default) / steps of k-mers that do not occur in the reference from the absence table
     check_process.ab = (getattr(check_process, "ab", 0) + 1) % 5
-    ctx.set_option("absent_table", 0 if check_process.ab == 4 else 1)
+    ctx.set_option("absent_table", 1 if check_process.ab in (1, 3) else 0)
     # genomes arrive as bytes or as 2-bit codes + separator positions (phylo_set_genomes_packed), alternating
     check_process.pk = 1 - getattr(check_process, "pk", 0)
     if check_process.pk:
@@ -104,7 +104,7 @@ def check_process(ctx, gs, ref, chunk=0, kmer=0, backend=0, complete_deletion=Fa
     ctx.set_option("pairs_kernel", 0)
     ctx.set_option("fold_blocks", 0)
     ctx.set_option("lean_batch", 0)
-    ctx.set_option("absent_table", 1)
+    ctx.set_option("absent_table", 0)
     return s, h
 
 
@@ -919,6 +919,38 @@ def test_many_queries_default_options(ctx):
     assert (s == so).all() and (h == ho).all()
     for j in (0, 7, 63, 139):  # read back on demand
         assert hom_tuples_gpu(ctx.homologies(j)) == hom_tuples_orc(r.homologies(j))
+
+
+@pytest.mark.parametrize("groups", [2, 4, 8])
+def test_phase_a_in_groups_of_queries(ctx, groups):
+    """Option pipeline_groups: the queries go through phase A in groups, a group's bridges, fold, filter and projection
+    on a second stream while the next group's speculative chains run.  270 short genomes (four groups need 64 queries
+    each; eight are cut down to four), some of them nearly the reference itself so that chunks end in open matches
+    that the per-group overrun pass has to close.  Tallies and lists equal the oracle's."""
+    gs = synth.make_genomes(258, 6000, seed=91, d_range=(0.005, 0.3), indel_per_mbp=600, inv_frac=0.06)
+    rng = np.random.default_rng(17)
+    base = gs[3]
+    for t in range(12):  # near-copies of the reference below: a substitution or two each
+        g = base.copy()
+        for p in rng.integers(0, len(g), size=1 + t % 3):
+            g[p] = ord("ACGT"[(b"ACGT".index(bytes([g[p]])) + 1) % 4]) if g[p] in b"ACGT" else g[p]
+        gs.insert(int(rng.integers(0, len(gs))), g)
+    ref = next(i for i, g in enumerate(gs) if g is base)
+    r = O.Run(gs, ref).process(threads=4)
+    so, ho = r.matrix()
+    ctx.set_option("filter", 0)
+    ctx.set_option("pipeline_groups", groups)
+    try:
+        for chunk in (256, 0):
+            ctx.set_option("chunk", chunk)
+            ctx.set_genomes(gs)
+            s, h = ctx.process(ref_idx=ref)
+            assert (h == ho).all() and (s == so).all(), chunk
+            for j in (0, 3, 64, 65, 130, 200, len(gs) - 1):
+                assert hom_tuples_gpu(ctx.homologies(j)) == hom_tuples_orc(r.homologies(j)), (chunk, j)
+    finally:
+        ctx.set_option("pipeline_groups", 1)
+        ctx.set_option("chunk", 0)
 
 
 @pytest.mark.parametrize("chunk,tail", [(256, 64), (512, 192), (1024, 256)])
