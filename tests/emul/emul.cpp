@@ -249,6 +249,9 @@ void *emul_run2(size_t n, const char *const *seq, const size_t *len, size_t ref_
 			run_lean_lane(ln, qbase.data(), R, X, LT, [&] { return ln.begin_step(A, X, R); }, [&] { ln.step_done(A, alloc); },
 						  &E->steps_bridge, &E->rounds, &E->slow_steps);
 			if (bstats) bridge_steps.push_back((uint32_t)(E->steps_bridge - before));
+			if (bstats && atoi(getenv("EMUL_BRIDGE_STATS")) > 1 && E->steps_bridge - before >= 30)
+				fprintf(stderr, "long bridge: query %u chunk %u steps %llu from q %u to q %u (last anchor q %u s %u len %u)\n", A.chunk_query[P.items[it]],
+						P.items[it], (unsigned long long)(E->steps_bridge - before), spec_exit[P.items[it]].q, ln.ln.q, ln.ln.lq, ln.ln.ls, ln.ln.ll);
 			continue;
 		}
 		BridgeLane ln;
