@@ -333,6 +333,7 @@ def main():
     ap.add_argument("--tail-groups", type=int, default=0, help="dev: phase A's tail on this many streams (library default when 0)")
     ap.add_argument("--sa-builder", type=int, default=-1, help="dev: who builds the reference's suffix array: 1 the device, 0 the host cores (library default when < 0)")
     ap.add_argument("--pipeline-groups", type=int, default=-1, help="dev: groups of queries phase A is pipelined over (0: the library chooses)")
+    ap.add_argument("--fold-blocks", type=int, default=-1, help="dev: blocks per query of the fold kernel (0: the library chooses)")
     ap.add_argument("--chunk-tail", type=int, default=0, help="dev: chunk length of the second half of every query (phase A)")
     ap.add_argument("--pairs-wchunk", type=int, default=0, help="dev: windows per chunk of the pair kernel (library's choice when 0)")
     ap.add_argument("--d-range", default="", help="dev: lo,hi — override the workload's divergence range")
@@ -401,6 +402,8 @@ def main():
         ctx.set_option("chunk_tail", args.chunk_tail)
     if args.pipeline_groups >= 0:
         ctx.set_option("pipeline_groups", args.pipeline_groups)
+    if args.fold_blocks >= 0:
+        ctx.set_option("fold_blocks", args.fold_blocks)
     if args.kmer:
         ctx.set_option("kmer", args.kmer)
     if args.anchor_kernel >= 0:

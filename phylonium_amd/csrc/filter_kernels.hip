@@ -513,46 +513,45 @@ __global__ __launch_bounds__(FILT_THREADS) void sort_filter_seg_kernel(const Raw
 
 
 // ── lists of more than FILT_MAX entries (queries of tens of Mbp: ~330 homologies per Mbp) ──
-// The same stretch-wise filter with the list in global memory: keys sorted by a bitonic network whose
-// passes with partners less than a tile apart run in LDS (tiles of FILT_MAX keys), the rest in global
-// memory; prefix maximum of the ends, cuts, stretches and output tile by tile with a carry.  One block per
-// list, scratch from a pool of LONG_SLOTS slots (a list that finds none goes to the host).
+// The same stretch-wise filter with the list in global memory.  The keys are sorted by a bitonic network spread over
+// the whole device: a list takes a scratch slot (a list that finds none goes to the host), and every stage of the
+// network is one launch over (slot, tile of FILT_MAX keys) — the passes whose partners lie inside a tile run in LDS
+// on that tile, the passes with partners a whole number of tiles apart on a *transposed* tile (the same columns of
+// every tile row), so a merge level k is two launches whatever its depth.  Then one block per list: prefix maximum
+// of the ends, cuts, stretches and output tile by tile with a carry.  (Round 2 sorted inside that one block: 2000
+// barrier-separated passes for C5's 33 k entries per list, 1.2 of the kernel's 1.7 ms on 64 of the 256 CUs.)
+struct LongMeta {
+	uint32_t n, n2, j, pad;
+};
 struct LongScratch {
 	uint64_t *keys; // [LONG_SLOTS][LONG_MAX_N] start << 32 | raw index
 	uint32_t *ends; // [LONG_SLOTS][LONG_MAX_N] end of the entry at that pile position
 	uint8_t *keep;  // [LONG_SLOTS][LONG_MAX_N] bit 0 kept, bit 1 a stretch starts here
+	LongMeta *meta; // [LONG_SLOTS] the list in the slot: entries, power of two the network runs over, query
 	uint32_t *next_slot;
 };
+static const uint32_t LONG_TILES = LONG_MAX_N / FILT_MAX; // tiles per slot
 
-__global__ __launch_bounds__(FILT_THREADS) void sort_filter_long_kernel(const RawHom *__restrict__ raw,
-																		 const uint64_t *__restrict__ raw_base,
-																		 const uint32_t *__restrict__ raw_cnt, uint32_t j0, uint32_t border,
-																		 DevHom *__restrict__ out, uint32_t *__restrict__ rng,
-																		 uint32_t *__restrict__ total, uint32_t *__restrict__ flag,
-																		 LongScratch S)
+// a slot for every long list, its keys (reverseEh, process.h:72-80) padded to a power of two; rng[2j] holds the slot
+__global__ __launch_bounds__(FILT_THREADS) void long_prepare_kernel(const RawHom *__restrict__ raw, const uint64_t *__restrict__ raw_base,
+																	 const uint32_t *__restrict__ raw_cnt, uint32_t j0, uint32_t border,
+																	 uint32_t *__restrict__ rng, uint32_t *__restrict__ flag, LongScratch S)
 {
-	__shared__ uint64_t tile[FILT_MAX];
-	__shared__ uint32_t wmax[FILT_WAVES], wsum[FILT_WAVES];
-	__shared__ uint32_t s_slot, s_tie, s_general, s_carry, s_base;
-	const uint32_t j = j0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	__shared__ uint32_t s_slot;
+	const uint32_t j = j0 + blockIdx.x, tid = threadIdx.x;
 	if (flag[j] != FLAG_LONG) return;
 	const RawHom *r = raw + raw_base[j];
 	const uint32_t n = raw_cnt[j];
-	if (tid == 0) {
-		s_slot = atomicAdd(S.next_slot, 1u);
-		s_tie = s_general = 0;
-	}
+	if (tid == 0) s_slot = atomicAdd(S.next_slot, 1u);
 	__syncthreads();
 	if (s_slot >= LONG_SLOTS) {
 		if (tid == 0) flag[j] = FLAG_HOST;
 		return;
 	}
 	uint64_t *K = S.keys + (size_t)s_slot * LONG_MAX_N;
-	uint32_t *E = S.ends + (size_t)s_slot * LONG_MAX_N;
-	uint8_t *KP = S.keep + (size_t)s_slot * LONG_MAX_N;
 	uint32_t n2 = FILT_MAX;
 	while (n2 < n) n2 <<= 1;
-	for (uint32_t t = tid; t < n2; t += FILT_THREADS) { // reverseEh (process.h:72-80)
+	for (uint32_t t = tid; t < n2; t += FILT_THREADS) {
 		uint64_t key = ~0ull;
 		if (t < n) {
 			const RawHom h = r[t];
@@ -561,50 +560,94 @@ __global__ __launch_bounds__(FILT_THREADS) void sort_filter_long_kernel(const Ra
 		}
 		K[t] = key;
 	}
+	if (tid == 0) {
+		S.meta[s_slot] = LongMeta{n, n2, j, 0u};
+		rng[2 * j] = s_slot;
+	}
+}
+
+// merge levels k_lo .. k_hi (powers of two), the passes with partners less than a tile apart: block = (slot, tile)
+__global__ __launch_bounds__(FILT_THREADS) void long_sort_low_kernel(LongScratch S, uint32_t k_lo, uint32_t k_hi)
+{
+	__shared__ uint64_t tile[FILT_MAX];
+	const uint32_t slot = blockIdx.x / LONG_TILES, base = (blockIdx.x % LONG_TILES) * FILT_MAX, tid = threadIdx.x;
+	const uint32_t used = *S.next_slot < LONG_SLOTS ? *S.next_slot : LONG_SLOTS;
+	if (slot >= used) return;
+	const uint32_t n2 = S.meta[slot].n2;
+	if (base >= n2 || k_lo > n2) return;
+	uint64_t *K = S.keys + (size_t)slot * LONG_MAX_N + base;
+	for (uint32_t t = tid; t < FILT_MAX; t += FILT_THREADS) tile[t] = K[t];
 	__syncthreads();
-	// bitonic sort of n2 keys: for every k, the passes with j >= FILT_MAX in global memory, the rest per tile in LDS
-	for (uint32_t k = 2; k <= n2; k <<= 1) {
-		uint32_t jj = k >> 1;
-		for (; jj >= FILT_MAX; jj >>= 1) {
-			for (uint32_t t = tid; t < n2; t += FILT_THREADS) {
-				const uint32_t x = t ^ jj;
+	for (uint32_t kk = k_lo; kk <= k_hi && kk <= n2; kk <<= 1) {
+		for (uint32_t j2 = (kk > FILT_MAX ? FILT_MAX : kk) >> 1; j2 > 0; j2 >>= 1) {
+			for (uint32_t t = tid; t < FILT_MAX; t += FILT_THREADS) {
+				const uint32_t x = t ^ j2;
 				if (x > t) {
-					const uint64_t u = K[t], v = K[x];
-					if ((u > v) == ((t & k) == 0)) {
-						K[t] = v;
-						K[x] = u;
+					const uint64_t u = tile[t], v = tile[x];
+					if ((u > v) == (((base + t) & kk) == 0)) {
+						tile[t] = v;
+						tile[x] = u;
 					}
 				}
 			}
-			__syncthreads();
-		}
-		if (k > FILT_MAX && jj == 0) continue;
-		// k <= FILT_MAX: the tile phases of all such k can run back to back in LDS — done once, below, for k == 2
-		if (k <= FILT_MAX && k != 2) continue;
-		for (uint32_t base = 0; base < n2; base += FILT_MAX) {
-			for (uint32_t t = tid; t < FILT_MAX; t += FILT_THREADS) tile[t] = K[base + t];
-			__syncthreads();
-			const uint32_t k_lo = k <= FILT_MAX ? 2u : k, k_hi = k <= FILT_MAX ? FILT_MAX : k;
-			for (uint32_t kk = k_lo; kk <= k_hi; kk <<= 1) {
-				for (uint32_t j2 = (kk > FILT_MAX ? FILT_MAX : kk) >> 1; j2 > 0; j2 >>= 1) {
-					for (uint32_t t = tid; t < FILT_MAX; t += FILT_THREADS) {
-						const uint32_t x = t ^ j2;
-						if (x > t) {
-							const uint64_t u = tile[t], v = tile[x];
-							if ((u > v) == (((base + t) & kk) == 0)) {
-								tile[t] = v;
-								tile[x] = u;
-							}
-						}
-					}
-					__syncthreads();
-				}
-				if (kk == k_hi) break;
-			}
-			for (uint32_t t = tid; t < FILT_MAX; t += FILT_THREADS) K[base + t] = tile[t];
 			__syncthreads();
 		}
 	}
+	for (uint32_t t = tid; t < FILT_MAX; t += FILT_THREADS) K[t] = tile[t];
+}
+
+// merge level k > FILT_MAX, the passes with partners a whole number of tiles apart: the list as rows of FILT_MAX keys,
+// block = (slot, group of columns) holds those columns of every row
+__global__ __launch_bounds__(FILT_THREADS) void long_sort_high_kernel(LongScratch S, uint32_t k)
+{
+	__shared__ uint64_t tile[FILT_MAX];
+	const uint32_t slot = blockIdx.x / LONG_TILES, grp = blockIdx.x % LONG_TILES, tid = threadIdx.x;
+	const uint32_t used = *S.next_slot < LONG_SLOTS ? *S.next_slot : LONG_SLOTS;
+	if (slot >= used) return;
+	const uint32_t n2 = S.meta[slot].n2;
+	if (k > n2) return;
+	const uint32_t rows = n2 / FILT_MAX; // >= 2, a power of two
+	if (grp >= rows) return;
+	const uint32_t cols = FILT_MAX / rows, col0 = grp * cols; // (rows * cols = FILT_MAX keys per block)
+	uint64_t *K = S.keys + (size_t)slot * LONG_MAX_N;
+	for (uint32_t t = tid; t < FILT_MAX; t += FILT_THREADS) tile[t] = K[(t / cols) * FILT_MAX + col0 + (t % cols)];
+	__syncthreads();
+	for (uint32_t jj = k >> 1; jj >= FILT_MAX; jj >>= 1) {
+		const uint32_t rr = jj / FILT_MAX;
+		for (uint32_t t = tid; t < FILT_MAX; t += FILT_THREADS) {
+			const uint32_t row = t / cols, c = t % cols;
+			if ((row ^ rr) > row) {
+				const uint32_t x = (row ^ rr) * cols + c;
+				const uint64_t u = tile[t], v = tile[x];
+				if ((u > v) == (((row * FILT_MAX) & k) == 0)) {
+					tile[t] = v;
+					tile[x] = u;
+				}
+			}
+		}
+		__syncthreads();
+	}
+	for (uint32_t t = tid; t < FILT_MAX; t += FILT_THREADS) K[(t / cols) * FILT_MAX + col0 + (t % cols)] = tile[t];
+}
+
+__global__ __launch_bounds__(FILT_THREADS) void sort_filter_long_kernel(const RawHom *__restrict__ raw,
+																		 const uint64_t *__restrict__ raw_base,
+																		 const uint32_t *__restrict__ raw_cnt, uint32_t j0, uint32_t border,
+																		 DevHom *__restrict__ out, uint32_t *__restrict__ rng,
+																		 uint32_t *__restrict__ total, uint32_t *__restrict__ flag,
+																		 LongScratch S)
+{
+	__shared__ uint32_t wmax[FILT_WAVES], wsum[FILT_WAVES];
+	__shared__ uint32_t s_tie, s_general, s_carry, s_base;
+	const uint32_t j = j0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	if (flag[j] != FLAG_LONG) return;
+	const RawHom *r = raw + raw_base[j];
+	const uint32_t n = raw_cnt[j];
+	const uint32_t slot = rng[2 * j]; // (long_prepare_kernel)
+	if (tid == 0) s_tie = s_general = 0;
+	uint64_t *K = S.keys + (size_t)slot * LONG_MAX_N;
+	uint32_t *E = S.ends + (size_t)slot * LONG_MAX_N;
+	uint8_t *KP = S.keep + (size_t)slot * LONG_MAX_N;
 	// ends, equal starts, prefix maximum of the ends and the cuts, tile by tile
 	if (tid == 0) s_carry = 0;
 	__syncthreads();
@@ -736,7 +779,7 @@ __global__ __launch_bounds__(FILT_THREADS) void sort_filter_long_kernel(const Ra
 	}
 }
 
-size_t long_filter_scratch_bytes() { return (size_t)LONG_SLOTS * LONG_MAX_N * (8 + 4 + 1) + 64; }
+size_t long_filter_scratch_bytes() { return (size_t)LONG_SLOTS * LONG_MAX_N * (8 + 4 + 1) + LONG_SLOTS * sizeof(LongMeta) + 64; }
 uint32_t long_filter_min_entries() { return FILT_MAX; }
 
 void launch_sort_filter_long(const RawHom *raw, const uint64_t *raw_base, const uint32_t *raw_cnt, uint32_t j0, uint32_t j1,
@@ -747,8 +790,16 @@ void launch_sort_filter_long(const RawHom *raw, const uint64_t *raw_base, const 
 	LongScratch S;
 	S.keys = (uint64_t *)scratch;
 	S.ends = (uint32_t *)(S.keys + (size_t)LONG_SLOTS * LONG_MAX_N);
-	S.keep = (uint8_t *)(S.ends + (size_t)LONG_SLOTS * LONG_MAX_N);
+	S.meta = (LongMeta *)(S.ends + (size_t)LONG_SLOTS * LONG_MAX_N);
+	S.keep = (uint8_t *)(S.meta + LONG_SLOTS);
 	S.next_slot = slot_counter;
+	hipLaunchKernelGGL(long_prepare_kernel, dim3(j1 - j0), dim3(FILT_THREADS), 0, st, raw, raw_base, raw_cnt, j0, border, rng, flag, S);
+	const dim3 grid(LONG_SLOTS * LONG_TILES);
+	hipLaunchKernelGGL(long_sort_low_kernel, grid, dim3(FILT_THREADS), 0, st, S, 2u, FILT_MAX);
+	for (uint32_t k = 2 * FILT_MAX; k <= LONG_MAX_N; k <<= 1) {
+		hipLaunchKernelGGL(long_sort_high_kernel, grid, dim3(FILT_THREADS), 0, st, S, k);
+		hipLaunchKernelGGL(long_sort_low_kernel, grid, dim3(FILT_THREADS), 0, st, S, k, k);
+	}
 	hipLaunchKernelGGL(sort_filter_long_kernel, dim3(j1 - j0), dim3(FILT_THREADS), 0, st, raw, raw_base, raw_cnt, j0, border, out, rng,
 					   total, flag, S);
 }
