@@ -10,7 +10,8 @@ out = {}
 
 NAMES = [  # substring of the kernel's name -> the name bench.py and the library's stats use; first match wins
     ("chain_kernel<0>", "anchor_spec"), ("chain_kernel<1>", "anchor_bridge"), ("fold_kernel", "anchor_fold"),
-    ("sort_filter_seg_kernel", "anchor_filter"), ("sort_filter_long_kernel", "anchor_filter_long"), ("sort_filter_kernel", "anchor_filter_general"),
+    ("sort_filter_seg_kernel", "anchor_filter"), ("sort_filter_long_kernel", "anchor_filter_long"),
+    ("long_sort_low_kernel", "anchor_filter_long_sort_tiles"), ("long_sort_high_kernel", "anchor_filter_long_sort_rows"), ("long_prepare_kernel", "anchor_filter_long_keys"), ("sort_filter_kernel", "anchor_filter_general"),
     ("lean_overrun_direct_kernel", "anchor_overruns_direct"), ("lean_overrun_chain_kernel", "anchor_overruns_chain"),
     ("gather_lists_kernel", "export_gather"), ("block_export_kernel", "exchange_block_export"), ("block_attach_kernel", "exchange_block_attach"),
     ("check_lists_kernel", "exchange_check_lists"), ("compact_raw_kernel", "anchor_compact"),
