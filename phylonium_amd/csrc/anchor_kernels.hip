@@ -284,6 +284,7 @@ __device__ __forceinline__ void lds_barrier()
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+static const uint32_t FOLD_STAGE = 1024;
 struct FoldShared {
 	uint32_t tgt[FOLD_WCH], idxm[FOLD_WCH], bn[FOLD_WCH], blk[FOLD_WCH], scnt[FOLD_WCH];
 	const Anchor *seg_ptr[FOLD_SEGS];
@@ -299,6 +300,9 @@ struct FoldShared {
 	uint32_t wl_q[FOLD_WAVES], wl_s[FOLD_WAVES], wl_len[FOLD_WAVES], wl_r[FOLD_WAVES]; // last anchor of each wave and its right flag
 	uint32_t st_has[FOLD_WAVES], st_s[FOLD_WAVES], st_q[FOLD_WAVES]; // latest non-right anchor of each wave
 	uint32_t ecnt[FOLD_WAVES];
+	// several blocks per query: a block's homologies wait here until FOLD_STAGE of them go out behind one atomic
+	RawHom stage[FOLD_STAGE];
+	uint32_t stage_base;
 };
 
 // Several blocks per query (nb of them; blockIdx = query * nb + part): every block walks the windows itself — the
@@ -325,6 +329,32 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j
 	uint32_t lq = 0, ls = 0, ll = 0, lr = 0, cs = 0, cq = 0, cnt = 0; // (cnt: homologies so far, one block per query only)
 	uint32_t gc = c_begin, idx = 0;
 	bool more = c_begin < c_end;
+	uint32_t stg_n = 0; // homologies in the block's stage (the same in every thread)
+	auto flush_stage = [&]() {
+		__syncthreads();
+		if (stg_n) {
+			if (tid == 0) sh.stage_base = atomicAdd(&out_cnt[j], stg_n);
+			__syncthreads();
+			const uint32_t b = sh.stage_base;
+			for (uint32_t t = tid; t < stg_n; t += FOLD_THREADS) {
+				if (b + t < cap) dst[b + t] = sh.stage[t];
+				else *A.error = 3;
+			}
+			__syncthreads();
+		}
+		stg_n = 0;
+	};
+#ifdef PHY_FOLD_TIMING
+	unsigned long long ft[6] = {0, 0, 0, 0, 0, 0}, ft_prev = __builtin_amdgcn_s_memrealtime();
+#define FOLD_TICK(i)                                                    \
+	{                                                                   \
+		const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); \
+		ft[i] += now_ - ft_prev;                                        \
+		ft_prev = now_;                                                 \
+	}
+#else
+#define FOLD_TICK(i)
+#endif
 
 	while (more) {
 		// (1) metadata window [gc, gc + FOLD_WCH)
@@ -339,6 +369,7 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j
 			sh.scnt[t] = A.spec_cnt[wbeg + t];
 		}
 		__syncthreads();
+		FOLD_TICK(0)
 		// (2) walk.  Every chunk has one outgoing link (its bridge's merge target), so the
 		// true chain inside the window is found without following it link by link:
 		//   jump[k][t]  by doubling;  dist[t] = number of links until the window is left;
@@ -348,17 +379,26 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j
 		// Then block-wide prefix sums over the chain give every live chunk its segment
 		// slots and anchor offsets.
 		const uint32_t SINK = wn; // any node >= wn means "outside the window"
+		bool plain_mine = true; // every chunk's link goes to the next chunk (or out of the window from the last one)
 		for (uint32_t t = tid; t <= wn; t += FOLD_THREADS) {
 			uint32_t nx = SINK;
 			if (t < wn) {
 				uint32_t tg = sh.tgt[t];
 				if (tg != BRIDGE_END && tg - wbeg < wn) nx = tg - wbeg;
+				plain_mine = plain_mine && nx == t + 1u;
 			}
 			sh.jump[0][t] = (uint16_t)nx;
 			sh.dist[t] = t < wn ? 1 : 0;
 			sh.live[t] = 0;
 		}
-		__syncthreads();
+		// Nearly every window is like that — a bridge that ends beyond the next chunk has walked a whole chunk without
+		// meeting the speculative chain — and then the chain is the window itself: no doubling, no marking (30 barriers).
+		const bool plain = __syncthreads_and(plain_mine ? 1 : 0) != 0;
+		if (plain) {
+			for (uint32_t t = tid; t < wn; t += FOLD_THREADS) sh.path[t] = (uint16_t)t;
+			if (tid == 0) sh.dist[0] = (uint16_t)wn;
+			__syncthreads();
+		} else {
 		for (uint32_t k = 0; k < 10; k++) {
 			uint32_t nd[FOLD_WCH / FOLD_THREADS + 1], nj[FOLD_WCH / FOLD_THREADS + 1], c = 0;
 			for (uint32_t t = tid; t <= wn; t += FOLD_THREADS, c++) {
@@ -385,10 +425,13 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j
 				}
 			__syncthreads();
 		}
-		const uint32_t npath = sh.dist[entry]; // live chunks in this window
+		const uint32_t npath_walked = sh.dist[entry]; // live chunks in this window
 		for (uint32_t t = tid; t < wn; t += FOLD_THREADS)
-			if (sh.live[t]) sh.path[npath - sh.dist[t]] = (uint16_t)t;
+			if (sh.live[t]) sh.path[npath_walked - sh.dist[t]] = (uint16_t)t;
 		__syncthreads();
+		}
+		const uint32_t npath = sh.dist[gc - wbeg];
+		FOLD_TICK(1)
 		// segments: every thread takes FOLD_PPT consecutive chain positions
 		{
 			uint32_t my_seg[FOLD_PPT], my_an[FOLD_PPT], my_spec[FOLD_PPT], my_idx[FOLD_PPT];
@@ -480,6 +523,7 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j
 		}
 		__syncthreads();
 		const uint32_t nseg = sh.nseg, total = sh.seg_off[nseg];
+		FOLD_TICK(2)
 		// (3) block-parallel fold over the window's `total` anchors, FOLD_ITER per iteration
 		// (FOLD_APT consecutive anchors per thread: the shuffles, scans and barriers of an
 		// iteration are a fixed latency chain, so it pays to put many anchors behind each).
@@ -548,6 +592,7 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j
 		const uint32_t it0 = (uint32_t)((uint64_t)n_it * part / nb), it1 = (uint32_t)((uint64_t)n_it * (part + 1) / nb);
 		const uint32_t base0 = it0 * FOLD_ITER, base1 = it1 * FOLD_ITER < total ? it1 * FOLD_ITER : total;
 		if (nb > 1 && it0 < it1) carry_at(base0);
+		FOLD_TICK(3)
 		uint32_t cur = 0; // segment cursor of this thread (anchor indices only grow)
 		Anchor an[FOLD_APT];
 		uint32_t evn = 0;
@@ -677,22 +722,37 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j
 			lds_barrier();
 			// slots of the query's list: one block per query counts them itself (query order); several blocks take them
 			// from the query's counter, a wavefront at a time
-			uint32_t slot;
+			// With several blocks the slots come from the query's counter.  An atomic per wavefront and iteration (round 3's
+			// first version) put its round trip — and, the counters being in-order, the wait for the next iteration's
+			// anchors already requested — into every iteration: 21 us instead of 10.  The block's homologies are staged in
+			// LDS instead and leave FOLD_STAGE at a time behind one atomic.
+			uint32_t slot = pe - ne, tot = 0;
+			for (uint32_t w2 = 0; w2 < wave; w2++) slot += sh.ecnt[w2];
+			for (uint32_t w2 = 0; w2 < FOLD_WAVES; w2++) tot += sh.ecnt[w2];
+			bool staged = false;
 			if (nb == 1) {
-				slot = cnt + pe - ne;
-				for (uint32_t w2 = 0; w2 < wave; w2++) slot += sh.ecnt[w2];
-				for (uint32_t w2 = 0; w2 < FOLD_WAVES; w2++) cnt += sh.ecnt[w2];
+				slot += cnt;
+				cnt += tot;
 			} else {
-				uint32_t wbase = 0;
-				if (lane == 63 && pe) wbase = atomicAdd(&out_cnt[j], pe);
-				slot = (uint32_t)__shfl((int)wbase, 63, 64) + pe - ne;
+				if (stg_n + tot > FOLD_STAGE) flush_stage();
+				if (tot > FOLD_STAGE) { // (more than the stage holds in one iteration: straight out)
+					if (tid == 0) sh.stage_base = atomicAdd(&out_cnt[j], tot);
+					__syncthreads();
+					slot += sh.stage_base;
+				} else {
+					slot += stg_n;
+					stg_n += tot;
+					staged = true;
+				}
 			}
 #pragma unroll
 			for (uint32_t e = 0; e < FOLD_APT; e++) {
 				if ((em >> e) & 1u) {
 					const Anchor &pv = e == 0 ? prev0 : a[e ? e - 1 : 0];
-					if (slot < cap) {
-						RawHom h = {rs, rq, pv.q + pv.len - rq};
+					const RawHom h = {rs, rq, pv.q + pv.len - rq};
+					if (staged) {
+						sh.stage[slot] = h;
+					} else if (slot < cap) {
 						dst[slot] = h;
 					} else {
 						*A.error = 3;
@@ -720,12 +780,20 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j
 		}
 		// the carry behind the window's last anchor: every block needs it for the next window (and block 0 for the
 		// query's last homology); the block that folded the window's end has it already
+		FOLD_TICK(4)
 		if (nb > 1 && !(it0 < it1 && base1 == total)) carry_at(total);
+		FOLD_TICK(5)
 		more = !sh.finished;
 		gc = sh.next_gc;
 		idx = sh.next_idx;
 		__syncthreads();
 	}
+	if (nb > 1) flush_stage();
+#ifdef PHY_FOLD_TIMING
+	if (tid == 0 && blockIdx.x / nb == 1)
+		printf("fold timing, query %u part %u of %u (us): metadata %.1f  walk %.1f  segments %.1f  carry in %.1f  fold %.1f  carry out %.1f\n", j, part,
+			   nb, ft[0] / 100.0, ft[1] / 100.0, ft[2] / 100.0, ft[3] / 100.0, ft[4] / 100.0, ft[5] / 100.0);
+#endif
 	// fold_finish (process.cxx:285-292)
 	if (tid == 0 && part == 0) {
 		uint32_t fs = cs, fq = cq, flen = lq + ll - cq;
