@@ -57,7 +57,10 @@ static __device__ __forceinline__ DevHom gload_hom(const DevHom *p)
 }
 
 static const uint32_t PROJ_TW = 64; // words per tile
-static const uint32_t PROJ_TG = 32; // genomes per tile (LDS: 5*64*33*4 = 42 KB → 3 blocks per CU)
+#ifndef PHY_PROJ_TG
+#define PHY_PROJ_TG 32
+#endif
+static const uint32_t PROJ_TG = PHY_PROJ_TG; // genomes per tile (LDS with three planes: 3*64*(TG+1)*4 = 25 KB at 32 → 5 blocks per CU)
 static const uint32_t PROJ_GPW = PROJ_TG / 4; // genomes per wavefront
 
 // Projection: one block per tile of 64 reference windows × 32 genomes.
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256) void tile_index_kernel(Pileup P, QuerySrc Q, c
 	first[tid] = lo | flag;
 }
 
-static const uint32_t PROJ_HM = 8; // homology descriptors cached per genome and tile
+static const uint32_t PROJ_HM = 256 / PROJ_TG; // homology descriptors cached per genome and tile (one per thread)
 
 // FIVE = false writes V, N0, N1 only (and still raises bang_flag when a projected
 // position holds '!'): the host then repeats the projection with all five planes.
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256) void project_kernel(Pileup P, QuerySrc Q,
 	}
 	// the tile's homology descriptors: two dependent rounds for the whole block
 	{
-		const uint32_t gl = threadIdx.x >> 3, e = threadIdx.x & 7u; // PROJ_TG * PROJ_HM == 256
+		const uint32_t gl = threadIdx.x / PROJ_HM, e = threadIdx.x % PROJ_HM; // PROJ_TG * PROJ_HM == 256
 		const uint32_t g = tg * PROJ_TG + gl;
 		DevHom hm = {0xffffffffu, 0, 0, 0};
 		uint32_t lo = 0, h1 = 0, bad = 0;
@@ -308,14 +311,15 @@ __global__ __launch_bounds__(256) void project_kernel(Pileup P, QuerySrc Q,
 	// rows [w][g0..g0+31] out: 128 contiguous bytes per row; a thread keeps its genome
 	// column and walks down the rows
 	{
-		const uint32_t gl = threadIdx.x & 31u, wl0 = threadIdx.x >> 5;
+		constexpr uint32_t RPP = 256 / PROJ_TG; // rows per pass of the block
+		const uint32_t gl = threadIdx.x % PROJ_TG, wl0 = threadIdx.x / PROJ_TG;
 		const uint32_t g = tg * PROJ_TG + gl;
 #pragma unroll
 		for (uint32_t p = 0; p < NP; p++) {
 			uint32_t *dst = P.plane[p] + (size_t)(tw * PROJ_TW + wl0) * P.Npad + g;
 #pragma unroll
-			for (uint32_t k = 0; k < PROJ_TW / 8; k++)
-				if (tw * PROJ_TW + wl0 + 8 * k < P.W) dst[(size_t)(8 * k) * P.Npad] = tile[p][wl0 + 8 * k][gl];
+			for (uint32_t k = 0; k < PROJ_TW / RPP; k++)
+				if (tw * PROJ_TW + wl0 + RPP * k < P.W) dst[(size_t)(RPP * k) * P.Npad] = tile[p][wl0 + RPP * k][gl];
 		}
 	}
 }
