@@ -68,7 +68,15 @@ const char *phylo_last_error(const phylo_ctx *ctx);
  * to the host, as the reference's order of such ties is libstdc++'s — 1 on the host cores; the results are
  * the same), "host_threads", "anchor_kernel" (phase A's chain
  * kernels: 1, the default, the lean kernels on 2-bit packed operands; 0 the general byte-wise ones — same
- * results), "lean_force_slow" (1: every step of the lean kernels through their wave-cooperative slow resolver). */
+ * results), "lean_force_slow" (1: every step of the lean kernels through their wave-cooperative slow resolver),
+ * "filter_kernel" (the device filter: 0 stretch by stretch, 1 the general dependent scan only), "sa_builder" (the
+ * reference's suffix array: 1 on the device, 0 on the host cores), "cache_quirk" (1, the default: a subject on which
+ * the reference's 6-mer cache holds over-deep intervals is matched as the reference matches it; 0: true longest
+ * matches), "pairs_kernel" (phase B's pair tallies: 0 on the matrix cores, 1 on the vector ALUs), "pairs_wchunk"
+ * (windows per chunk of the pair kernels), "fold_blocks" (blocks per query of the fold kernel, 0: the library
+ * chooses), "pipeline_groups" (phase A in that many groups of queries, a group's tail under the next group's chains;
+ * 1, the default: one group), "tail_groups", "lean_batch", "absent_table" (variants of the chain kernels kept for the
+ * tests: measured, not faster — DESIGN.md section 12).  Every setting gives the same results. */
 int phylo_set_option(phylo_ctx *ctx, const char *key, long value);
 /* Accumulated since the last phylo_reset_stats: "ms:<kernel>", "n:<kernel>"
  * (HIP-event time and launch count per kernel when profiling is on),

@@ -377,6 +377,22 @@ int emul_suffix_array_buckets(const uint8_t *s, uint32_t n, uint32_t *sa, uint32
 	return suffix_array_buckets(padded.data(), n, sa, fan, threads) ? 1 : 0;
 }
 void emul_lcp(const uint8_t *s, uint32_t n, const uint32_t *sa, uint32_t *lcp) { lcp_kasai(s, n, sa, lcp); }
+// the chunk plan of `nq` queries for `groups` groups with boundaries gb[0..groups] (hostlogic.hpp: plan_chunks,
+// group_items): out_items[nchunks] = the work order, out_first[groups + 1] = the groups' first items, info = {C, nchunks}
+size_t emul_plan_groups(const uint32_t *qlen, uint32_t nq, uint32_t threshold, uint32_t lanes, uint32_t groups, const uint32_t *gb,
+						uint32_t *out_items, uint32_t *out_first, uint32_t *out_qchunk0, uint32_t *info)
+{
+	std::vector<uint32_t> ql(qlen, qlen + nq);
+	ChunkPlan P = plan_chunks(ql, threshold, 0, lanes, 0, 0, groups);
+	std::vector<uint32_t> first = {0u, P.nchunks};
+	if (groups > 1) first = group_items(P, std::vector<uint32_t>(gb, gb + groups + 1));
+	if (out_items) std::copy(P.items.begin(), P.items.end(), out_items);
+	if (out_first) std::copy(first.begin(), first.end(), out_first);
+	if (out_qchunk0) std::copy(P.qchunk0.begin(), P.qchunk0.end(), out_qchunk0);
+	info[0] = P.C;
+	info[1] = P.nchunks;
+	return P.items.size();
+}
 size_t emul_kmer_table(const uint8_t *s, uint32_t n, uint32_t k, uint32_t *out)
 {
 	std::vector<uint32_t> T;

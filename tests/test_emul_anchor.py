@@ -332,3 +332,29 @@ def test_cache_quirk_is_reproduced():
         finally:
             os.environ.pop("EMUL_NO_QUIRK", None)
     assert differs > 0
+
+
+def test_work_order_for_groups_of_queries():
+    """hostlogic.hpp: plan_chunks(groups) + group_items (option pipeline_groups).  The chunk length is planned for a
+    group's share of the bases; the work order is a permutation of all chunks in which every group's chunks are
+    contiguous, and inside a group the runs of 256 chunks are dealt round-robin over its queries as in the plain plan."""
+    rng = np.random.default_rng(3)
+    qlen = rng.integers(200_000, 3_000_000, size=40).astype(np.uint32)
+    qlen[7] = 0  # the subject among the queries has no chunks
+    lanes = 64 * 256
+    c1, items1, first1, qc1 = E.plan_groups(qlen, 15, lanes, [0, 40])
+    assert first1.tolist() == [0, items1.size] and sorted(items1.tolist()) == list(range(items1.size))
+    gb = [0, 9, 22, 31, 40]
+    c4, items, first, qc0 = E.plan_groups(qlen, 15, lanes, gb)
+    assert c4 <= c1 and c4 % 64 == 0  # a quarter of the bases per group: shorter chunks (or the shortest allowed)
+    n = items.size
+    assert n == qc0[-1] and sorted(items.tolist()) == list(range(n))
+    assert first[0] == 0 and first[-1] == n
+    for g in range(4):
+        mine = items[first[g]:first[g + 1]]
+        lo, hi = qc0[gb[g]], qc0[gb[g + 1]]
+        assert mine.size == hi - lo and mine.min(initial=lo) >= lo and mine.max(initial=lo) < hi
+        # the first item of every run of a query's chunks: runs of one query ascend
+        for j in range(gb[g], gb[g + 1]):
+            own = mine[(mine >= qc0[j]) & (mine < qc0[j + 1])]
+            assert (np.diff(own.astype(np.int64)) > 0).all()
