@@ -227,6 +227,9 @@ int phylo_triangle_to_matrices(phylo_ctx *ctx, const uint32_t *dev_tri, uint64_t
 
 /* ── B2 in one call ── */
 int phylo_process(phylo_ctx *ctx, size_t ref_idx, int flags, uint64_t *subst, uint64_t *homologs);
+/* phylo_anchor(all genomes) + phylo_compare_all against the reference already set, as the one call they are in
+ * process() (src/process.cxx:408-556): phase B is queued behind phase A and the host waits once, for the result. */
+int phylo_anchor_compare(phylo_ctx *ctx, uint64_t *subst, uint64_t *homologs);
 
 /* ── several GPUs of one node behind one host (csrc/group.hip) ──
  * process() shards without a data-path collective inside either phase: phase A by query block (the loop at

@@ -32,7 +32,7 @@ SYMBOLS = [
     "phylo_group_create", "phylo_group_destroy", "phylo_group_last_error", "phylo_group_size", "phylo_group_ctx", "phylo_group_backend",
     "phylo_group_set_option", "phylo_group_get_stat", "phylo_group_set_genomes_packed", "phylo_group_set_reference", "phylo_group_anchor",
     "phylo_group_compare", "phylo_group_process",
-    "phylo_complete_delete", "phylo_compare", "phylo_compare_all", "phylo_process", "phylo_seqcmp",
+    "phylo_complete_delete", "phylo_compare", "phylo_compare_all", "phylo_process", "phylo_anchor_compare", "phylo_seqcmp",
     "phylo_revseqcmp", "phylo_seqcmp_batch", "phylo_host_suffix_array", "phylo_host_reference_suffix_array", "phylo_host_min_anchor_length",
     "phylo_host_read_fasta", "phylo_host_read_fasta_packed", "phylo_host_free_packed", "phylo_host_free", "phylo_host_median_length_index",
     "phylo_host_sort_filter", "phylo_estimate", "phylo_format_phylip", "phylo_version",
@@ -115,6 +115,7 @@ def load():
     L.phylo_group_compare.argtypes = [vp, vp, vp]
     L.phylo_group_process.argtypes = [vp, vp, vp]
     L.phylo_process.argtypes = [vp, sz, C.c_int, vp, vp]
+    L.phylo_anchor_compare.argtypes = [vp, vp, vp]
     L.phylo_seqcmp.restype = sz
     L.phylo_seqcmp.argtypes = [vp, vp, sz]
     L.phylo_revseqcmp.restype = sz
@@ -405,6 +406,13 @@ class Context:
             h = np.empty((self.n, self.n), np.uint64)
         self._chk(self.L.phylo_compare(self.h, part, nparts, s.ctypes.data_as(C.c_void_p),
                                        h.ctypes.data_as(C.c_void_p)))
+        return s, h
+
+    def anchor_compare(self, out=None):
+        """anchor() over all genomes + compare() as one call (phylo_anchor_compare): the host waits once, for the result."""
+        n = self.n
+        s, h = out if out is not None else (np.empty((n, n), np.uint64), np.empty((n, n), np.uint64))
+        self._chk(self.L.phylo_anchor_compare(self.h, s.ctypes.data_as(C.c_void_p), h.ctypes.data_as(C.c_void_p)))
         return s, h
 
     def process(self, ref_idx, complete_deletion=False):

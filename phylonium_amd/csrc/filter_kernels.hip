@@ -698,7 +698,10 @@ __global__ __launch_bounds__(FILT_THREADS) void sort_filter_long_kernel(const Ra
 		__syncthreads();
 	}
 	if (s_tie) {
-		if (tid == 0) flag[j] = FLAG_HOST;
+		if (tid == 0) {
+			flag[j] = FLAG_HOST;
+			rng[2 * j] = 0; // (held the slot) an empty list until the host has done this query
+		}
 		return;
 	}
 	// the stretches that start at this thread's entries
@@ -738,7 +741,10 @@ __global__ __launch_bounds__(FILT_THREADS) void sort_filter_long_kernel(const Ra
 	}
 	__syncthreads();
 	if (s_general) { // an entangled stretch beyond what a thread takes: the host does this list
-		if (tid == 0) flag[j] = FLAG_HOST;
+		if (tid == 0) {
+			flag[j] = FLAG_HOST;
+			rng[2 * j] = 0;
+		}
 		return;
 	}
 	// output in pile order, tile by tile

@@ -256,6 +256,9 @@ struct phylo_ctx {
 	int filter_mode = 0; // option "filter": 0 device sort + filter for 128 queries or more, host below; 1 host; 2 device
 	DevBuf<uint32_t> a_flt; // [0] kept total, [1..nq] per-query flags of the device sort + filter
 	DevBuf<uint8_t> a_long; // scratch slots of the long-list filter kernel (allocated when a query is long enough to need it)
+	bool anchor_pending = false; // a deferred phase A is queued: its flags (h_rng) have not been read yet
+	double pend_t0 = 0, pend_t1 = 0, pend_t2 = 0, pend_total = 0;
+	uint32_t pend_nch = 0, pend_C = 0;
 	bool homs_staged = false;
 	// ... and has projected them for the whole reference (part 0 of 1); with five planes or three
 	bool eager_valid = false, eager_five = false;
@@ -1175,9 +1178,12 @@ static int make_pileup(phylo_ctx *c, size_t part, size_t nparts, Pileup *out)
 	return 0;
 }
 
-int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
+// defer: when this call covers every genome and leaves lists and projection on the device, do not wait for its flags —
+// the caller queues phase B behind it and reads them with the result (phylo_anchor_compare); anchor_pending says so.
+static int anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, bool defer)
 {
 	if (!c) return 1;
+	c->anchor_pending = false;
 	if (!c->have_ref) return c->fail("phylo_anchor: no reference set");
 	if (q_begin > q_end || q_end > c->n) return c->fail("phylo_anchor: bad query range");
 	HIPOK(c, hipSetDevice(c->device));
@@ -1546,6 +1552,14 @@ int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end)
 		HIPOK(c, hipMemcpyAsync(hr + 3 * nq, c->a_flt.p, 4, hipMemcpyDeviceToHost, st));
 		HIPOK(c, hipMemcpyAsync(hr + 3 * nq + 1, c->a_misc.p, 32, hipMemcpyDeviceToHost, st));
 		HIPOK(c, hipGetLastError());
+		if (defer && tail_eager) { // (tail_eager: all genomes, device filter, projection queued)
+			c->pend_t0 = t0, c->pend_t1 = t1, c->pend_t2 = now_ms(), c->pend_total = (double)total, c->pend_nch = nch, c->pend_C = P.C;
+			c->att_homs = c->b_homs.p;
+			c->homs_staged = true;
+			c->eager_valid = true;
+			c->anchor_pending = true;
+			return 0;
+		}
 		if (sync_stream(c)) return 1;
 		double t2d = now_ms();
 		const uint32_t *dmisc = hr + 3 * nq + 1;
@@ -2683,6 +2697,71 @@ int phylo_triangle_to_matrices(phylo_ctx *c, const uint32_t *dev_tri, uint64_t *
 	return 0;
 }
 
+int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end) { return anchor_impl(c, q_begin, q_end, false); }
+
+// what phylo_anchor does with the flags it waits for, after a deferred call's stream has been synchronised by somebody
+// else: 0 lists and ranges are in place, 1 error, 2 a list needs the host (the optimistic state is withdrawn)
+static int anchor_finish(phylo_ctx *c)
+{
+	const size_t N = c->n;
+	const uint32_t *hr = c->h_rng.p, *dmisc = hr + 3 * N + 1;
+	c->anchor_pending = false;
+	size_t flagged = 0;
+	for (size_t j = 0; j < N; j++) flagged += hr[2 * N + j] != 0;
+	if (dmisc[3] || flagged) {
+		c->homs_staged = false;
+		c->eager_valid = false;
+		c->att_homs = nullptr;
+		c->host_stale.clear();
+		if (dmisc[3]) return c->fail("phase A scratch overflow (code %u: 1 chunk log, 2 bridge pool, 3 homology buffer)", dmisc[3]);
+		return 2;
+	}
+	c->att_rng_on_device = false;
+	if (c->att_begin.size() != N) {
+		c->att_begin.assign(N, 0);
+		c->att_count.assign(N, 0);
+	}
+	c->host_stale.assign(N, 0);
+	for (size_t j = 0; j < N; j++) {
+		c->att_begin[j] = hr[2 * j];
+		c->att_count[j] = hr[2 * j + 1] - hr[2 * j];
+		c->host_stale[j] = 1;
+	}
+	c->stats["ms:anchor_setup"] += c->pend_t1 - c->pend_t0;
+	c->stats["ms:anchor_total"] += c->pend_t2 - c->pend_t0; // (the host's part: the device's time is in phase B's wait)
+	c->stats["n:anchor_calls"] += 1;
+	c->stats["n:anchor_calls_without_a_wait"] += 1;
+	c->stats["count:query_bases"] += c->pend_total;
+	c->stats["count:chunks"] += c->pend_nch;
+	c->stats["count:filtered_homologies"] += (double)hr[3 * N];
+	c->stats["count:pool_blocks_used"] += dmisc[2];
+	c->stats["count:overrun_runs"] += dmisc[5];
+	c->stats["count:overrun_bytes_compared"] += dmisc[6];
+	c->stats["anchor:chunk"] = c->pend_C;
+	return 0;
+}
+
+// phylo_anchor(all genomes) + phylo_compare_all as the one call they are in the reference (process(), process.cxx:408-556):
+// phase B is queued behind phase A without the host reading phase A's flags in between — one wait instead of two — and
+// the flags are read with the result.  A list that needs the host after all (two homologies with the same projected
+// start: the reference's order of such ties is libstdc++'s) sends the call the long way round.
+int phylo_anchor_compare(phylo_ctx *c, uint64_t *subst, uint64_t *homologs)
+{
+	if (!c) return 1;
+	int rc = anchor_impl(c, 0, c->n, true);
+	if (rc) return rc;
+	if (!c->anchor_pending) return phylo_compare(c, 0, 1, subst, homologs);
+	rc = phylo_compare(c, 0, 1, subst, homologs); // (synchronises the stream whichever way it ends)
+	if (c->anchor_pending && hipStreamSynchronize(c->stream) != hipSuccess) return c->fail("phylo_anchor_compare: the device failed");
+	const int f = anchor_finish(c);
+	if (f == 1) return 1;
+	if (f == 0) return rc;
+	c->stats["count:anchor_compare_calls_repeated"] += 1;
+	rc = anchor_impl(c, 0, c->n, false);
+	if (rc) return rc;
+	return phylo_compare(c, 0, 1, subst, homologs);
+}
+
 int phylo_compare_all(phylo_ctx *c, uint64_t *subst, uint64_t *homologs)
 {
 	return phylo_compare(c, 0, 1, subst, homologs);
@@ -2693,12 +2772,11 @@ int phylo_process(phylo_ctx *c, size_t ref_idx, int flags, uint64_t *subst, uint
 	if (!c) return 1;
 	int rc = phylo_set_reference(c, ref_idx, nullptr, 0);
 	if (rc) return rc;
+	if (!(flags & PHYLO_COMPLETE_DELETION)) return phylo_anchor_compare(c, subst, homologs);
 	rc = phylo_anchor(c, 0, c->n);
 	if (rc) return rc;
-	if (flags & PHYLO_COMPLETE_DELETION) {
-		rc = phylo_complete_delete(c);
-		if (rc) return rc;
-	}
+	rc = phylo_complete_delete(c);
+	if (rc) return rc;
 	return phylo_compare_all(c, subst, homologs);
 }
 

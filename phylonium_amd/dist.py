@@ -173,6 +173,8 @@ def process_sharded(ctx, ref_idx, rank, world, device=None, lengths=None, set_re
     lens = lengths or getattr(ctx, "lengths", None)
     bounds = [query_shard(ctx.n, r, world, lens)[0] for r in range(world)] + [ctx.n]
     qb, qe = bounds[rank], bounds[rank + 1]
+    if world == 1 and not _FORCE_COLLECTIVES and hasattr(ctx, "anchor_compare"):
+        return ctx.anchor_compare(out=out)  # one rank: both phases as the one call they are in the reference
     ctx.anchor(qb, qe)
     on_gpu = device is not None and torch.device(device).type == "cuda" and hasattr(ctx, "attach_packed_device")
     if on_gpu and (world > 1 or _FORCE_COLLECTIVES) and hasattr(ctx, "export_block_device") and not _LEGACY_DEVICE_EXCHANGE:

@@ -280,11 +280,18 @@ Matrix process(Run &r, size_t ref_idx, const int64_t *sa = nullptr)
 					 "its answers are reproduced here, so the distances are phylonium's, not those of the true longest matches" << std::endl;
 	// phase A: every GPU anchors its block of the queries, then every GPU holds all lists (rank 0's context
 	// hands out any of them)
+	std::vector<uint64_t> s(N * N), h(N * N);
+	if (!r.grp && !(r.flags & (F_COMPLETE_DELETION | F_POSITIONS))) {
+		// nothing between the phases: both as one call, the host waits once
+		ok(r, phylo_anchor_compare(r.ctx, s.data(), h.data()));
+		Matrix m(N * N);
+		for (size_t k = 0; k < N * N; k++) m[k] = Tally{s[k], h[k]};
+		return m;
+	}
 	if (r.grp) gok(r, phylo_group_anchor(r.grp));
 	else ok(r, phylo_anchor(r.ctx, 0, N));
 	if (r.flags & F_COMPLETE_DELETION) ok(r, phylo_complete_delete(r.ctx));
 	if (r.flags & F_POSITIONS) write_positions(r, ref_idx);
-	std::vector<uint64_t> s(N * N), h(N * N);
 	// phase B: by range of reference windows over the GPUs — or, after the N-way intersection of the lists on the
 	// host (complete deletion, src/process.cxx:467-469), on rank 0's GPU, which holds the result of it
 	if (r.grp && !(r.flags & F_COMPLETE_DELETION)) gok(r, phylo_group_compare(r.grp, s.data(), h.data()));

@@ -372,6 +372,59 @@ def test_process_repeats(ctx):
         check_process(ctx, [a, b, c], ref, chunk=64)
 
 
+def test_both_phases_as_one_call(ctx):
+    """phylo_anchor_compare: phase B queued behind phase A, phase A's flags read with the result.  Same tallies and
+    lists as the two calls and as the oracle — on plain sets, on sets whose lists go to the host after all (exact
+    repeats: homologies with equal projected starts; the call then goes the long way round), with '!' in the
+    genomes, and again after the options that change where lists live."""
+    rng = np.random.default_rng(77)
+    unit = synth.random_base(700, rng)
+    sp = [synth.random_base(1500, rng) for _ in range(5)]
+    a = np.concatenate([sp[0], unit, sp[1], unit, sp[2], synth.revcomp(unit), sp[3], sp[4]])
+    repeats = [a, synth.mutate(a, 0.02, rng), np.concatenate([sp[2], unit, unit, sp[0]])]
+    # a query that carries stretches of the reference once forward and once reverse-complemented between random
+    # flanks: the two homologies of a stretch project onto the same reference interval — equal starts, the host's case
+    # (a homology begins where a step of the chain lands, a base or a few into the stretch: with 38 stretches some pairs
+    # begin at the same base — asserted below on the oracle's raw list)
+    ref40 = synth.random_base(40000, rng)
+    pieces = []
+    for x in range(1000, 39000, 1000):
+        seg = ref40[x:x + 500]
+        pieces += [synth.random_base(100, rng), seg, synth.random_base(100, rng), synth.revcomp(seg)]
+    ties = [ref40, np.concatenate(pieces + [synth.random_base(200, rng)]), synth.mutate(ref40, 0.03, rng)]
+    starts = [int(x["iproj"]) for x in O.Run(ties, 0).process(compare=False).homologies(1, filtered=False)]
+    assert len(set(starts)) < len(starts)
+    sets = [(synth.make_genomes(6, 30000, seed=12, d_range=(0.01, 0.25), indel_per_mbp=500, inv_frac=0.05, contigs=3), 2),
+            (repeats, 0), (repeats, 2), (ties, 0),
+            (synth.make_genomes(70, 5000, seed=13, d_range=(0.01, 0.2)), 5)]
+    repeated = 0
+    for gs, ref in sets:
+        r = O.Run(gs, ref).process(threads=4)
+        so, ho = r.matrix()
+        ctx.set_option("filter", 0)
+        ctx.set_genomes(gs)
+        ctx.set_reference(ref)
+        for attempt in range(2):
+            before = ctx.stat("count:anchor_compare_calls_repeated") or 0
+            s, h = ctx.anchor_compare()
+            repeated += (ctx.stat("count:anchor_compare_calls_repeated") or 0) - before
+            assert (h == ho).all() and (s == so).all(), (ref, attempt)
+            for j in range(min(len(gs), 8)):
+                assert hom_tuples_gpu(ctx.homologies(j)) == hom_tuples_orc(r.homologies(j)), (ref, attempt, j)
+        ctx.anchor()  # the two calls after the one: nothing of the deferred state is left behind
+        s, h = ctx.compare()
+        assert (h == ho).all() and (s == so).all()
+        ctx.set_option("filter", 1)  # lists through the host: the one call has nothing to defer
+        s, h = ctx.anchor_compare()
+        assert (h == ho).all() and (s == so).all()
+        ctx.set_option("filter", 0)
+    assert repeated >= 1  # (the set with equal starts)
+    s, h = ctx.process(ref_idx=1)  # phylo_process takes the same road
+    r = O.Run(sets[-1][0], 1).process(threads=4)
+    so, ho = r.matrix()
+    assert (h == ho).all() and (s == so).all()
+
+
 def test_external_suffix_array_is_accepted(ctx):
     gs = synth.make_genomes(3, 20000, seed=41, d_range=(0.02, 0.1))
     S = gs[1].tobytes() + b"#" + O.revcomp(gs[1].tobytes())
