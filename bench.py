@@ -584,11 +584,20 @@ def main():
             dom = "anchor_spec" if "anchor_spec" in kern else max(kern, key=lambda k: kern[k])
             avg_ms = kern[dom] / launches[dom]
             achieved = alg.get(dom, 0.0) / (avg_ms * 1e-3) / 1e9
-            traffic = None
+            traffic, traffic_current = None, None
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get(args.workload, {}).get(dom)
+                    pj = json.load(open(pmc))
+                    traffic = pj.get(args.workload, {}).get(dom)
+                    # were the counters taken on the kernels this run executes?  (sha256 over csrc's sources, written by
+                    # tools/tools_pmc_traffic.py when the profile was made)
+                    import glob, hashlib
+                    hh = hashlib.sha256()
+                    cs = os.path.join(ROOT, "phylonium_amd", "csrc")
+                    for f in sorted(glob.glob(os.path.join(cs, "*.hip")) + glob.glob(os.path.join(cs, "*.h")) + glob.glob(os.path.join(cs, "*.hpp"))):
+                        hh.update(open(f, "rb").read())
+                    traffic_current = pj.get("kernels_sha256_" + args.workload) == hh.hexdigest() if traffic else None
                 except Exception:
                     traffic = None
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -598,9 +607,11 @@ def main():
                     # this run's launch time): the request-granular view of the same kernel
                     "traffic_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic else None,
                     "traffic_frac": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                    "traffic_of_these_kernels": traffic_current,
                     "traffic_source": "profiles/pmc_traffic.json (rocprofv3 PMC passes of this workload; its source_<workload> "
-                                      "entry names the profile; regenerate with tools/tools_prof.sh + tools/tools_pmc_traffic.py "
-                                      "when the kernels change)",
+                                      "entry names the profile; traffic_of_these_kernels says whether csrc's sources are the ones "
+                                      "the profile was taken on (sha256 recorded by tools/tools_pmc_traffic.py); regenerate "
+                                      "with tools/tools_prof.sh + tools/tools_pmc_traffic.py when the kernels change)",
                     "note": "anchor_spec fetches one random 64-B k-mer slot (a 128-B line at the memory) per chain step: its time "
                             "is its line transactions (~122 M per launch at ~48 G lines/s, the rate of uniformly random line "
                             "fetches on this chip) — `frac` prices SURVEY 8d's algorithmic bytes (query bytes + one pass over the "

@@ -23,5 +23,12 @@ cur["method"] = ("HBM-side bytes per launch from rocprofv3 PMC (separate passes)
                  "+ _32B*32 (FETCH_SIZE tallies every request at 64 B, i.e. half the bytes of the 128-B requests, as "
                  "MI355X_MICROARCH.md warns); writes = WRITE_SIZE KB. Sources: the source_<workload> entries")
 cur["source_" + wl] = label
+# the kernels' source at the time of the profile: bench.py compares it with what it runs and says so when they differ
+import hashlib, glob
+hh = hashlib.sha256()
+for f in sorted(glob.glob(os.path.join(root, "phylonium_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "phylonium_amd", "csrc", "*.h"))
+                + glob.glob(os.path.join(root, "phylonium_amd", "csrc", "*.hpp"))):
+    hh.update(open(f, "rb").read())
+cur["kernels_sha256_" + wl] = hh.hexdigest()
 json.dump(cur, open(out, "w"), indent=1)
 print(json.dumps(tot, indent=1))
