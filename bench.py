@@ -590,13 +590,13 @@ def main():
                 try:
                     pj = json.load(open(pmc))
                     traffic = pj.get(args.workload, {}).get(dom)
-                    # were the counters taken on the kernels this run executes?  (sha256 over csrc's sources, written by
+                    # were the counters taken on the kernels this run executes?  (sha256 over the chain and phase-B kernels' sources, written by
                     # tools/tools_pmc_traffic.py when the profile was made)
                     import glob, hashlib
                     hh = hashlib.sha256()
                     cs = os.path.join(ROOT, "phylonium_amd", "csrc")
-                    for f in sorted(glob.glob(os.path.join(cs, "*.hip")) + glob.glob(os.path.join(cs, "*.h")) + glob.glob(os.path.join(cs, "*.hpp"))):
-                        hh.update(open(f, "rb").read())
+                    for f in ("lean_kernels.hip", "lean_core.h", "anchor_core.h", "pileup_kernels.hip"):  # the kernels the traffic is reported for
+                        hh.update(open(os.path.join(cs, f), "rb").read())
                     traffic_current = pj.get("kernels_sha256_" + args.workload) == hh.hexdigest() if traffic else None
                 except Exception:
                     traffic = None
@@ -609,7 +609,7 @@ def main():
                     "traffic_frac": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                     "traffic_of_these_kernels": traffic_current,
                     "traffic_source": "profiles/pmc_traffic.json (rocprofv3 PMC passes of this workload; its source_<workload> "
-                                      "entry names the profile; traffic_of_these_kernels says whether csrc's sources are the ones "
+                                      "entry names the profile; traffic_of_these_kernels says whether the chain and phase-B kernels' sources are the ones "
                                       "the profile was taken on (sha256 recorded by tools/tools_pmc_traffic.py); regenerate "
                                       "with tools/tools_prof.sh + tools/tools_pmc_traffic.py when the kernels change)",
                     "note": "anchor_spec fetches one random 64-B k-mer slot (a 128-B line at the memory) per chain step: its time "

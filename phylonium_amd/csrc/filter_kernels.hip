@@ -566,7 +566,15 @@ __global__ __launch_bounds__(FILT_THREADS) void long_prepare_kernel(const RawHom
 	}
 }
 
-// merge levels k_lo .. k_hi (powers of two), the passes with partners less than a tile apart: block = (slot, tile)
+// merge levels k_lo .. k_hi (powers of two), the passes with partners less than a tile apart: block = (slot, tile).
+// A thread holds four consecutive keys in registers: partners 1 or 2 apart are its own, partners 4 .. 128 apart sit in
+// another lane of the same wavefront (a shuffle, no barrier), only partners 256 or more apart go through LDS — 10 of
+// the first sweep's 78 passes, 4 of the 12 of every later one.
+static __device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int mask)
+{
+	const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, mask, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), mask, 64);
+	return (uint64_t)hi << 32 | lo;
+}
 __global__ __launch_bounds__(FILT_THREADS) void long_sort_low_kernel(LongScratch S, uint32_t k_lo, uint32_t k_hi)
 {
 	__shared__ uint64_t tile[FILT_MAX];
@@ -576,24 +584,55 @@ __global__ __launch_bounds__(FILT_THREADS) void long_sort_low_kernel(LongScratch
 	const uint32_t n2 = S.meta[slot].n2;
 	if (base >= n2 || k_lo > n2) return;
 	uint64_t *K = S.keys + (size_t)slot * LONG_MAX_N + base;
-	for (uint32_t t = tid; t < FILT_MAX; t += FILT_THREADS) tile[t] = K[t];
-	__syncthreads();
+	uint64_t v[4];
+	{
+		const ulonglong2 a = *(const ulonglong2 *)(K + 4 * tid), b = *(const ulonglong2 *)(K + 4 * tid + 2);
+		v[0] = a.x, v[1] = a.y, v[2] = b.x, v[3] = b.y;
+	}
+	const uint32_t e0 = base + 4u * tid; // list index of v[0]
+	auto cx = [](uint64_t &lo_el, uint64_t &hi_el, bool asc) { // the pair in order: ascending when asc
+		if ((lo_el > hi_el) == asc) {
+			const uint64_t t = lo_el;
+			lo_el = hi_el;
+			hi_el = t;
+		}
+	};
 	for (uint32_t kk = k_lo; kk <= k_hi && kk <= n2; kk <<= 1) {
 		for (uint32_t j2 = (kk > FILT_MAX ? FILT_MAX : kk) >> 1; j2 > 0; j2 >>= 1) {
-			for (uint32_t t = tid; t < FILT_MAX; t += FILT_THREADS) {
-				const uint32_t x = t ^ j2;
-				if (x > t) {
-					const uint64_t u = tile[t], v = tile[x];
-					if ((u > v) == (((base + t) & kk) == 0)) {
-						tile[t] = v;
-						tile[x] = u;
-					}
+			if (j2 == 2u) {
+				cx(v[0], v[2], (e0 & kk) == 0);
+				cx(v[1], v[3], ((e0 + 1u) & kk) == 0);
+			} else if (j2 == 1u) {
+				cx(v[0], v[1], (e0 & kk) == 0);
+				cx(v[2], v[3], ((e0 + 2u) & kk) == 0);
+			} else {
+				// the partner of key e0 + i is key (e0 + i) ^ j2: key i of thread tid ^ (j2 / 4); kk >= 8 here, so the four
+				// keys of a thread share their direction
+				const uint32_t d = j2 >> 2;
+				const bool asc = (e0 & kk) == 0, lower = (tid & d) == 0;
+				uint64_t o[4];
+				if (d < 64u) {
+#pragma unroll
+					for (int i = 0; i < 4; i++) o[i] = shfl_xor64(v[i], (int)d);
+				} else {
+					__syncthreads(); // (the partners' reads of the pass before)
+					*(ulonglong2 *)(tile + 4 * tid) = ulonglong2{v[0], v[1]};
+					*(ulonglong2 *)(tile + 4 * tid + 2) = ulonglong2{v[2], v[3]};
+					__syncthreads();
+					const ulonglong2 a = *(const ulonglong2 *)(tile + 4 * (tid ^ d)), b = *(const ulonglong2 *)(tile + 4 * (tid ^ d) + 2);
+					o[0] = a.x, o[1] = a.y, o[2] = b.x, o[3] = b.y;
+				}
+#pragma unroll
+				for (int i = 0; i < 4; i++) {
+					const bool take_min = lower == asc; // the lower index keeps the smaller key of an ascending pair
+					const uint64_t mn = v[i] < o[i] ? v[i] : o[i], mx = v[i] < o[i] ? o[i] : v[i];
+					v[i] = take_min ? mn : mx;
 				}
 			}
-			__syncthreads();
 		}
 	}
-	for (uint32_t t = tid; t < FILT_MAX; t += FILT_THREADS) K[t] = tile[t];
+	*(ulonglong2 *)(K + 4 * tid) = ulonglong2{v[0], v[1]};
+	*(ulonglong2 *)(K + 4 * tid + 2) = ulonglong2{v[2], v[3]};
 }
 
 // merge level k > FILT_MAX, the passes with partners a whole number of tiles apart: the list as rows of FILT_MAX keys,

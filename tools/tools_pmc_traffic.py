@@ -26,9 +26,9 @@ cur["source_" + wl] = label
 # the kernels' source at the time of the profile: bench.py compares it with what it runs and says so when they differ
 import hashlib, glob
 hh = hashlib.sha256()
-for f in sorted(glob.glob(os.path.join(root, "phylonium_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "phylonium_amd", "csrc", "*.h"))
-                + glob.glob(os.path.join(root, "phylonium_amd", "csrc", "*.hpp"))):
-    hh.update(open(f, "rb").read())
+# (the kernels whose traffic bench.py reports: the chain kernels and phase B's)
+for f in ("lean_kernels.hip", "lean_core.h", "anchor_core.h", "pileup_kernels.hip"):
+    hh.update(open(os.path.join(root, "phylonium_amd", "csrc", f), "rb").read())
 cur["kernels_sha256_" + wl] = hh.hexdigest()
 json.dump(cur, open(out, "w"), indent=1)
 print(json.dumps(tot, indent=1))
