@@ -703,6 +703,9 @@ def main():
                                    "nccl (RCCL), one rank per GPU, device-resident exchange")},
             "ms_per_step_noprofile": round(dt_plain / K * 1e3, 3) if dt_plain else None,
             "roofline": roof, "roofline_valu": roof_valu, "roofline_mfma": roof_mfma, "cpu_baseline": cpu,
+            "phases_note": ("one rank queues both phases as one call (phylo_anchor_compare): anchor_total is the host's part of "
+                            "phase A, compare_total ends with the one wait for both phases' kernels; the kernels' own times "
+                            "are under `kernels`") if stats.get("n:anchor_calls_without_a_wait") else None,
             "phases_ms_per_step": {k[3:]: round(v / K, 3) for k, v in stats.items()
                                    if k in ("ms:anchor_total", "ms:anchor_gpu", "ms:anchor_setup", "ms:anchor_copyback",
                                             "ms:host_sort_filter", "ms:compare_total")},
