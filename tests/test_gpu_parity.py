@@ -419,6 +419,21 @@ def test_both_phases_as_one_call(ctx):
         assert (h == ho).all() and (s == so).all()
         ctx.set_option("filter", 0)
     assert repeated >= 1  # (the set with equal starts)
+    # the same on a stream of the caller's (phylo_ctx_set_stream): a context of its own, a side stream of torch's
+    import torch
+    side = torch.cuda.Stream(device=0)
+    c2 = api.Context(0)
+    try:
+        c2.set_stream(side.cuda_stream)
+        gs, ref = sets[0]
+        c2.set_genomes(gs)
+        c2.set_reference(ref)
+        so, ho = O.Run(gs, ref).process(threads=4).matrix()
+        for _ in range(3):
+            s, h = c2.anchor_compare()
+            assert (h == ho).all() and (s == so).all()
+    finally:
+        c2.close()
     s, h = ctx.process(ref_idx=1)  # phylo_process takes the same road
     r = O.Run(sets[-1][0], 1).process(threads=4)
     so, ho = r.matrix()
