@@ -916,25 +916,28 @@ void launch_lean_spec(const PhaseA &A, const RefIndex &R, const LeanIndex &X, in
 // and runs whole trips for them.  A fifth of the lanes, each taking bridge after bridge from the counter, keeps the
 // wavefronts filled until the queue is empty and leaves only the last walkers' tail (C3: 0.90 -> 0.59 ms at 192
 // blocks; 64 blocks are too few to hide the fetches: 1.08 ms).
-static int lean_bridge_blocks(uint32_t count, int n_cu)
+// ... and not beyond three blocks on four CUs however many bridges there are (C4's 571 k: 1.21 ms at the 446 blocks a
+// fifth would be, 1.05 at 192, 1.07 at 256, 1.32 at 128), unless the slot table is k = 14's, whose fetches want more
+// of them in flight (C5: 0.75 ms at 591, 0.73 at 512, 0.76 at 256, 1.31 at 128).
+static int lean_bridge_blocks(uint32_t count, int n_cu, uint32_t k)
 {
 	int blocks = lean_resident((const void *)lean_chain_kernel<1>, n_cu);
 	const int need = (int)((count + 255) / 256);
 	if (need < blocks) blocks = need > 0 ? need : 1;
-	const int few = std::max(n_cu / 2, need / 5);
+	const int few = std::min(std::max(n_cu / 2, need / 5), k >= 14u ? 2 * n_cu : 3 * n_cu / 4);
 	if (few < blocks) blocks = few;
 	if (const char *e = getenv("PHY_BRIDGE_BLOCKS")) blocks = std::max(1, std::min(std::max(need, 1), atoi(e))); // experiments
 	return blocks;
 }
 void launch_lean_bridge(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st)
 {
-	hipLaunchKernelGGL(lean_chain_kernel<1>, dim3(lean_bridge_blocks(A.nchunks, n_cu)), dim3(256), 0, st, A, R, X, 0u, 0u, 0u);
+	hipLaunchKernelGGL(lean_chain_kernel<1>, dim3(lean_bridge_blocks(A.nchunks, n_cu, R.k)), dim3(256), 0, st, A, R, X, 0u, 0u, 0u);
 }
 void launch_lean_bridge_range(const PhaseA &A, const RefIndex &R, const LeanIndex &X, uint32_t c_lo, uint32_t c_hi,
 							  uint32_t fetch_slot, int n_cu, hipStream_t st)
 {
 	if (c_hi <= c_lo) return;
-	hipLaunchKernelGGL(lean_chain_kernel<1>, dim3(lean_bridge_blocks(c_hi - c_lo, n_cu)), dim3(256), 0, st, A, R, X, c_lo, c_hi - c_lo,
+	hipLaunchKernelGGL(lean_chain_kernel<1>, dim3(lean_bridge_blocks(c_hi - c_lo, n_cu, R.k)), dim3(256), 0, st, A, R, X, c_lo, c_hi - c_lo,
 					   fetch_slot);
 }
 
