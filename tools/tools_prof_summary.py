@@ -30,8 +30,8 @@ def short(name):
 
 
 # kernel trace
-for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_trace.csv"), recursive=True):
-    agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0, None])
+agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0, None])
+for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_trace.csv"), recursive=True):  # (one file per traced process)
     with open(f) as fh:
         for r in csv.DictReader(fh):
             k = short(r.get("Kernel_Name", ""))
@@ -42,6 +42,7 @@ for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_trace.csv"), recursiv
             a[0] += 1; a[1] += dur; a[2] = min(a[2], dur); a[3] = max(a[3], dur)
             a[4] = {x: r.get(x) for x in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size",
                                           "Workgroup_Size", "Grid_Size") if x in r}
+if agg:
     out["kernel_trace"] = {k: {"calls": a[0], "total_ms": round(a[1], 4), "avg_ms": round(a[1] / a[0], 4),
                                "min_ms": round(a[2], 4), "max_ms": round(a[3], 4), "resources": a[4]} for k, a in agg.items()}
     tot = sum(a[1] for a in agg.values())
