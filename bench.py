@@ -484,7 +484,7 @@ def main():
                 return r
             return ctx.compare(emu[0], emu[1])
         return dist.process_sharded(ctx, ref_idx, rank, world, device=None if shared else device, lengths=lens,
-                                    set_reference=False, out=out_mats, copy=False)
+                                    set_reference=False, out=out_mats, copy=False, result_rank=0 if world > 1 else None)
 
     if emu:  # the other ranks' lists must exist for the projection: compute them once, untimed
         if args.emulate_exchange:

@@ -128,7 +128,7 @@ def _exchange_plan(ctx, n, rank, world, bounds, device):
             "tri": torch.empty(max(2 * P, 1), dtype=torch.int32, device=device)}
 
 
-def process_sharded_device(ctx, rank, world, bounds, device, out=None):
+def process_sharded_device(ctx, rank, world, bounds, device, out=None, result_rank=None):
     """One step with the exchange left to the device: the context works on torch's current stream, so the library's
     kernels and the collectives are ordered by the stream and the host waits twice — at the end of phase A (its
     error and tie flags) and for the result.  Lists travel as fixed-shape blocks (one all-gather), tallies as a u32
@@ -154,20 +154,28 @@ def process_sharded_device(ctx, rank, world, bounds, device, out=None):
                 ctx._xplan = None
                 continue
             raise
-        td.all_reduce(plan["tri"], op=td.ReduceOp.SUM)
         ctx._attached_records = plan["all"]  # still the source of the other ranks' lists should the caller ask for them
-        return ctx.triangle_to_matrices(plan["tri"].data_ptr(), out)
+        if result_rank is None:  # every rank gets the matrices
+            td.all_reduce(plan["tri"], op=td.ReduceOp.SUM)
+            return ctx.triangle_to_matrices(plan["tri"].data_ptr(), out)
+        # the job's one result, on one rank (as the reference prints one matrix): a reduce instead of the all-reduce, and
+        # the other ranks neither copy 2 N^2 words home nor widen them on host cores the result's rank could use
+        td.reduce(plan["tri"], dst=result_rank, op=td.ReduceOp.SUM)
+        if rank == result_rank:
+            return ctx.triangle_to_matrices(plan["tri"].data_ptr(), out)
+        return None, None
     raise RuntimeError("process_sharded_device: the exchange blocks overflowed twice")
 
 
-def process_sharded(ctx, ref_idx, rank, world, device=None, lengths=None, set_reference=True, out=None, copy=True):
+def process_sharded(ctx, ref_idx, rank, world, device=None, lengths=None, set_reference=True, out=None, copy=True, result_rank=None):
     """process() with queries and pair tiles sharded over `world` ranks.
     ctx: an api.Context (or any object with the same methods) holding all genomes.
     Returns (subst, homologs), two N x N uint64 arrays.  With `out` = (subst, homologs) the result is written
     there and those arrays are returned; without it the arrays are the caller's own (fresh copies) on every
     path — the device-resident path keeps a pinned staging buffer of its own that the next call overwrites;
     copy=False hands out views of that buffer instead (valid until the next call: a timing loop that looks at
-    the last result only)."""
+    the last result only).  result_rank = r (device-side exchange only): the tallies are reduced to rank r alone, which
+    returns the matrices; the other ranks return (None, None)."""
     if set_reference:
         ctx.set_reference(ref_idx)
     lens = lengths or getattr(ctx, "lengths", None)
@@ -178,7 +186,7 @@ def process_sharded(ctx, ref_idx, rank, world, device=None, lengths=None, set_re
     ctx.anchor(qb, qe)
     on_gpu = device is not None and torch.device(device).type == "cuda" and hasattr(ctx, "attach_packed_device")
     if on_gpu and (world > 1 or _FORCE_COLLECTIVES) and hasattr(ctx, "export_block_device") and not _LEGACY_DEVICE_EXCHANGE:
-        return process_sharded_device(ctx, rank, world, bounds, device, out=out)
+        return process_sharded_device(ctx, rank, world, bounds, device, out=out, result_rank=result_rank)
     if on_gpu and (world > 1 or _FORCE_COLLECTIVES):
         # device-resident: records and tallies never visit the host between the ranks
         keep = exchange_homologies_device(ctx, ctx.n, rank, world, bounds, device)

@@ -906,6 +906,8 @@ def _nccl_one_rank_worker(rank, world, port, out):
     s, h = s.copy(), h.copy()
     s3, h3 = dist.process_sharded(c, 1, rank, world, device=dev)  # once more: the planned capacity is reused
     assert (s3 == s).all() and (h3 == h).all()
+    s4, h4 = dist.process_sharded(c, 1, rank, world, device=dev, result_rank=0)  # a reduce to the result's rank (bench.py --gpus N)
+    assert (s4 == s).all() and (h4 == h).all()
     dist._LEGACY_DEVICE_EXCHANGE = True  # round 2's exchange: counts through the host, u64 matrices on the wire
     s2, h2 = dist.process_sharded(c, 1, rank, world, device=dev)
     assert (s2 == s).all() and (h2 == h).all()
