@@ -1018,6 +1018,9 @@ def test_phase_a_in_groups_of_queries(ctx, groups):
             assert (h == ho).all() and (s == so).all(), chunk
             for j in (0, 3, 64, 65, 130, 200, len(gs) - 1):
                 assert hom_tuples_gpu(ctx.homologies(j)) == hom_tuples_orc(r.homologies(j)), (chunk, j)
+            ctx.anchor(10, 250)  # a block of the queries only (a rank's share): the groups are counted from its first query
+            for j in (10, 11, 73, 74, 138, 249):
+                assert hom_tuples_gpu(ctx.homologies(j)) == hom_tuples_orc(r.homologies(j)), (chunk, j, "block")
     finally:
         ctx.set_option("pipeline_groups", 1)
         ctx.set_option("chunk", 0)
