@@ -327,14 +327,8 @@ def main():
     ap.add_argument("--filter", type=int, default=0, help="dev: sort + chain filter 1 on the host, 2 on the device (0: the library chooses)")
     ap.add_argument("--host-threads", type=int, default=0, help="dev: size of the library's host worker pool")
     ap.add_argument("--kmer", type=int, default=0, help="dev: force the bucket k of the reference index")
-    ap.add_argument("--anchor-kernel", type=int, default=-1, help="dev: 1 lean 2-bit chains, 0 general byte-wise chains (library default when < 0)")
-    ap.add_argument("--absent-table", type=int, default=-1, help="dev: 1 steps of k-mers that do not occur in the reference from the absence table, 0 every step fetches its slot")
-    ap.add_argument("--lean-batch", type=int, default=-1, help="dev: the chain kernels' rarer phases on every n-th trip only")
-    ap.add_argument("--tail-groups", type=int, default=0, help="dev: phase A's tail on this many streams (library default when 0)")
     ap.add_argument("--sa-builder", type=int, default=-1, help="dev: who builds the reference's suffix array: 1 the device, 0 the host cores (library default when < 0)")
-    ap.add_argument("--pipeline-groups", type=int, default=-1, help="dev: groups of queries phase A is pipelined over (0: the library chooses)")
     ap.add_argument("--fold-blocks", type=int, default=-1, help="dev: blocks per query of the fold kernel (0: the library chooses)")
-    ap.add_argument("--chunk-tail", type=int, default=0, help="dev: chunk length of the second half of every query (phase A)")
     ap.add_argument("--pairs-wchunk", type=int, default=0, help="dev: windows per chunk of the pair kernel (library's choice when 0)")
     ap.add_argument("--d-range", default="", help="dev: lo,hi — override the workload's divergence range")
     ap.add_argument("--emulate-rank", default="", help="dev: R/N — time rank R of N's share of the work on this one GPU "
@@ -398,22 +392,10 @@ def main():
     ctx.set_option("profile", 0 if args.no_profile else 1)
     if args.chunk:
         ctx.set_option("chunk", args.chunk)
-    if args.chunk_tail:
-        ctx.set_option("chunk_tail", args.chunk_tail)
-    if args.pipeline_groups >= 0:
-        ctx.set_option("pipeline_groups", args.pipeline_groups)
     if args.fold_blocks >= 0:
         ctx.set_option("fold_blocks", args.fold_blocks)
     if args.kmer:
         ctx.set_option("kmer", args.kmer)
-    if args.anchor_kernel >= 0:
-        ctx.set_option("anchor_kernel", args.anchor_kernel)
-    if args.lean_batch >= 0:
-        ctx.set_option("lean_batch", args.lean_batch)
-    if args.absent_table >= 0:
-        ctx.set_option("absent_table", args.absent_table)
-    if args.tail_groups > 0:
-        ctx.set_option("tail_groups", args.tail_groups)
     if args.pairs_wchunk > 0:
         ctx.set_option("pairs_wchunk", args.pairs_wchunk)
     if args.sa_builder >= 0:

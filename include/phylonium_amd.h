@@ -60,23 +60,23 @@ int phylo_ctx_set_stream(phylo_ctx *ctx, void *hip_stream);
 int phylo_ctx_device(const phylo_ctx *ctx);
 /* ctx may be NULL: last error of a failed phylo_ctx_create on this thread. */
 const char *phylo_last_error(const phylo_ctx *ctx);
-/* Tunables, mostly for tests: "chunk" (phase-A chunk length, a multiple of 64), "chunk_tail"
- * (the second half of every query in chunks of this length instead),
- * "kmer" (bucket k), "profile" (1: time every kernel with HIP events),
- * "compare_backend" (0 pileup, 1 segment list), "filter" (where phase A's sort + chain filter
- * runs: 0 and 2 on the device — a query whose list has two entries with the same projected start still goes
- * to the host, as the reference's order of such ties is libstdc++'s — 1 on the host cores; the results are
- * the same), "host_threads", "anchor_kernel" (phase A's chain
- * kernels: 1, the default, the lean kernels on 2-bit packed operands; 0 the general byte-wise ones — same
- * results), "lean_force_slow" (1: every step of the lean kernels through their wave-cooperative slow resolver),
- * "filter_kernel" (the device filter: 0 stretch by stretch, 1 the general dependent scan only), "sa_builder" (the
- * reference's suffix array: 1 on the device, 0 on the host cores), "cache_quirk" (1, the default: a subject on which
- * the reference's 6-mer cache holds over-deep intervals is matched as the reference matches it; 0: true longest
- * matches), "pairs_kernel" (phase B's pair tallies: 0 on the matrix cores, 1 on the vector ALUs), "pairs_wchunk"
- * (windows per chunk of the pair kernels), "fold_blocks" (blocks per query of the fold kernel, 0: the library
- * chooses), "pipeline_groups" (phase A in that many groups of queries, a group's tail under the next group's chains;
- * 1, the default: one group), "tail_groups", "lean_batch", "absent_table" (variants of the chain kernels kept for the
- * tests: measured, not faster — DESIGN.md section 12).  Every setting gives the same results. */
+/* Tunables, mostly for tests — every setting gives the same results:
+ *   "chunk"            phase-A chunk length (a multiple of 64; 0: the library's plan)
+ *   "kmer"             k of the k-mer slot table (0: smallest k with 4^k >= |S|)
+ *   "filter"           where phase A's sort + chain filter runs: 0 and 2 on the device (a query whose list has two
+ *                      entries with the same projected start still goes to the host, as the reference's order of such
+ *                      ties is libstdc++'s), 1 on the host cores
+ *   "filter_kernel"    the device filter: 0 stretch by stretch, 1 the general dependent scan only
+ *   "fold_blocks"      blocks per query of the fold kernel (0: the library chooses)
+ *   "lean_force_slow"  1: every step of the chain kernels through their wave-cooperative slow resolver
+ *   "cache_quirk"      1 (default): a subject on which the reference's 6-mer cache holds over-deep intervals is matched
+ *                      as the reference matches it; 0: true longest matches (results then differ from the reference's)
+ *   "sa_builder"       the reference's suffix array when the caller brings none: 1 on the device, 0 on the host cores
+ *   "compare_backend"  0 pileup, 1 explicit segment list (the literal seqcmp/revseqcmp calls)
+ *   "pairs_kernel"     phase B's pair tallies: 0 on the matrix cores, 1 on the vector ALUs
+ *   "pairs_wchunk"     windows per chunk of the pair kernels (0: chosen from the L2 size)
+ *   "host_threads"     size of the context's host worker pool
+ *   "profile"          1: time every kernel with HIP events ("ms:<kernel>" stats) */
 int phylo_set_option(phylo_ctx *ctx, const char *key, long value);
 /* Accumulated since the last phylo_reset_stats: "ms:<kernel>", "n:<kernel>"
  * (HIP-event time and launch count per kernel when profiling is on),
@@ -132,11 +132,12 @@ size_t phylo_threshold(const phylo_ctx *ctx);
  * them at src/esa.cxx:74), copied from the device: with sa == NULL above it was built there (option
  * "sa_builder": 1, the default, prefix doubling on the device; 0 the host cores). */
 int phylo_reference_suffix_array(phylo_ctx *ctx, int64_t *sa);
-/* 1 when the reference build would NOT give the longest match on this subject: its 6-mer interval cache
+/* 1 when the reference build does NOT report the longest match on this subject: its 6-mer interval cache
  * stores an over-deep interval when a nucleotide string of <= 4 characters occurs at least twice in S and
  * only in front of the same contig join (src/esa.cxx:174-199) — possible for references of a few kbp
- * in several contigs, never beyond.  This library always computes the true longest match; results can
- * then differ from the reference's, and a host should say so (phylonium-amd -v does). */
+ * in several contigs, never beyond.  By default (option "cache_quirk" = 1) this library reproduces what the
+ * reference answers there, so results equal the reference's; with "cache_quirk" = 0 it computes the true longest
+ * matches and results then differ.  A host may want to say so (phylonium-amd -v does). */
 int phylo_reference_cache_quirk(const phylo_ctx *ctx);
 
 /* ── phase A: anchor_homologies + sort + filter_overlaps_max for queries

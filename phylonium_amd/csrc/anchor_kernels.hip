@@ -1,14 +1,10 @@
-// anchor_kernels.hip — phase A on gfx950: speculative chunk chains, bridges and
-// the anchor→homology fold.  Replaces the OpenMP loop over queries and
-// anchor_homologies (/root/reference/src/process.cxx:433-437, 198-295) and the
-// ESA walk under it (src/esa.cxx:361-563).  The per-lane logic lives in
-// anchor_core.h (shared with the CPU emulation tests); this file adds what only
-// exists on the GPU: persistent lanes with dynamic work fetch, wave-cooperative
-// resolution of long suffix comparisons, and the wave-parallel fold.
+// anchor_kernels.hip — phase A on gfx950, the part behind the chains: the fold of the accepted
+// anchors into homologies.  Replaces the homology bookkeeping of anchor_homologies
+// (/root/reference/src/process.cxx:246-292); the chains themselves (speculative chunks, bridges)
+// are lean_kernels.hip.  The per-anchor logic lives in anchor_core.h (shared with the CPU
+// emulation tests); this file adds the block-parallel walk over a query's chunks and bridges.
 //
-// Roofline: latency / random-access bound (SA, LCP, T and S are gathered), not
-// an HBM streaming kernel.  Algorithmic bytes per launch:
-// Σ|Q| + 26·|S|.
+// Roofline: a per-query latency chain (LDS scans and shuffles), not an HBM streaming kernel.
 #include <hip/hip_runtime.h>
 
 #include "anchor_core.h"
@@ -23,9 +19,6 @@ static __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src)
 	return (uint64_t)__shfl((unsigned long long)v, src, 64);
 }
 
-// All currently active lanes of the wave resolve the leader's comparison
-// together: lane r of the m active lanes takes the 16-byte piece r of each
-// m*16-byte block.  `s_end` is the first byte past S's zero padding.
 // A pointer that went through LDS or a lane shuffle comes back generic, and a generic
 // load is a FLAT instruction that also counts against LDS waits.  These restate that the
 // address is in global memory.
@@ -41,211 +34,6 @@ static __device__ __forceinline__ Anchor gload_anchor(const Anchor *p)
 	Anchor v;
 	__builtin_memcpy(&v, (global_bytes)(uintptr_t)p, sizeof(Anchor));
 	return v;
-}
-
-static __device__ __forceinline__ void coop_compare(const uint8_t *qp, const uint8_t *sp, uint32_t pos,
-													uint32_t maxn, const uint8_t *s_end, uint32_t *out_len,
-													uint32_t *out_less)
-{
-	const uint64_t active = __ballot(1);
-	const uint32_t m = (uint32_t)__popcll(active);
-	const uint32_t r = (uint32_t)__popcll(active & ((1ull << lane_id()) - 1ull));
-	uint32_t base = pos;
-	for (;;) {
-		uint32_t off = base + r * 16u;
-		bool in_q = off < maxn;
-		uint32_t d = 0;
-		uint32_t qb = 1, sb = 0;
-		if (in_q) {
-			U4 a = gload16(qp + off), b = {0, 0, 0, 0};
-			if (sp + off + 16 <= s_end) b = gload16(sp + off); // else past the end of S: the NUL the reference stops at
-			d = first_diff(a, b);
-			if (d < 16) {
-				qb = byte_at(a, d);
-				sb = byte_at(b, d);
-			}
-		}
-		bool hit = !in_q || d < 16;
-		uint64_t hm = __ballot(hit);
-		if (hm) {
-			int first = __ffsll((unsigned long long)hm) - 1;
-			uint32_t len = in_q ? off + d : maxn;
-			uint32_t less = (in_q && len < maxn) ? (sb < qb ? 1u : 0u) : 0u;
-			if (len > maxn) len = maxn;
-			*out_len = (uint32_t)__shfl((int)len, first, 64);
-			*out_less = (uint32_t)__shfl((int)less, first, 64);
-			return;
-		}
-		base += m * 16u;
-	}
-}
-
-static const uint32_t QRING_BYTES = 128;
-#ifndef PHY_CHAIN_SUBTRIPS
-#define PHY_CHAIN_SUBTRIPS 2
-#endif
-static const int CHAIN_SUBTRIPS = PHY_CHAIN_SUBTRIPS;
-
-struct DevAlloc {
-	const PhaseA *A;
-	__device__ uint32_t operator()() const
-	{
-		uint32_t b = atomicAdd(A->pool_next, 1u);
-		return b < A->pool_blocks ? b : NO_BLOCK;
-	}
-};
-
-// MODE 0: speculative chunk chains. MODE 1: bridges.
-// Persistent lanes: every lane runs one chain at a time and fetches the next
-// chunk when it finishes.  One loop trip runs the phases of anchor_core.h's
-// Chain in their fixed order; a phase is skipped by the wavefront when none of
-// its lanes is in it.
-template <int MODE> __global__ __launch_bounds__(256) void chain_kernel(PhaseA A, RefIndex R)
-{
-	typename std::conditional<MODE == 0, SpecLane, BridgeLane>::type ln;
-	Chain &ch = ln.ch;
-	const uint8_t *s_end = R.S + R.n + 64;
-	bool active = false, done = false;
-	DevAlloc alloc = {&A};
-	ch.fin = false;
-	ch.st = ST_STEP;
-	// per-lane window of the query, [wbase, wbase + QRING_BYTES); row-major by dword so
-	// that lane l always hits LDS bank l whatever offset it reads
-	__shared__ uint32_t qring[QRING_BYTES / 4 + 1][256];
-	uint32_t wbase = 0;
-
-	for (;;) {
-		// Two sub-trips of the common path (finish the previous step, start the next:
-		// STEP + T + FIN) per loop trip, so the rarer phases below (CAND, GEN, EXT) and
-		// their divergence cost are paid once per two steps.
-#pragma nounroll
-		for (int sub = 0; sub < CHAIN_SUBTRIPS; sub++) {
-			// finish the previous step, start the next one or the next chunk — straight-line
-			// code (no loop): a finished lane picks up its next chunk now and steps it below
-			if (active && ch.fin) {
-				if constexpr (MODE == 0) ln.step_done(A);
-				else ln.step_done(A, alloc);
-				ch.fin = false;
-			}
-			if (active && ch.st == ST_STEP) {
-				bool go;
-				if constexpr (MODE == 0) go = ln.begin_step(A);
-				else go = ln.begin_step(A, R);
-				active = go;
-			}
-			if (!active && !done) {
-				uint32_t it = atomicAdd(&A.fetch[MODE], 1u);
-				done = it >= A.nchunks;
-				if (!done) {
-					ln.start(A, A.items[it]);
-					wbase = 0xffffff00u; // force a refill of the query ring
-					bool go;
-					if constexpr (MODE == 0) go = ln.begin_step(A);
-					else go = ln.begin_step(A, R);
-					active = go;
-				}
-			}
-			const bool live = active;
-			// ── STEP + T: query window from the lane's LDS ring; the lucky window and the
-			//    k-mer's slot line are fetched together, one memory hop for both ──
-			{
-				const bool stp = live && ch.st == ST_STEP;
-				if (stp && (ch.q < wbase || ch.q + 16u > wbase + QRING_BYTES)) {
-					wbase = ch.q & ~15u;
-					const uint8_t *src = ch.Q + wbase;
-	#pragma unroll
-					for (uint32_t sl = 0; sl < QRING_BYTES / 16; sl++) {
-						U4 v = load16(src + 16 * sl);
-						qring[4 * sl + 0][threadIdx.x] = v.x;
-						qring[4 * sl + 1][threadIdx.x] = v.y;
-						qring[4 * sl + 2][threadIdx.x] = v.z;
-						qring[4 * sl + 3][threadIdx.x] = v.w;
-					}
-				}
-				if (stp) {
-					const uint32_t p = ch.q - wbase, i0 = p >> 2, sh = p & 3u;
-					const uint32_t d0 = qring[i0][threadIdx.x], d1 = qring[i0 + 1][threadIdx.x],
-								   d2 = qring[i0 + 2][threadIdx.x], d3 = qring[i0 + 3][threadIdx.x],
-								   d4 = qring[i0 + 4][threadIdx.x];
-					U4 qw;
-					qw.x = __builtin_amdgcn_alignbyte(d1, d0, sh);
-					qw.y = __builtin_amdgcn_alignbyte(d2, d1, sh);
-					qw.z = __builtin_amdgcn_alignbyte(d3, d2, sh);
-					qw.w = __builtin_amdgcn_alignbyte(d4, d3, sh);
-					ch.pre_step(qw);
-					const uint8_t *a0, *a1 = nullptr;
-					const uint32_t nl = ch.issue_step(R, &a0, &a1);
-					const uint8_t *sa = ch.slot_of_window(R);
-					U4 sw = {0, 0, 0, 0}, hdr = {0, 0, 0, 0};
-					Data d;
-					d.w[0] = d.w[1] = d.w[2] = d.w[3] = sw;
-					if (nl > 1) sw = load16(a1);
-					if (sa) slot_unpack(load16(sa), load16(sa + 16), load16(sa + 32), load16(sa + 48), &hdr, &d);
-					ch.post_step(R, sw);
-					if (ch.st == ST_T) ch.consume_T(R, hdr, d); // st == ST_T implies the k-mer was valid, so sa != nullptr
-				}
-			}
-			if (live && ch.st == ST_FIN) {
-				if (ch.fin_needs_lcp(R)) ch.consume_lcp(load16(ch.issue_lcp(R)));
-			}
-		}
-		if (__all(done && !active)) break;
-		const bool live = active;
-		// A lane can arrive here in ST_T: when the threshold exceeds the 16 bytes the lucky
-		// check sees in the STEP phase, the check continues in EXT, and if it then fails the
-		// k-mer lookup is still owed (thresholds >= 17, i.e. references beyond ~60 Mbp).
-		if (live && ch.st == ST_T) {
-			const uint8_t *sa = ch.issue_T(R);
-			U4 hdr;
-			Data d;
-			slot_unpack(load16(sa), load16(sa + 16), load16(sa + 32), load16(sa + 48), &hdr, &d);
-			ch.consume_T(R, hdr, d);
-		}
-		if (live && ch.st == ST_CAND) {
-			Data d;
-			d.w[0] = load16(R.S + ch.c_pos0);
-			d.w[1] = d.w[2] = d.w[3] = d.w[0];
-			if (ch.c_n > 1) d.w[1] = load16(R.S + ch.c_pos1);
-			if (ch.c_n > 2) d.w[2] = load16(R.S + ch.c_pos2);
-			if (ch.c_n > 3) d.w[3] = load16(R.S + ch.c_pos3);
-			ch.consume_cand(R, d);
-		}
-		if (live && ch.in_gen()) {
-			if (ch.gen_advance(R)) {
-				if (ch.consume_probe_sa(load16(ch.issue_probe_sa(R)))) ch.consume_probe_s(load16(ch.issue_probe_s(R)));
-				if (ch.in_gen()) ch.gen_advance(R);
-			}
-		}
-		{
-			bool want = false;
-			if (live && ch.st == ST_EXT) {
-				const uint8_t *a[4];
-				Data d;
-				ch.issue_ext(R, a);
-				d.w[0] = load16(a[0]);
-				d.w[1] = load16(a[1]);
-				d.w[2] = load16(a[2]);
-				d.w[3] = load16(a[3]);
-				want = ch.consume_ext(R, d);
-			}
-			// comparisons that ran past EXT_COOP_AT bytes are finished by the whole wave
-			uint64_t pending = __ballot(want);
-			while (pending) {
-				int leader = __ffsll((unsigned long long)pending) - 1;
-				const uint8_t *qp = (const uint8_t *)shfl64((uint64_t)(ch.Q + ch.q), leader);
-				const uint8_t *sp = (const uint8_t *)shfl64((uint64_t)(R.S + ch.e_p), leader);
-				uint32_t p0 = (uint32_t)__shfl((int)ch.e_pos, leader, 64);
-				uint32_t mx = (uint32_t)__shfl((int)(ch.qlen - ch.q), leader, 64);
-				uint32_t len, less;
-				coop_compare(qp, sp, p0, mx, s_end, &len, &less);
-				if ((int)lane_id() == leader) ch.deliver(R, len, less);
-				pending &= pending - 1;
-			}
-		}
-		if (live && ch.st == ST_FIN) {
-			if (ch.fin_needs_lcp(R)) ch.consume_lcp(load16(ch.issue_lcp(R)));
-		}
-	}
 }
 
 // ───────────────────────── fold: anchors → homologies ─────────────────────────
@@ -817,38 +605,6 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j
 
 // ───────────────────────── launch wrappers ─────────────────────────
 
-static int resident_blocks(const void *fn, int n_cu)
-{
-	int per_cu = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-	return per_cu * n_cu;
-}
-
-int spec_resident_blocks(int n_cu)
-{
-	static int cached_cu = 0, cached = 0;
-	if (cached_cu != n_cu) {
-		cached = resident_blocks((const void *)chain_kernel<0>, n_cu);
-		cached_cu = n_cu;
-	}
-	return cached;
-}
-
-// blocks_cap: never more lanes than chunks
-void launch_spec(const PhaseA &A, const RefIndex &R, int n_cu, hipStream_t st)
-{
-	int blocks = spec_resident_blocks(n_cu);
-	int need = (int)((A.nchunks + 255) / 256);
-	if (need < blocks) blocks = need > 0 ? need : 1;
-	hipLaunchKernelGGL(chain_kernel<0>, dim3(blocks), dim3(256), 0, st, A, R);
-}
-void launch_bridge(const PhaseA &A, const RefIndex &R, int n_cu, hipStream_t st)
-{
-	int blocks = resident_blocks((const void *)chain_kernel<1>, n_cu);
-	int need = (int)((A.nchunks + 255) / 256);
-	if (need < blocks) blocks = need > 0 ? need : 1;
-	hipLaunchKernelGGL(chain_kernel<1>, dim3(blocks), dim3(256), 0, st, A, R);
-}
 // queries [j0, j1)
 void launch_fold(const PhaseA &A, uint32_t j0, uint32_t j1, uint32_t border, uint32_t thr, RawHom *out,
 				 const uint64_t *out_base, const uint32_t *out_cap, uint32_t *out_cnt, hipStream_t st, uint32_t blocks_per_query)

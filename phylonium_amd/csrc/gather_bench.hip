@@ -1,98 +1,106 @@
-// gather_bench.hip — micro-benchmark (not on the product path): the ceiling for
-// what the anchor kernel does to memory, i.e. uniformly random lines fetched out of
-// a table far larger than the Infinity Cache (128-byte lines with 5 x 16 bytes read,
-// or 64-byte lines read whole), `ILP` independent lookups in flight per lane.  Gives
-// the "peak" that the anchor kernel's random-line rate is compared with, and shows
-// what that peak depends on — the pages in play (argv[1] = table bytes: 53 G lines/s
-// up to ~3 GB, ~20 G/s beyond), not the bytes per line.
+// gather_bench.hip — micro-benchmark (not on the product path): the ceiling for what the
+// anchor kernel does to memory — uniformly random rows fetched out of a table — as a
+// function of the table's size (L2 / Infinity Cache / HBM / translation reach), the row's
+// length (8 … 128 bytes, read whole) and the lanes in flight.  Two modes:
+//   rate  — every lookup's index comes from a generator in registers: the throughput ceiling;
+//   chase — the next index depends on the loaded row (a dependent chain per lane, as a
+//           chain step's slot fetch is): the time of one hop under full load.
+// usage: gather_bench <table MB> [<table MB> ...]   (one JSON line per size)
+// DESIGN.md §3.1, §13; profiles/r01_gather_bench.jsonl (round 1: 1–16 GB, 64/128-byte rows),
+// profiles/r04_gather_bench.jsonl (32 MB–16 GB, 8–128-byte rows).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
-// LINE_U4: line length in 16-byte units (8 = 128 B, 4 = 64 B); READS of them are loaded
-template <int ILP, int LINE_U4 = 8, int READS = 5>
-__global__ __launch_bounds__(256) void gather_kernel(const uint4 *__restrict__ table, uint64_t lines, uint32_t iters,
+// ROW bytes per row, read whole with the widest loads (8: one dwordx2; 16 and more: dwordx4s)
+template <int ROW, bool CHASE>
+__global__ __launch_bounds__(256) void gather_kernel(const uint8_t *__restrict__ table, uint64_t rows, uint32_t iters,
 													 uint32_t *__restrict__ out)
 {
 	uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
 	x *= 0x9E3779B97F4A7C15ull;
 	uint32_t acc = 0;
 	for (uint32_t it = 0; it < iters; it++) {
-		uint4 v[ILP][READS];
+		x ^= x << 13;
+		x ^= x >> 7;
+		x ^= x << 17;
+		const uint64_t r = (x + (CHASE ? acc : 0u)) % rows;
+		const uint8_t *p = table + r * ROW;
+		if constexpr (ROW == 8) {
+			const uint2 v = *(const uint2 *)p;
+			acc ^= v.x ^ v.y;
+		} else {
+			uint4 v[ROW / 16];
 #pragma unroll
-		for (int k = 0; k < ILP; k++) {
-			x ^= x << 13;
-			x ^= x >> 7;
-			x ^= x << 17;
-			const uint4 *p = table + (x % lines) * LINE_U4;
+			for (int j = 0; j < ROW / 16; j++) v[j] = ((const uint4 *)p)[j];
 #pragma unroll
-			for (int j = 0; j < READS; j++) v[k][j] = p[j];
+			for (int j = 0; j < ROW / 16; j++) acc ^= v[j].x ^ v[j].w;
 		}
-#pragma unroll
-		for (int k = 0; k < ILP; k++)
-#pragma unroll
-			for (int j = 0; j < READS; j++) acc ^= v[k][j].x ^ v[k][j].w;
 	}
 	out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
-int main(int argc, char **argv)
+template <int ROW, bool CHASE> static float run(const uint8_t *table, uint64_t bytes, int blocks, uint32_t iters, uint32_t *out)
 {
-	uint64_t table_bytes = argc > 1 ? strtoull(argv[1], 0, 10) : (2ull << 30);
-	uint64_t lines = table_bytes / 128;
-	uint4 *table;
-	uint32_t *out;
-	hipMalloc((void **)&table, lines * 128);
-	hipMemset(table, 1, lines * 128);
-	int blocks_per_cu[] = {1, 2, 4, 8};
-	hipDeviceProp_t prop;
-	hipGetDeviceProperties(&prop, 0);
-	hipMalloc((void **)&out, (size_t)prop.multiProcessorCount * 8 * 256 * 4);
 	hipEvent_t a, b;
 	hipEventCreate(&a);
 	hipEventCreate(&b);
-	printf("{\"table_MB\": %llu", (unsigned long long)(table_bytes >> 20));
-	for (int bi = 0; bi < 4; bi++) {
-		int blocks = prop.multiProcessorCount * blocks_per_cu[bi];
-		uint32_t iters = 256;
-		for (int ilp = 1; ilp <= 4; ilp *= 2) {
-			float best = 1e30f;
-			for (int rep = 0; rep < 3; rep++) {
-				hipEventRecord(a, 0);
-				if (ilp == 1) hipLaunchKernelGGL(gather_kernel<1>, dim3(blocks), dim3(256), 0, 0, table, lines, iters, out);
-				if (ilp == 2) hipLaunchKernelGGL(gather_kernel<2>, dim3(blocks), dim3(256), 0, 0, table, lines, iters, out);
-				if (ilp == 4) hipLaunchKernelGGL(gather_kernel<4>, dim3(blocks), dim3(256), 0, 0, table, lines, iters, out);
-				hipEventRecord(b, 0);
-				hipEventSynchronize(b);
-				float ms;
-				hipEventElapsedTime(&ms, a, b);
-				if (ms < best) best = ms;
-			}
-			double n = (double)blocks * 256 * iters * ilp;
-			printf(", \"b%d_ilp%d_Glines_s\": %.2f", blocks_per_cu[bi], ilp, n / (best * 1e-3) / 1e9);
-		}
+	float best = 1e30f;
+	for (int rep = 0; rep < 4; rep++) { // the first pass warms the caches and the translations
+		hipEventRecord(a, 0);
+		hipLaunchKernelGGL((gather_kernel<ROW, CHASE>), dim3(blocks), dim3(256), 0, 0, table, bytes / ROW, iters, out);
+		hipEventRecord(b, 0);
+		hipEventSynchronize(b);
+		float ms;
+		hipEventElapsedTime(&ms, a, b);
+		if (rep && ms < best) best = ms;
 	}
-	// the same with 64-byte lines (4 x 16 bytes read per line): what a slot half the size would cost
-	{
-		const uint64_t lines64 = table_bytes / 64;
-		for (int bi = 2; bi < 4; bi++) {
-			int blocks = prop.multiProcessorCount * blocks_per_cu[bi];
-			uint32_t iters = 256;
-			float best = 1e30f;
-			for (int rep = 0; rep < 3; rep++) {
-				hipEventRecord(a, 0);
-				hipLaunchKernelGGL((gather_kernel<4, 4, 4>), dim3(blocks), dim3(256), 0, 0, table, lines64, iters, out);
-				hipEventRecord(b, 0);
-				hipEventSynchronize(b);
-				float ms;
-				hipEventElapsedTime(&ms, a, b);
-				if (ms < best) best = ms;
-			}
-			double n = (double)blocks * 256 * iters * 4;
-			printf(", \"line64_b%d_ilp4_Glines_s\": %.2f", blocks_per_cu[bi], n / (best * 1e-3) / 1e9);
+	hipEventDestroy(a);
+	hipEventDestroy(b);
+	return best;
+}
+
+int main(int argc, char **argv)
+{
+	hipDeviceProp_t prop;
+	hipGetDeviceProperties(&prop, 0);
+	const int cus = prop.multiProcessorCount;
+	uint32_t *out;
+	hipMalloc((void **)&out, (size_t)cus * 8 * 256 * 4);
+	for (int ai = 1; ai < argc; ai++) {
+		const uint64_t bytes = strtoull(argv[ai], 0, 10) << 20;
+		uint8_t *table;
+		if (hipMalloc((void **)&table, bytes) != hipSuccess) {
+			fprintf(stderr, "hipMalloc(%llu MB) failed\n", (unsigned long long)(bytes >> 20));
+			continue;
 		}
+		hipMemset(table, 1, bytes);
+		hipDeviceSynchronize();
+		printf("{\"table_MB\": %llu", (unsigned long long)(bytes >> 20));
+		const int bpcs[] = {3, 4, 8};
+		for (int bi = 0; bi < 3; bi++) {
+			const int bpc = bpcs[bi], blocks = cus * bpc;
+			const uint32_t iters = 512;
+			const double n = (double)blocks * 256 * iters;
+#define RATE(ROW)                                                                                                       \
+	{                                                                                                                   \
+		const float ms = run<ROW, false>(table, bytes, blocks, iters, out);                                             \
+		printf(", \"rate_row%d_b%d_Grows_s\": %.2f", ROW, bpc, n / (ms * 1e-3) / 1e9);                                  \
 	}
-	printf("}\n");
+			RATE(8) RATE(16) RATE(32) RATE(64) RATE(128)
+#define CHASE_(ROW)                                                                                                     \
+	{                                                                                                                   \
+		const float ms = run<ROW, true>(table, bytes, blocks, iters, out);                                              \
+		printf(", \"chase_row%d_b%d_us_per_hop\": %.3f, \"chase_row%d_b%d_Grows_s\": %.2f", ROW, bpc, ms * 1e3 / iters, ROW, \
+			   bpc, n / (ms * 1e-3) / 1e9);                                                                             \
+	}
+			if (bpc != 8) { CHASE_(16) CHASE_(64) }
+		}
+		printf("}\n");
+		fflush(stdout);
+		hipFree(table);
+	}
 	return 0;
 }

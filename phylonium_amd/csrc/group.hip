@@ -526,6 +526,7 @@ int phylo_group_set_reference(phylo_group *g, size_t ref_idx, const int64_t *sa,
 	if (!g) return 1;
 	g->clear_error();
 	g->lists_everywhere = false;
+	g->plan_valid = false; // another subject, other lists: the next pass sizes the exchange blocks anew
 	g->threads->run([&](size_t r) {
 		if (phylo_set_reference(g->ctx[r], ref_idx, sa, threshold)) g->fail("rank %zu: %s", r, phylo_last_error(g->ctx[r]));
 	});
@@ -539,6 +540,7 @@ int phylo_group_anchor(phylo_group *g)
 	g->clear_error();
 	const size_t W = g->world, n = g->n;
 	g->lists_everywhere = false;
+	if (g->bounds.size() != W + 1) return g->fail("phylo_group_anchor: no genomes set");
 	g->threads->run([&](size_t r) {
 		const size_t qb = g->bounds[r], qe = g->bounds[r + 1];
 		bool bad = false;

@@ -765,17 +765,15 @@ static inline double estimate_jc(uint64_t s, uint64_t h, bool zero_on_error)
 // ───────────────────────── phase-A work layout ─────────────────────────
 
 struct ChunkPlan {
-	uint32_t C = 0, Cs = 0, cap = 0, caps = 0, nchunks = 0;
+	uint32_t C = 0, cap = 0, nchunks = 0;
 	uint64_t anchor_slots = 0;         // size of the speculative log array
 	std::vector<uint32_t> qchunk0;     // [nq+1]
-	std::vector<uint32_t> qnb;         // [nq] long chunks of each query (the rest are short)
 	std::vector<uint32_t> qanc0;       // [nq] first log slot of each query
 	std::vector<uint32_t> chunk_query; // [nchunks]
 	std::vector<uint32_t> items;       // [nchunks] work order (see plan_chunks)
 };
 
 static const uint32_t CHUNK_MIN = 1536, CHUNK_MAX = 10240;
-static const bool AUTO_TAIL = false; // see plan_chunks: measured, it loses
 static const uint32_t ITEM_RUN = 256; // consecutive chunks of one query in the work order (= lanes of a block)
 
 // Chunks per query and the order they are worked on.
@@ -788,32 +786,19 @@ static const uint32_t ITEM_RUN = 256; // consecutive chunks of one query in the 
 // 4 %), and below one chunk per lane 1536 is the best length (shorter ones only
 // add bridge and fold work).  So: the fewest rounds with C <= CHUNK_MAX, the chunk
 // count 3 % under a whole number of rounds (every query also ends in a partial
-// chunk), and never below CHUNK_MIN.
-//
-// With exactly one round the lanes finish far apart — a chunk of a close relative has
-// few, long steps, one of a distant genome many short ones: on C3 the completions
-// spread over the last 40 % of the kernel's time — and nothing is left for the early
-// ones.  The grid therefore allows a query's head in long chunks, one per lane, and
-// its tail in shorter ones queued behind all long ones (tail_frac of the query, a
-// quarter as long).  Measured on C3 this LOSES (speculative kernel 4.7 -> 6.0 ms, bridges
-// 1.0 -> 1.4 ms): a lane that picks up a second chunk restarts alone while its
-// wavefront waits, the wavefront then mixes genomes, and every extra chunk is an
-// extra bridge.  So AUTO_TAIL is off; the non-uniform grid stays for tests
-// (forced_Cs: chunk length of the tail, half of every query) and later use.
+// chunk), and never below CHUNK_MIN.  (A query's tail in shorter chunks, queued
+// behind the long ones for the lanes that finish early, was measured in rounds 1
+// and 3 and lost both times: DESIGN.md, history.)
 // `quantum` (0: not used) = lanes of one block on every CU: below one chunk per lane the chunk count aims at a whole
 // number of blocks per CU — 3.2 blocks per CU means a fifth of the CUs works a third longer than the rest (64 x 5 Mbp:
 // 2.46 -> 2.24 ms per pass with 3.0).
-// `groups` > 1: the queries go through the kernels in that many groups one behind the other (group_items below), so
-// the chunk length is what a group's share of the bases asks for.
 static inline ChunkPlan plan_chunks(const std::vector<uint32_t> &qlen, uint32_t threshold, uint32_t forced_C,
-									uint32_t lanes = 256u * 4u * 256u, uint32_t forced_Cs = 0, uint32_t quantum = 0, uint32_t groups = 1)
+									uint32_t lanes = 256u * 4u * 256u, uint32_t quantum = 0)
 {
 	ChunkPlan P;
 	uint64_t total = 0;
 	for (uint32_t l : qlen) total += l;
-	if (groups > 1) total = (total + groups - 1) / groups;
-	uint32_t C = forced_C, Cs = forced_Cs;
-	double tail_frac = forced_Cs ? 0.5 : 0.0;
+	uint32_t C = forced_C;
 	if (C == 0) {
 		const uint64_t L = lanes ? lanes : 1;
 		if (total <= L * CHUNK_MIN) {
@@ -828,42 +813,28 @@ static inline ChunkPlan plan_chunks(const std::vector<uint32_t> &qlen, uint32_t 
 			const uint64_t rounds = (total + L * CHUNK_MAX - 1) / (L * CHUNK_MAX);
 			// every query also ends in a partial chunk: aim 3 % under the whole number
 			const uint64_t want = (uint64_t)((double)(rounds * L) * 0.97);
-			if (AUTO_TAIL && rounds == 1 && !forced_Cs) tail_frac = 0.25;
-			uint64_t c = ((uint64_t)((double)total * (1.0 - tail_frac)) + want - 1) / want;
+			uint64_t c = (total + want - 1) / want;
 			c = (c + 63) / 64 * 64;
 			C = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(c, CHUNK_MIN), CHUNK_MAX);
-			if (tail_frac > 0 && !Cs) Cs = std::max<uint32_t>(512, (C / 4 + 63) / 64 * 64);
 		}
 	}
 	C = (C + 63) / 64 * 64;
 	while (C <= 2 * threshold + 32) C += 64; // chunk starts must be lucky-ineligible from (0,0,0)
-	if (!Cs || tail_frac <= 0) Cs = C;
-	Cs = (Cs + 63) / 64 * 64;
-	while (Cs <= 2 * threshold + 32) Cs += 64;
 	P.C = C;
-	P.Cs = Cs;
 	P.cap = C / (threshold + 1) + 2;
-	P.caps = Cs / (threshold + 1) + 2;
 	size_t nq = qlen.size();
 	P.qchunk0.resize(nq + 1);
-	P.qnb.resize(nq);
 	P.qanc0.resize(nq);
-	uint32_t acc = 0, maxb = 0, maxs = 0;
+	uint32_t acc = 0, maxb = 0;
 	uint64_t slots = 0;
 	for (size_t j = 0; j < nq; j++) {
 		P.qchunk0[j] = acc;
-		const uint64_t ql = qlen[j];
-		// long chunks cover the head; without a tail they cover everything (the last one partly)
-		uint32_t nb = Cs == C ? (uint32_t)((ql + C - 1) / C) : (uint32_t)((uint64_t)((double)ql * (1.0 - tail_frac)) / C);
-		const uint64_t rest = ql > (uint64_t)nb * C ? ql - (uint64_t)nb * C : 0;
-		const uint32_t ns = (uint32_t)((rest + Cs - 1) / Cs);
-		P.qnb[j] = nb;
-		if (slots + (uint64_t)nb * P.cap + (uint64_t)ns * P.caps >= 0xffffffffull) return ChunkPlan(); // log slots are 32-bit indices
+		const uint32_t nb = (uint32_t)(((uint64_t)qlen[j] + C - 1) / C);
+		if (slots + (uint64_t)nb * P.cap >= 0xffffffffull) return ChunkPlan(); // log slots are 32-bit indices
 		P.qanc0[j] = (uint32_t)slots;
-		slots += (uint64_t)nb * P.cap + (uint64_t)ns * P.caps;
-		acc += nb + ns;
+		slots += (uint64_t)nb * P.cap;
+		acc += nb;
 		maxb = std::max(maxb, nb);
-		maxs = std::max(maxs, ns);
 	}
 	P.anchor_slots = slots;
 	P.qchunk0[nq] = acc;
@@ -876,46 +847,13 @@ static inline ChunkPlan plan_chunks(const std::vector<uint32_t> &qlen, uint32_t 
 	// alike (divergence decides how many steps a chunk has and how long its matches run), so
 	// the wavefronts stay in the same phases: 8 % faster on C3 than one chunk per query in turn
 	// (4.9 vs 5.3 ms), and better than whole queries one after the other when the queue is
-	// several rounds long (C4: 18.1 vs 18.8 ms).  All long chunks come before the short ones.
+	// several rounds long (C4: 18.1 vs 18.8 ms).
 	P.items.reserve(acc);
 	for (uint32_t r = 0; r < maxb; r += ITEM_RUN)
 		for (size_t j = 0; j < nq; j++)
 			for (uint32_t e = 0; e < ITEM_RUN; e++)
-				if (r + e < P.qnb[j]) P.items.push_back(P.qchunk0[j] + r + e);
-	for (uint32_t r = 0; r < maxs; r += ITEM_RUN)
-		for (size_t j = 0; j < nq; j++)
-			for (uint32_t e = 0; e < ITEM_RUN; e++)
-				if (P.qchunk0[j] + P.qnb[j] + r + e < P.qchunk0[j + 1]) P.items.push_back(P.qchunk0[j] + P.qnb[j] + r + e);
+				if (P.qchunk0[j] + r + e < P.qchunk0[j + 1]) P.items.push_back(P.qchunk0[j] + r + e);
 	return P;
-}
-
-// The work order for groups of queries that go through phase A one behind the other (group g = queries
-// [gb[g], gb[g+1])): each group's chunks in plan_chunks' order among themselves, the groups back to back.
-// Returns the groups' first items (and the total at the end).
-static inline std::vector<uint32_t> group_items(ChunkPlan &P, const std::vector<uint32_t> &gb)
-{
-	std::vector<uint32_t> first;
-	std::vector<uint32_t> items;
-	items.reserve(P.nchunks);
-	for (size_t g = 0; g + 1 < gb.size(); g++) {
-		first.push_back((uint32_t)items.size());
-		uint32_t maxb = 0, maxs = 0;
-		for (uint32_t j = gb[g]; j < gb[g + 1]; j++) {
-			maxb = std::max(maxb, P.qnb[j]);
-			maxs = std::max(maxs, P.qchunk0[j + 1] - P.qchunk0[j] - P.qnb[j]);
-		}
-		for (uint32_t r = 0; r < maxb; r += ITEM_RUN)
-			for (uint32_t j = gb[g]; j < gb[g + 1]; j++)
-				for (uint32_t e = 0; e < ITEM_RUN; e++)
-					if (r + e < P.qnb[j]) items.push_back(P.qchunk0[j] + r + e);
-		for (uint32_t r = 0; r < maxs; r += ITEM_RUN)
-			for (uint32_t j = gb[g]; j < gb[g + 1]; j++)
-				for (uint32_t e = 0; e < ITEM_RUN; e++)
-					if (P.qchunk0[j] + P.qnb[j] + r + e < P.qchunk0[j + 1]) items.push_back(P.qchunk0[j] + P.qnb[j] + r + e);
-	}
-	first.push_back((uint32_t)items.size());
-	P.items.swap(items);
-	return first;
 }
 
 } // namespace phy

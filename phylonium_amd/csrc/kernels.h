@@ -12,18 +12,8 @@ namespace phy {
 // lean_kernels.hip: the chain kernels on 2-bit packed operands (default), and the packed tables
 int lean_spec_resident_blocks(int n_cu);
 void launch_lean_spec(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st, int max_blocks = 0); // max_blocks > 0: no more blocks than that
-// the speculative chunks A.items[item_lo .. item_lo + item_count) only (a group of queries), work counter A.fetch[fetch_slot]
-void launch_lean_spec_range(const PhaseA &A, const RefIndex &R, const LeanIndex &X, uint32_t item_lo, uint32_t item_count,
-							uint32_t fetch_slot, int n_cu, hipStream_t st, int max_blocks = 0);
 void launch_lean_overruns(const PhaseA &A, const RefIndex &R, uint32_t nq, hipStream_t st); // between spec and bridge
-// ... of the queries [j0, j1), whose chunks are [c_lo, c_hi)
-void launch_lean_overruns_range(const PhaseA &A, const RefIndex &R, uint32_t c_lo, uint32_t c_hi, uint32_t j0, uint32_t j1, hipStream_t st);
 void launch_lean_bridge(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st);
-// the bridges of chunks [c_lo, c_hi) only (a group of queries), work counter A.fetch[fetch_slot]
-void launch_lean_bridge_range(const PhaseA &A, const RefIndex &R, const LeanIndex &X, uint32_t c_lo, uint32_t c_hi,
-							  uint32_t fetch_slot, int n_cu, hipStream_t st);
-// the absence table of the index in R (4^k bytes; lean_core.h: LeanIndex::absent) — after the slots, for R.threshold
-void launch_build_absent(const RefIndex &R, uint8_t *absent, hipStream_t st);
 void launch_pack2(const uint8_t *src, uint64_t bytes, uint32_t *dst, hipStream_t st); // bytes: a multiple of 16
 // Q2 → byte arena (bytes: the whole arena, a multiple of 16), then '!' at the nbad listed positions; code bits of Q2
 // outside the genomes or under a separator are cleared on the way
@@ -36,9 +26,6 @@ void launch_bad_positions(const uint8_t *base, const uint64_t *off, const uint32
 						  hipStream_t st);
 
 // anchor_kernels.hip
-int spec_resident_blocks(int n_cu); // blocks of the speculative-chain kernel the device holds at once
-void launch_spec(const PhaseA &A, const RefIndex &R, int n_cu, hipStream_t st);
-void launch_bridge(const PhaseA &A, const RefIndex &R, int n_cu, hipStream_t st);
 // queries [j0, j1), blocks_per_query blocks each (with more than one a query's homologies leave in the order its
 // blocks got their slots, not in query order)
 void launch_fold(const PhaseA &A, uint32_t j0, uint32_t j1, uint32_t border, uint32_t thr, RawHom *out,

@@ -57,18 +57,7 @@ struct LeanIndex {
 	// goes through the slow resolver (force_slow is set with them), which reproduces that.
 	const U4 *quirk;
 	uint32_t nquirk;
-	uint32_t batch; // the chain kernels run the rarer phases on every batch-th trip only (0, 1: every trip)
-	// One byte per k-mer of the index (4^k; null: not in use): 0 when the k-mer occurs in S (or its step needs the
-	// full path for another reason), else 1 + the length of the longest match of any query window that starts with
-	// it.  A k-mer that does not occur in S matches less than k bases, which its own letters decide — and less than
-	// the threshold, so the step accepts no anchor: position + length + 1 is all there is to it (process.cxx:281),
-	// without the k-mer's 64-byte slot out of a table a hundred times this one's size.
-	const uint8_t *absent;
 };
-#ifndef PHY_QUICK_MAX
-#define PHY_QUICK_MAX 6
-#endif
-static const int LEAN_QUICK_MAX = PHY_QUICK_MAX; // such steps a lane may take in one trip before the wavefront moves on
 
 static const uint32_t LEAN_NO_QUIRK = 0xffffffffu;
 // the cache entry the window Q (n bytes left in the query) falls under: get_match_cached, src/esa.cxx:542-563
@@ -666,7 +655,7 @@ struct LeanBridge {
 	uint32_t n, first_block, cur_block;
 	// what every step would otherwise fetch again: the query's chunk grid, the position of the
 	// speculative log's next anchor, the word of the visited bitmap last looked at
-	uint32_t g_nb, g_anc0, g_chunk0, nx_q, vw_idx, vw_word;
+	uint32_t g_anc0, g_chunk0, nx_q, vw_idx, vw_word;
 
 	PHY_HD void start(const PhaseA &A, const LeanIndex &X, uint32_t chunk)
 	{
@@ -674,7 +663,6 @@ struct LeanBridge {
 		const uint32_t j = A.chunk_query[chunk];
 		qj = j;
 		const SpecExit x = A.spec_exit[chunk];
-		g_nb = A.qnb[j];
 		g_anc0 = A.qanc0[j];
 		g_chunk0 = A.qchunk0[j];
 		ln.reset((uint32_t)(A.qoff[j] >> 4), A.qlen[j], x.q, x.lq, x.ls, x.ll);
@@ -704,18 +692,10 @@ struct LeanBridge {
 			return false;
 		}
 		if (cur_gc == BRIDGE_END || ln.q - cur_q0 >= cur_len) { // entered another chunk (chunk_of_pos + chunk_geom)
-			const uint32_t split = g_nb * A.C;
-			const uint32_t lc = ln.q < split ? ln.q / A.C : g_nb + (ln.q - split) / A.Cs;
-			if (lc < g_nb) {
-				cur_q0 = lc * A.C;
-				cur_len = A.C;
-				cur_log = g_anc0 + lc * A.cap;
-			} else {
-				const uint32_t t = lc - g_nb;
-				cur_q0 = split + t * A.Cs;
-				cur_len = A.Cs;
-				cur_log = g_anc0 + g_nb * A.cap + t * A.caps;
-			}
+			const uint32_t lc = ln.q / A.C; // chunk_of_pos + chunk_geom
+			cur_q0 = lc * A.C;
+			cur_len = A.C;
+			cur_log = g_anc0 + lc * A.cap;
 			cur_gc = g_chunk0 + lc;
 			sp_cnt = A.spec_cnt[cur_gc];
 			sp_idx = 0;

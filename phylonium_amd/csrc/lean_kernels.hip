@@ -424,13 +424,10 @@ struct LeanAlloc {
 #ifndef PHY_PRIO_ROT
 #define PHY_PRIO_ROT 16u // trips between two turns of the wavefronts' issue priorities (0: no rotation)
 #endif
-// MODE 0: speculative chunk chains.  MODE 1: bridges.  Persistent lanes with dynamic work fetch.
-// it_count != 0: the work items are the chunks it_base .. it_base + it_count - 1 themselves (the bridges of a group of
-// queries) or, with bit 31 of fetch_slot set, A.items[it_base .. it_base + it_count) (a group's speculative chunks in
-// their work order), counted through A.fetch[fetch_slot & 0xff]; else A.items[0 .. nchunks) through A.fetch[MODE].
+// MODE 0: speculative chunk chains, the work items are A.items[0 .. nchunks) (the plan's work order).  MODE 1: bridges,
+// one per chunk.  Persistent lanes with dynamic work fetch through A.fetch[MODE].
 template <int MODE>
-__global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, LeanIndex X, uint32_t it_base, uint32_t it_count,
-														 uint32_t fetch_slot)
+__global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, LeanIndex X)
 {
 	typename std::conditional<MODE == 0, LeanSpec, LeanBridge>::type L;
 	LeanLane &ln = L.ln;
@@ -484,10 +481,10 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 			else active = L.begin_step(A, X, R);
 		}
 		if (!active && !done) {
-			const uint32_t it = atomicAdd(&A.fetch[it_count ? (fetch_slot & 0xffu) : (uint32_t)MODE], 1u);
-			done = it >= (it_count ? it_count : A.nchunks);
+			const uint32_t it = atomicAdd(&A.fetch[MODE], 1u);
+			done = it >= A.nchunks;
 			if (!done) {
-				const uint32_t item = !it_count ? A.items[it] : (fetch_slot >> 31) ? A.items[it_base + it] : it_base + it;
+				const uint32_t item = A.items[it];
 				L.start(A, X, item);
 #ifdef PHY_LEAN_TIMING
 				if (first_query == ~0ull) first_query = A.chunk_query[item];
@@ -513,38 +510,6 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 				ln.qcode = code_window(ring[w & 15u][tid], ring[(w + 1u) & 15u][tid], ln.q & 15u);
 			}
 		}
-		// Quick steps.  More than half of the windows of diverged sequence start with a k-mer that does not occur in S:
-		// their step is "advance by the table's byte" (lean_core.h: LeanIndex::absent) — no slot, no candidates, no
-		// anchor — unless the last anchor is near enough for the lucky check (process.cxx:227-242), which reads S.  A
-		// lane takes up to LEAN_QUICK_MAX of them here, while the wavefront's other lanes wait for the trip's one slot
-		// fetch anyway; what is left in STEP afterwards has a k-mer that occurs.
-		if (X.absent) {
-			for (int it = 0; it < LEAN_QUICK_MAX; it++) {
-				const bool ask = active && ph == LP_STEP && !ln.lucky_ok(R);
-				uint32_t e = 0;
-				if (ask) e = X.absent[ln.qcode >> (2u * (16u - R.k))];
-				if (!__any(e != 0u)) break;
-				if (e) {
-					ln.finish(0u, e - 1u, false); // no anchor: nothing for step_done to log
-					ln.fin = false;
-					if constexpr (MODE == 0) active = L.begin_step(A, X, vis);
-					else active = L.begin_step(A, X, R);
-					ph = (uint32_t)LP_SLOW + 8u;
-					if (active) {
-						ph = lean_step_phase(ln, X);
-						ln.ph = ph;
-						if (ph == LP_STEP) {
-							const uint32_t w = ln.q >> 4;
-							ln.qcode = code_window(ring[w & 15u][tid], ring[(w + 1u) & 15u][tid], ln.q & 15u);
-						}
-					}
-				}
-			}
-		}
-		// Phase batching (X.batch = M > 1): a wavefront pays for the code of every phase one of its lanes is in, and with
-		// 64 lanes nearly every trip has a lane or two in each of the rarer ones (EXT, SCAN, REFILL, SEARCH, the slow
-		// resolver).  Those phases are run on every M-th trip only; in between their lanes sit the trip out and the
-		// wavefront runs the STEP path alone.
 		trip++;
 #if PHY_PRIO_ROT
 		// The SIMD's arbiter breaks ties between ready wavefronts by age: of the three or four chain wavefronts a SIMD holds,
@@ -558,7 +523,6 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 			else __builtin_amdgcn_s_setprio(3);
 		}
 #endif
-		if (X.batch > 1 && ph != LP_STEP && (trip % X.batch) != 0) ph = (uint32_t)LP_SLOW + 8u;
 		// one batch of loads for every phase
 		const uint8_t *pA = s2_b, *pB = s2_b, *pY = s2_b;
 		if (ph == LP_STEP || ph == LP_SEARCH) {
@@ -640,7 +604,7 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 		}
 		LEAN_TICK(3)
 		// what the packed path could not answer: the wavefront resolves it, one lane at a time
-		uint64_t slow = __ballot(active && (ln.ph == LP_SLOW || ln.ph == LP_SLOWEXT) && (X.batch <= 1 || (trip % X.batch) == 0));
+		uint64_t slow = __ballot(active && (ln.ph == LP_SLOW || ln.ph == LP_SLOWEXT));
 		while (slow) {
 			const int leader = __ffsll((unsigned long long)slow) - 1;
 			const uint32_t lph = bcast(ln.ph, leader);
@@ -677,37 +641,6 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 		}
 	}
 #endif
-}
-
-// The absence table (lean_core.h: LeanIndex::absent): one thread per k-mer runs the full path's own digest
-// (lean_search on the k-mer's slot) with the k-mer as the window, and keeps the outcome when it is the plain one —
-// the bucket is empty and the step ends without an anchor.  The window's bases behind the k-mer cannot matter then:
-// every suffix differs from it inside the k-mer.
-__global__ __launch_bounds__(256) void build_absent_kernel(RefIndex R, uint64_t codes, uint8_t *__restrict__ absent)
-{
-	const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= codes) return;
-	uint32_t w[16];
-	const U4 *slot = R.SLOT + c * SLOT_RECS;
-#pragma unroll
-	for (int i = 0; i < 4; i++) {
-		const U4 v = slot[i];
-		w[4 * i] = v.x, w[4 * i + 1] = v.y, w[4 * i + 2] = v.z, w[4 * i + 3] = v.w;
-	}
-	uint8_t out = 0;
-	if (w[0] == w[1]) { // T[c] == T[c + 1]: no suffix starts with this k-mer
-		LeanLane ln;
-		ln.reset(0u, 0x7fffffffu, 0u, 0u, 0u, 0u);
-		ln.qcode = (uint32_t)(c << (2u * (16u - R.k)));
-		lean_search(ln, R, w);
-		if (ln.fin && ln.ph == LP_STEP && !ln.r_accepted && ln.r_len < R.k && ln.r_len < 255u) out = (uint8_t)(ln.r_len + 1u);
-	}
-	absent[c] = out;
-}
-void launch_build_absent(const RefIndex &R, uint8_t *absent, hipStream_t st)
-{
-	const uint64_t codes = (uint64_t)1 << (2u * R.k);
-	hipLaunchKernelGGL(build_absent_kernel, dim3((uint32_t)((codes + 255) / 256)), dim3(256), 0, st, R, codes, absent);
 }
 
 // ───────────────────────── packed tables ─────────────────────────
@@ -868,13 +801,9 @@ void launch_bad_positions(const uint8_t *base, const uint64_t *off, const uint32
 
 void launch_lean_overruns(const PhaseA &A, const RefIndex &R, uint32_t nq, hipStream_t st)
 {
-	launch_lean_overruns_range(A, R, 0u, A.nchunks, 0u, nq, st);
-}
-void launch_lean_overruns_range(const PhaseA &A, const RefIndex &R, uint32_t c_lo, uint32_t c_hi, uint32_t j0, uint32_t j1, hipStream_t st)
-{
-	if (j1 <= j0 || c_hi <= c_lo) return;
-	hipLaunchKernelGGL(lean_overrun_direct_kernel, dim3((c_hi - c_lo + 63u) / 64u), dim3(64), 0, st, A, R, c_lo, c_hi);
-	hipLaunchKernelGGL(lean_overrun_chain_kernel, dim3(j1 - j0), dim3(64), 0, st, A, j0, j1);
+	if (!nq || !A.nchunks) return;
+	hipLaunchKernelGGL(lean_overrun_direct_kernel, dim3((A.nchunks + 63u) / 64u), dim3(64), 0, st, A, R, 0u, A.nchunks);
+	hipLaunchKernelGGL(lean_overrun_chain_kernel, dim3(nq), dim3(64), 0, st, A, 0u, nq);
 }
 
 static int lean_resident(const void *fn, int n_cu)
@@ -893,23 +822,13 @@ int lean_spec_resident_blocks(int n_cu)
 	cache.store(((uint64_t)(uint32_t)n_cu << 32) | (uint32_t)blocks, std::memory_order_release);
 	return blocks;
 }
-void launch_lean_spec_range(const PhaseA &A, const RefIndex &R, const LeanIndex &X, uint32_t item_lo, uint32_t item_count,
-							uint32_t fetch_slot, int n_cu, hipStream_t st, int max_blocks)
-{
-	if (!item_count) return;
-	int blocks = lean_spec_resident_blocks(n_cu);
-	if (max_blocks > 0 && max_blocks < blocks) blocks = max_blocks;
-	const int need = (int)((item_count + 255) / 256);
-	if (need < blocks) blocks = need;
-	hipLaunchKernelGGL(lean_chain_kernel<0>, dim3(blocks), dim3(256), 0, st, A, R, X, item_lo, item_count, fetch_slot | 0x80000000u);
-}
 void launch_lean_spec(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st, int max_blocks)
 {
 	int blocks = lean_spec_resident_blocks(n_cu);
 	if (max_blocks > 0 && max_blocks < blocks) blocks = max_blocks;
 	const int need = (int)((A.nchunks + 255) / 256);
 	if (need < blocks) blocks = need > 0 ? need : 1;
-	hipLaunchKernelGGL(lean_chain_kernel<0>, dim3(blocks), dim3(256), 0, st, A, R, X, 0u, 0u, 0u);
+	hipLaunchKernelGGL(lean_chain_kernel<0>, dim3(blocks), dim3(256), 0, st, A, R, X);
 }
 // Blocks for `count` bridges.  Most bridges end at their first step (the chain has merged already) and a few walk
 // for dozens: with a lane per bridge nearly every wavefront is left with a handful of walkers after the first trip
@@ -931,14 +850,7 @@ static int lean_bridge_blocks(uint32_t count, int n_cu, uint32_t k)
 }
 void launch_lean_bridge(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st)
 {
-	hipLaunchKernelGGL(lean_chain_kernel<1>, dim3(lean_bridge_blocks(A.nchunks, n_cu, R.k)), dim3(256), 0, st, A, R, X, 0u, 0u, 0u);
-}
-void launch_lean_bridge_range(const PhaseA &A, const RefIndex &R, const LeanIndex &X, uint32_t c_lo, uint32_t c_hi,
-							  uint32_t fetch_slot, int n_cu, hipStream_t st)
-{
-	if (c_hi <= c_lo) return;
-	hipLaunchKernelGGL(lean_chain_kernel<1>, dim3(lean_bridge_blocks(c_hi - c_lo, n_cu, R.k)), dim3(256), 0, st, A, R, X, c_lo, c_hi - c_lo,
-					   fetch_slot);
+	hipLaunchKernelGGL(lean_chain_kernel<1>, dim3(lean_bridge_blocks(A.nchunks, n_cu, R.k)), dim3(256), 0, st, A, R, X);
 }
 
 } // namespace phy

@@ -183,10 +183,11 @@ def process_sharded(ctx, ref_idx, rank, world, device=None, lengths=None, set_re
     qb, qe = bounds[rank], bounds[rank + 1]
     if world == 1 and not _FORCE_COLLECTIVES and hasattr(ctx, "anchor_compare"):
         return ctx.anchor_compare(out=out)  # one rank: both phases as the one call they are in the reference
-    ctx.anchor(qb, qe)
     on_gpu = device is not None and torch.device(device).type == "cuda" and hasattr(ctx, "attach_packed_device")
     if on_gpu and (world > 1 or _FORCE_COLLECTIVES) and hasattr(ctx, "export_block_device") and not _LEGACY_DEVICE_EXCHANGE:
+        # (phase A is this path's own first step — on the caller's stream, and again should the exchange blocks overflow)
         return process_sharded_device(ctx, rank, world, bounds, device, out=out, result_rank=result_rank)
+    ctx.anchor(qb, qe)
     if on_gpu and (world > 1 or _FORCE_COLLECTIVES):
         # device-resident: records and tallies never visit the host between the ranks
         keep = exchange_homologies_device(ctx, ctx.n, rank, world, bounds, device)

@@ -281,9 +281,11 @@ Matrix process(Run &r, size_t ref_idx, const int64_t *sa = nullptr)
 	// phase A: every GPU anchors its block of the queries, then every GPU holds all lists (rank 0's context
 	// hands out any of them)
 	std::vector<uint64_t> s(N * N), h(N * N);
-	if (!r.grp && !(r.flags & (F_COMPLETE_DELETION | F_POSITIONS))) {
-		// nothing between the phases: both as one call, the host waits once
-		ok(r, phylo_anchor_compare(r.ctx, s.data(), h.data()));
+	if (!(r.flags & (F_COMPLETE_DELETION | F_POSITIONS))) {
+		// nothing between the phases: both as one call — the host waits once; the group repeats a pass whose lists
+		// outgrew the planned exchange blocks
+		if (r.grp) gok(r, phylo_group_process(r.grp, s.data(), h.data()));
+		else ok(r, phylo_anchor_compare(r.ctx, s.data(), h.data()));
 		Matrix m(N * N);
 		for (size_t k = 0; k < N * N; k++) m[k] = Tally{s[k], h[k]};
 		return m;

@@ -1,5 +1,5 @@
 // emul.cpp — TEST INFRASTRUCTURE. Compiles the product's host/device chain code
-// (phylonium_amd/csrc/anchor_core.h, hostlogic.hpp) with g++ and runs the
+// (phylonium_amd/csrc/anchor_core.h, lean_core.h, hostlogic.hpp) with g++ and runs the
 // phase-A pipeline (speculative chunks → bridges → walk + fold → sort + filter)
 // serially on the CPU, so the algorithm can be checked against the oracle in
 // the GPU-less build container.  The product library never links this file.
@@ -19,38 +19,6 @@ struct EmulOut {
 	uint64_t steps_spec = 0, steps_bridge = 0, cmp_calls = 0, pool_used = 0, rounds = 0, slow_steps = 0, overruns = 0;
 	int error = 0;
 };
-
-template <class Lane, class Begin, class Done>
-static void run_lane(Lane &ln, const RefIndex &R, Begin begin, Done done, uint64_t *steps, uint64_t *trips,
-					 uint64_t *tails)
-{
-	// stands in for the wave-cooperative tail comparison of the GPU kernel
-	auto tail = [&](const Chain &ch, uint32_t *len, uint32_t *less) {
-		const uint8_t *qp = ch.Q + ch.q, *sp = R.S + ch.e_p;
-		uint32_t n = ch.qlen - ch.q, i = ch.e_pos;
-		(*tails)++;
-		while (i < n && qp[i] == sp[i]) i++;
-		*len = i;
-		*less = (i < n && sp[i] < qp[i]) ? 1u : 0u;
-	};
-	uint64_t lane_trips = 0;
-	for (;;) {
-		if (ln.ch.fin) {
-			done();
-			(*steps)++;
-			ln.ch.fin = false;
-		}
-		if (ln.ch.st == ST_STEP && !begin()) break;
-		chain_trip(ln.ch, R, tail);
-		(*trips)++;
-		if (++lane_trips > 50000000ull) { // a chunk is a few thousand positions: this lane is stuck
-			const Chain &c = ln.ch;
-			fprintf(stderr, "emul: lane stuck: st %u q %u qlen %u qv %u qcode %08x lo %u hi %u mid %u l_lo %u l_hi %u c_rank0 %u c_n %u e_kind %u e_pos %u e_p %u\n",
-					(unsigned)c.st, c.q, c.qlen, c.qv, c.qcode, c.lo, c.hi, c.mid, c.l_lo, c.l_hi, c.c_rank0, c.c_n, (unsigned)c.e_kind, c.e_pos, c.e_p);
-			abort();
-		}
-	}
-}
 
 // the lean (2-bit) chain of lean_core.h, one lane at a time
 template <class Lane, class Begin, class Done>
@@ -77,7 +45,7 @@ static void run_lean_lane(Lane &L, const uint8_t *qbase, const RefIndex &R, cons
 
 extern "C" {
 
-// mode: bit 0 the lean chain (lean_core.h) instead of the general one, bit 1 every step through its slow resolver
+// mode: bit 1 every step through the chain's slow resolver (bit 0 is ignored: there is one chain, lean_core.h's)
 void *emul_run2(size_t n, const char *const *seq, const size_t *len, size_t ref_idx, size_t threshold,
 				unsigned forced_C, unsigned forced_k, unsigned mode);
 void *emul_run(size_t n, const char *const *seq, const size_t *len, size_t ref_idx, size_t threshold,
@@ -131,9 +99,7 @@ void *emul_run2(size_t n, const char *const *seq, const size_t *len, size_t ref_
 	std::vector<uint8_t> qbase(tot, 0);
 	for (size_t j = 0; j < n; j++) memcpy(qbase.data() + qoff[j], seq[j], len[j]);
 
-	// EMUL_CHUNK_TAIL: chunk length of the short tail chunks (half of every query), as the "chunk_tail" option
-	const char *tail_env = getenv("EMUL_CHUNK_TAIL");
-	ChunkPlan P = plan_chunks(qlen, (uint32_t)threshold, forced_C, 256u * 4u * 256u, tail_env ? (uint32_t)atoi(tail_env) : 0u);
+	ChunkPlan P = plan_chunks(qlen, (uint32_t)threshold, forced_C, 256u * 4u * 256u);
 	E->C = P.C;
 	E->nchunks = P.nchunks;
 	std::vector<Anchor> spec_anchors((size_t)P.anchor_slots + 1);
@@ -153,9 +119,6 @@ void *emul_run2(size_t n, const char *const *seq, const size_t *len, size_t ref_
 	A.nchunks = P.nchunks;
 	A.C = P.C;
 	A.cap = P.cap;
-	A.Cs = P.Cs;
-	A.caps = P.caps;
-	A.qnb = P.qnb.data();
 	A.qanc0 = P.qanc0.data();
 	A.spec_anchors = spec_anchors.data();
 	A.spec_cnt = spec_cnt.data();
@@ -176,8 +139,8 @@ void *emul_run2(size_t n, const char *const *seq, const size_t *len, size_t ref_
 	const std::vector<CacheQuirk> quirks = getenv("EMUL_NO_QUIRK") ? std::vector<CacheQuirk>() : esa_cache_quirks(S.data(), ns, SA.data());
 	std::vector<U4> quirk_tab;
 	for (const CacheQuirk &e : quirks) quirk_tab.push_back(U4{e.prefix, e.k | (e.depth << 8), e.lo, e.hi});
-	if (!quirk_tab.empty()) mode |= 3u;
-	const bool lean = (mode & 1u) != 0;
+	if (!quirk_tab.empty()) mode |= 2u;
+	const bool lean = true;
 	std::vector<uint32_t> S2, SBAD, Q2, QBAD, qbad_off;
 	LeanIndex X = {};
 	LeanTables LT = {};
@@ -223,10 +186,6 @@ void *emul_run2(size_t n, const char *const *seq, const size_t *len, size_t ref_
 						  &E->steps_spec, &E->rounds, &E->slow_steps);
 			continue;
 		}
-		SpecLane ln;
-		ln.start(A, P.items[it]);
-		run_lane(ln, R, [&] { return ln.begin_step(A); }, [&] { ln.step_done(A); }, &E->steps_spec, &E->rounds,
-				 &E->cmp_calls);
 	}
 	// K1b: the open ends of cut comparisons (lean chains)
 	E->overruns = 0;
@@ -254,11 +213,6 @@ void *emul_run2(size_t n, const char *const *seq, const size_t *len, size_t ref_
 						P.items[it], (unsigned long long)(E->steps_bridge - before), spec_exit[P.items[it]].q, ln.ln.q, ln.ln.lq, ln.ln.ls, ln.ln.ll);
 			continue;
 		}
-		BridgeLane ln;
-		ln.start(A, P.items[it]);
-		run_lane(ln, R, [&] { return ln.begin_step(A, R); }, [&] { ln.step_done(A, alloc); }, &E->steps_bridge,
-				 &E->rounds, &E->cmp_calls);
-		if (bstats) bridge_steps.push_back((uint32_t)(E->steps_bridge - before));
 	}
 	if (bstats && !bridge_steps.empty()) {
 		std::sort(bridge_steps.begin(), bridge_steps.end());
@@ -377,22 +331,6 @@ int emul_suffix_array_buckets(const uint8_t *s, uint32_t n, uint32_t *sa, uint32
 	return suffix_array_buckets(padded.data(), n, sa, fan, threads) ? 1 : 0;
 }
 void emul_lcp(const uint8_t *s, uint32_t n, const uint32_t *sa, uint32_t *lcp) { lcp_kasai(s, n, sa, lcp); }
-// the chunk plan of `nq` queries for `groups` groups with boundaries gb[0..groups] (hostlogic.hpp: plan_chunks,
-// group_items): out_items[nchunks] = the work order, out_first[groups + 1] = the groups' first items, info = {C, nchunks}
-size_t emul_plan_groups(const uint32_t *qlen, uint32_t nq, uint32_t threshold, uint32_t lanes, uint32_t groups, const uint32_t *gb,
-						uint32_t *out_items, uint32_t *out_first, uint32_t *out_qchunk0, uint32_t *info)
-{
-	std::vector<uint32_t> ql(qlen, qlen + nq);
-	ChunkPlan P = plan_chunks(ql, threshold, 0, lanes, 0, 0, groups);
-	std::vector<uint32_t> first = {0u, P.nchunks};
-	if (groups > 1) first = group_items(P, std::vector<uint32_t>(gb, gb + groups + 1));
-	if (out_items) std::copy(P.items.begin(), P.items.end(), out_items);
-	if (out_first) std::copy(first.begin(), first.end(), out_first);
-	if (out_qchunk0) std::copy(P.qchunk0.begin(), P.qchunk0.end(), out_qchunk0);
-	info[0] = P.C;
-	info[1] = P.nchunks;
-	return P.items.size();
-}
 size_t emul_kmer_table(const uint8_t *s, uint32_t n, uint32_t k, uint32_t *out)
 {
 	std::vector<uint32_t> T;

@@ -49,8 +49,6 @@ def lib():
     L.emul_lcp.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p]
     L.emul_kmer_table.restype = C.c_size_t
     L.emul_kmer_table.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]
-    L.emul_plan_groups.restype = C.c_size_t
-    L.emul_plan_groups.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     _LIB = L
     return L
 
@@ -63,8 +61,7 @@ def cache_quirk(seq):
 
 class EmulRun:
     def __init__(self, genomes, ref_idx, threshold=0, chunk=0, kmer=0, mode=0):
-        """mode: 0 the general chain (anchor_core.h), 1 the lean 2-bit chain (lean_core.h), 3 the lean chain with
-        every step through its slow resolver."""
+        """mode: 1 (or 0) the chain on its packed path (lean_core.h), 3 with every step through its slow resolver."""
         self.n = len(genomes)
         self._a = [np.frombuffer(bytes(g), np.uint8) if isinstance(g, (bytes, bytearray))
                    else np.ascontiguousarray(g, np.uint8) for g in genomes]
@@ -134,18 +131,3 @@ def kmer_table(s, k):
     out = np.zeros(4 ** k + 1, np.uint32)
     lib().emul_kmer_table(a.ctypes.data_as(C.c_void_p), a.size, k, out.ctypes.data_as(C.c_void_p))
     return out
-
-
-def plan_groups(qlen, threshold, lanes, gb):
-    """The product's chunk plan for queries of the given lengths when they go through phase A in len(gb) - 1 groups
-    (queries [gb[g], gb[g+1])): (chunk length, work order, the groups' first items, first chunk of every query)."""
-    ql = np.ascontiguousarray(qlen, np.uint32)
-    g = np.ascontiguousarray(gb, np.uint32)
-    info = np.zeros(2, np.uint32)
-    p = lambda a: a.ctypes.data_as(C.c_void_p)
-    lib().emul_plan_groups(p(ql), ql.size, threshold, lanes, g.size - 1, p(g), None, None, None, p(info))
-    items = np.zeros(int(info[1]), np.uint32)
-    first = np.zeros(g.size, np.uint32)
-    qc0 = np.zeros(ql.size + 1, np.uint32)
-    lib().emul_plan_groups(p(ql), ql.size, threshold, lanes, g.size - 1, p(g), p(items), p(first), p(qc0), p(info))
-    return int(info[0]), items, first, qc0

@@ -147,52 +147,6 @@ def test_host_fasta_reader_and_reference_choice(lib, tmp_path):
     assert (sa == O.suffix_array(full)).all()
 
 
-def test_mgpu_block_layout():
-    from phylonium_amd import mgpu
-    lens = [100, 64, 0, 5000, 7, 130]
-    bounds = [0, 2, 2, 5, 6]
-    cap, offs = mgpu.block_layout(lens, bounds)
-    assert cap % 4096 == 0
-    for r in range(4):
-        js = range(bounds[r], bounds[r + 1])
-        for j in js:
-            assert offs[j] % 64 == 0 and offs[j] - r * cap >= 64
-            nxt = offs[j + 1] if j + 1 in js else (r + 1) * cap - 256
-            assert offs[j] + lens[j] + 64 <= nxt
-
-
-def test_mgpu_warnings_follow_print_matrix(lib):
-    """The N-rank driver's vectorised warning pass against the per-pair statement of io.cxx:106-139."""
-    import io
-    from phylonium_amd import mgpu
-    rng = np.random.default_rng(8)
-    n = 9
-    lens = rng.integers(50, 400, n)
-    h = rng.integers(0, 60, (n, n)).astype(np.uint64)
-    h[rng.random((n, n)) < 0.2] = 0
-    s = (h * rng.random((n, n))).astype(np.uint64)
-    s[2, 1], h[2, 1] = 3, 4      # 1 - 4/3 * 0.75 == 0: log gives -inf, distance +inf, not nan
-    s[3, 1], h[3, 1] = 40, 50    # beyond: nan
-    s, h = np.tril(s) + np.tril(s, -1).T, np.tril(h) + np.tril(h, -1).T
-    for kind in ("jc", "raw", "ani"):
-        want, status = [], 0
-        for i in range(n):
-            for j in range(i):
-                v = api.estimate(kind, s[i, j], h[i, j])
-                if v != v:
-                    want.append(f"'{i}' and '{j}' the distance computation failed")
-                else:
-                    c1, c2 = float(h[i, j]) / lens[i], float(h[i, j]) / lens[j]
-                    if c1 < 0.2 or c2 < 0.2:
-                        want.append(f"'{i}' and '{j}' less than 20% homology were found ({c1:f} and {c2:f}, respectively).")
-        buf = io.StringIO()
-        st = mgpu.warnings_and_status([str(i) for i in range(n)], lens, s, h, kind, api, err=buf)
-        got = buf.getvalue().splitlines()
-        assert len(got) == len(want) and st == (1 if want else 0)
-        for g, w in zip(got, want):
-            assert w in g
-
-
 def _fasta_zoo(tmp_path, rng):
     """FASTA files that exercise the reader: line widths around the 32-byte pieces, lower case, IUPAC codes and
     gaps, CRLF, blank lines, many records, an empty record, no newline at the end."""

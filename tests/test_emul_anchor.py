@@ -13,19 +13,14 @@ import oracle_lib as O
 from phylonium_amd import synth
 
 
-MODES = (0, 1, 3)  # the general chain, the lean 2-bit chain, the lean chain with every step through its slow resolver
+MODES = (1, 3)  # the chain on its packed path, and with every step through its slow resolver
 
 
-def assert_same(gs, ref, chunk=0, kmer=0, allow_quirk=False, threshold=0, tail=0, modes=MODES):
+def assert_same(gs, ref, chunk=0, kmer=0, allow_quirk=False, threshold=0, modes=MODES):
     r = O.Run(gs, ref, threshold=threshold).process(compare=False)
     e = None
     for mode in modes:
-        if tail:
-            os.environ["EMUL_CHUNK_TAIL"] = str(tail)
-        try:
-            e = E.EmulRun(gs, ref, chunk=chunk, kmer=kmer, threshold=threshold, mode=mode)
-        finally:
-            os.environ.pop("EMUL_CHUNK_TAIL", None)
+        e = E.EmulRun(gs, ref, chunk=chunk, kmer=kmer, threshold=threshold, mode=mode)
         assert e.error == 0
         assert e.threshold == r.threshold
         for j in range(len(gs)):
@@ -222,15 +217,6 @@ def test_long_repeat_beyond_the_lcp_clip():
     assert_same(gs, 3, chunk=1024)
 
 
-@pytest.mark.parametrize("chunk,tail", [(256, 64), (512, 128), (320, 192), (1024, 256)])
-def test_long_head_and_short_tail_chunks(chunk, tail):
-    """A query's head in long chunks and its tail in short ones (what the plan does when one round of
-    chunks fills the device): the chunk grid is no longer uniform."""
-    gs = synth.make_genomes(5, 30000, seed=chunk + tail, d_range=(0.005, 0.3), indel_per_mbp=400, inv_frac=0.08, contigs=2)
-    assert_same(gs, 0, chunk=chunk, tail=tail)
-    assert_same(gs, 3, chunk=chunk, tail=tail, threshold=18)
-
-
 @pytest.mark.parametrize("chunk", [64, 256, 1024, 0])
 def test_overruns_of_near_identical_genomes(chunk):
     """Genomes that equal the reference over many chunk lengths: the lean chains cut every speculative
@@ -332,29 +318,3 @@ def test_cache_quirk_is_reproduced():
         finally:
             os.environ.pop("EMUL_NO_QUIRK", None)
     assert differs > 0
-
-
-def test_work_order_for_groups_of_queries():
-    """hostlogic.hpp: plan_chunks(groups) + group_items (option pipeline_groups).  The chunk length is planned for a
-    group's share of the bases; the work order is a permutation of all chunks in which every group's chunks are
-    contiguous, and inside a group the runs of 256 chunks are dealt round-robin over its queries as in the plain plan."""
-    rng = np.random.default_rng(3)
-    qlen = rng.integers(200_000, 3_000_000, size=40).astype(np.uint32)
-    qlen[7] = 0  # the subject among the queries has no chunks
-    lanes = 64 * 256
-    c1, items1, first1, qc1 = E.plan_groups(qlen, 15, lanes, [0, 40])
-    assert first1.tolist() == [0, items1.size] and sorted(items1.tolist()) == list(range(items1.size))
-    gb = [0, 9, 22, 31, 40]
-    c4, items, first, qc0 = E.plan_groups(qlen, 15, lanes, gb)
-    assert c4 <= c1 and c4 % 64 == 0  # a quarter of the bases per group: shorter chunks (or the shortest allowed)
-    n = items.size
-    assert n == qc0[-1] and sorted(items.tolist()) == list(range(n))
-    assert first[0] == 0 and first[-1] == n
-    for g in range(4):
-        mine = items[first[g]:first[g + 1]]
-        lo, hi = qc0[gb[g]], qc0[gb[g + 1]]
-        assert mine.size == hi - lo and mine.min(initial=lo) >= lo and mine.max(initial=lo) < hi
-        # the first item of every run of a query's chunks: runs of one query ascend
-        for j in range(gb[g], gb[g + 1]):
-            own = mine[(mine >= qc0[j]) & (mine < qc0[j + 1])]
-            assert (np.diff(own.astype(np.int64)) > 0).all()

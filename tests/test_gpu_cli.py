@@ -203,86 +203,6 @@ def test_fasta_reader_errors_in_command_line_order(tmp_path):
     assert rc == 1 and "missing.fa" in err
 
 
-# ── the N-rank driver (phylonium_amd.mgpu): same text as the single-GPU driver ──
-
-def run_mgpu(args, cwd, ranks=1, backend=None):
-    import sys
-    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    if ranks == 1:
-        cmd = [sys.executable, "-m", "phylonium_amd.mgpu", *args]
-    else:
-        import socket
-        with socket.socket() as s:
-            s.bind(("127.0.0.1", 0))
-            port = s.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "phylonium_amd.mgpu",
-               "--backend", backend or "gloo", *args]
-    p = subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, env=env, timeout=600)
-    return p.returncode, p.stdout, p.stderr
-
-
-def _mgpu_set(tmp_path):
-    gs = synth.make_genomes(7, 30000, seed=91, d_range=(0.01, 0.2), indel_per_mbp=300, inv_frac=0.08, contigs=3,
-                            inv_len=(200, 1500))
-    gs[5] = gs[5][:21000].copy()  # ragged lengths: the median choice and the block balance see them
-    names = [f"m{i}" for i in range(7)]
-    for n, g in zip(names, gs):
-        write_fasta(tmp_path / f"{n}.fa", g)
-    return gs, names, [f"{n}.fa" for n in names]
-
-
-def test_mgpu_one_rank_matches_the_driver(tmp_path):
-    gs, names, files = _mgpu_set(tmp_path)
-    for extra_cli, extra in (([], []), (["-r", files[2]], ["-r", files[2]]), (["--distance=raw"], ["--raw"]),
-                             (["--distance=ani"], ["--ani"])):
-        rc0, out0, err0 = run([*extra_cli, *files], tmp_path)
-        rc1, out1, err1 = run_mgpu([*extra, *files], tmp_path)
-        assert out1 == out0 and rc1 == rc0, err1[-2000:]
-    rc, out, err = run_mgpu(["--timing", *files], tmp_path)
-    assert "timing: ranks 1" in err
-    rc, out2, err = run_mgpu(["--sa", "host", *files], tmp_path)  # the suffix array from the host cores
-    assert out2 == out
-
-
-def test_mgpu_two_ranks_with_the_host_suffix_array(tmp_path):
-    """--sa host: the rank that read the reference sorts its suffixes on the host cores and broadcasts the array."""
-    gs, names, files = _mgpu_set(tmp_path)
-    rc0, out0, err0 = run(files, tmp_path)
-    rc, out, err = run_mgpu(["--sa", "host", *files], tmp_path, ranks=2, backend="gloo")
-    assert out == out0 and rc == rc0, err[-2000:]
-
-
-def test_mgpu_two_ranks_on_one_gpu(tmp_path):
-    """Two processes (torchrun), collectives over gloo because the test box has one GPU: file blocks,
-    genome all-gather, suffix-array broadcast, sharded phases — the text must not change."""
-    gs, names, files = _mgpu_set(tmp_path)
-    rc0, out0, err0 = run(files, tmp_path)
-    rc2, out2, err2 = run_mgpu(files, tmp_path, ranks=2)
-    assert out2 == out0 and rc2 == rc0, err2[-3000:]
-    r = O.Run(gs, 4).process()
-    s, h = r.matrix()
-    rc2, out2, err2 = run_mgpu(["-r", files[4], *files], tmp_path, ranks=3)
-    assert out2 == O.phylip(names, s, h), err2[-3000:]
-
-
-def test_mgpu_warnings_and_bad_files(tmp_path):
-    rng = np.random.default_rng(6)
-    write_fasta(tmp_path / "a.fasta", synth.random_base(50000, rng))
-    write_fasta(tmp_path / "b.fasta", synth.random_base(50000, rng))
-    rc0, out0, err0 = run(["a.fasta", "b.fasta"], tmp_path)
-    rc1, out1, err1 = run_mgpu(["a.fasta", "b.fasta"], tmp_path)
-    assert rc1 == rc0 == 1 and out1 == out0
-    assert [l for l in err1.split("\n") if "reported as nan" in l] == [l for l in err0.split("\n") if "reported as nan" in l]
-    (tmp_path / "bad.fasta").write_text("this is not FASTA\n")
-    rc0, out0, err0 = run(["a.fasta", "bad.fasta", "b.fasta"], tmp_path)
-    rc1, out1, err1 = run_mgpu(["a.fasta", "bad.fasta", "b.fasta"], tmp_path)
-    assert rc1 == rc0 == 1 and out1 == out0 == ""
-    assert "bad.fasta: File is not in FASTA format." in err1 and "bad.fasta: File is not in FASTA format." in err0
-    rc1, out1, err1 = run_mgpu(["a.fasta", "missing.fasta", "b.fasta"], tmp_path)
-    assert rc1 == 1 and "missing.fasta" in err1
-
-
 @pytest.mark.parametrize("backend", ["auto", "copies"])
 def test_several_gpus_print_the_same(tmp_path, backend):
     """`phylonium-amd --gpus N` (one host thread and one context per rank, csrc/group.hip: the genomes' blocks

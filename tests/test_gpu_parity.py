@@ -31,80 +31,91 @@ def hom_tuples_orc(h):
     return [(int(a["rev"]), int(a["iref"]), int(a["iproj"]), int(a["iq"]), int(a["len"])) for a in h]
 
 
-def check_process(ctx, gs, ref, chunk=0, kmer=0, backend=0, complete_deletion=False, threshold=0, filt=None, tail=0):
-    if filt is None:  # both homes of the sort + chain filter, alternating from call to call
-        check_process.flip = 3 - getattr(check_process, "flip", 1)
-        filt = check_process.flip
-    ctx.set_option("filter", filt)
-    # the device filter's two kernels, alternating: stretch by stretch (default) / the general dependent scan
-    check_process.fk = (getattr(check_process, "fk", 0) + 1) % 3
-    ctx.set_option("filter_kernel", 1 if check_process.fk == 2 else 0)
+# Option bundles of the parity checks.  Every check_process call runs under ONE named bundle; which one is a function
+# of the test's id and of the call's index inside that test — never of what ran before it — so `pytest -k name` hits
+# the same combinations as the whole suite, and every assertion message names the bundle.  PHY_OPTION_BUNDLE=<name or
+# index> pins one bundle for every call (to reproduce a failure, or to sweep the suite under one configuration).
+# "default" is the library as it ships; the others move the steps that have a second home: the sort + chain filter
+# (host cores / the device's general kernel), the pair tallies (vector ALUs instead of the matrix cores), the fold's
+# blocks per query, the genomes' way in (2-bit codes + separator positions instead of bytes), and "recheck" repeats
+# phase A with every step sent through the chains' slow resolver (the definition, from the raw bytes).
+BUNDLES = [
+    ("default", {}),
+    ("default+recheck", {"recheck": 1}),
+    ("packed-ingest", {"packed": 1, "fold_blocks": 3}),
+    ("host-filter+valu-pairs", {"filter": 1, "pairs_kernel": 1, "fold_blocks": 8, "recheck": 1}),
+    ("general-filter-kernel", {"filter": 2, "filter_kernel": 1, "packed": 1, "fold_blocks": 1}),
+    ("device-filter+valu-pairs", {"filter": 2, "pairs_kernel": 1}),
+]
+BUNDLE_NAMES = [b[0] for b in BUNDLES]
+_calls = {}
+
+
+def pick_bundle(bundle=None):
+    """(name, options) for this check: an explicit name, else PHY_OPTION_BUNDLE, else by test id and call index."""
+    import zlib
+    forced = bundle if bundle is not None else os.environ.get("PHY_OPTION_BUNDLE")
+    if forced is not None and forced != "":
+        i = int(forced) if str(forced).isdigit() else BUNDLE_NAMES.index(forced)
+        return BUNDLES[i]
+    test = os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]
+    k = _calls.get(test, 0)
+    _calls[test] = k + 1
+    return BUNDLES[(zlib.crc32(test.encode()) + k) % len(BUNDLES)]
+
+
+def check_process(ctx, gs, ref, chunk=0, kmer=0, backend=0, complete_deletion=False, threshold=0, filt=None, bundle=None):
+    name, opts = pick_bundle(bundle)
+    opts = dict(opts)
+    if filt is not None:
+        opts["filter"] = filt
+    tag = f"[bundle {name}: {opts}; chunk {chunk}, kmer {kmer}, backend {backend}, threshold {threshold}, ref {ref}]"
+    ctx.set_option("filter", opts.get("filter", 0))
+    ctx.set_option("filter_kernel", opts.get("filter_kernel", 0))
+    ctx.set_option("pairs_kernel", opts.get("pairs_kernel", 0))
+    ctx.set_option("fold_blocks", opts.get("fold_blocks", 0))
     ctx.set_option("chunk", chunk)
-    ctx.set_option("chunk_tail", tail)
     ctx.set_option("kmer", kmer)
     ctx.set_option("compare_backend", backend)
-    # the pair kernels, alternating: the matrix cores on three planes with the '!' settled from a list (default) /
-    # the vector ALUs on three or five planes
-    check_process.pkern = (getattr(check_process, "pkern", 0) + 1) % 3
-    ctx.set_option("pairs_kernel", 1 if check_process.pkern == 2 else 0)
-    # blocks per query of the fold kernel: the library's choice, three, eight (lists then arrive out of query order)
-    check_process.fb = (getattr(check_process, "fb", 0) + 1) % 4
-    ctx.set_option("fold_blocks", (0, 3, 8, 1)[check_process.fb])
-    ctx.set_option("lean_batch", (0, 0, 2, 3)[check_process.fb])  # the chains' rarer phases on every n-th trip only
-    # every step through its k-mer's slot (default) / steps of k-mers that do not occur in the reference from the absence table
-    check_process.ab = (getattr(check_process, "ab", 0) + 1) % 5
-    ctx.set_option("absent_table", 1 if check_process.ab in (1, 3) else 0)
-    # genomes arrive as bytes or as 2-bit codes + separator positions (phylo_set_genomes_packed), alternating
-    check_process.pk = 1 - getattr(check_process, "pk", 0)
-    if check_process.pk:
-        ctx.set_genomes_packed([api.pack_genome(g) for g in gs])
-    else:
-        ctx.set_genomes(gs)
-    ctx.set_reference(ref, threshold=threshold)
-    r = O.Run(gs, ref, threshold=threshold).process(complete_deletion=complete_deletion)
-    assert ctx.threshold == r.threshold
-    # a subject on which the reference's 6-mer cache holds an over-deep interval (esa.cxx:174-199) is flagged, and
-    # the reference's answers on it are reproduced all the same (option "cache_quirk", default on)
-    assert ctx.reference_cache_quirk == bool(O.Esa(gs[ref]).cache_quirks())
-    ctx.anchor()
-    if complete_deletion:
-        ctx.complete_delete()
-    for j in range(len(gs)):
-        assert hom_tuples_gpu(ctx.homologies(j)) == hom_tuples_orc(r.homologies(j)), f"homologies of genome {j}"
-    s, h = ctx.compare()
-    so, ho = r.matrix()
-    assert (h == ho).all(), "homologs differ"
-    assert (s == so).all(), "substitutions differ"
-    # phase A once more through the other chain kernels, alternating from call to call: the general
-    # byte-wise chains (anchor_kernel 0), and the lean chains with every step sent to the wavefront's
-    # slow resolver — the lists must come out the same
-    check_process.alt = 1 - getattr(check_process, "alt", 0)
-    ctx.set_option("anchor_kernel", 0 if check_process.alt else 1)
-    ctx.set_option("lean_force_slow", 0 if check_process.alt else 1)
     try:
+        if opts.get("packed"):
+            ctx.set_genomes_packed([api.pack_genome(g) for g in gs])
+        else:
+            ctx.set_genomes(gs)
+        ctx.set_reference(ref, threshold=threshold)
+        r = O.Run(gs, ref, threshold=threshold).process(complete_deletion=complete_deletion)
+        assert ctx.threshold == r.threshold, tag
+        # a subject on which the reference's 6-mer cache holds an over-deep interval (esa.cxx:174-199) is flagged, and
+        # the reference's answers on it are reproduced all the same (option "cache_quirk", default on)
+        assert ctx.reference_cache_quirk == bool(O.Esa(gs[ref]).cache_quirks()), tag
         ctx.anchor()
         if complete_deletion:
             ctx.complete_delete()
         for j in range(len(gs)):
-            assert hom_tuples_gpu(ctx.homologies(j)) == hom_tuples_orc(r.homologies(j)), \
-                f"homologies of genome {j} ({'general chains' if check_process.alt else 'slow resolver'})"
+            assert hom_tuples_gpu(ctx.homologies(j)) == hom_tuples_orc(r.homologies(j)), f"homologies of genome {j} {tag}"
+        s, h = ctx.compare()
+        so, ho = r.matrix()
+        assert (h == ho).all(), f"homologs differ {tag}"
+        assert (s == so).all(), f"substitutions differ {tag}"
+        if opts.get("recheck"):
+            # phase A once more with every step sent to the wavefront's slow resolver: the lists must come out the same
+            ctx.set_option("lean_force_slow", 1)
+            try:
+                ctx.anchor()
+                if complete_deletion:
+                    ctx.complete_delete()
+                for j in range(len(gs)):
+                    assert hom_tuples_gpu(ctx.homologies(j)) == hom_tuples_orc(r.homologies(j)), \
+                        f"homologies of genome {j} (slow resolver) {tag}"
+            finally:
+                ctx.set_option("lean_force_slow", 0)
+        for i in range(len(gs)):
+            for j in range(len(gs)):
+                a, b = api.estimate("jc", s[i, j], h[i, j]), O.estimate("jc", so[i, j], ho[i, j])
+                assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= 1e-12, tag
     finally:
-        ctx.set_option("anchor_kernel", 1)
-        ctx.set_option("lean_force_slow", 0)
-    for i in range(len(gs)):
-        for j in range(len(gs)):
-            a, b = api.estimate("jc", s[i, j], h[i, j]), O.estimate("jc", so[i, j], ho[i, j])
-            assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= 1e-12
-    ctx.set_option("chunk", 0)
-    ctx.set_option("chunk_tail", 0)
-    ctx.set_option("kmer", 0)
-    ctx.set_option("compare_backend", 0)
-    ctx.set_option("filter", 0)
-    ctx.set_option("filter_kernel", 0)
-    ctx.set_option("pairs_kernel", 0)
-    ctx.set_option("fold_blocks", 0)
-    ctx.set_option("lean_batch", 0)
-    ctx.set_option("absent_table", 0)
+        for key in ("chunk", "kmer", "compare_backend", "filter", "filter_kernel", "pairs_kernel", "fold_blocks"):
+            ctx.set_option(key, 0)
     return s, h
 
 
@@ -152,6 +163,36 @@ def test_process_star(ctx, chunk):
     gs = synth.make_genomes(6, 30000, seed=3, d_range=(0.01, 0.25))
     check_process(ctx, gs, 0, chunk=chunk)
     check_process(ctx, gs, 4, chunk=chunk, backend=1)
+
+
+def _five_sets():
+    """Five small sets that between them reach every branch of the path: substitutions only; indels, inversions and
+    contigs; a tree at low divergence; '!' inside homologies on both strands; near-identical genomes (overruns)."""
+    rng = np.random.default_rng(31)
+    base = synth.random_base(30000, rng)
+    bang = [base.copy()]
+    for g in range(4):
+        x = synth.mutate(base, 0.02, rng)
+        x = (synth.revcomp(x) if g % 2 else x).copy()
+        x[rng.integers(1000, 29000, 6)] = ord("!")
+        bang.append(x)
+    a = synth.random_base(40000, rng)
+    b = a.copy()
+    b[[7000, 7001, 23000]] = synth.random_base(3, rng)
+    near = [a, a.copy(), b, np.concatenate([a[:15000], a[15010:]]), synth.mutate(a, 0.0003, rng)]
+    return [(synth.make_genomes(6, 30000, seed=3, d_range=(0.01, 0.25)), 0),
+            (synth.make_genomes(7, 40000, seed=5, d_range=(0.01, 0.3), indel_per_mbp=500, inv_frac=0.1, contigs=3, inv_len=(100, 1500)), 5),
+            (synth.make_genomes(9, 60000, seed=9, d_range=(0.0005, 0.03), tree=True, indel_per_mbp=200, inv_frac=0.05), 7),
+            (bang, 0), (near, 4)]
+
+
+@pytest.mark.parametrize("bundle", ["default", "host-filter+valu-pairs", "general-filter-kernel"])
+def test_named_bundles_over_the_same_five_sets(ctx, bundle):
+    """The library's default configuration and two named non-default bundles over the same five input sets: whatever
+    the per-test rotation picks elsewhere, these combinations are always exercised on these inputs."""
+    for gs, ref in _five_sets():
+        check_process(ctx, gs, ref, bundle=bundle)
+        check_process(ctx, gs, ref, chunk=128, bundle=bundle)
 
 
 @pytest.mark.parametrize("seed", [5, 6])
@@ -246,10 +287,9 @@ def test_device_filter_on_entangled_lists(ctx):
         parts += [synth.random_base(int(rng.integers(500, 4000)), rng), synth.mutate(rep, 0.01 * i, rng)]
     a = np.concatenate(parts + [synth.random_base(2000, rng)])
     gs = [a] + [synth.mutate(a, d, rng) for d in (0.005, 0.02, 0.05, 0.1)]
-    for fk in (0, 1):
-        ctx.set_option("filter_kernel", fk)
+    for bundle in ("device-filter+valu-pairs", "general-filter-kernel"):  # filter_kernel 0 and 1, both on the device
         for ref in (0, 2):
-            check_process(ctx, gs, ref, filt=2)
+            check_process(ctx, gs, ref, bundle=bundle)
 
 
 def test_installed_lists_that_overlap_go_through_the_segment_backend(ctx):
@@ -885,8 +925,7 @@ def test_fuzz_small_random_sets(ctx, seed):
     kmer = int(rng.choice([0, 0, 2, 5]))
     backend = int(rng.integers(0, 2))
     threshold = int(rng.choice([0, 0, 0, 17, 21]))  # 17+: what references beyond ~60 Mbp have
-    tail = int(rng.choice([0, 0, 64, 128])) if chunk else 0  # a query's tail in shorter chunks
-    check_process(ctx, gs, ref, chunk=chunk, kmer=kmer, backend=backend, threshold=threshold, tail=tail)
+    check_process(ctx, gs, ref, chunk=chunk, kmer=kmer, backend=backend, threshold=threshold)
 
 
 def _nccl_one_rank_worker(rank, world, port, out):
@@ -989,48 +1028,6 @@ def test_many_queries_default_options(ctx):
     assert (s == so).all() and (h == ho).all()
     for j in (0, 7, 63, 139):  # read back on demand
         assert hom_tuples_gpu(ctx.homologies(j)) == hom_tuples_orc(r.homologies(j))
-
-
-@pytest.mark.parametrize("groups", [2, 4, 8])
-def test_phase_a_in_groups_of_queries(ctx, groups):
-    """Option pipeline_groups: the queries go through phase A in groups, a group's bridges, fold, filter and projection
-    on a second stream while the next group's speculative chains run.  270 short genomes (four groups need 64 queries
-    each; eight are cut down to four), some of them nearly the reference itself so that chunks end in open matches
-    that the per-group overrun pass has to close.  Tallies and lists equal the oracle's."""
-    gs = synth.make_genomes(258, 6000, seed=91, d_range=(0.005, 0.3), indel_per_mbp=600, inv_frac=0.06)
-    rng = np.random.default_rng(17)
-    base = gs[3]
-    for t in range(12):  # near-copies of the reference below: a substitution or two each
-        g = base.copy()
-        for p in rng.integers(0, len(g), size=1 + t % 3):
-            g[p] = ord("ACGT"[(b"ACGT".index(bytes([g[p]])) + 1) % 4]) if g[p] in b"ACGT" else g[p]
-        gs.insert(int(rng.integers(0, len(gs))), g)
-    ref = next(i for i, g in enumerate(gs) if g is base)
-    r = O.Run(gs, ref).process(threads=4)
-    so, ho = r.matrix()
-    ctx.set_option("filter", 0)
-    ctx.set_option("pipeline_groups", groups)
-    try:
-        for chunk in (256, 0):
-            ctx.set_option("chunk", chunk)
-            ctx.set_genomes(gs)
-            s, h = ctx.process(ref_idx=ref)
-            assert (h == ho).all() and (s == so).all(), chunk
-            for j in (0, 3, 64, 65, 130, 200, len(gs) - 1):
-                assert hom_tuples_gpu(ctx.homologies(j)) == hom_tuples_orc(r.homologies(j)), (chunk, j)
-            ctx.anchor(10, 250)  # a block of the queries only (a rank's share): the groups are counted from its first query
-            for j in (10, 11, 73, 74, 138, 249):
-                assert hom_tuples_gpu(ctx.homologies(j)) == hom_tuples_orc(r.homologies(j)), (chunk, j, "block")
-    finally:
-        ctx.set_option("pipeline_groups", 1)
-        ctx.set_option("chunk", 0)
-
-
-@pytest.mark.parametrize("chunk,tail", [(256, 64), (512, 192), (1024, 256)])
-def test_long_head_and_short_tail_chunks(ctx, chunk, tail):
-    gs = synth.make_genomes(7, 50000, seed=chunk, d_range=(0.005, 0.3), indel_per_mbp=400, inv_frac=0.08, contigs=2)
-    check_process(ctx, gs, 0, chunk=chunk, tail=tail)
-    check_process(ctx, gs, 4, chunk=chunk, tail=tail, backend=1, threshold=17)
 
 
 @pytest.mark.timeout(900)

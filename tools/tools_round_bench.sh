@@ -4,18 +4,18 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/final
-python bench.py > gpurun_out/final/r03_bench_c3.json 2> gpurun_out/final/c3.err
-python bench.py --workload c4 --steps 20 --warmup 3 --check > gpurun_out/final/r03_bench_c4.json 2> gpurun_out/final/c4.err
-python bench.py --workload c5 --steps 5 --warmup 2 --cpu-sample 0 --check > gpurun_out/final/r03_bench_c5.json 2> gpurun_out/final/c5.err
-python bench.py --workload c3tree --steps 50 --warmup 3 --cpu-sample 0 --check > gpurun_out/final/r03_bench_c3tree.json 2> gpurun_out/final/c3tree.err
-python bench.py --workload c2like --steps 100 --warmup 5 --cpu-sample 0 --check > gpurun_out/final/r03_bench_c2like.json 2> gpurun_out/final/c2like.err
-python bench.py --workload c3dup --steps 100 --warmup 5 --cpu-sample 0 --check > gpurun_out/final/r03_bench_c3dup.json 2> gpurun_out/final/c3dup.err
-python bench.py --workload c3 --genomes 64 --steps 100 --warmup 5 --cpu-sample 0 > gpurun_out/final/r03_bench_c3_64.json 2> gpurun_out/final/c3_64.err
-python bench.py --gpus 2 --workload small --steps 20 --warmup 3 > gpurun_out/final/r03_bench_small_2ranks.json 2> gpurun_out/final/small2.err
-for r in 0 3 7; do python bench.py --workload c4 --steps 20 --warmup 3 --cpu-sample 0 --emulate-rank $r/8 --emulate-exchange > gpurun_out/final/r03_emulated_c4_rank${r}of8.json 2> gpurun_out/final/emu$r.err; done
-python tools/tools_wallclock.py --workload c3 --out gpurun_out/final/r03_wallclock_c3.json > /dev/null 2>&1
-python tools/tools_wallclock.py --workload c4 --gpus 1,2,8 --mgpu 1 --out gpurun_out/final/r03_wallclock_c4.json > /dev/null 2>&1
-python tools/tools_wallclock.py --workload c5 --out gpurun_out/final/r03_wallclock_c5.json > /dev/null 2>&1
+python bench.py > gpurun_out/final/r04_bench_c3.json 2> gpurun_out/final/c3.err
+python bench.py --workload c4 --steps 20 --warmup 3 --check > gpurun_out/final/r04_bench_c4.json 2> gpurun_out/final/c4.err
+python bench.py --workload c5 --steps 5 --warmup 2 --cpu-sample 0 --check > gpurun_out/final/r04_bench_c5.json 2> gpurun_out/final/c5.err
+python bench.py --workload c3tree --steps 50 --warmup 3 --cpu-sample 0 --check > gpurun_out/final/r04_bench_c3tree.json 2> gpurun_out/final/c3tree.err
+python bench.py --workload c2like --steps 100 --warmup 5 --cpu-sample 0 --check > gpurun_out/final/r04_bench_c2like.json 2> gpurun_out/final/c2like.err
+python bench.py --workload c3dup --steps 100 --warmup 5 --cpu-sample 0 --check > gpurun_out/final/r04_bench_c3dup.json 2> gpurun_out/final/c3dup.err
+python bench.py --workload c3 --genomes 64 --steps 100 --warmup 5 --cpu-sample 0 > gpurun_out/final/r04_bench_c3_64.json 2> gpurun_out/final/c3_64.err
+python bench.py --gpus 2 --workload small --steps 20 --warmup 3 > gpurun_out/final/r04_bench_small_2ranks.json 2> gpurun_out/final/small2.err
+for r in 0 3 7; do python bench.py --workload c4 --steps 20 --warmup 3 --cpu-sample 0 --emulate-rank $r/8 --emulate-exchange > gpurun_out/final/r04_emulated_c4_rank${r}of8.json 2> gpurun_out/final/emu$r.err; done
+python tools/tools_wallclock.py --workload c3 --out gpurun_out/final/r04_wallclock_c3.json > /dev/null 2>&1
+python tools/tools_wallclock.py --workload c4 --gpus 1,2,8 --out gpurun_out/final/r04_wallclock_c4.json > /dev/null 2>&1
+python tools/tools_wallclock.py --workload c5 --out gpurun_out/final/r04_wallclock_c5.json > /dev/null 2>&1
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 python tools/tools_round_summary.py gpurun_out/final
 grep -h "emulated\|check" gpurun_out/final/*.err | head

@@ -17,8 +17,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="c3", choices=sorted(bench.WORKLOADS))
     ap.add_argument("--genomes", type=int, default=0)
-    ap.add_argument("--mgpu", default="", help="also run the N-rank driver: comma list of rank counts, e.g. 1,2 "
-                    "(more ranks than GPUs: collectives over gloo, all ranks on GPU 0)")
     ap.add_argument("--gpus", default="", help="also run `phylonium-amd --gpus N` (the C++ host with one thread and one context per "
                     "rank, csrc/group.hip): comma list of rank counts, e.g. 1,2,8 (more ranks than GPUs: they share them)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "wallclock.json"))
@@ -95,20 +93,6 @@ def drive(args, n, desc, files, want, meta):
             runs.append({"label": f"phylonium-amd --gpus {ranks} ({meta['devices']} GPU(s) in the box), run {rep + 1}",
                          "wall_s_including_exec": round(wall, 3), "timing": m.group(1) if m else err[-400:],
                          "ranks": m2.group(1) if m2 else None, "matrix_identical": p.stdout.decode() == want, "exit": p.returncode})
-    for ranks in [int(x) for x in args.mgpu.split(",") if x]:
-        env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
-        backend = "nccl" if ranks <= meta["devices"] else "gloo"
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr",
-               "127.0.0.1", "--master-port", "29631", "-m", "phylonium_amd.mgpu", "--backend", backend, "--timing",
-               "-r", files[0]] + files
-        t0 = time.time()
-        p = subprocess.run(cmd, capture_output=True, env=env)
-        wall = time.time() - t0
-        err = p.stderr.decode()
-        m = re.search(r"timing: (.*)", err)
-        runs.append({"label": f"phylonium_amd.mgpu, {ranks} rank(s), {backend}", "wall_s_including_exec": round(wall, 3),
-                     "timing": m.group(1) if m else err[-600:], "matrix_identical": p.stdout.decode() == want,
-                     "exit": p.returncode})
     out = {"workload": f"{args.workload}: {desc}", "genomes": n, "bases": meta["bases"],
            "fasta_bytes": sum(os.path.getsize(f) for f in files), "fasta_write_s": meta["fasta_write_s"], "runs": runs,
            "note": "exit 1 is the reference's soft-warning status (io.cxx:106-139): this workload has pairs with less than "
