@@ -248,7 +248,10 @@ const char *phylo_group_last_error(const phylo_group *g); /* g may be NULL: a fa
 size_t phylo_group_size(const phylo_group *g);
 phylo_ctx *phylo_group_ctx(phylo_group *g, size_t rank);   /* rank 0 holds every list after phylo_group_anchor */
 const char *phylo_group_backend(const phylo_group *g);     /* "rccl", "device-to-device copies" or "one rank" */
-int phylo_group_set_option(phylo_group *g, const char *key, long value); /* phylo_set_option on every rank */
+/* phylo_set_option on every rank; and the group's own "exchange_cap": records per exchange block of the next plan
+ * (0, the default: sized from the lists' lengths, which costs one host round trip per new reference; a pass whose lists
+ * outgrow a pinned capacity is repeated by phylo_group_process with a plan of its own) */
+int phylo_group_set_option(phylo_group *g, const char *key, long value);
 /* phylo_get_stat of a rank, plus "group:ms_anchor", "group:ms_exchange", "group:ms_compare", "group:ms_reduce" (the
  * rank's host-side milliseconds in the last pass) */
 int phylo_group_get_stat(phylo_group *g, size_t rank, const char *key, double *out);

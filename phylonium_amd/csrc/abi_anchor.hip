@@ -93,6 +93,7 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, bool defer)
 		HIPOK(c, c->a_qanc0.ensure(nq));
 		HIPOK(c, c->a_spec_exit.ensure(nchp + 1));
 		HIPOK(c, c->a_bridge.ensure(nchp + 1));
+		HIPOK(c, c->a_bridge_start.ensure(((size_t)nchp + 1) * LeanBridge::PACKED_WORDS));
 		HIPOK(c, c->a_pool.ensure(nchp / 4 + 4096));
 		HIPOK(c, c->a_raw.ensure(raw_total + 1));
 		HIPOK(c, c->a_out_base.ensure(nq + 1));
@@ -143,11 +144,13 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, bool defer)
 	A.bridge = c->a_bridge.p;
 	A.pool = c->a_pool.p;
 	A.pool_blocks = pool_blocks;
+	A.bridge_start = c->a_bridge_start.p;
+	A.bridge_todo = c->a_misc.p + 8;
 	A.fetch = c->a_misc.p;          // [0] spec, [1] bridge
 	A.pool_next = c->a_misc.p + 2;
 	A.error = c->a_misc.p + 3;
 	A.overrun = c->a_misc.p + 4;
-	RefIndex R = {c->d_S.p, c->d_SAX.p, c->d_LCP.p, c->d_SLOT.p, c->ns, c->k, c->threshold};
+	RefIndex R = {c->d_S.p, c->d_SAX.p, c->d_LCP.p, c->d_SLOT.p, c->d_T.p, c->ns, c->k, c->threshold};
 	// A subject on which the reference's 6-mer cache holds over-deep intervals (esa.cxx:174-199): the reference's
 	// answers there are reproduced by the lean chains' slow resolver, so every step goes through it (such subjects
 	// are a few kbp in several contigs; option "cache_quirk" = 0 computes the true longest matches instead).
@@ -155,7 +158,7 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, bool defer)
 				   (uint32_t)(c->lean_force_slow || quirk_mode), nullptr, quirk_mode ? c->d_quirk.p : nullptr, quirk_mode ? c->nquirk : 0u};
 #ifdef PHY_LEAN_TIMING
 	static unsigned long long *dbg_buf = nullptr;
-	const size_t dbg_words = 16 + 4 * 8192 + 64;
+	const size_t dbg_words = 16 + 4 * 8192 + 64 + 16;
 	if (!dbg_buf) (void)hipMalloc((void **)&dbg_buf, dbg_words * 8);
 	(void)hipMemsetAsync(dbg_buf, 0, dbg_words * 8, st);
 	X.dbg = dbg_buf;
@@ -276,6 +279,34 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, bool defer)
 			const unsigned long long *e = h + 16 + 4 * 8192 + 34 + m * 6;
 			fprintf(stderr, "[lean timing] mode %d EXT lane-trips: first of a lucky check %llu, first of a candidate %llu, later %llu; of the first ones: match < 32 bases %llu, < 48 bases %llu, on to SEARCH/SLOW %llu\n",
 					m, e[0], e[1], e[2], e[3], e[4], e[5]);
+		}
+		{
+			const unsigned long long *b = h + 16 + 4 * 8192 + 64;
+			fprintf(stderr, "[lean timing] bridges walked, by steps: 1: %llu  2: %llu  3-4: %llu  5-8: %llu  9-16: %llu  17-32: %llu  33-64: %llu  65+: %llu; the longest %llu\n",
+					b[1], b[2], b[3], b[4], b[5], b[6], b[7], b[8], b[9]);
+		}
+		for (int m = 0; m < 2; m++) { // the wavefronts' lifetimes (100 MHz counter) and trips
+			std::vector<double> dur, ends;
+			std::vector<unsigned long long> tr;
+			unsigned long long t0 = ~0ull;
+			for (size_t w = 0; w < 4096; w++) {
+				const unsigned long long *r = h + 16 + 4 * (m * 4096 + w);
+				if (r[1]) t0 = std::min(t0, r[0]);
+			}
+			for (size_t w = 0; w < 4096; w++) {
+				const unsigned long long *r = h + 16 + 4 * (m * 4096 + w);
+				if (!r[1]) continue;
+				dur.push_back((double)(r[1] - r[0]) / 100.0);
+				ends.push_back((double)(r[1] - t0) / 100.0);
+				tr.push_back(r[2]);
+			}
+			if (dur.empty()) continue;
+			std::sort(dur.begin(), dur.end());
+			std::sort(ends.begin(), ends.end());
+			std::sort(tr.begin(), tr.end());
+			const size_t n = dur.size();
+			fprintf(stderr, "[lean timing] mode %d: %zu wavefronts; lifetime us min %.0f median %.0f p90 %.0f max %.0f; end (from the first start) us median %.0f p90 %.0f p99 %.0f max %.0f; trips min %llu median %llu p90 %llu max %llu\n",
+					m, n, dur[0], dur[n / 2], dur[n * 9 / 10], dur[n - 1], ends[n / 2], ends[n * 9 / 10], ends[n * 99 / 100], ends[n - 1], tr[0], tr[n / 2], tr[n * 9 / 10], tr[n - 1]);
 		}
 		if (const char *wf = getenv("PHY_LEAN_WAVES_OUT")) {
 			if (FILE *f = fopen(wf, "w")) { // the last call's speculative wavefronts: start, end (10 ns), trips, query

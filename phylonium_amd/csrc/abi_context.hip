@@ -96,6 +96,7 @@ void phylo_ctx_destroy(phylo_ctx *c)
 	c->a_spec_anchors.release();
 	c->a_spec_exit.release();
 	c->a_bridge.release();
+	c->a_bridge_start.release();
 	c->a_pool.release();
 	c->a_raw.release();
 	c->a_raw_compact.release();

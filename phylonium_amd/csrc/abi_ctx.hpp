@@ -230,6 +230,7 @@ struct phylo_ctx {
 	DevBuf<Anchor> a_spec_anchors;
 	DevBuf<SpecExit> a_spec_exit;
 	DevBuf<BridgeRec> a_bridge;
+	DevBuf<uint32_t> a_bridge_start; // the bridges that need walking, packed (lean_core.h: LeanBridge::pack)
 	DevBuf<PoolBlock> a_pool;
 	DevBuf<RawHom> a_raw, a_raw_compact;
 	DevBuf<uint64_t> a_out_base, a_cmp_base;

@@ -9,20 +9,13 @@ using namespace phyabi;
 
 extern "C" {
 
-// One 64-byte slot per k-mer (anchor_core.h: slot_pack): {T[c], T[c+1]} and the SAX
-// records of ranks base..base+3, base = T[c] ? T[c]-1 : 0.  One thread per slot.
+// One 16-byte slot per k-mer (anchor_core.h: slot_make), from T and the SAX records.  One thread per slot.
 __global__ __launch_bounds__(256) void build_slots_kernel(const uint32_t *__restrict__ T, const U4 *__restrict__ sax,
-														   uint32_t n, uint64_t codes, U4 *__restrict__ slot)
+														   uint32_t n, uint32_t k, uint64_t codes, U4 *__restrict__ slot)
 {
 	const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= codes) return;
-	const uint32_t lo = T[c], hi = T[c + 1];
-	const uint32_t base = lo ? lo - 1 : 0;
-	U4 rec[4];
-	for (uint32_t i = 0; i < 4; i++) rec[i] = base + i < n ? sax[base + i] : U4{0, 0, 0, 0};
-	U4 out[4];
-	slot_pack(lo, hi, rec, out);
-	for (uint32_t i = 0; i < 4; i++) slot[c * SLOT_RECS + i] = out[i];
+	slot[c] = slot_make(c, k, T[c], T[c + 1], n, [&](uint32_t r) { return sax[r]; });
 }
 
 int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t threshold)
@@ -113,7 +106,7 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 		HIPOK(c, c->d_SAX.ensure((size_t)ns + 4));
 		HIPOK(c, c->d_LCP.ensure((size_t)ns + 1 + 4));
 		HIPOK(c, c->d_T.ensure(codes + 1 + 4 + kmer_table_scratch(k)));
-		HIPOK(c, c->d_SLOT.ensure(codes * SLOT_RECS));
+		HIPOK(c, c->d_SLOT.ensure(codes + 8)); // (+8: the chain kernels' load batch reads up to 64 bytes from a slot's address)
 		c->stats["ms:ref_alloc"] += now_ms() - ta; // hipMalloc of tens of GB stalls when other processes have just released as much
 	}
 	HIPOK(c, hipMemsetAsync(c->a_misc.p, 0, 64, st));
@@ -137,7 +130,7 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 	launch_sax(c->d_S.p, c->d_SA.p, c->d_LCP.p, ns, c->d_SAX.p, st);
 	{
 		hipLaunchKernelGGL(build_slots_kernel, dim3((uint32_t)((codes + 255) / 256)), dim3(256), 0, st, c->d_T.p,
-						   c->d_SAX.p, ns, codes, c->d_SLOT.p);
+						   c->d_SAX.p, ns, k, codes, c->d_SLOT.p);
 	}
 	HIPOK(c, hipGetLastError());
 	HIPOK(c, hipStreamSynchronize(st));

@@ -40,7 +40,8 @@ struct RefIndex {
 	const uint8_t *S;    // n bytes of subject + '#' + revcomp, then >= 64 zero bytes
 	const U4 *SAX;       // n records (+4 pad), one per rank: see sax_record()
 	const uint32_t *LCP; // n+1 entries (+4 pad); LCP[r] = lcp(suffix SA[r-1], suffix SA[r]); LCP[0]=LCP[n]=0
-	const U4 *SLOT;      // 4^k slots of 64 bytes (SLOT_RECS U4 each): see slot_pack
+	const U4 *SLOT;      // 4^k slots of 16 bytes, one per k-mer: see slot_make
+	const uint32_t *T;   // 4^k + 1 bucket bounds: the suffixes that start with k-mer c have ranks [T[c], T[c+1])
 	uint32_t n;          // |S| = 2L+1
 	uint32_t k;          // bucket k-mer length (1..14)
 	uint32_t threshold;  // minimum anchor length
@@ -144,28 +145,93 @@ PHY_HD U4 sax_record(const uint8_t *S, uint32_t sa, uint32_t lcp_r, uint32_t lcp
 	return r;
 }
 
-// Slot of k-mer c: 64 bytes = 16 dwords: lo = T[c], hi = T[c+1], then the SAX records of
-// ranks base .. base+3 (base = lo ? lo-1 : 0: the bucket's predecessor, up to two
-// members and its successor for buckets of <= 2 suffixes) at 12 bytes each — SA, prefix
-// code, and valid length (5 bits) | LCP[r] (13) | LCP[r+1] (13) in one dword.  A whole
-// small-bucket search is therefore ONE fetch of half a cache line.  64 rather than 128
-// bytes because the table is gathered from at random and what that costs on this chip is
-// set by how many pages are in play (TLB reach, ~3 GB: csrc/gather_bench.hip), not by the
-// bytes: at 128 B the table alone is 2.1 GB for a 5 Mbp reference.
-static const uint32_t SLOT_RECS = 4; // U4 units per slot
+// Slot of k-mer c: 16 bytes — ONE load answers a whole step for a bucket of up to two suffixes, which is all but a
+// few per cent of the k-mers at k = ceil(log4 |S|).  The suffixes that start with the k-mer ("members", ranks
+// [lo, hi) = [T[c], T[c+1])) share at least k bases with a query window that starts with it; the bucket's
+// predecessor (rank lo - 1) and successor (rank hi) share fewer than k, and how many is a property of the k-mer
+// alone.  Word 0 carries a type in bits 0..2:
+//   SLOT_EMPTY  no member.  The longest match is the better of predecessor and successor: bits 3..7.
+//   SLOT_ONE    one member: words 1..3 are its record — SA, the 2-bit codes of its first 16 bytes, and
+//               valid length (5 bits) | LCP[r] (13) | LCP[r+1] (13), both clipped (sax_record).  Whatever side of
+//               the query it lies on, the neighbour across shares fewer than k bases, so it is the best neighbour
+//               and, with both of its LCPs below k, unique.
+//   SLOT_TWO    two members (k >= 8: what of their codes lies behind the k-mer fits 16 bits each): word 1 = SA of the
+//               first, word 3 = SA of the second, word 2 = the codes' tails (first | second << 16), word 0 also holds
+//               their valid lengths (bits 3..7, 8..12) and lcp(first, second) clipped to 13 bits (bits 13..25).
+//               With l1, l2 the query's matches with the two: the longer one is the best neighbour, and it is unique
+//               iff it is longer than what the two share — wherever the query's insertion point lies:
+//                 before both:  l2 = min(l1, c12), best = first, unique iff LCP[its rank + 1] = c12 < l1;
+//                 between:      c12 = min(l1, l2), the other LCPs (towards predecessor / successor) are below k;
+//                 behind both:  l1 = min(l2, c12), best = second, unique iff LCP[its rank] = c12 < l2.
+//   SLOT_MANY   3 .. LEAN_SCAN_MAX members: word 1 = the first member's rank, word 2 = the rank behind the last; the
+//               chain walks their SAX records.
+//   SLOT_SLOW   more than that: left to the wavefront's resolver.
+// 16 rather than 64 bytes (rounds 1-3: {lo, hi} and four 12-byte records): a step then costs one load instruction
+// and one translation instead of four — what the random-row rate of a table beyond ~3 GB is made of
+// (profiles/r04_gather_bench.jsonl: 16 GB, 64-byte rows in four loads 16.5 G rows/s, 16-byte rows 39.5) — the table
+// is a quarter the size (k = 14: 4.3 GB instead of 17), and the digest is two comparisons instead of four.
+enum SlotType : uint32_t { SLOT_EMPTY = 0, SLOT_ONE = 1, SLOT_TWO = 2, SLOT_MANY = 3, SLOT_SLOW = 4 };
+static const uint32_t LEAN_SCAN_MAX = 24; // buckets with more members go to the slow resolver
 
-PHY_HD void slot_pack(uint32_t lo, uint32_t hi, const U4 rec[4], U4 out[4])
+// min(number of leading bases the two 16-base codes share, sv)
+PHY_HD uint32_t code_lcp(uint32_t a, uint32_t b, uint32_t sv)
 {
-	uint32_t d[16];
-	d[0] = lo;
-	d[1] = hi;
-	for (int i = 0; i < 4; i++) {
-		d[2 + 3 * i] = rec[i].x;
-		d[3 + 3 * i] = rec[i].y;
-		d[4 + 3 * i] = (rec[i].z & 31u) | ((rec[i].w & LCP_CLIP) << 5) | (((rec[i].w >> 16) & LCP_CLIP) << 18);
+	const uint32_t x = a ^ b;
+	const uint32_t d = x ? clz32(x) >> 1 : 16u;
+	return d < sv ? d : sv;
+}
+
+// the slot of k-mer `c` of an index with n suffixes: lo = T[c], hi = T[c+1]; sax(r) = the SAX record of rank r.
+// The ranks [lo, hi) are the suffixes that start with the k-mer — the members — followed by those that end (in '!',
+// '#' or S's end) inside their first k bytes on a prefix of the next k-mers: T counts such a suffix before every k-mer
+// that shares its prefix (index_kernels.hip: kmer_hist_kernel), i.e. at the end of the range in front.  Like the
+// successor proper they share fewer than k bases with a window that starts with the k-mer: what follows the last
+// member is "the successor" whichever it is.
+template <class Sax> PHY_HD U4 slot_make(uint64_t c, uint32_t k, uint32_t lo, uint32_t hi, uint32_t n, Sax sax)
+{
+	const uint32_t kcode = (uint32_t)(c << (2u * (16u - k)));
+	U4 out = {0, 0, 0, 0};
+	if (hi - lo > LEAN_SCAN_MAX) {
+		out.x = SLOT_SLOW;
+		return out;
 	}
-	d[14] = d[15] = 0;
-	for (int i = 0; i < 4; i++) out[i] = U4{d[4 * i], d[4 * i + 1], d[4 * i + 2], d[4 * i + 3]};
+	uint32_t members = 0;
+	while (lo + members < hi) {
+		const U4 r = sax(lo + members);
+		if (r.z < k || (r.y >> (2u * (16u - k))) != (uint32_t)c) break;
+		members++;
+	}
+	if (members == 0) {
+		uint32_t l = 0;
+		if (lo > 0) {
+			const U4 p = sax(lo - 1);
+			l = code_lcp(kcode, p.y, p.z);
+		}
+		if (lo < n) {
+			const U4 q = sax(lo);
+			const uint32_t l2 = code_lcp(kcode, q.y, q.z);
+			l = l2 > l ? l2 : l;
+		}
+		out.x = SLOT_EMPTY | (l << 3);
+	} else if (members == 1) {
+		const U4 r = sax(lo);
+		out.x = SLOT_ONE;
+		out.y = r.x;
+		out.z = r.y;
+		out.w = (r.z & 31u) | ((r.w & LCP_CLIP) << 5) | (((r.w >> 16) & LCP_CLIP) << 18);
+	} else if (members == 2 && k >= 8) {
+		const U4 a = sax(lo), b = sax(lo + 1);
+		const uint32_t tmask = 0xffffffffu >> (2u * k); // the codes behind the k-mer: 32 - 2k <= 16 bits
+		out.x = SLOT_TWO | ((a.z & 31u) << 3) | ((b.z & 31u) << 8) | ((b.w & LCP_CLIP) << 13); // b.w's low half: LCP[lo + 1]
+		out.y = a.x;
+		out.z = (a.y & tmask) | ((b.y & tmask) << 16);
+		out.w = b.x;
+	} else {
+		out.x = SLOT_MANY;
+		out.y = lo;
+		out.z = lo + members;
+	}
+	return out;
 }
 
 PHY_HD uint32_t sel4(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t i)
@@ -245,6 +311,10 @@ struct PhaseA {
 	uint32_t pool_blocks;
 	uint32_t *pool_next;       // bump allocator
 	uint32_t *error;           // set nonzero on pool exhaustion / capacity overflow
+	// bridges that need walking, as left by lean_bridge_prepare_kernel: records of LeanBridge::PACKED_WORDS words,
+	// *bridge_todo of them (lean_core.h); the others merged where their chunk's chain ended
+	uint32_t *bridge_start;
+	uint32_t *bridge_todo;
 	// counters for dynamic work fetch
 	uint32_t *fetch;           // [2]
 	// lean chains: set nonzero when a speculative chain stopped a comparison that ran a chunk length past its

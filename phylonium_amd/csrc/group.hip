@@ -195,6 +195,7 @@ struct phylo_group {
 	std::vector<size_t> own_total;
 	bool lists_everywhere = false; // the last phylo_group_anchor left every rank with all lists
 	size_t replans = 0;            // passes repeated because the lists had outgrown the planned blocks
+	size_t forced_cap = 0;         // option "exchange_cap": records per exchange block of the next plan (0: from the lists' lengths)
 
 	std::vector<double> t_anchor, t_exchange, t_compare, t_reduce; // ms of the last pass, per rank
 
@@ -437,6 +438,12 @@ int phylo_group_set_option(phylo_group *g, const char *key, long value)
 {
 	if (!g) return 1;
 	g->clear_error();
+	if (key && !strcmp(key, "exchange_cap")) { // a host that knows its lists' sizes; a pass that outgrows it is repeated with a plan of its own
+		if (value < 0) return g->fail("exchange_cap must be >= 0");
+		g->forced_cap = (size_t)value;
+		g->plan_valid = false;
+		return 0;
+	}
 	for (size_t r = 0; r < g->world; r++)
 		if (phylo_set_option(g->ctx[r], key, value)) return g->fail("rank %zu: %s", r, phylo_last_error(g->ctx[r]));
 	return 0;
@@ -563,7 +570,7 @@ int phylo_group_anchor(phylo_group *g)
 					most = std::max(most, g->own_total[o]);
 					mq = std::max(mq, g->bounds[o + 1] - g->bounds[o]);
 				}
-				g->cap = most + most / 4 + 64;
+				g->cap = g->forced_cap ? g->forced_cap : most + most / 4 + 64;
 				g->maxq = std::max<size_t>(4, (mq + 3) / 4 * 4);
 				g->block_bytes = phylo_exchange_block_bytes(g->maxq, g->cap);
 			}
@@ -621,7 +628,16 @@ int phylo_group_compare(phylo_group *g, uint64_t *subst, uint64_t *homologs)
 		if (r == 0 && phylo_triangle_to_matrices(g->ctx[0], g->d_tri[0], subst, homologs)) g->fail("rank 0: %s", phylo_last_error(g->ctx[0]));
 		g->t_reduce[r] = now_ms() - t1;
 	});
-	return g->failed() ? 1 : 0;
+	if (g->failed()) {
+		// lists that outgrew the planned blocks: whoever anchors next (phylo_group_process, or a caller of the two
+		// calls that tries again) gets a plan made from that pass's own lists
+		if (g->err.find("overflowed") != std::string::npos) {
+			g->plan_valid = false;
+			g->forced_cap = 0;
+		}
+		return 1;
+	}
+	return 0;
 }
 
 // process() in one call.  The exchange blocks are sized from an earlier pass's list lengths; should a pass outgrow

@@ -379,21 +379,14 @@ static inline void build_sax(const uint8_t *s, uint32_t n, const uint32_t *sa, c
 	for (uint32_t r = 0; r < n; r++) out[r] = sax_record(s, sa[r], lcp[r], lcp[r + 1]);
 }
 
-// Slot table for the emulation / small cases on the host (the product builds it
-// on the device, phylo_abi.hip: build_slots_kernel).
+// Slot table for the emulation on the host (the product builds it on the device, abi_reference.hip:
+// build_slots_kernel, with the same slot_make).
 static inline void build_slots(const std::vector<uint32_t> &T, const std::vector<U4> &sax, uint32_t n, uint32_t k,
 							   std::vector<U4> &out)
 {
-	size_t codes = (size_t)1 << (2 * k);
-	out.assign(codes * SLOT_RECS, U4{0, 0, 0, 0});
-	for (size_t c = 0; c < codes; c++) {
-		uint32_t lo = T[c], hi = T[c + 1];
-		uint32_t base = lo ? lo - 1 : 0;
-		U4 rec[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-		for (uint32_t i = 0; i < 4; i++)
-			if (base + i < n) rec[i] = sax[base + i];
-		slot_pack(lo, hi, rec, &out[c * SLOT_RECS]);
-	}
+	const size_t codes = (size_t)1 << (2 * k);
+	out.assign(codes + 8, U4{0, 0, 0, 0}); // (+8: a trip's load batch reads up to 64 bytes from a slot's address)
+	for (size_t c = 0; c < codes; c++) out[c] = slot_make(c, k, T[c], T[c + 1], n, [&](uint32_t r) { return sax[r]; });
 }
 
 // Does the reference's 6-mer interval cache hold an entry that claims more than its key shares with S?

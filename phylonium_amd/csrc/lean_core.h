@@ -14,8 +14,8 @@
 //    loads from up to three addresses (pA: 32 B, pB: 32 B, pY: 8 B), then
 //    digest".  The kernel issues that one batch for all 64 lanes whatever
 //    phases they are in — one memory round trip per loop trip — and only the
-//    digest is per phase.  Phases: STEP (k-mer slot + lucky window), SEARCH (slot
-//    again after a failed long lucky check), SCAN (four more SAX records of a
+//    digest is per phase.  Phases: STEP (the k-mer's 16-byte slot + lucky window),
+//    SEARCH (slot again after a failed long lucky check), SCAN (four SAX records of a
 //    bucket with more than two members), EXT (128 more bases of one
 //    comparison), REFILL (16 dwords of the query into the lane's ring).
 //  * Everything else — a window that touches '!' or the query's end, two
@@ -82,7 +82,6 @@ enum LeanPhase : uint32_t { LP_STEP = 0, LP_SEARCH, LP_SCAN, LP_EXT, LP_REFILL, 
 static const uint32_t LEAN_RING_WORDS = 16;         // dwords of the query a lane keeps at hand (256 bases)
 static const uint32_t LEAN_EXT_BASES = 128;         // bases per EXT trip
 static const uint32_t LEAN_EXT_COOP = 16 + 32 * 128; // a comparison this long is handed to the wavefront
-static const uint32_t LEAN_SCAN_MAX = 24;           // buckets with more members go to the slow resolver
 static const uint32_t NO_BAD = 0xffffffffu;
 static const uint32_t LEAN_OVERRUN_BIT = 0x80000000u; // in spec_cnt: the chunk's last anchor and exit are lower bounds
 static const uint32_t LEAN_LINK_BIT = 0x40000000u;    // ... and its match is continued by the next chunk's (GPU resolve, pass 1)
@@ -359,23 +358,61 @@ PHY_HD void lean_group(LeanLane &ln, const RefIndex &R, uint32_t nex, bool more,
 			 sel4(meta0, meta1, meta2, meta3, is));
 }
 
-// the slot of the window's k-mer: header {lo, hi} and the records of ranks base .. base+3
-PHY_HD void lean_search(LeanLane &ln, const RefIndex &R, const uint32_t *w)
+// The slot of the window's k-mer (anchor_core.h: slot_make) — anchor(), process.cxx:219-225, for a bucket of up to
+// two suffixes in one go; written with selects for the three common types (none, one, two members), which share a
+// wavefront in any mix.
+PHY_HD void lean_search(LeanLane &ln, const RefIndex &R, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
 {
-	const uint32_t lo = w[0], hi = w[1];
-	if (hi - lo > LEAN_SCAN_MAX) {
-		LEAN_WHY(SW_BUCKET);
+	const uint32_t type = w0 & 7u;
+	if (type >= SLOT_MANY) {
+		if (type == SLOT_MANY) { // the bucket's members, four SAX records a trip (its predecessor and successor share
+			ln.p_len = ln.p_pos = ln.p_meta = 0; // fewer than k bases with the window: never the better neighbour)
+			ln.npend = 0;
+			ln.s_rank = w1;
+			ln.s_last = w2 - 1u;
+			ln.ph = LP_SCAN;
+		} else {
+			LEAN_WHY(SW_BUCKET);
+			ln.ph = LP_SLOW;
+		}
+		return;
+	}
+	const bool one = type == SLOT_ONE, two = type == SLOT_TWO;
+	const uint32_t tmask = 0xffffffffu >> (2u * R.k);
+	const uint32_t qt = ln.qcode & tmask;
+	// the first member: its whole code (one member) or the code's tail behind the k-mer (two)
+	const uint32_t x1 = one ? ln.qcode ^ w2 : qt ^ (w2 & 0xffffu);
+	const uint32_t x2 = qt ^ (w2 >> 16);
+	const uint32_t sv1 = one ? w3 & 31u : (w0 >> 3) & 31u, sv2 = (w0 >> 8) & 31u;
+	const uint32_t d1 = x1 ? clz32(x1) >> 1 : 16u, d2 = x2 ? clz32(x2) >> 1 : 16u;
+	const uint32_t l1 = d1 < sv1 ? d1 : sv1;
+	const uint32_t l2 = two ? (d2 < sv2 ? d2 : sv2) : 0u;
+	const uint32_t c12 = two ? (w0 >> 13) & LCP_CLIP : 0u; // what the two members share (one member: nothing to share)
+	const bool pend1 = l1 == 16u, pend2 = l2 == 16u;
+	if (type == SLOT_EMPTY) {
+		const uint32_t l = (w0 >> 3) & 31u;
+		if (l >= R.threshold) { // (thresholds below k: tiny subjects) predecessor or successor could be an anchor
+			LEAN_WHY(SW_BUCKET);
+			ln.ph = LP_SLOW;
+			return;
+		}
+		ln.finish(0u, l, false);
+		return;
+	}
+	if (pend1 && pend2) { // both share the window's 16 bases (a repeat): bytes decide
+		LEAN_WHY(SW_PEND_MANY);
 		ln.ph = LP_SLOW;
 		return;
 	}
-	const uint32_t base = lo ? lo - 1 : 0;
-	const uint32_t last = hi < R.n ? hi : R.n - 1; // the successor, when there is one
-	const uint32_t c_n = last - base + 1;          // ranks base .. last matter
-	ln.p_len = ln.p_pos = ln.p_meta = 0;
-	ln.npend = 0;
-	ln.s_rank = base + 4;
-	ln.s_last = last;
-	lean_group(ln, R, c_n < 4 ? c_n : 4, c_n > 4, w[2], w[5], w[8], w[11], w[3], w[6], w[9], w[12], w[4], w[7], w[10], w[13]);
+	if (pend1 || pend2) { // the one that does is the best neighbour on either side: extend it.  Its LCP towards the other
+		// member is c12; towards the bucket's predecessor / successor it is below k, i.e. below what an extension verifies
+		const uint32_t meta = one ? w3 : pend1 ? (sv1 | (c12 << 18)) : (sv2 | (c12 << 5));
+		ln.start_ext(EXT_CAND, pend1 ? w1 : w3, meta);
+		return;
+	}
+	const bool first = l1 > l2;
+	const uint32_t l = first ? l1 : l2;
+	ln.finish(first ? w1 : w3, l, l >= R.threshold && l > c12);
 }
 
 // four SAX records of ranks s_rank .. s_rank+3
@@ -448,10 +485,8 @@ PHY_HD LeanAddr lean_addr(const LeanLane &ln, const RefIndex &R)
 	a.baseA = a.baseB = a.baseY = LB_NONE;
 	a.offA = a.offB = a.offY = 0;
 	if (ln.ph == LP_STEP || ln.ph == LP_SEARCH) {
-		const uint64_t s = (uint64_t)(ln.qcode >> (2u * (16u - R.k))) * 64u;
-		a.baseA = a.baseB = LB_SLOT;
-		a.offA = s;
-		a.offB = s + 32;
+		a.baseA = LB_SLOT;
+		a.offA = (uint64_t)(ln.qcode >> (2u * (16u - R.k))) * 16u;
 		if (ln.ph == LP_STEP && ln.lucky_ok(R)) {
 			a.baseY = LB_S2;
 			a.offY = (uint64_t)((ln.ls + (ln.q - ln.lq)) >> 4) * 4u;
@@ -475,7 +510,7 @@ PHY_HD LeanAddr lean_addr(const LeanLane &ln, const RefIndex &R)
 	return a;
 }
 
-// STEP, part 2: d[0..16) = the slot, y0/y1 = the two S2 words of the lucky window
+// STEP, part 2: d[0..4) = the slot, y0/y1 = the two S2 words of the lucky window
 PHY_HD void lean_step(LeanLane &ln, const RefIndex &R, const LeanIndex &X, const uint32_t *d, uint32_t y0, uint32_t y1)
 {
 	if (ln.lucky_ok(R)) { // lucky_anchor, process.cxx:227-242
@@ -492,7 +527,7 @@ PHY_HD void lean_step(LeanLane &ln, const RefIndex &R, const LeanIndex &X, const
 			return;
 		}
 	}
-	lean_search(ln, R, d);
+	lean_search(ln, R, d[0], d[1], d[2], d[3]);
 }
 
 // ───────────────── the slow resolver's definition, in plain loops (CPU emulation) ─────────────────
@@ -677,6 +712,38 @@ struct LeanBridge {
 		n = 0;
 		first_block = cur_block = NO_BLOCK;
 	}
+	// A bridge that is past its first begin_step — started, in the chunk it stands in, not merged there — as 32 words:
+	// what lean_bridge_prepare_kernel leaves for the lanes of the bridge kernel, so that taking a bridge up is one
+	// batch of loads instead of the chain of dependent ones start() + begin_step() are (work item -> query -> exit
+	// state -> chunk -> log -> visited word), paid inside a trip by every lane of the wavefront.  w[24..32) are the
+	// eight words of the query from the one that holds position q: the lane's ring, filled.
+	static const uint32_t PACKED_WORDS = 32, PACKED_RING = 8;
+	PHY_HD void pack(uint32_t *w) const
+	{
+		w[0] = src, w[1] = ln.qw0, w[2] = ln.qlen, w[3] = ln.q, w[4] = ln.lq, w[5] = ln.ls, w[6] = ln.ll;
+		w[7] = ln.qb_next, w[8] = ln.qb_idx, w[9] = ln.qb_end;
+		w[10] = cur_gc, w[11] = sp_cnt, w[12] = sp_idx, w[13] = Ls.q, w[14] = Ls.s, w[15] = Ls.len;
+		w[16] = g_anc0, w[17] = g_chunk0, w[18] = nx_q, w[19] = vw_idx, w[20] = vw_word;
+		w[21] = w[22] = w[23] = 0;
+	}
+	PHY_HD void unpack(const PhaseA &A, const uint32_t *w)
+	{
+		src = w[0];
+		qj = 0; // (only start() needs the query's index)
+		ln.reset(w[1], w[2], w[3], w[4], w[5], w[6]);
+		ln.qb_next = w[7], ln.qb_idx = w[8], ln.qb_end = w[9];
+		cur_gc = w[10], sp_cnt = w[11], sp_idx = w[12];
+		Ls.q = w[13], Ls.s = w[14], Ls.len = w[15];
+		g_anc0 = w[16], g_chunk0 = w[17], nx_q = w[18], vw_idx = w[19], vw_word = w[20];
+		const uint32_t lc = cur_gc - g_chunk0; // chunk_geom
+		cur_q0 = lc * A.C;
+		cur_len = A.C;
+		cur_log = g_anc0 + lc * A.cap;
+		n = 0;
+		first_block = cur_block = NO_BLOCK;
+		ln.wb = ln.q >> 4; // the ring as the record's last eight words fill it
+		ln.we = ln.wb + PACKED_RING;
+	}
 	PHY_HD void finish(const PhaseA &A, uint32_t target, uint32_t idx_m)
 	{
 		BridgeRec *b = &A.bridge[src];
@@ -858,7 +925,7 @@ inline void lean_trip_cpu(LeanLane &ln, uint32_t *ring, const uint8_t *qbase, co
 	memcpy(y, lean_ptr(T, a.baseY, a.offY), 8);
 	switch (ln.ph) {
 		case LP_STEP: lean_step(ln, R, X, d, y[0], y[1]); break;
-		case LP_SEARCH: lean_search(ln, R, d); break;
+		case LP_SEARCH: lean_search(ln, R, d[0], d[1], d[2], d[3]); break;
 		case LP_SCAN: {
 			U4 r[4];
 			memcpy(r, d, 64);

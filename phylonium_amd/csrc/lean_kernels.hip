@@ -13,8 +13,9 @@
 // log64 rounds, and every special case ('!' in the window, the query's end, repeats)
 // is just byte comparison there.
 //
-// Roofline: random 64-byte slot fetches out of the k-mer table (HBM, translation
-// reach) + instruction issue; algorithmic bytes per launch as anchor_kernels.hip.
+// Roofline: one random 16-byte slot per step out of the k-mer table (a memory request each: the
+// chip serves ~55 G random rows a second whatever their size, profiles/r04_gather_bench.jsonl) +
+// instruction issue; algorithmic bytes per launch: Σ|Q| + 26·|S|.
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -195,7 +196,7 @@ static __device__ void coop_resolve(LeanLane &ln, int leader, const PhaseA &A, c
 			const uint32_t code = window_code(lg16(Q), &valid);
 			const uint32_t qv = valid < n ? valid : n;
 			if (qv >= R.k) {
-				const U4 hdr = lg16((const uint8_t *)(R.SLOT + (size_t)(code >> (2u * (16u - R.k))) * SLOT_RECS));
+				const U2 hdr = lg8((const uint8_t *)(R.T + (size_t)(code >> (2u * (16u - R.k)))));
 				lo = hdr.x;
 				hi = hdr.y;
 			}
@@ -424,8 +425,31 @@ struct LeanAlloc {
 #ifndef PHY_PRIO_ROT
 #define PHY_PRIO_ROT 16u // trips between two turns of the wavefronts' issue priorities (0: no rotation)
 #endif
-// MODE 0: speculative chunk chains, the work items are A.items[0 .. nchunks) (the plan's work order).  MODE 1: bridges,
-// one per chunk.  Persistent lanes with dynamic work fetch through A.fetch[MODE].
+// Every chunk's exit state is continued into the chunk behind it until the continuation stands on a position that
+// chunk's own chain visited in an equivalent state (LeanBridge::begin_step).  Where that is the case at once — the
+// chunk's last match ran on into the next chunk and that chunk's chain found the same match — there is nothing to
+// walk: one thread per chunk finds out, writes those bridges' records, and leaves the others started and packed
+// (LeanBridge::pack + the first words of the query) for the lanes of lean_chain_kernel<1>.
+__global__ __launch_bounds__(256) void lean_bridge_prepare_kernel(PhaseA A, RefIndex R, LeanIndex X)
+{
+	const uint32_t gc = blockIdx.x * 256u + threadIdx.x;
+	if (gc >= A.nchunks) return;
+	LeanBridge L;
+	L.start(A, X, gc);
+	if (!L.begin_step(A, X, R)) return;
+	const uint32_t slot = atomicAdd(A.bridge_todo, 1u);
+	uint32_t w[LeanBridge::PACKED_WORDS];
+	L.pack(w);
+	const uint32_t *q2 = X.Q2 + L.ln.qw0 + (L.ln.q >> 4);
+#pragma unroll
+	for (uint32_t i = 0; i < LeanBridge::PACKED_RING; i++) w[24 + i] = q2[i];
+	U4 *dst = (U4 *)(A.bridge_start + (size_t)slot * LeanBridge::PACKED_WORDS);
+#pragma unroll
+	for (int i = 0; i < 8; i++) dst[i] = U4{w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]};
+}
+
+// MODE 0: speculative chunk chains, the work items are A.items[0 .. nchunks) (the plan's work order).  MODE 1: the
+// bridges lean_bridge_prepare_kernel left to walk.  Persistent lanes with dynamic work fetch through A.fetch[MODE].
 template <int MODE>
 __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, LeanIndex X)
 {
@@ -451,9 +475,11 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 	LeanAlloc alloc = {&A};
 	ln.fin = false;
 	ln.ph = LP_STEP;
+	const uint32_t n_items = MODE == 0 ? A.nchunks : *A.bridge_todo;
 #ifdef PHY_LEAN_TIMING
 	const unsigned long long t_wave0 = __builtin_amdgcn_s_memrealtime();
 	unsigned long long first_query = ~0ull;
+	uint32_t bsteps = 0;
 	unsigned long long ext_cnt[6] = {0, 0, 0, 0, 0, 0};
 	unsigned long long phase_trips[8] = {0, 0, 0, 0, 0, 0, 0, 0}, phase_lanes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	unsigned long long tm[6] = {0, 0, 0, 0, 0, 0}, t_prev = clock64();
@@ -479,22 +505,48 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 		if (active && ln.ph == LP_STEP) {
 			if constexpr (MODE == 0) active = L.begin_step(A, X, vis);
 			else active = L.begin_step(A, X, R);
+#ifdef PHY_LEAN_TIMING
+			if constexpr (MODE == 1) { // how many steps the bridges that end here took
+				if (active) {
+					bsteps++;
+				} else if (X.dbg) {
+					const uint32_t b = bsteps <= 2u ? bsteps : bsteps <= 4u ? 3u : bsteps <= 8u ? 4u : bsteps <= 16u ? 5u : bsteps <= 32u ? 6u : bsteps <= 64u ? 7u : 8u;
+					atomicAdd(&X.dbg[16 + 4 * 8192 + 64 + b], 1ull);
+					atomicMax(&X.dbg[16 + 4 * 8192 + 64 + 9], (unsigned long long)bsteps);
+				}
+			}
+#endif
 		}
 		if (!active && !done) {
 			const uint32_t it = atomicAdd(&A.fetch[MODE], 1u);
-			done = it >= A.nchunks;
+			done = it >= n_items;
 			if (!done) {
-				const uint32_t item = A.items[it];
-				L.start(A, X, item);
-#ifdef PHY_LEAN_TIMING
-				if (first_query == ~0ull) first_query = A.chunk_query[item];
-#endif
 				if constexpr (MODE == 0) {
+					const uint32_t item = A.items[it];
+					L.start(A, X, item);
+#ifdef PHY_LEAN_TIMING
+					if (first_query == ~0ull) first_query = A.chunk_query[item];
+#endif
 					vis.lo = L.vis_idx; // the chunk's words: from its first position to its end (chunks are multiples of 64 positions)
 					vis.hi = lean_visited_word(ln, L.q_end_full);
+					active = L.begin_step(A, X, vis);
+				} else {
+					// a bridge as lean_bridge_prepare_kernel left it: started, past its first begin_step, its ring filled
+					uint32_t w[LeanBridge::PACKED_WORDS];
+					const uint8_t *rec = (const uint8_t *)(A.bridge_start + (size_t)it * LeanBridge::PACKED_WORDS);
+#pragma unroll
+					for (int i = 0; i < 8; i++) {
+						const U4 v = lg16(rec + 16 * i);
+						w[4 * i] = v.x, w[4 * i + 1] = v.y, w[4 * i + 2] = v.z, w[4 * i + 3] = v.w;
+					}
+					L.unpack(A, w);
+#ifdef PHY_LEAN_TIMING
+					bsteps = 1;
+#endif
+#pragma unroll
+					for (uint32_t i = 0; i < LeanBridge::PACKED_RING; i++) ring[(ln.wb + i) & 15u][tid] = w[24 + i];
+					active = true;
 				}
-				if constexpr (MODE == 0) active = L.begin_step(A, X, vis);
-				else active = L.begin_step(A, X, R);
 			}
 		}
 		if (__all(done && !active)) break;
@@ -524,22 +576,27 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 		}
 #endif
 		// one batch of loads for every phase
+		// (a STEP / SEARCH lane needs the 16 bytes of its slot only: the batch's other loads go to one address that
+		// every such lane shares)
 		const uint8_t *pA = s2_b, *pB = s2_b, *pY = s2_b;
+		uint32_t a1 = 0; // where the second 16 bytes of pA's 32 lie
 		if (ph == LP_STEP || ph == LP_SEARCH) {
-			pA = slot_b + (uint64_t)(ln.qcode >> (2u * (16u - R.k))) * 64u;
-			pB = pA + 32;
+			pA = slot_b + (uint64_t)(ln.qcode >> (2u * (16u - R.k))) * 16u;
 			if (ph == LP_STEP && ln.lucky_ok(R)) pY = s2_b + (uint64_t)((ln.ls + (ln.q - ln.lq)) >> 4) * 4u;
 		} else if (ph == LP_EXT) {
 			const uint32_t e0 = ln.e_pos - ((ln.q + ln.e_pos) & 15u);
 			pA = q2_b + ((uint64_t)ln.qw0 + ((ln.q + e0) >> 4)) * 4u;
 			pB = s2_b + (uint64_t)((ln.e_p + e0) >> 4) * 4u;
 			pY = pB + 32;
+			a1 = 16;
 		} else if (ph == LP_SCAN) {
 			pA = sax_b + (uint64_t)ln.s_rank * 16u;
 			pB = pA + 32;
+			a1 = 16;
 		} else if (ph == LP_REFILL) {
 			pA = q2_b + ((uint64_t)ln.qw0 + (ln.q >> 4)) * 4u;
 			pB = pA + 32;
+			a1 = 16;
 		}
 		LEAN_TICK(1)
 #ifdef PHY_LEAN_TIMING
@@ -552,7 +609,7 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 #endif
 		uint32_t d[16], y[2];
 		{
-			const U4 x0 = lg16(pA), x1 = lg16(pA + 16), x2 = lg16(pB), x3 = lg16(pB + 16);
+			const U4 x0 = lg16(pA), x1 = lg16(pA + a1), x2 = lg16(pB), x3 = lg16(pB + 16);
 			const U2 yy = lg8(pY);
 			y[0] = yy.x, y[1] = yy.y;
 			d[0] = x0.x, d[1] = x0.y, d[2] = x0.z, d[3] = x0.w;
@@ -565,7 +622,7 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 		if (ph == LP_STEP) {
 			lean_step(ln, R, X, d, y[0], y[1]);
 		} else if (ph == LP_SEARCH) {
-			lean_search(ln, R, d);
+			lean_search(ln, R, d[0], d[1], d[2], d[3]);
 		} else if (ph == LP_EXT) {
 			uint32_t sw[9];
 			ln.wb = (ln.q + (ln.e_pos - ((ln.q + ln.e_pos) & 15u))) >> 4;
@@ -632,8 +689,8 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 			if (lane64() == 0) atomicAdd(&X.dbg[16 + 4 * 8192 + 34 + MODE * 6 + i], v);
 		}
 		if (X.dbg && lane64() == 0) {
-		if (MODE == 0) { // per wavefront: start, end (100 MHz counter), trips, the first chunk's query
-			unsigned long long *w = X.dbg + 16 + 4 * (size_t)(blockIdx.x * 4 + (tid >> 6));
+		{ // per wavefront: start, end (100 MHz counter), trips, the first chunk's query (MODE 1: behind MODE 0's 4096 records)
+			unsigned long long *w = X.dbg + 16 + 4 * (size_t)(MODE * 4096 + (blockIdx.x * 4 + (tid >> 6)) % 4096);
 			w[0] = t_wave0;
 			w[1] = __builtin_amdgcn_s_memrealtime();
 			w[2] = trip;
@@ -850,6 +907,7 @@ static int lean_bridge_blocks(uint32_t count, int n_cu, uint32_t k)
 }
 void launch_lean_bridge(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st)
 {
+	hipLaunchKernelGGL(lean_bridge_prepare_kernel, dim3((A.nchunks + 255u) / 256u), dim3(256), 0, st, A, R, X);
 	hipLaunchKernelGGL(lean_chain_kernel<1>, dim3(lean_bridge_blocks(A.nchunks, n_cu, R.k)), dim3(256), 0, st, A, R, X);
 }
 

@@ -23,9 +23,11 @@ struct EmulOut {
 // the lean (2-bit) chain of lean_core.h, one lane at a time
 template <class Lane, class Begin, class Done>
 static void run_lean_lane(Lane &L, const uint8_t *qbase, const RefIndex &R, const LeanIndex &X, const LeanTables &T,
-						  Begin begin, Done done, uint64_t *steps, uint64_t *trips, uint64_t *slow)
+						  Begin begin, Done done, uint64_t *steps, uint64_t *trips, uint64_t *slow, const uint32_t *ring0 = nullptr)
 {
 	uint32_t ring[LEAN_RING_WORDS] = {0};
+	if (ring0) // a bridge taken up from its packed form: the ring holds the record's words [wb, we)
+		for (uint32_t i = 0; i < L.ln.we - L.ln.wb; i++) ring[(L.ln.wb + i) % LEAN_RING_WORDS] = ring0[i];
 	uint64_t lane_trips = 0;
 	for (;;) {
 		if (L.ln.fin) {
@@ -34,7 +36,26 @@ static void run_lean_lane(Lane &L, const uint8_t *qbase, const RefIndex &R, cons
 			L.ln.fin = false;
 		}
 		if (L.ln.ph == LP_STEP && !begin()) break;
+		static const bool self_check = getenv("EMUL_SELF_CHECK") != nullptr; // every step against the definition
+		static LeanLane want;
+		static bool have_want = false;
+		if (self_check && L.ln.ph == LP_STEP) {
+			want = L.ln;
+			want.q_cap = NO_BAD; // the definition's answer, uncut
+			lean_resolve_scalar(want, qbase, R, X);
+			have_want = true;
+		}
 		lean_trip_cpu(L.ln, ring, qbase, R, X, T, slow);
+		if (self_check && L.ln.fin && have_want && !L.ln.ovr) {
+			if (L.ln.r_len != want.r_len || L.ln.r_accepted != want.r_accepted || (want.r_accepted && L.ln.r_s != want.r_s)) {
+				const uint32_t code = (uint32_t)(L.ln.qcode >> (2u * (16u - R.k)));
+				const U4 sl = R.SLOT[code];
+				fprintf(stderr, "emul self-check: step at q %u: got (s %u, len %u, acc %d), the definition says (s %u, len %u, acc %d); k-mer %u slot %08x %08x %08x %08x bucket [%u, %u)\n",
+						L.ln.r_q, L.ln.r_s, L.ln.r_len, (int)L.ln.r_accepted, want.r_s, want.r_len, (int)want.r_accepted, code, sl.x, sl.y, sl.z, sl.w, R.T[code], R.T[code + 1]);
+				abort();
+			}
+			have_want = false;
+		}
 		(*trips)++;
 		if (++lane_trips > 50000000ull) {
 			fprintf(stderr, "emul: lean lane stuck: ph %u q %u qlen %u\n", L.ln.ph, L.ln.q, L.ln.qlen);
@@ -80,7 +101,7 @@ void *emul_run2(size_t n, const char *const *seq, const size_t *len, size_t ref_
 	build_sax(S.data(), ns, SA.data(), LCP.data(), SAX);
 	std::vector<U4> SLOT;
 	build_slots(T, SAX, ns, k, SLOT);
-	RefIndex R = {S.data(), SAX.data(), LCP.data(), SLOT.data(), ns, k, (uint32_t)threshold};
+	RefIndex R = {S.data(), SAX.data(), LCP.data(), SLOT.data(), T.data(), ns, k, (uint32_t)threshold};
 	E->threshold = (uint32_t)threshold;
 	E->k = k;
 
@@ -203,10 +224,20 @@ void *emul_run2(size_t n, const char *const *seq, const size_t *len, size_t ref_
 	for (uint32_t it = 0; it < P.nchunks; it++) {
 		const uint64_t before = E->steps_bridge;
 		if (lean) {
-			LeanBridge ln;
-			ln.start(A, X, P.items[it]);
+			// as the product does it: started and taken through its first begin_step by one pass (lean_bridge_prepare_kernel),
+			// packed, and taken up from the packed form by the lane that walks it — its ring filled from the record
+			LeanBridge first, ln;
+			first.start(A, X, P.items[it]);
+			if (!first.begin_step(A, X, R)) {
+				if (bstats) bridge_steps.push_back(0);
+				continue;
+			}
+			uint32_t w[LeanBridge::PACKED_WORDS];
+			first.pack(w);
+			for (uint32_t i = 0; i < LeanBridge::PACKED_RING; i++) w[24 + i] = Q2[first.ln.qw0 + (first.ln.q >> 4) + i];
+			ln.unpack(A, w);
 			run_lean_lane(ln, qbase.data(), R, X, LT, [&] { return ln.begin_step(A, X, R); }, [&] { ln.step_done(A, alloc); },
-						  &E->steps_bridge, &E->rounds, &E->slow_steps);
+						  &E->steps_bridge, &E->rounds, &E->slow_steps, w + 24);
 			if (bstats) bridge_steps.push_back((uint32_t)(E->steps_bridge - before));
 			if (bstats && atoi(getenv("EMUL_BRIDGE_STATS")) > 1 && E->steps_bridge - before >= 30)
 				fprintf(stderr, "long bridge: query %u chunk %u steps %llu from q %u to q %u (last anchor q %u s %u len %u)\n", A.chunk_query[P.items[it]],

@@ -855,8 +855,8 @@ def test_group_of_ranks_gives_one_contexts_result(world):
             c0 = g.rank_context(0)
             for j in range(n):
                 assert hom_tuples_gpu(c0.homologies(j)) == hom_tuples_orc(r.homologies(j)), j
-        # lists that outgrow the plan: against an unrelated reference the lists are all but empty and so is the plan;
-        # back on a related one the blocks overflow, every rank sees it, and the pass is repeated with a new plan
+        # a reference change drops the plan (another subject, other lists): against an unrelated reference the lists are
+        # all but empty, back on a related one they are long again — no pass overflows
         rng = np.random.default_rng(3)
         big = [synth.random_base(90000, rng)]
         big += [synth.mutate(big[0], 0.2, rng) for _ in range(n - 2)] + [synth.random_base(90000, rng)]
@@ -866,7 +866,20 @@ def test_group_of_ranks_gives_one_contexts_result(world):
             so, ho = O.Run(big, ref).process(threads=4).matrix()
             assert (s == so).all() and (h == ho).all(), ref
         if world > 1:
-            assert g.stat(0, "group:replans") >= 1
+            assert g.stat(0, "group:replans") == 0
+            # lists that outgrow the blocks (a capacity the host pinned too small): every rank sees the overflow mark, the
+            # pass is repeated with a plan made from its own lists, and a caller of the two separate calls gets the error
+            g.set_option("exchange_cap", 40)
+            s, h = g.process()
+            assert (s == so).all() and (h == ho).all()
+            assert g.stat(0, "group:replans") == 1
+            g.set_option("exchange_cap", 40)
+            g.anchor()
+            with pytest.raises(api.PhyloniumError, match="overflow"):
+                g.compare()
+            g.anchor()  # the failed comparison dropped the plan: the next pass fits
+            s, h = g.compare()
+            assert (s == so).all() and (h == ho).all()
 
 
 def _two_rank_worker(rank, world, port, out):
