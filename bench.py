@@ -238,6 +238,47 @@ def wallclock_leg(torch, holder, offs, lens, contigs_sep, want_text, n_gpus, run
         shutil.rmtree(d, ignore_errors=True)
 
 
+def verify_ranks(torch, api, dist, ctx, s, h, buf, offs, lens, ref_idx, world, local):
+    """The result of an N-rank run against two routes that share nothing with the exchange between the ranks:
+    (1) the reference's row from rank 0's lists through seam B0 (seqcmp / revseqcmp over the resident genomes, summed over
+        each query's list) — the lists every rank sent are what the tallies were made from;
+    (2) a sub-matrix of up to 32 genomes — the reference, the first genome of every rank's block, the rest evenly spread —
+        against a fresh one-context run of those genomes alone (a pair's tallies depend on the reference and the two
+        genomes only): lists damaged or mixed up on their way between the ranks change it."""
+    import hashlib
+    n = len(lens)
+    bounds = [dist.query_shard(n, r, world, lens)[0] for r in range(world)] + [n]
+    row_sample = sorted({j for j in [1, n // 3, n // 2, n - 1] + bounds[:-1] if 0 <= j < n and j != ref_idx})[:12]
+    row_bad = []
+    for j in row_sample:
+        hom = ctx.homologies(j)
+        m = hom.size
+        ln = hom["length"]
+        sub = ctx.seqcmp_batch(np.full(m, ref_idx, np.uint32), hom["index_reference_projected"], np.full(m, j, np.uint32),
+                               hom["index_query"], ln, (hom["direction"] != 0).astype(np.uint8))
+        if int(sub.sum()) != int(s[ref_idx, j]) or int(ln.sum()) != int(h[ref_idx, j]):
+            row_bad.append(j)
+    want = min(n, 32)
+    idx = {ref_idx} | {b for b in bounds[:-1] if b < n}
+    for t in range(want):
+        if len(idx) >= want:
+            break
+        idx.add(min(n - 1, (t * n) // want))
+    idx = sorted(idx)[:max(want, 1)]
+    if ref_idx not in idx:
+        idx = sorted(idx[:-1] + [ref_idx])
+    with api.Context(local) as c2:
+        c2.set_genomes_device(buf.data_ptr(), [offs[j] for j in idx], [lens[j] for j in idx])
+        s2, h2 = c2.process(idx.index(ref_idx))
+    sub_s, sub_h = np.ascontiguousarray(s[np.ix_(idx, idx)]), np.ascontiguousarray(h[np.ix_(idx, idx)])
+    digest = lambda a, b: hashlib.sha256(a.tobytes() + b.tobytes()).hexdigest()[:16]
+    sub_ok = bool((sub_s == s2).all() and (sub_h == h2).all())
+    bad_pairs = [] if sub_ok else [(idx[i], idx[j]) for i, j in zip(*np.nonzero((sub_s != s2) | (sub_h != h2)))][:8]
+    return {"ok": not row_bad and sub_ok, "reference_row": {"genomes": row_sample, "mismatching": row_bad},
+            "submatrix": {"genomes": len(idx), "sha256_n_ranks": digest(sub_s, sub_h), "sha256_one_context": digest(s2, h2),
+                          "identical": sub_ok, "first_mismatching_pairs": [[int(a), int(b)] for a, b in bad_pairs]}}
+
+
 def usable_cpus():
     """CPUs this process may actually burn: the cgroup CPU-time quota (cpu.max) when there is
     one — the GPU boxes show 256 CPUs but meter a job to a fraction of them — else cpu_count."""
@@ -323,6 +364,10 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not time kernels with HIP events")
     ap.add_argument("--no-wallclock", action="store_true", help="skip the FASTA -> PHYLIP wall-clock leg (the C++ host driver as a child process)")
     ap.add_argument("--check", action="store_true", help="verify a sample of the result against the oracle")
+    ap.add_argument("--verify-ranks", action="store_true", help="after the timed steps rank 0 checks the N-rank result by two other routes — "
+                    "the reference's row recomputed through the B0 kernels, and a sub-matrix of up to 32 genomes (the first genome of every "
+                    "rank's block among them) against a one-context run of those genomes alone — and prints the verdict with every rank's "
+                    "timings as one JSON line on stderr; exit status 3 when a check fails")
     ap.add_argument("--chunk", type=int, default=0, help="dev: force the phase-A chunk length")
     ap.add_argument("--filter", type=int, default=0, help="dev: sort + chain filter 1 on the host, 2 on the device (0: the library chooses)")
     ap.add_argument("--host-threads", type=int, default=0, help="dev: size of the library's host worker pool")
@@ -459,7 +504,7 @@ def main():
                 ctx.attach_blocks_device(pl["all"].data_ptr(), bounds, pl["maxq"], pl["cap"], qb, qe)
                 tl = lap("attach (queued)", tl)
                 ctx.compare_triangle_device(emu[0], W, pl["tri"].data_ptr())
-                tl = lap("compare (waits for the flag)", tl)
+                tl = lap("compare (queued)", tl)
                 td.all_reduce(pl["tri"])
                 r = ctx.triangle_to_matrices(pl["tri"].data_ptr(), out_mats)
                 tl = lap("all_reduce + triangle to matrices", tl)
@@ -487,7 +532,7 @@ def main():
             torch.cuda.synchronize()
             emu_state["plan"] = {"maxq": maxq, "cap": cap, "nbytes": nbytes, "all": allb,
                                  "block": torch.empty(nbytes, dtype=torch.uint8, device=device),
-                                 "tri": torch.empty(n * (n - 1), dtype=torch.int32, device=device)}
+                                 "tri": torch.empty(ctx.triangle_words(n), dtype=torch.int32, device=device)}
             print(f"# emulated exchange: blocks of {nbytes / 1e6:.2f} MB x {W} ranks, triangle {n * (n - 1) * 4 / 1e6:.2f} MB", file=sys.stderr)
         else:
             ctx.anchor(0, n)
@@ -539,6 +584,19 @@ def main():
     if seg and rank == 0:
         print("# emulated rank, ms per step: " + "  ".join(f"{k} {v / args.steps * 1e3:.3f}" for k, v in seg.items()),
               file=sys.stderr, flush=True)
+    verdict = None
+    rank_report = None
+    if args.verify_ranks:  # every rank's view of the timed steps, gathered on rank 0 (one JSON line on stderr, below)
+        mine = {"rank": rank, "device": local, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                "phases_ms": {k[3:]: round(v / args.steps, 3) for k, v in stats.items()
+                              if k in ("ms:anchor_total", "ms:anchor_gpu", "ms:compare_total", "ms:triangle_zero_copy", "ms:triangle_copy", "ms:triangle_widen")},
+                "kernels_ms": {k[3:]: round(v / max(1.0, stats.get("n:" + k[3:], 1.0)), 4) for k, v in stats.items()
+                               if k.startswith("ms:") and ("n:" + k[3:]) in stats}}
+        if world > 1:
+            rank_report = [None] * world
+            td.all_gather_object(rank_report, mine)
+        else:
+            rank_report = [mine]
     if rank == 0:
         K = args.steps
         P = n * (n - 1) // 2
@@ -660,6 +718,8 @@ def main():
                 cpu["sample"] += f"; {threads} threads ({cpu_note})"
             except Exception as e:  # the baseline is a report, never a reason to lose the bench line
                 cpu = {"value": None, "unit": "Gbp/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
+        if args.verify_ranks:
+            verdict = verify_ranks(torch, api, dist, ctx, s, h, buf, offs, lens, ref_idx, world, local)
         if args.check:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as O
@@ -723,6 +783,10 @@ def main():
         }
         if args.dump_matrix:
             np.savez(args.dump_matrix, subst=np.asarray(s), homologs=np.asarray(h))
+        if verdict is not None:
+            out["verify_ranks"] = verdict
+            print("# verify-ranks: " + json.dumps({"n_ranks": world, "backend": out["config"]["backend"], **verdict, "ranks": rank_report}),
+                  file=sys.stderr, flush=True)
     else:
         out = None
     # BASELINE.json's second metric, wall-clock FASTA -> PHYLIP: the C++ host driver as a fresh process on the same
@@ -757,6 +821,8 @@ def main():
     os.close(real_stdout)
     if out is not None:
         print(json.dumps(out), flush=True)
+        if out.get("verify_ranks") and not out["verify_ranks"]["ok"]:
+            raise SystemExit(3)
 
 
 if __name__ == "__main__":

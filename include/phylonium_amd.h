@@ -75,6 +75,7 @@ const char *phylo_last_error(const phylo_ctx *ctx);
  *   "compare_backend"  0 pileup, 1 explicit segment list (the literal seqcmp/revseqcmp calls)
  *   "pairs_kernel"     phase B's pair tallies: 0 on the matrix cores, 1 on the vector ALUs
  *   "pairs_wchunk"     windows per chunk of the pair kernels (0: chosen from the L2 size)
+ *   "result_zero_copy" 1 (default): see phylo_triangle_to_matrices
  *   "host_threads"     size of the context's host worker pool
  *   "profile"          1: time every kernel with HIP events ("ms:<kernel>" stats) */
 int phylo_set_option(phylo_ctx *ctx, const char *key, long value);
@@ -220,9 +221,15 @@ int phylo_compare_device(phylo_ctx *ctx, size_t part, size_t nparts, uint64_t *d
 
 /* The tallies of a part as a u32 upper triangle in device memory — what crosses the wire between ranks: tri[k]
  * substitutions and tri[P + k] homologs of pair i < j, k = i (2n - i - 1) / 2 + (j - i - 1), P = n (n - 1) / 2 (a tally
- * is at most the reference's length, < 2^31; a quarter of the bytes of the two u64 matrices).  The parts' triangles add
- * up (one all-reduce); phylo_triangle_to_matrices copies a triangle to the host and writes the two symmetric n x n
- * matrices process() returns. */
+ * is at most the reference's length, < 2^31; a quarter of the bytes of the two u64 matrices), followed by four words of
+ * the part's own: what its comparison has to report ('!' list overflow, a gathered list out of order, a gathered block
+ * beyond its capacity, 1) — phylo_triangle_words(n) = n (n - 1) + 4 words in all.  On the default (matrix-core) path the
+ * call queues its kernels and returns without waiting for them: the parts' triangles AND their reports add up (one
+ * all-reduce / reduce of phylo_triangle_words(n) words on the context's stream), and phylo_triangle_to_matrices — on the
+ * rank that wants the result — writes the two symmetric n x n matrices process() returns and fails if any part
+ * reported.  A caller that hands the same (16-byte aligned) host matrices over again and again has them written by the
+ * device directly (they are registered with the HIP runtime on their second use; option "result_zero_copy" = 0: never). */
+size_t phylo_triangle_words(size_t n);
 int phylo_compare_triangle_device(phylo_ctx *ctx, size_t part, size_t nparts, uint32_t *dev_tri);
 int phylo_triangle_to_matrices(phylo_ctx *ctx, const uint32_t *dev_tri, uint64_t *subst, uint64_t *homologs);
 
@@ -247,6 +254,7 @@ void phylo_group_destroy(phylo_group *g);
 const char *phylo_group_last_error(const phylo_group *g); /* g may be NULL: a failed phylo_group_create on this thread */
 size_t phylo_group_size(const phylo_group *g);
 phylo_ctx *phylo_group_ctx(phylo_group *g, size_t rank);   /* rank 0 holds every list after phylo_group_anchor */
+size_t phylo_group_rank_begin(const phylo_group *g, size_t rank); /* first genome of the rank's block (rank = size: n) */
 const char *phylo_group_backend(const phylo_group *g);     /* "rccl", "device-to-device copies" or "one rank" */
 /* phylo_set_option on every rank; and the group's own "exchange_cap": records per exchange block of the next plan
  * (0, the default: sized from the lists' lengths, which costs one host round trip per new reference; a pass whose lists

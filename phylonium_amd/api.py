@@ -28,7 +28,7 @@ SYMBOLS = [
     "phylo_export_homologies", "phylo_import_homologies", "phylo_export_packed", "phylo_import_packed",
     "phylo_export_packed_device", "phylo_attach_packed_device", "phylo_compare_device",
     "phylo_ctx_set_stream", "phylo_ctx_device", "phylo_exchange_block_bytes", "phylo_export_block_device", "phylo_attach_blocks_device",
-    "phylo_compare_triangle_device", "phylo_triangle_to_matrices", "phylo_host_device_count",
+    "phylo_compare_triangle_device", "phylo_triangle_to_matrices", "phylo_triangle_words", "phylo_group_rank_begin", "phylo_host_device_count",
     "phylo_group_create", "phylo_group_destroy", "phylo_group_last_error", "phylo_group_size", "phylo_group_ctx", "phylo_group_backend",
     "phylo_group_set_option", "phylo_group_get_stat", "phylo_group_set_genomes_packed", "phylo_group_set_reference", "phylo_group_anchor",
     "phylo_group_compare", "phylo_group_process",
@@ -95,6 +95,8 @@ def load():
     L.phylo_attach_blocks_device.argtypes = [vp, vp, sz, vp, sz, sz, sz, sz]
     L.phylo_compare_triangle_device.argtypes = [vp, sz, sz, vp]
     L.phylo_triangle_to_matrices.argtypes = [vp, vp, vp, vp]
+    L.phylo_triangle_words.restype = sz
+    L.phylo_triangle_words.argtypes = [sz]
     L.phylo_host_device_count.argtypes = [C.POINTER(C.c_int)]
     L.phylo_group_create.argtypes = [C.POINTER(vp), sz, vp]
     L.phylo_group_destroy.argtypes = [vp]
@@ -103,6 +105,8 @@ def load():
     L.phylo_group_last_error.argtypes = [vp]
     L.phylo_group_size.restype = sz
     L.phylo_group_size.argtypes = [vp]
+    L.phylo_group_rank_begin.restype = sz
+    L.phylo_group_rank_begin.argtypes = [vp, sz]
     L.phylo_group_ctx.restype = vp
     L.phylo_group_ctx.argtypes = [vp, sz]
     L.phylo_group_backend.restype = C.c_char_p
@@ -360,8 +364,13 @@ class Context:
         self._chk(self.L.phylo_attach_blocks_device(self.h, C.c_void_p(dev_ptr), len(bounds) - 1, b, max_queries, cap_records,
                                                     keep_begin, keep_end))
 
+    def triangle_words(self, n=None):
+        """u32 words of a part's triangle: 2 x n (n - 1) / 2 tallies + the part's four report words."""
+        return int(self.L.phylo_triangle_words(self.n if n is None else n))
+
     def compare_triangle_device(self, part, nparts, dev_tri_ptr):
-        """compare() with the part's tallies as a u32 upper triangle (2 x n (n - 1) / 2 words) in device memory."""
+        """compare() with the part's tallies as a u32 upper triangle (triangle_words() words) in device memory; on the
+        default path the kernels are queued on the context's stream and the call returns without waiting for them."""
         self._chk(self.L.phylo_compare_triangle_device(self.h, part, nparts, C.c_void_p(dev_tri_ptr)))
 
     def triangle_to_matrices(self, dev_tri_ptr, out=None):

@@ -174,8 +174,62 @@ __global__ __launch_bounds__(256) void pack_triangle_kernel(uint32_t N, const un
 	tri[P + k] = (uint32_t)h[t];
 }
 
+// The four words behind a part's triangle (phylo_triangle_words): what this part's comparison has to report, in a form
+// that adds up over the parts like the tallies do — {the projection's list of '!' overflowed, a gathered list is not
+// sorted and disjoint, a gathered block overflowed its capacity, 1 per part}.  A rank queues its whole comparison and
+// the collective behind it without a host round trip; whoever reads the summed triangle reads the ranks' flags with it.
+__global__ void triangle_flags_kernel(const uint32_t *__restrict__ flag, int att, uint32_t *__restrict__ tail)
+{
+	if (threadIdx.x == 0) {
+		tail[0] = (flag[0] & 2u) ? 1u : 0u;
+		tail[1] = att && flag[1] ? 1u : 0u;
+		tail[2] = att && flag[2] ? 1u : 0u;
+		tail[3] = 1u;
+	}
+}
+
+// A (summed) triangle straight into the caller's two n x n u64 matrices in host memory that the device can address
+// (registered by phylo_triangle_to_matrices): 16-byte stores over PCIe, no staging copy and no pass on the host cores.
+// A thread takes two neighbouring columns of one row; *sites += the homologs it wrote.
+__global__ __launch_bounds__(256) void triangle_to_host_kernel(uint32_t N, const uint32_t *__restrict__ tri, unsigned long long *__restrict__ s,
+																 unsigned long long *__restrict__ h, unsigned long long *__restrict__ sites)
+{
+	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, half = ((uint64_t)N + 1) / 2;
+	unsigned long long mine = 0;
+	if (t < (uint64_t)N * half) {
+		const uint32_t i = (uint32_t)(t / half), j0 = (uint32_t)(t % half) * 2u;
+		const uint64_t P = (uint64_t)N * (N - 1) / 2;
+		unsigned long long vs[2] = {0, 0}, vh[2] = {0, 0};
+#pragma unroll
+		for (uint32_t e = 0; e < 2; e++) {
+			const uint32_t j = j0 + e;
+			if (j < N && j != i) {
+				const uint32_t a = i < j ? i : j, b = i < j ? j : i;
+				const uint64_t k = (uint64_t)a * (2ull * N - a - 1) / 2 + (b - a - 1);
+				vs[e] = tri[k];
+				vh[e] = tri[P + k];
+			}
+		}
+		const uint64_t o = (uint64_t)i * N + j0;
+		if (j0 + 1 < N && (o & 1) == 0) {
+			*(ulonglong2 *)(s + o) = ulonglong2{vs[0], vs[1]};
+			*(ulonglong2 *)(h + o) = ulonglong2{vh[0], vh[1]};
+		} else {
+			s[o] = vs[0];
+			h[o] = vh[0];
+			if (j0 + 1 < N) {
+				s[o + 1] = vs[1];
+				h[o + 1] = vh[1];
+			}
+		}
+		mine = vh[0] + vh[1];
+	}
+	for (int d = 32; d; d >>= 1) mine += __shfl_xor(mine, d, 64);
+	if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(sites, mine);
+}
+
 // out_mode 0: the caller's host matrices; 1: the caller's device matrices (subst / homologs are device pointers);
-// 2: the caller's device u32 triangle (subst is the device pointer, homologs unused)
+// 2: the caller's device u32 triangle + its four flag words (subst is the device pointer, homologs unused)
 static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *subst, uint64_t *homologs, int out_mode = 0)
 {
 	const bool dev_out = out_mode != 0;
@@ -323,6 +377,8 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 			wchunk = (wchunk + 1u) & ~1u;
 			if (c->opt_pairs_wchunk) wchunk = (c->opt_pairs_wchunk + 1u) & ~1u;
 			wchunk = std::min(wchunk, pairs_mfma_max_wchunk() & ~1u);
+			// (the kernel addresses a chunk's rows with 32-bit byte offsets, the loads it issues ahead included)
+			wchunk = std::min<uint32_t>(wchunk, (uint32_t)((0xffffffffull / ((uint64_t)P.Npad * 4u)) & ~1ull) - 16u);
 			{
 				KernelSpan s(c, "pileup_pairs_mfma");
 				launch_pairs_mfma(P, c->b_tiles.p + tiles.size(), (uint32_t)mtiles.size(), wchunk, acc_s, acc_h, st);
@@ -377,6 +433,18 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 	if (!projected && project(have_five)) return 1;
 	double t1 = now_ms();
 	do_correct = sparse;
+	if (out_mode == 2 && sparse) {
+		// A part's triangle on the matrix-core path: everything is queued — pair kernel, the '!' corrections, the packed
+		// triangle and, behind it, what this part has to report (triangle_flags_kernel) — and the call returns without
+		// a host round trip: the caller's collective goes straight behind it on the stream.
+		if (pairs(bang)) return 1;
+		hipLaunchKernelGGL(triangle_flags_kernel, dim3(1), dim3(64), 0, st, c->b_flag.p, c->att_unchecked ? 1 : 0, (uint32_t *)subst + N * (N - 1));
+		HIPOK(c, hipGetLastError());
+		c->att_unchecked = false;
+		c->stats["ms:compare_project_phase"] += t1 - t0;
+		c->stats["ms:compare_pairs_phase"] += now_ms() - t1;
+		return 0;
+	}
 	if (pairs(bang) || fetch()) return 1;
 	const bool att_bad = c->att_unchecked && (flagp[1] || flagp[2]);
 	c->att_unchecked = false;
@@ -396,6 +464,11 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		flag = *flagp;
 	}
 	if (!sparse) c->pileup_five = flag != 0;
+	if (out_mode == 2) { // (this path has looked at its flags itself: nothing to report but "a part")
+		const uint32_t tail[4] = {0, 0, 0, 1};
+		HIPOK(c, hipMemcpyAsync((uint32_t *)subst + N * (N - 1), tail, 16, hipMemcpyHostToDevice, st));
+		HIPOK(c, hipStreamSynchronize(st));
+	}
 	if (dev_out) {
 		c->stats["ms:compare_project_phase"] += t1 - t0;
 		c->stats["ms:compare_pairs_phase"] += now_ms() - t1;
@@ -476,6 +549,34 @@ int phylo_compare_triangle_device(phylo_ctx *c, size_t part, size_t nparts, uint
 	return rc;
 }
 
+size_t phylo_triangle_words(size_t n) { return n * (n - 1) + 4; }
+
+// the caller's result matrix as the device sees it, when the caller keeps handing the same buffer over: registered
+// (mapped) the second time it is seen, for as long as the context lives
+static void *host_matrix_on_device(phylo_ctx *c, void *p, size_t bytes)
+{
+	if (!c->opt_result_zero_copy || bytes < 1024) return nullptr;
+	for (auto &r : c->host_regs)
+		if (r.ptr == p && r.bytes == bytes) {
+			if (r.dev) return r.dev;
+			if (r.failed) return nullptr;
+			void *d = nullptr;
+			if (hipHostRegister(p, bytes, hipHostRegisterMapped) != hipSuccess || hipHostGetDevicePointer(&d, p, 0) != hipSuccess || !d) {
+				(void)hipGetLastError();
+				r.failed = true;
+				return nullptr;
+			}
+			r.dev = d;
+			return d;
+		}
+	if (c->host_regs.size() >= 8) { // callers that keep changing buffers: forget the oldest
+		if (c->host_regs.front().dev) (void)hipHostUnregister(c->host_regs.front().ptr);
+		c->host_regs.erase(c->host_regs.begin());
+	}
+	c->host_regs.push_back(phylo_ctx::HostReg{p, bytes, nullptr, false});
+	return nullptr;
+}
+
 int phylo_triangle_to_matrices(phylo_ctx *c, const uint32_t *dev_tri, uint64_t *subst, uint64_t *homologs)
 {
 	if (!c) return 1;
@@ -486,15 +587,43 @@ int phylo_triangle_to_matrices(phylo_ctx *c, const uint32_t *dev_tri, uint64_t *
 	HIPOK(c, c->h_mat.ensure(2 * N * N + 8));
 	HIPOK(c, c->b_sym32.ensure(2 * N * N + 4));
 	const double t0 = now_ms();
-	hipLaunchKernelGGL(sym32_from_triangle_kernel, dim3((uint32_t)((N * N + 255) / 256)), dim3(256), 0, c->stream, (uint32_t)N, dev_tri, c->b_sym32.p);
-	HIPOK(c, hipGetLastError());
-	HIPOK(c, hipMemcpyAsync(c->h_mat.p, c->b_sym32.p, 2 * N * N * 4, hipMemcpyDeviceToHost, c->stream));
-	if (sync_stream(c)) return 1;
-	const double t1 = now_ms();
-	const double sites = widen_result(c, (const uint32_t *)c->h_mat.p, subst, homologs);
-	c->stats["ms:triangle_copy"] += t1 - t0;
-	c->stats["ms:triangle_widen"] += now_ms() - t1;
+	uint32_t *tail = (uint32_t *)(c->h_mat.p + 2 * N * N); // the parts' flags (phylo_triangle_words), read with the result
+	unsigned long long *h_sites = (unsigned long long *)(c->h_mat.p + 2 * N * N + 2);
+	void *ds = nullptr, *dh = nullptr;
+	if ((((uintptr_t)subst | (uintptr_t)homologs) & 15u) == 0) { // (the kernel stores 16 bytes at a time)
+		ds = host_matrix_on_device(c, subst, N * N * 8);
+		dh = host_matrix_on_device(c, homologs, N * N * 8);
+	}
+	double sites = 0;
+	if (ds && dh) {
+		// the caller reuses its matrices: the device writes them itself (triangle_to_host_kernel)
+		HIPOK(c, c->b_flag.ensure(8));
+		unsigned long long *d_sites = (unsigned long long *)(c->b_flag.p + 4);
+		HIPOK(c, hipMemsetAsync(d_sites, 0, 8, c->stream));
+		const uint64_t threads = (uint64_t)N * ((N + 1) / 2);
+		hipLaunchKernelGGL(triangle_to_host_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, (uint32_t)N, dev_tri,
+						   (unsigned long long *)ds, (unsigned long long *)dh, d_sites);
+		HIPOK(c, hipGetLastError());
+		HIPOK(c, hipMemcpyAsync(tail, dev_tri + N * (N - 1), 16, hipMemcpyDeviceToHost, c->stream));
+		HIPOK(c, hipMemcpyAsync(h_sites, d_sites, 8, hipMemcpyDeviceToHost, c->stream));
+		if (sync_stream(c)) return 1;
+		sites = (double)*h_sites;
+		c->stats["ms:triangle_zero_copy"] += now_ms() - t0;
+	} else {
+		hipLaunchKernelGGL(sym32_from_triangle_kernel, dim3((uint32_t)((N * N + 255) / 256)), dim3(256), 0, c->stream, (uint32_t)N, dev_tri, c->b_sym32.p);
+		HIPOK(c, hipGetLastError());
+		HIPOK(c, hipMemcpyAsync(c->h_mat.p, c->b_sym32.p, 2 * N * N * 4, hipMemcpyDeviceToHost, c->stream));
+		HIPOK(c, hipMemcpyAsync(tail, dev_tri + N * (N - 1), 16, hipMemcpyDeviceToHost, c->stream));
+		if (sync_stream(c)) return 1;
+		const double t1 = now_ms();
+		sites = widen_result(c, (const uint32_t *)c->h_mat.p, subst, homologs);
+		c->stats["ms:triangle_copy"] += t1 - t0;
+		c->stats["ms:triangle_widen"] += now_ms() - t1;
+	}
 	c->stats["count:compare_sites"] += 0.5 * sites;
+	if (tail[2]) return c->fail("the lists gathered from the ranks overflowed their blocks' capacity (phylo_attach_blocks_device)");
+	if (tail[1]) return c->fail("a gathered list is not sorted by projected start, disjoint and inside the reference");
+	if (tail[0]) return c->fail("more '!' inside homologies than the genomes hold separators (lists installed by a caller that overlap on the query): compare with option pairs_kernel = 1");
 	return 0;
 }
 

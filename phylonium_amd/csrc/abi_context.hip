@@ -65,6 +65,9 @@ void phylo_ctx_destroy(phylo_ctx *c)
 	c->h_raw.release();
 	c->h_devhom.release();
 	c->h_mat.release();
+	for (auto &r : c->host_regs)
+		if (r.dev) (void)hipHostUnregister(r.ptr);
+	(void)hipGetLastError();
 	c->genomes_store.release();
 	c->d_goff.release();
 	c->d_glen.release();
@@ -160,6 +163,8 @@ int phylo_set_option(phylo_ctx *c, const char *key, long value)
 	} else if (k == "pairs_kernel") {
 		if (value != 0 && value != 1) return c->fail("pairs_kernel must be 0 (matrix cores unless '!' is projected) or 1 (vector ALUs)");
 		c->opt_pairs_kernel = (int)value;
+	} else if (k == "result_zero_copy") {
+		c->opt_result_zero_copy = value != 0;
 	} else if (k == "lean_force_slow") {
 		c->lean_force_slow = value != 0;
 	} else if (k == "profile") {

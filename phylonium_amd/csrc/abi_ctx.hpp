@@ -273,6 +273,16 @@ struct phylo_ctx {
 	PinBuf<RawHom> h_raw;
 	PinBuf<DevHom> h_devhom;
 	PinBuf<uint64_t> h_mat;
+	// result matrices of a caller that keeps handing the same host buffers over, registered so that the device writes them
+	// itself (phylo_triangle_to_matrices); option "result_zero_copy" = 0 turns that off
+	struct HostReg {
+		void *ptr;
+		size_t bytes;
+		void *dev;
+		bool failed;
+	};
+	std::vector<HostReg> host_regs;
+	int opt_result_zero_copy = 1;
 	std::unique_ptr<WorkerPool> pool;
 	// cached phase-A plan
 	bool plan_valid = false;

@@ -13,7 +13,23 @@
 // single-GPU host never pays for it — and by device-to-device copies when ranks share a GPU (a test box with one)
 // or RCCL is not there.  Written over the public C ABI and the HIP runtime: it is the host a maintainer would write.
 #include <hip/hip_runtime.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#define PHY_HAVE_RCCL_HEADER 1
+#else // a build without the RCCL development package: the handful of declarations the dlopen'ed library is called through
+typedef struct ncclComm *ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclUint8 = 1, ncclUint32 = 3 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+extern "C" {
+ncclResult_t ncclCommInitAll(ncclComm_t *comm, int ndev, const int *devlist);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclAllGather(const void *sendbuff, void *recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclReduce(const void *sendbuff, void *recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op, int root, ncclComm_t comm,
+						hipStream_t stream);
+const char *ncclGetErrorString(ncclResult_t result);
+}
+#endif
 
 #include <dlfcn.h>
 #include <execinfo.h>
@@ -141,6 +157,13 @@ class Barrier
 		return result;
 	}
 };
+
+// tests of the hosts' self-check (phylonium-amd --verify-ranks): PHYLONIUM_AMD_TEST_CORRUPT_RANK=r makes rank r send one damaged
+// record — its first homology's query position moved by one base, a list as valid as any — into the exchange
+__global__ void corrupt_block_kernel(uint32_t *block, uint32_t maxq)
+{
+	if (threadIdx.x == 0 && block[0] > 0) block[4 + maxq + 1] += 1u; // (block: 4 header words, the lengths, the records {start, iq, len, rev})
+}
 
 __global__ __launch_bounds__(256) void add_u32_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, size_t n)
 {
@@ -427,6 +450,7 @@ void phylo_group_destroy(phylo_group *g)
 }
 
 size_t phylo_group_size(const phylo_group *g) { return g ? g->world : 0; }
+size_t phylo_group_rank_begin(const phylo_group *g, size_t rank) { return g && rank < g->bounds.size() ? g->bounds[rank] : 0; }
 phylo_ctx *phylo_group_ctx(phylo_group *g, size_t rank) { return g && rank < g->world ? g->ctx[rank] : nullptr; }
 const char *phylo_group_backend(const phylo_group *g)
 {
@@ -580,13 +604,18 @@ int phylo_group_anchor(phylo_group *g)
 			if (g->d_tri[r]) (void)hipFree(g->d_tri[r]);
 			g->d_all[r] = nullptr;
 			g->d_tri[r] = nullptr;
-			const size_t tri_bytes = std::max<size_t>(4, n * (n - 1) * 4);
+			const size_t tri_bytes = phylo_triangle_words(n) * 4;
 			if (!bad && (hipMalloc(&g->d_all[r], W * g->block_bytes) != hipSuccess || hipMalloc((void **)&g->d_tri[r], tri_bytes) != hipSuccess))
 				bad = g->fail("rank %zu: out of device memory for the exchange buffers", r) != 0;
 		}
 		// own block straight into its place of the gathered buffer; the all-gather fills the rest in place
 		if (!bad && phylo_export_block_device(g->ctx[r], qb, qe, (char *)g->d_all[r] + r * g->block_bytes, g->maxq, g->cap))
 			bad = g->fail("rank %zu: %s", r, phylo_last_error(g->ctx[r])) != 0;
+		if (!bad) {
+			const char *cr = getenv("PHYLONIUM_AMD_TEST_CORRUPT_RANK");
+			if (cr && *cr && (size_t)atoi(cr) == r)
+				hipLaunchKernelGGL(corrupt_block_kernel, dim3(1), dim3(64), 0, g->stream[r], (uint32_t *)((char *)g->d_all[r] + r * g->block_bytes), (uint32_t)g->maxq);
+		}
 		if (all_gather(g, r, g->d_all, g->block_bytes, bad)) return;
 		if (phylo_attach_blocks_device(g->ctx[r], g->d_all[r], W, g->bounds.data(), g->maxq, g->cap, qb, qe))
 			g->fail("rank %zu: %s", r, phylo_last_error(g->ctx[r]));
@@ -624,7 +653,7 @@ int phylo_group_compare(phylo_group *g, uint64_t *subst, uint64_t *homologs)
 		if (phylo_compare_triangle_device(g->ctx[r], r, W, g->d_tri[r])) bad = g->fail("rank %zu: %s", r, phylo_last_error(g->ctx[r])) != 0;
 		const double t1 = now_ms();
 		g->t_compare[r] = t1 - t0;
-		if (reduce_to_rank0(g, r, g->d_tri, n * (n - 1), bad)) return;
+		if (reduce_to_rank0(g, r, g->d_tri, phylo_triangle_words(n), bad)) return; // tallies and the parts' reports alike
 		if (r == 0 && phylo_triangle_to_matrices(g->ctx[0], g->d_tri[0], subst, homologs)) g->fail("rank 0: %s", phylo_last_error(g->ctx[0]));
 		g->t_reduce[r] = now_ms() - t1;
 	});

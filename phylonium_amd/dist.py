@@ -20,6 +20,14 @@ _FORCE_COLLECTIVES = False
 _LEGACY_DEVICE_EXCHANGE = False
 
 
+def _corrupt_rank():
+    """Tests of the self-check (bench.py --verify-ranks): PHYLONIUM_AMD_TEST_CORRUPT_RANK=r makes rank r send one damaged
+    record — its first homology's query position moved by one base, a list as valid as any — into the exchange."""
+    import os
+    v = os.environ.get("PHYLONIUM_AMD_TEST_CORRUPT_RANK", "")
+    return int(v) if v.isdigit() else -1
+
+
 def query_shard(n, rank, world, lengths=None):
     """Contiguous block of queries for this rank, balanced by total length."""
     if lengths is None:
@@ -49,6 +57,9 @@ def exchange_homologies(ctx, n, rank, world, bounds, device=None, _n_pad=1):
     dev = _dev(device)
     qb, qe = bounds[rank], bounds[rank + 1]
     counts, flat = ctx.export_packed(qb, qe)  # 16-byte wire records
+    if rank == _corrupt_rank() and flat.size:
+        flat = flat.copy()
+        flat["index_query"][0] += 1
     call = np.zeros(n, np.int64)
     call[qb:qe] = counts.astype(np.int64)
     ct = torch.from_numpy(call).to(dev)
@@ -125,7 +136,7 @@ def _exchange_plan(ctx, n, rank, world, bounds, device):
     return {"maxq": maxq, "cap": cap, "bounds": tuple(bounds),
             "block": torch.empty(nbytes, dtype=torch.uint8, device=device),
             "all": torch.empty(world * nbytes, dtype=torch.uint8, device=device),
-            "tri": torch.empty(max(2 * P, 1), dtype=torch.int32, device=device)}
+            "tri": torch.empty(ctx.triangle_words(n), dtype=torch.int32, device=device)}
 
 
 def process_sharded_device(ctx, rank, world, bounds, device, out=None, result_rank=None):
@@ -142,28 +153,42 @@ def process_sharded_device(ctx, rank, world, bounds, device, out=None, result_ra
     for attempt in range(2):
         ctx.anchor(qb, qe)
         plan = getattr(ctx, "_xplan", None)
-        if plan is None or plan["bounds"] != tuple(bounds) or plan["tri"].numel() != max(n * (n - 1), 1):
+        if plan is None or plan["bounds"] != tuple(bounds) or plan["tri"].numel() != ctx.triangle_words(n):
             plan = ctx._xplan = _exchange_plan(ctx, n, rank, world, bounds, device)
+        # everything from here to the result is queued on the stream: the block export, the all-gather, the attach, the
+        # comparison (its kernels and what it has to report ride in the triangle's last four words) and the reduction;
+        # the host waits once, for the result — or, on a rank that does not get it, for the 16 bytes of the report
+        ctx.export_block_device(qb, qe, plan["block"].data_ptr(), plan["maxq"], plan["cap"])
+        if rank == _corrupt_rank():
+            words = plan["block"].view(torch.int32)
+            words[4 + plan["maxq"] + 1] += (words[0] > 0).to(torch.int32)  # record 0's query position (block: 4 header words, the lengths, the records)
+        td.all_gather_into_tensor(plan["all"], plan["block"])
+        ctx.attach_blocks_device(plan["all"].data_ptr(), bounds, plan["maxq"], plan["cap"], qb, qe)
+        ctx.compare_triangle_device(rank, world, plan["tri"].data_ptr())
+        ctx._attached_records = plan["all"]  # still the source of the other ranks' lists should the caller ask for them
         try:
-            ctx.export_block_device(qb, qe, plan["block"].data_ptr(), plan["maxq"], plan["cap"])
-            td.all_gather_into_tensor(plan["all"], plan["block"])
-            ctx.attach_blocks_device(plan["all"].data_ptr(), bounds, plan["maxq"], plan["cap"], qb, qe)
-            ctx.compare_triangle_device(rank, world, plan["tri"].data_ptr())
-        except Exception as e:  # a block overflowed its capacity (every rank sees every block's flag): plan again
+            if result_rank is None:  # every rank gets the matrices
+                td.all_reduce(plan["tri"], op=td.ReduceOp.SUM)
+                return ctx.triangle_to_matrices(plan["tri"].data_ptr(), out)
+            # the job's one result, on one rank (as the reference prints one matrix): a reduce instead of the all-reduce, and
+            # the other ranks neither copy 2 N^2 words home nor widen them on host cores the result's rank could use; the
+            # parts' reports are all-reduced beside it (16 bytes), so that every rank learns of a pass to repeat
+            report = plan["tri"][-4:].clone()
+            td.reduce(plan["tri"], dst=result_rank, op=td.ReduceOp.SUM)
+            td.all_reduce(report, op=td.ReduceOp.SUM)
+            if rank == result_rank:
+                return ctx.triangle_to_matrices(plan["tri"].data_ptr(), out)
+            rep = report.cpu()
+            if int(rep[2]):
+                raise RuntimeError("the lists gathered from the ranks overflowed their blocks' capacity")
+            if int(rep[0]) or int(rep[1]):
+                raise RuntimeError("a part of the comparison reported unusable lists")
+            return None, None
+        except Exception as e:  # a block overflowed its capacity (every rank learns of it): plan again
             if attempt == 0 and "overflow" in str(e):
                 ctx._xplan = None
                 continue
             raise
-        ctx._attached_records = plan["all"]  # still the source of the other ranks' lists should the caller ask for them
-        if result_rank is None:  # every rank gets the matrices
-            td.all_reduce(plan["tri"], op=td.ReduceOp.SUM)
-            return ctx.triangle_to_matrices(plan["tri"].data_ptr(), out)
-        # the job's one result, on one rank (as the reference prints one matrix): a reduce instead of the all-reduce, and
-        # the other ranks neither copy 2 N^2 words home nor widen them on host cores the result's rank could use
-        td.reduce(plan["tri"], dst=result_rank, op=td.ReduceOp.SUM)
-        if rank == result_rank:
-            return ctx.triangle_to_matrices(plan["tri"].data_ptr(), out)
-        return None, None
     raise RuntimeError("process_sharded_device: the exchange blocks overflowed twice")
 
 

@@ -303,6 +303,85 @@ Matrix process(Run &r, size_t ref_idx, const int64_t *sa = nullptr)
 	return m;
 }
 
+// --verify-ranks: the matrix of an N-GPU run against two routes that share nothing with the exchange between the
+// ranks.  (1) The reference's row from rank 0's lists through seam B0 (phylo_seqcmp_batch: seqcmp / revseqcmp over the
+// resident genomes, libs/seqcmp.h:14, libs/revseqcmp.h:25, summed over each query's list).  (2) A sub-matrix of up to 32
+// genomes — the reference, the first genome of every rank's block, the rest evenly spread — against a fresh one-context
+// run of those genomes alone (a pair's tallies depend on the reference and the two genomes only, process.cxx:524-529):
+// lists damaged or mixed up on their way between the ranks change it.  One JSON line on stderr; false = a check failed.
+bool verify_group_result(Run &r, const std::vector<PackedGenome> &pk, const std::vector<const uint32_t *> &pk_q2, size_t ref_idx, const Matrix &m, int device)
+{
+	const size_t N = GLEN.size(), W = phylo_group_size(r.grp);
+	std::vector<size_t> row_bad, rows;
+	for (size_t k = 0; k <= W + 3; k++) {
+		const size_t j = k < W ? phylo_group_rank_begin(r.grp, k) : k == W ? 1 : k == W + 1 ? N / 3 : k == W + 2 ? N / 2 : N - 1;
+		if (j < N && j != ref_idx && std::find(rows.begin(), rows.end(), j) == rows.end() && rows.size() < 12) rows.push_back(j);
+	}
+	for (size_t j : rows) {
+		const phylo_homology *h = nullptr;
+		size_t n = 0;
+		ok(r, phylo_get_homologies(r.ctx, j, &h, &n));
+		std::vector<uint32_t> ga(n, (uint32_t)ref_idx), gb(n, (uint32_t)j);
+		std::vector<uint64_t> oa(n), ob(n), ln(n), out(n);
+		std::vector<uint8_t> rev(n);
+		uint64_t hsum = 0, ssum = 0;
+		for (size_t t = 0; t < n; t++) {
+			oa[t] = h[t].index_reference_projected, ob[t] = h[t].index_query, ln[t] = h[t].length, rev[t] = h[t].direction != 0;
+			hsum += h[t].length;
+		}
+		if (n) ok(r, phylo_seqcmp_batch(r.ctx, n, ga.data(), oa.data(), gb.data(), ob.data(), ln.data(), rev.data(), out.data()));
+		for (uint64_t v : out) ssum += v;
+		if (ssum != m[ref_idx * N + j].subst || hsum != m[ref_idx * N + j].homologs) row_bad.push_back(j);
+	}
+	std::vector<size_t> idx = {ref_idx};
+	const size_t want = std::min<size_t>(N, 32);
+	for (size_t k = 0; k < W; k++) idx.push_back(std::min(N - 1, phylo_group_rank_begin(r.grp, k)));
+	for (size_t t = 0; t < want; t++) idx.push_back(std::min(N - 1, t * N / want));
+	std::sort(idx.begin(), idx.end());
+	idx.erase(std::unique(idx.begin(), idx.end()), idx.end());
+	while (idx.size() > std::max<size_t>(want, W + 1)) { // (never the reference)
+		const size_t drop = idx.back() == ref_idx ? idx.size() - 2 : idx.size() - 1;
+		idx.erase(idx.begin() + drop);
+	}
+	const size_t M = idx.size(), sub_ref = std::find(idx.begin(), idx.end(), ref_idx) - idx.begin();
+	std::vector<const uint32_t *> q2(M), bad(M);
+	std::vector<size_t> len(M), nbad(M);
+	for (size_t t = 0; t < M; t++) q2[t] = pk_q2[idx[t]], bad[t] = pk[idx[t]].bad.data(), len[t] = pk[idx[t]].len, nbad[t] = pk[idx[t]].bad.size();
+	std::vector<uint64_t> s2(M * M), h2(M * M);
+	phylo_ctx *c2 = nullptr;
+	std::string one_err;
+	if (phylo_ctx_create(&c2, device)) one_err = phylo_last_error(nullptr);
+	else if (phylo_set_genomes_packed(c2, M, q2.data(), len.data(), bad.data(), nbad.data()) || phylo_process(c2, sub_ref, 0, s2.data(), h2.data()))
+		one_err = phylo_last_error(c2);
+	if (c2) phylo_ctx_destroy(c2);
+	size_t diff = 0;
+	std::string first;
+	for (size_t a = 0; a < M && one_err.empty(); a++)
+		for (size_t b = 0; b < M; b++)
+			if (s2[a * M + b] != m[idx[a] * N + idx[b]].subst || h2[a * M + b] != m[idx[a] * N + idx[b]].homologs) {
+				if (diff < 8) first += (first.empty() ? "" : ", ") + ("[" + std::to_string(idx[a]) + ", " + std::to_string(idx[b]) + "]");
+				diff++;
+			}
+	const bool pass = row_bad.empty() && one_err.empty() && diff == 0;
+	std::string rb;
+	for (size_t j : row_bad) rb += (rb.empty() ? "" : ", ") + std::to_string(j);
+	fprintf(stderr, "verify-ranks: {\"ok\": %s, \"n_ranks\": %zu, \"backend\": \"%s\", \"reference_row\": {\"genomes\": %zu, \"mismatching\": [%s]}, "
+					"\"submatrix\": {\"genomes\": %zu, \"identical\": %s, \"cells_differing\": %zu, \"first_mismatching_pairs\": [%s]%s%s%s}, \"ranks\": [",
+			pass ? "true" : "false", W, phylo_group_backend(r.grp), rows.size(), rb.c_str(), M, diff == 0 && one_err.empty() ? "true" : "false", diff, first.c_str(),
+			one_err.empty() ? "" : ", \"error\": \"", one_err.c_str(), one_err.empty() ? "" : "\"");
+	for (size_t k = 0; k < W; k++) {
+		double a = 0, e = 0, c = 0, d = 0;
+		phylo_group_get_stat(r.grp, k, "group:ms_anchor", &a);
+		phylo_group_get_stat(r.grp, k, "group:ms_exchange", &e);
+		phylo_group_get_stat(r.grp, k, "group:ms_compare", &c);
+		phylo_group_get_stat(r.grp, k, "group:ms_reduce", &d);
+		fprintf(stderr, "%s{\"rank\": %zu, \"first_genome\": %zu, \"ms_anchor\": %.3f, \"ms_exchange\": %.3f, \"ms_compare\": %.3f, \"ms_reduce\": %.3f}", k ? ", " : "", k,
+				phylo_group_rank_begin(r.grp, k), a, e, c, d);
+	}
+	fprintf(stderr, "]}\n");
+	return pass;
+}
+
 [[noreturn]] void usage(int status)
 {
 	const char str[] = {
@@ -320,6 +399,10 @@ Matrix process(Run &r, size_t ref_idx, const int64_t *sa = nullptr)
 		"      --ingest=HOW     packed (default: 2-bit codes made while reading, a quarter of the\n"
 		"                       bytes uploaded) or bytes\n"
 		"      --timing         Print where the wall-clock went to stderr\n"
+		"      --verify-ranks   With --gpus N: check the result by two other routes (the reference's\n"
+		"                       row through the seqcmp/revseqcmp kernels; a sub-matrix of up to 32\n"
+		"                       genomes against a one-GPU run of those genomes), print the verdict and\n"
+		"                       every rank's timings as one JSON line on stderr; exit status 3 on failure\n"
 		"  -d, --device=N       GPU ordinal (default 0; with --gpus: the first of them)\n"
 		"      --gpus=N         Shard the queries (phase A) and the reference's windows (phase B) over N\n"
 		"                       GPUs: one host thread and one context per GPU, RCCL between them\n"
@@ -341,7 +424,7 @@ int main(int argc, char *argv[])
 	std::random_device rd;
 	const char *seed_env = getenv("PHYLONIUM_AMD_SEED");
 	std::mt19937 prng(seed_env ? (std::mt19937::result_type)strtoul(seed_env, nullptr, 10) : rd());
-	int version_flag = 0, timing = 0, flags = 0, device = 0, gpus = 0;
+	int version_flag = 0, timing = 0, verify_ranks = 0, flags = 0, device = 0, gpus = 0;
 	bool packed_ingest = true, host_sa = false;
 	long threads = 0;
 	bool two_pass = false;
@@ -359,6 +442,7 @@ int main(int argc, char *argv[])
 										   {"verbose", no_argument, NULL, 'v'},
 										   {"version", no_argument, &version_flag, 1},
 										   {"timing", no_argument, &timing, 1},
+										   {"verify-ranks", no_argument, &verify_ranks, 1},
 										   {"ingest", required_argument, NULL, 0},
 										   {"sa", required_argument, NULL, 0},
 										   {"gpus", required_argument, NULL, 0},
@@ -501,6 +585,7 @@ int main(int argc, char *argv[])
 		if (threads > 0) ok(r, phylo_set_option(r.ctx, "host_threads", threads));
 		ok(r, phylo_set_option(r.ctx, "sa_builder", host_sa ? 0 : 1));
 	}
+	std::vector<const uint32_t *> pk_q2; // the genomes' packed codes (they stay mapped until the process ends: --verify-ranks reads them again)
 	if (packed_ingest) {
 		std::vector<const uint32_t *> q2(q.size()), bad(q.size());
 		std::vector<size_t> nbad(q.size());
@@ -514,6 +599,7 @@ int main(int argc, char *argv[])
 		// pk_arena stays mapped until the process ends: unmapping 1.3 GB that has just been the source of
 		// device copies costs 0.3 s here (measured at 1024 genomes; the GPU driver's MMU notifier walks the
 		// range), the process's exit does not
+		pk_q2 = q2;
 		for (auto &g : pk)
 			if (!g.own) g.q2 = nullptr;
 	} else {
@@ -533,6 +619,7 @@ int main(int argc, char *argv[])
 	}
 	print_matrix(q, m, flags, bootstrap, ref_idx, prng);
 	t_done = now_s();
+	if (verify_ranks && r.grp && !(flags & (F_COMPLETE_DELETION | F_POSITIONS)) && !verify_group_result(r, pk, pk_q2, ref_idx, m, device)) RETURN_CODE = 3;
 	if (timing) {
 		auto stat = [&](const char *k) {
 			double v = 0;

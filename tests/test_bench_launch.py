@@ -51,3 +51,29 @@ def test_two_ranks_started_by_bench_itself_equal_one_rank(tmp_path):
         outs[n] = np.load(dump)
     assert (outs[1]["subst"] == outs[2]["subst"]).all() and (outs[1]["homologs"] == outs[2]["homologs"]).all()
     assert outs[1]["homologs"].sum() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_verify_ranks_passes_and_catches_a_damaged_block(ranks):
+    """`bench.py --gpus N --verify-ranks`: rank 0 recomputes the reference's row through the B0 kernels and compares a
+    sub-matrix of up to 32 genomes (the first genome of every rank's block among them) with a one-context run of those
+    genomes; the verdict and every rank's timings are one JSON line on stderr.  It passes for 2 and 8 ranks (sharing the
+    test box's GPU), and fails — exit status 3, the damaged pairs named — when a rank sends a damaged record."""
+    base = [sys.executable, BENCH, "--gpus", str(ranks), "--workload", "small", "--steps", "2", "--warmup", "1", "--cpu-sample", "0",
+            "--no-wallclock", "--verify-ranks"]
+    r = subprocess.run(base, capture_output=True, text=True, timeout=800, env=_env())
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
+    assert line["verify_ranks"]["ok"] and line["verify_ranks"]["submatrix"]["identical"]
+    rep = [l for l in r.stderr.splitlines() if l.startswith("# verify-ranks: ")]
+    assert len(rep) == 1
+    rep = json.loads(rep[0][len("# verify-ranks: "):])
+    assert rep["n_ranks"] == ranks and len(rep["ranks"]) == ranks and all("kernels_ms" in x for x in rep["ranks"])
+    env = dict(_env(), PHYLONIUM_AMD_TEST_CORRUPT_RANK=str(ranks - 1))
+    r = subprocess.run(base, capture_output=True, text=True, timeout=800, env=env)
+    assert r.returncode == 3, (r.returncode, r.stderr[-3000:])
+    line = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
+    v = line["verify_ranks"]
+    assert not v["ok"] and not v["submatrix"]["identical"] and v["submatrix"]["first_mismatching_pairs"]

@@ -239,3 +239,31 @@ def test_several_gpus_print_the_same(tmp_path, backend):
     assert got == one and (tmp_path / "p1.txt").read_bytes() == (tmp_path / "p3.txt").read_bytes()
     rc, out, err = run_env(["--gpus", "3", "--timing", "-r", files[4], *files])
     assert out == want and "3 ranks over" in err
+
+
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_verify_ranks_of_the_driver(tmp_path, ranks):
+    """`phylonium-amd --gpus N --verify-ranks`: after printing, the reference's row is recomputed through the B0 kernels and
+    a sub-matrix of up to 32 genomes (the first genome of every rank's block among them) is compared with a one-GPU run of
+    those genomes; one JSON line on stderr carries the verdict and every rank's timings.  Passes for 2 and 8 ranks sharing
+    the test box's GPU with the matrix unchanged; a rank that sends a damaged record (PHYLONIUM_AMD_TEST_CORRUPT_RANK) is
+    caught — exit status 3, the damaged pairs named."""
+    import json
+    gs = synth.make_genomes(40, 20000, seed=97, d_range=(0.01, 0.2), indel_per_mbp=300, inv_frac=0.05, contigs=2, inv_len=(200, 1500))
+    names = [f"v{i:02d}" for i in range(len(gs))]
+    for n, g in zip(names, gs):
+        write_fasta(tmp_path / f"{n}.fa", g)
+    files = [f"{n}.fa" for n in names]
+    plain = run(["--gpus", str(ranks), "-r", files[3], *files], tmp_path)
+    rc, out, err = run(["--gpus", str(ranks), "--verify-ranks", "-r", files[3], *files], tmp_path)
+    assert (rc, out) == plain[:2], err[-2000:]
+    line = [l for l in err.splitlines() if l.startswith("verify-ranks: ")]
+    assert len(line) == 1, err[-2000:]
+    v = json.loads(line[0][len("verify-ranks: "):])
+    assert v["ok"] and v["n_ranks"] == ranks and len(v["ranks"]) == ranks and v["submatrix"]["identical"] and not v["reference_row"]["mismatching"]
+    assert v["submatrix"]["genomes"] >= min(32, len(gs))
+    env = dict(os.environ, PHYLONIUM_AMD_TEST_CORRUPT_RANK=str(ranks - 1))
+    p = subprocess.run([CLI, "--gpus", str(ranks), "--verify-ranks", "-r", files[3], *files], cwd=tmp_path, capture_output=True, text=True, env=env)
+    assert p.returncode == 3, p.stderr[-2000:]
+    v = json.loads([l for l in p.stderr.splitlines() if l.startswith("verify-ranks: ")][0][len("verify-ranks: "):])
+    assert not v["ok"] and not v["submatrix"]["identical"] and v["submatrix"]["first_mismatching_pairs"]

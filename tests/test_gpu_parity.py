@@ -801,26 +801,37 @@ def test_block_exchange_between_three_contexts():
         for cap, fits in ((200000, True), (40, False), (200000, True)):
             nbytes = ctxs[0].exchange_block_bytes(maxq, cap)
             gathered = torch.zeros(world * nbytes, dtype=torch.uint8, device=dev)
-            P = n * (n - 1) // 2
-            total = torch.zeros(2 * P, dtype=torch.int32, device=dev)
+            nw = ctxs[0].triangle_words()
+            total = torch.zeros(nw, dtype=torch.int32, device=dev)
             for r, c in enumerate(ctxs):
                 c.anchor(bounds[r], bounds[r + 1])
                 c.export_block_device(bounds[r], bounds[r + 1], gathered.data_ptr() + r * nbytes, maxq, cap)
-            failed = 0
             for r, c in enumerate(ctxs):
                 c.attach_blocks_device(gathered.data_ptr(), bounds, maxq, cap, bounds[r], bounds[r + 1])
-                t = torch.empty(2 * P, dtype=torch.int32, device=dev)
-                try:
-                    c.compare_triangle_device(r, world, t.data_ptr())
-                    total += t
-                except api.PhyloniumError as e:
-                    assert "overflow" in str(e)
-                    failed += 1
-            assert failed == (0 if fits else world)
-            if not fits:
+                t = torch.empty(nw, dtype=torch.int32, device=dev)
+                c.compare_triangle_device(r, world, t.data_ptr())  # queued: what the part has to report rides behind its tallies
+                total += t
+            assert int(total[-1].item()) == world
+            if not fits:  # every rank saw every block's overflow mark; whoever reads the summed triangle learns of it
+                assert int(total[-2].item()) == world
+                with pytest.raises(api.PhyloniumError, match="overflow"):
+                    ctxs[1].triangle_to_matrices(total.data_ptr())
                 continue
-            s, h = ctxs[1].triangle_to_matrices(total.data_ptr())
-            assert (s == so).all() and (h == ho).all()
+            out = (np.zeros((n, n), np.uint64), np.zeros((n, n), np.uint64))
+            for rep in range(3):  # the same host matrices again and again: from the second time on the device writes them itself
+                out[0][:] = 7
+                out[1][:] = 7
+                s, h = ctxs[1].triangle_to_matrices(total.data_ptr(), out)
+                assert (s == so).all() and (h == ho).all(), rep
+            assert ctxs[1].stat("ms:triangle_zero_copy") is not None and ctxs[1].stat("ms:triangle_widen") is not None
+            ctxs[1].set_option("pairs_kernel", 1)  # the vector-ALU kernels look at their flags themselves
+            t = torch.empty(nw, dtype=torch.int32, device=dev)
+            ctxs[1].compare_triangle_device(1, world, t.data_ptr())
+            ctxs[1].set_option("pairs_kernel", 0)
+            t2 = torch.empty(nw, dtype=torch.int32, device=dev)
+            ctxs[1].compare_triangle_device(1, world, t2.data_ptr())
+            torch.cuda.synchronize()
+            assert torch.equal(t, t2)
             for j in range(n):
                 want = hom_tuples_orc(r_orc.homologies(j))
                 for c in ctxs:
