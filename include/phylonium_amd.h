@@ -227,8 +227,10 @@ int phylo_compare_device(phylo_ctx *ctx, size_t part, size_t nparts, uint64_t *d
  * call queues its kernels and returns without waiting for them: the parts' triangles AND their reports add up (one
  * all-reduce / reduce of phylo_triangle_words(n) words on the context's stream), and phylo_triangle_to_matrices — on the
  * rank that wants the result — writes the two symmetric n x n matrices process() returns and fails if any part
- * reported.  A caller that hands the same (16-byte aligned) host matrices over again and again has them written by the
- * device directly (they are registered with the HIP runtime on their second use; option "result_zero_copy" = 0: never). */
+ * reported.  A caller that hands the same (16-byte aligned) host matrices of a megabyte or more over again and again has
+ * them written by the device directly (they are registered with the HIP runtime on their second use and stay so while
+ * the context lives: do not free them before it, or set option "result_zero_copy" = 0 first — which lets go of them and
+ * turns this off until it is set to 1 again). */
 size_t phylo_triangle_words(size_t n);
 int phylo_compare_triangle_device(phylo_ctx *ctx, size_t part, size_t nparts, uint32_t *dev_tri);
 int phylo_triangle_to_matrices(phylo_ctx *ctx, const uint32_t *dev_tri, uint64_t *subst, uint64_t *homologs);

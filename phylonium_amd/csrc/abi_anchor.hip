@@ -284,6 +284,8 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, bool defer)
 			const unsigned long long *b = h + 16 + 4 * 8192 + 64;
 			fprintf(stderr, "[lean timing] bridges walked, by steps: 1: %llu  2: %llu  3-4: %llu  5-8: %llu  9-16: %llu  17-32: %llu  33-64: %llu  65+: %llu; the longest %llu\n",
 					b[1], b[2], b[3], b[4], b[5], b[6], b[7], b[8], b[9]);
+			fprintf(stderr, "[lean timing] look-ahead: trips with a leader %llu (helpers %.1f, of them plain %.1f per trip), trips in which the leader's own step was plain %llu, hops gained %llu\n",
+					b[12], b[12] ? (double)b[13] / b[12] : 0.0, b[12] ? (double)b[14] / b[12] : 0.0, b[10], b[11]);
 		}
 		for (int m = 0; m < 2; m++) { // the wavefronts' lifetimes (100 MHz counter) and trips
 			std::vector<double> dur, ends;

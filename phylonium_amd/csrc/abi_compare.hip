@@ -555,7 +555,10 @@ size_t phylo_triangle_words(size_t n) { return n * (n - 1) + 4; }
 // (mapped) the second time it is seen, for as long as the context lives
 static void *host_matrix_on_device(phylo_ctx *c, void *p, size_t bytes)
 {
-	if (!c->opt_result_zero_copy || bytes < 1024) return nullptr;
+	// (a buffer of its own pages only: an allocation of a megabyte comes from mmap, while a small one shares its pages
+	// with whatever else the heap holds — and the runtime then takes copies to those neighbours for copies into the
+	// registered range)
+	if (!c->opt_result_zero_copy || bytes < ((size_t)1 << 20)) return nullptr;
 	for (auto &r : c->host_regs)
 		if (r.ptr == p && r.bytes == bytes) {
 			if (r.dev) return r.dev;

@@ -165,6 +165,14 @@ int phylo_set_option(phylo_ctx *c, const char *key, long value)
 		c->opt_pairs_kernel = (int)value;
 	} else if (k == "result_zero_copy") {
 		c->opt_result_zero_copy = value != 0;
+		if (!value) { // and let go of the caller's matrices (a caller about to free them says so this way)
+			HIPOK(c, hipSetDevice(c->device));
+			HIPOK(c, hipStreamSynchronize(c->stream));
+			for (auto &r : c->host_regs)
+				if (r.dev) (void)hipHostUnregister(r.ptr);
+			(void)hipGetLastError();
+			c->host_regs.clear();
+		}
 	} else if (k == "lean_force_slow") {
 		c->lean_force_slow = value != 0;
 	} else if (k == "profile") {

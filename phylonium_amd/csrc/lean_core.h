@@ -77,7 +77,12 @@ PHY_HD uint32_t lean_quirk_lookup(const LeanIndex &X, const uint8_t *Q, uint32_t
 	return LEAN_NO_QUIRK;
 }
 
-enum LeanPhase : uint32_t { LP_STEP = 0, LP_SEARCH, LP_SCAN, LP_EXT, LP_REFILL, LP_SLOW, LP_SLOWEXT };
+enum LeanPhase : uint32_t { LP_STEP = 0, LP_SEARCH, LP_SCAN, LP_EXT, LP_REFILL, LP_SLOW, LP_SLOWEXT,
+							 LP_LOOK }; // (LP_LOOK: a lane of the bridge kernel working out a position ahead of a walker, lean_kernels.hip)
+#ifndef PHY_LOOK_MAX_LIVE
+#define PHY_LOOK_MAX_LIVE 8
+#endif
+static const uint32_t LEAN_LOOK_MAX_LIVE = PHY_LOOK_MAX_LIVE; // the bridge kernel looks ahead when a wavefront has at most this many walkers left
 
 static const uint32_t LEAN_RING_WORDS = 16;         // dwords of the query a lane keeps at hand (256 bases)
 static const uint32_t LEAN_EXT_BASES = 128;         // bases per EXT trip
@@ -769,18 +774,22 @@ struct LeanBridge {
 			Ls.q = Ls.s = Ls.len = 0;
 			nx_q = sp_cnt ? A.spec_anchors[(size_t)cur_log].q : 0xffffffffu;
 		}
-		const Anchor *log = A.spec_anchors + (size_t)cur_log;
-		while (nx_q < ln.q) { // the speculative chain's last anchor before q
-			Ls = log[sp_idx];
-			sp_idx++;
-			nx_q = sp_idx < sp_cnt ? log[sp_idx].q : 0xffffffffu;
-		}
 		const uint32_t wi = lean_visited_word(ln, ln.q);
 		if (wi != vw_idx) {
 			vw_idx = wi;
 			vw_word = A.visited[wi];
 		}
 		if ((vw_word >> (ln.q & 31)) & 1u) {
+			// The chunk's own chain stood here too: the same chain from here on iff the two are in equivalent states,
+			// which takes that chain's last anchor before q.  The cursor into its log is moved up only now — a walker
+			// that passes five anchors a step through homologous sequence would otherwise pay a chain of dependent
+			// loads for each in every trip, and the wavefront with it; most walkers look at the log once, where they merge.
+			const Anchor *log = A.spec_anchors + (size_t)cur_log;
+			while (nx_q < ln.q) {
+				Ls = log[sp_idx];
+				sp_idx++;
+				nx_q = sp_idx < sp_cnt ? log[sp_idx].q : 0xffffffffu;
+			}
 			const bool eb = lucky_eligible(ln.q, ln.lq, ln.ls, ln.ll, R);
 			const bool es = lucky_eligible(ln.q, Ls.q, Ls.s, Ls.len, R);
 			bool merged = false;

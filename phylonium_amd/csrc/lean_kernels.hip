@@ -473,6 +473,9 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 	const uint32_t prio_pass = (uint32_t)(((uint64_t)blockIdx.x * 4u) / gridDim.x);
 #endif
 	LeanAlloc alloc = {&A};
+#ifdef PHY_BRIDGE_CAP
+	uint32_t cap_steps = 0;
+#endif
 	ln.fin = false;
 	ln.ph = LP_STEP;
 	const uint32_t n_items = MODE == 0 ? A.nchunks : *A.bridge_todo;
@@ -505,6 +508,14 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 		if (active && ln.ph == LP_STEP) {
 			if constexpr (MODE == 0) active = L.begin_step(A, X, vis);
 			else active = L.begin_step(A, X, R);
+#ifdef PHY_BRIDGE_CAP // timing experiments (wrong results): no bridge walks more than this many steps
+			if constexpr (MODE == 1) {
+				if (active && ++cap_steps > (uint32_t)(PHY_BRIDGE_CAP)) {
+					L.finish(A, BRIDGE_END, 0);
+					active = false;
+				}
+			}
+#endif
 #ifdef PHY_LEAN_TIMING
 			if constexpr (MODE == 1) { // how many steps the bridges that end here took
 				if (active) {
@@ -540,6 +551,9 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 						w[4 * i] = v.x, w[4 * i + 1] = v.y, w[4 * i + 2] = v.z, w[4 * i + 3] = v.w;
 					}
 					L.unpack(A, w);
+#ifdef PHY_BRIDGE_CAP
+					cap_steps = 1;
+#endif
 #ifdef PHY_LEAN_TIMING
 					bsteps = 1;
 #endif
@@ -562,6 +576,48 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 				ln.qcode = code_window(ring[w & 15u][tid], ring[(w + 1u) & 15u][tid], ln.q & 15u);
 			}
 		}
+		// Look-ahead for the bridge kernel's tail.  Once the queue is empty a wavefront is left with a few long walks —
+		// two chains on sequence that does not align meet by chance, one step in thirteen — and runs whole trips for
+		// them.  While the walker's last anchor is out of lucky_anchor's reach (process.cxx:227-242) and it accepts
+		// none, its step at a position is a function of that position alone (anchor(), process.cxx:219-225): the lanes
+		// without a bridge work out the steps at the positions q + 1, q + 2, ... in the same trip — same ring, a slot
+		// each — and the walker then follows its own steps through them, testing for the merge at every landing, as
+		// many steps as stay inside what was looked at (~5) instead of one.
+		int look_leader = -1;
+		uint32_t look_k = 0, look_q0 = 0, look_vis0 = 0;
+		if constexpr (MODE == 1) {
+			const uint64_t live = __ballot(active), idle = __ballot(!active);
+			if (__ballot(!active && !done) == 0 && live && (uint32_t)__popcll(live) <= LEAN_LOOK_MAX_LIVE && !X.force_slow) {
+				const uint64_t can = __ballot(active && ph == LP_STEP && !ln.lucky_ok(R) && L.cur_gc != BRIDGE_END);
+				if (can) {
+					const uint32_t rot = trip & 63u; // the walkers take turns
+					const uint64_t hi = can & ~((1ull << rot) - 1ull);
+					look_leader = __ffsll((unsigned long long)(hi ? hi : can)) - 1;
+					look_q0 = bcast(ln.q, look_leader);
+					const uint32_t l_wb = bcast(ln.wb, look_leader), l_we = bcast(ln.we, look_leader), l_qlen = bcast(ln.qlen, look_leader);
+					const uint32_t l_qb = bcast(ln.qb_next, look_leader);
+					const uint32_t l_c0 = bcast(L.cur_q0, look_leader), l_cl = bcast(L.cur_len, look_leader);
+					look_vis0 = bcast(lean_visited_word(ln, ln.q), look_leader);
+					if (!active) {
+						const uint32_t k = (uint32_t)__popcll(idle & ((1ull << lane64()) - 1ull)) + 1u; // this helper's position: q0 + k
+						const uint32_t hq = look_q0 + k, w = hq >> 4;
+						// a position whose step the walker could take on the packed path from where it stands: the window in
+						// its ring, pure nucleotides with a base to spare, the same chunk (the same visited words' owner)
+						const bool fits = w >= l_wb && w + 1u < l_we && hq + 17u <= l_qlen && (l_qb == NO_BAD || l_qb >= hq + 16u) &&
+										  hq - l_c0 < l_cl && hq - look_q0 < 96u;
+						if (fits) {
+							const uint32_t ltid = (tid & ~63u) + (uint32_t)look_leader;
+							ln.q = hq;
+							ln.qcode = code_window(ring[w & 15u][ltid], ring[(w + 1u) & 15u][ltid], hq & 15u);
+							ln.fin = false;
+							ln.ph = LP_STEP;
+							look_k = k;
+							ph = LP_LOOK;
+						}
+					}
+				}
+			}
+		}
 		trip++;
 #if PHY_PRIO_ROT
 		// The SIMD's arbiter breaks ties between ready wavefronts by age: of the three or four chain wavefronts a SIMD holds,
@@ -580,9 +636,11 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 		// every such lane shares)
 		const uint8_t *pA = s2_b, *pB = s2_b, *pY = s2_b;
 		uint32_t a1 = 0; // where the second 16 bytes of pA's 32 lie
-		if (ph == LP_STEP || ph == LP_SEARCH) {
+		if (ph == LP_STEP || ph == LP_SEARCH || ph == LP_LOOK) {
 			pA = slot_b + (uint64_t)(ln.qcode >> (2u * (16u - R.k))) * 16u;
 			if (ph == LP_STEP && ln.lucky_ok(R)) pY = s2_b + (uint64_t)((ln.ls + (ln.q - ln.lq)) >> 4) * 4u;
+			if constexpr (MODE == 1) // the walker that is looked ahead for: the visited bits of the positions ahead of it
+				if ((int)lane64() == look_leader) pB = (const uint8_t *)(A.visited + look_vis0);
 		} else if (ph == LP_EXT) {
 			const uint32_t e0 = ln.e_pos - ((ln.q + ln.e_pos) & 15u);
 			pA = q2_b + ((uint64_t)ln.qw0 + ((ln.q + e0) >> 4)) * 4u;
@@ -621,7 +679,7 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 		// digest
 		if (ph == LP_STEP) {
 			lean_step(ln, R, X, d, y[0], y[1]);
-		} else if (ph == LP_SEARCH) {
+		} else if (ph == LP_SEARCH || ph == LP_LOOK) {
 			lean_search(ln, R, d[0], d[1], d[2], d[3]);
 		} else if (ph == LP_EXT) {
 			uint32_t sw[9];
@@ -658,6 +716,56 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 #pragma unroll
 			for (int i = 0; i < 16; i++) ring[(ln.wb + (uint32_t)i) & 15u][tid] = d[i];
 			ln.ph = LP_STEP;
+		}
+		if constexpr (MODE == 1) {
+			if (look_leader >= 0) {
+				// the helpers' answers: a plain step (finished on the packed path, no anchor) and where it leads
+				const bool plain = ph == LP_LOOK && ln.fin && !ln.r_accepted && ln.ph == LP_STEP;
+				const uint32_t nxt = ln.q;
+				if (ph == LP_LOOK) { // a lane without a bridge again
+					ln.fin = false;
+					ln.ph = LP_STEP;
+				}
+				const bool lead_plain = bcast((active && ln.fin && !ln.r_accepted && ln.ph == LP_STEP) ? 1u : 0u, look_leader) != 0;
+				if (lead_plain) {
+					uint32_t p = bcast(ln.q, look_leader); // where the walker's own step has taken it
+#ifdef PHY_LEAN_TIMING
+					uint32_t look_hops = 0;
+#endif
+					const uint32_t v0 = bcast(d[8], look_leader), v1 = bcast(d[9], look_leader), v2 = bcast(d[10], look_leader), v3 = bcast(d[11], look_leader);
+					const uint32_t qw0 = bcast(ln.qw0, look_leader);
+					for (;;) {
+						const uint32_t k = p - look_q0;
+						const uint64_t at = __ballot(ph == LP_LOOK && look_k == k);
+						if (!at) break; // beyond what was looked at: the walker's next trip
+						// a landing the chunk's own chain visited too may be where the two merge: LeanBridge::begin_step decides
+						// that (with that chain's log) — the walker stops here
+						const uint32_t wr = ((qw0 >> 1) + (p >> 5)) - look_vis0;
+						const uint32_t vw = wr == 0u ? v0 : wr == 1u ? v1 : wr == 2u ? v2 : v3;
+						if (wr > 3u || ((vw >> (p & 31u)) & 1u)) break;
+						const int who = __ffsll((unsigned long long)at) - 1;
+						if (!bcast(plain ? 1u : 0u, who)) break;
+						p = bcast(nxt, who);
+#ifdef PHY_LEAN_TIMING
+						look_hops++;
+#endif
+					}
+					if ((int)lane64() == look_leader) ln.q = p;
+#ifdef PHY_LEAN_TIMING
+					if (X.dbg && lane64() == 0) {
+						atomicAdd(&X.dbg[16 + 4 * 8192 + 64 + 10], 1ull);
+						atomicAdd(&X.dbg[16 + 4 * 8192 + 64 + 11], (unsigned long long)look_hops);
+					}
+#endif
+				}
+#ifdef PHY_LEAN_TIMING
+				if (X.dbg && lane64() == 0) {
+					atomicAdd(&X.dbg[16 + 4 * 8192 + 64 + 12], 1ull);
+					atomicAdd(&X.dbg[16 + 4 * 8192 + 64 + 13], (unsigned long long)__popcll(__ballot(ph == LP_LOOK)));
+					atomicAdd(&X.dbg[16 + 4 * 8192 + 64 + 14], (unsigned long long)__popcll(__ballot(plain)));
+				}
+#endif
+			}
 		}
 		LEAN_TICK(3)
 		// what the packed path could not answer: the wavefront resolves it, one lane at a time

@@ -817,13 +817,8 @@ def test_block_exchange_between_three_contexts():
                 with pytest.raises(api.PhyloniumError, match="overflow"):
                     ctxs[1].triangle_to_matrices(total.data_ptr())
                 continue
-            out = (np.zeros((n, n), np.uint64), np.zeros((n, n), np.uint64))
-            for rep in range(3):  # the same host matrices again and again: from the second time on the device writes them itself
-                out[0][:] = 7
-                out[1][:] = 7
-                s, h = ctxs[1].triangle_to_matrices(total.data_ptr(), out)
-                assert (s == so).all() and (h == ho).all(), rep
-            assert ctxs[1].stat("ms:triangle_zero_copy") is not None and ctxs[1].stat("ms:triangle_widen") is not None
+            s, h = ctxs[1].triangle_to_matrices(total.data_ptr())
+            assert (s == so).all() and (h == ho).all()
             ctxs[1].set_option("pairs_kernel", 1)  # the vector-ALU kernels look at their flags themselves
             t = torch.empty(nw, dtype=torch.int32, device=dev)
             ctxs[1].compare_triangle_device(1, world, t.data_ptr())
@@ -841,6 +836,35 @@ def test_block_exchange_between_three_contexts():
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_result_matrices_written_by_the_device(ctx):
+    """phylo_triangle_to_matrices with host matrices the caller keeps (a megabyte or more each): copied and widened on the
+    host the first time, registered and written by the device itself (triangle_to_host_kernel) from the second time on —
+    the same matrices either way, equal to phylo_compare's, for an even and an odd number of genomes."""
+    import torch
+    for n in (380, 363):
+        gs = synth.make_genomes(n, 2500, seed=n, d_range=(0.01, 0.2), indel_per_mbp=400, inv_frac=0.05)
+        ctx.set_genomes(gs)
+        ctx.set_reference(1)
+        ctx.anchor()
+        so, ho = ctx.compare()
+        assert (so == so.T).all() and int(ho.sum()) > 0
+        tri = torch.empty(ctx.triangle_words(), dtype=torch.int32, device="cuda:0")
+        ctx.compare_triangle_device(0, 1, tri.data_ptr())
+        out = (np.zeros((n, n), np.uint64), np.zeros((n, n), np.uint64))
+        ctx.reset_stats()
+        for rep in range(3):
+            out[0][:] = 7
+            out[1][:] = 7
+            s, h = ctx.triangle_to_matrices(tri.data_ptr(), out)
+            assert (s == so).all() and (h == ho).all(), (n, rep)
+        assert ctx.stat("ms:triangle_zero_copy") is not None and ctx.stat("ms:triangle_widen") is not None
+        ctx.set_option("result_zero_copy", 0)
+        ctx.reset_stats()
+        s, h = ctx.triangle_to_matrices(tri.data_ptr(), out)
+        ctx.set_option("result_zero_copy", 1)
+        assert (s == so).all() and (h == ho).all() and ctx.stat("ms:triangle_zero_copy") is None
 
 
 @pytest.mark.parametrize("world", [1, 2, 4, 7])
