@@ -449,6 +449,10 @@ def main():
         ctx.set_option("host_threads", args.host_threads)
     if args.filter:
         ctx.set_option("filter", args.filter)
+    if world > 1 or args.emulate_rank:
+        # the result's rank keeps its two host matrices for the whole run and nothing forks while the context lives: the device
+        # may write them itself (phylo_triangle_to_matrices)
+        ctx.set_option("result_zero_copy", 1)
     ctx.set_genomes_device(buf.data_ptr(), offs, lens)
     print(f"# genomes generated in {t_gen:.1f} s", file=sys.stderr, flush=True)
     if world > 1:  # every rank must hold the same genomes (same seed, same generator): compare a checksum

@@ -75,7 +75,7 @@ const char *phylo_last_error(const phylo_ctx *ctx);
  *   "compare_backend"  0 pileup, 1 explicit segment list (the literal seqcmp/revseqcmp calls)
  *   "pairs_kernel"     phase B's pair tallies: 0 on the matrix cores, 1 on the vector ALUs
  *   "pairs_wchunk"     windows per chunk of the pair kernels (0: chosen from the L2 size)
- *   "result_zero_copy" 1 (default): see phylo_triangle_to_matrices
+ *   "result_zero_copy" 0 (default) / 1: see phylo_triangle_to_matrices
  *   "host_threads"     size of the context's host worker pool
  *   "profile"          1: time every kernel with HIP events ("ms:<kernel>" stats) */
 int phylo_set_option(phylo_ctx *ctx, const char *key, long value);
@@ -227,10 +227,10 @@ int phylo_compare_device(phylo_ctx *ctx, size_t part, size_t nparts, uint64_t *d
  * call queues its kernels and returns without waiting for them: the parts' triangles AND their reports add up (one
  * all-reduce / reduce of phylo_triangle_words(n) words on the context's stream), and phylo_triangle_to_matrices — on the
  * rank that wants the result — writes the two symmetric n x n matrices process() returns and fails if any part
- * reported.  A caller that hands the same (16-byte aligned) host matrices of a megabyte or more over again and again has
- * them written by the device directly (they are registered with the HIP runtime on their second use and stay so while
- * the context lives: do not free them before it, or set option "result_zero_copy" = 0 first — which lets go of them and
- * turns this off until it is set to 1 again). */
+ * reported.  With option "result_zero_copy" = 1 a caller that hands the same (16-byte aligned) host matrices of a
+ * megabyte or more over again and again has them written by the device directly (they are registered with the HIP runtime
+ * on their second use and stay so while the context lives).  Off by default: such memory must not be freed, reallocated
+ * or forked over while it is registered — set the option back to 0 (which lets go of it) before any of that. */
 size_t phylo_triangle_words(size_t n);
 int phylo_compare_triangle_device(phylo_ctx *ctx, size_t part, size_t nparts, uint32_t *dev_tri);
 int phylo_triangle_to_matrices(phylo_ctx *ctx, const uint32_t *dev_tri, uint64_t *subst, uint64_t *homologs);

@@ -55,13 +55,15 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, bool defer)
 			// speculative chunk compare to the end of the genome.
 			if (q_begin + j == c->ref_idx) qlen[j] = 0;
 		}
-		// Blocks of the chain kernels per CU, for the plan and for the launch alike.  The kernels are bound by the
-		// instructions they issue, not by waiting, as long as the k-mer slot table is the 1-4 GB of k <= 13: a fourth
-		// wavefront on a SIMD then only makes every trip of the other three longer, and since the speculative kernel
-		// ends with its slowest chain, three blocks with longer chunks finish earlier than four with shorter ones
-		// (C3: 3.51 -> 3.29 ms, C4: 13.06 -> 12.38, 128 x 20 Mbp: 8.49 -> 7.64, close or distant genomes alike).
-		// The 17 GB table of k = 14 (C5's 100 Mbp subject) answers slowly enough for the fourth to pay: 21.9 against 24.1 ms.
-		int per_cu_cap = c->k >= 14 ? 4 : 3;
+		// Blocks of the chain kernels per CU, for the plan and for the launch alike: three.  A chain's time is its trips
+		// times the trip's duration, the speculative kernel ends with its slowest chain, and a fourth wavefront on a
+		// SIMD makes every trip of the other three longer by more than the shorter chunks save (C3: 2.78 against
+		// 2.86 ms) — unless the queries go through in several rounds of chunks anyway (C4: 9.90 against 10.11 ms with
+		// four) or the slot table is k = 14's 4 GB, whose fetches answer slowly enough for the fourth to pay (C5:
+		// 16.0 against 18.7 ms; five: 16.4).
+		uint64_t plan_bases = 0;
+		for (size_t j = 0; j < nq; j++) plan_bases += qlen[j];
+		int per_cu_cap = (c->k >= 14 || plan_bases > 2500000000ull) ? 4 : 3;
 		if (const char *e = getenv("PHY_SPEC_PER_CU")) per_cu_cap = std::max(1, atoi(e)); // experiments
 		c->plan_spec_per_cu = per_cu_cap;
 		const int resident = std::min(lean_spec_resident_blocks(c->n_cu), per_cu_cap * c->n_cu);

@@ -36,6 +36,7 @@ int phylo_ctx_create(phylo_ctx **out, int device)
 		return 4;
 	}
 	c->own_stream = c->stream;
+	if (const char *e = getenv("PHYLONIUM_AMD_ZERO_COPY")) c->opt_result_zero_copy = atoi(e) != 0; // experiments
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
 	*out = c;

@@ -274,7 +274,10 @@ struct phylo_ctx {
 	PinBuf<DevHom> h_devhom;
 	PinBuf<uint64_t> h_mat;
 	// result matrices of a caller that keeps handing the same host buffers over, registered so that the device writes them
-	// itself (phylo_triangle_to_matrices); option "result_zero_copy" = 0 turns that off
+	// itself (phylo_triangle_to_matrices): option "result_zero_copy" = 1.  Off by default: memory registered with the HIP
+	// runtime must not be freed, forked over or handed to another registration while it is — a promise only the caller can
+	// make (measured: a process that registered and released numpy arrays took a GPU "write access to a read-only page"
+	// fault in unrelated work minutes later)
 	struct HostReg {
 		void *ptr;
 		size_t bytes;
@@ -282,7 +285,7 @@ struct phylo_ctx {
 		bool failed;
 	};
 	std::vector<HostReg> host_regs;
-	int opt_result_zero_copy = 1;
+	int opt_result_zero_copy = 0;
 	std::unique_ptr<WorkerPool> pool;
 	// cached phase-A plan
 	bool plan_valid = false;

@@ -422,6 +422,17 @@ struct LeanAlloc {
 	}
 };
 
+// STEP-only trips between two full ones (0: none), taken while at least NUM / DEN of the wavefront's live lanes are in
+// STEP.  Same-box A/B on C3, anchor_spec / anchor_bridge: none 3.14 / 0.45 ms; 1 trip at 3/4 2.79 / 0.36; 2 at 1/2
+// 2.78 / 0.36; 4 at 1/2 2.76 / 0.345; 4 at 1/4 2.75 / 0.344; 8 at 1/4 2.91 / 0.37 (C5: 19.1 -> 16.4 / 0.74 -> 0.50;
+// c2like 0.568 -> 0.503; C4 11.7 -> 10.2).
+#ifndef PHY_FAST_TRIPS
+#define PHY_FAST_TRIPS 4
+#endif
+#ifndef PHY_FAST_NUM
+#define PHY_FAST_NUM 1
+#define PHY_FAST_DEN 4
+#endif
 #ifndef PHY_PRIO_ROT
 #define PHY_PRIO_ROT 16u // trips between two turns of the wavefronts' issue priorities (0: no rotation)
 #endif
@@ -566,6 +577,41 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 		if (__all(done && !active)) break;
 		LEAN_TICK(0)
 
+#if PHY_FAST_TRIPS
+		// Fast trips.  A trip of the loop below carries the code of every phase one of the wavefront's lanes is in, five
+		// loads and their unpacking; most lanes, most of the time, are in STEP.  While nearly all of the wavefront's
+		// lanes are, up to PHY_FAST_TRIPS trips are taken here that know nothing else: window, the slot's 16 bytes (and
+		// the lucky window), lean_step, and a finished step's bookkeeping.  The few lanes in another phase (an extension,
+		// a bucket walk, a refill, the slow resolver) sit these out and have their turn in the full trip that follows.
+		for (int f = 0; f < PHY_FAST_TRIPS; f++) {
+			bool go = active && ln.ph == LP_STEP && !X.force_slow;
+			if (go) go = lean_step_phase(ln, X) == LP_STEP;
+			const uint32_t n_go = (uint32_t)__popcll(__ballot(go)), n_act = (uint32_t)__popcll(__ballot(active));
+			if (!n_go || n_go * PHY_FAST_DEN < n_act * PHY_FAST_NUM) break;
+			const uint8_t *fA = s2_b, *fY = s2_b;
+			if (go) {
+				const uint32_t w = ln.q >> 4;
+				ln.qcode = code_window(ring[w & 15u][tid], ring[(w + 1u) & 15u][tid], ln.q & 15u);
+				fA = slot_b + (uint64_t)(ln.qcode >> (2u * (16u - R.k))) * 16u;
+				if (ln.lucky_ok(R)) fY = s2_b + (uint64_t)((ln.ls + (ln.q - ln.lq)) >> 4) * 4u;
+			}
+			const U4 fx = lg16(fA);
+			const U2 fy = lg8(fY);
+			if (go) {
+				const uint32_t fd[4] = {fx.x, fx.y, fx.z, fx.w};
+				lean_step(ln, R, X, fd, fy.x, fy.y);
+				if (ln.fin) {
+					if constexpr (MODE == 0) L.step_done(A);
+					else L.step_done(A, alloc);
+					ln.fin = false;
+					if constexpr (MODE == 0) active = L.begin_step(A, X, vis);
+					else active = L.begin_step(A, X, R);
+				}
+			}
+			trip++;
+		}
+		if (__all(done && !active)) break;
+#endif
 		// which phase is the lane in this trip; a STEP needs its window from the ring
 		uint32_t ph = active ? ln.ph : (uint32_t)LP_SLOW + 8u;
 		if (active && ph == LP_STEP) {
@@ -995,20 +1041,20 @@ void launch_lean_spec(const PhaseA &A, const RefIndex &R, const LeanIndex &X, in
 	if (need < blocks) blocks = need > 0 ? need : 1;
 	hipLaunchKernelGGL(lean_chain_kernel<0>, dim3(blocks), dim3(256), 0, st, A, R, X);
 }
-// Blocks for `count` bridges.  Most bridges end at their first step (the chain has merged already) and a few walk
-// for dozens: with a lane per bridge nearly every wavefront is left with a handful of walkers after the first trip
-// and runs whole trips for them.  A fifth of the lanes, each taking bridge after bridge from the counter, keeps the
-// wavefronts filled until the queue is empty and leaves only the last walkers' tail (C3: 0.90 -> 0.59 ms at 192
-// blocks; 64 blocks are too few to hide the fetches: 1.08 ms).
-// ... and not beyond three blocks on four CUs however many bridges there are (C4's 571 k: 1.21 ms at the 446 blocks a
-// fifth would be, 1.05 at 192, 1.07 at 256, 1.32 at 128), unless the slot table is k = 14's, whose fetches want more
-// of them in flight (C5: 0.75 ms at 591, 0.73 at 512, 0.76 at 256, 1.31 at 128).
+// Blocks for `count` chunks' bridges (about half of them need walking: lean_bridge_prepare_kernel settles the rest).  Most
+// walks end within a few steps and a few run for dozens, so with a lane per bridge nearly every wavefront is soon left
+// with a handful of walkers and runs whole trips for them: fewer lanes, each taking bridge after bridge from the counter,
+// keep the wavefronts filled until the queue is empty and leave only the last walkers' tail.  How few is a matter of what
+// a trip costs — with the STEP-only trips (PHY_FAST_TRIPS) a block per CU, a third of a lane per chunk, at most three
+// blocks on two CUs (C3, 742 blocks' worth of chunks: 0.41 ms at 96 blocks, 0.36 at 128, 0.325 at 192, 0.319 at 256,
+// 0.343 at 384; C4, 2230: 0.81 at 128, 0.66 at 192, 0.59 at 256, 0.56 at 384) — and twice the CUs with k = 14's
+// slot table, whose fetches want more of them in flight.
 static int lean_bridge_blocks(uint32_t count, int n_cu, uint32_t k)
 {
 	int blocks = lean_resident((const void *)lean_chain_kernel<1>, n_cu);
 	const int need = (int)((count + 255) / 256);
 	if (need < blocks) blocks = need > 0 ? need : 1;
-	const int few = std::min(std::max(n_cu / 2, need / 5), k >= 14u ? 2 * n_cu : 3 * n_cu / 4);
+	const int few = std::min(std::max(n_cu, need / 3), k >= 14u ? 2 * n_cu : 3 * n_cu / 2);
 	if (few < blocks) blocks = few;
 	if (const char *e = getenv("PHY_BRIDGE_BLOCKS")) blocks = std::max(1, std::min(std::max(need, 1), atoi(e))); // experiments
 	return blocks;
