@@ -656,11 +656,16 @@ def main():
                                       "entry names the profile; traffic_of_these_kernels says whether the chain and phase-B kernels' sources are the ones "
                                       "the profile was taken on (sha256 recorded by tools/tools_pmc_traffic.py); regenerate "
                                       "with tools/tools_prof.sh + tools/tools_pmc_traffic.py when the kernels change)",
-                    "note": "anchor_spec fetches one random 64-B k-mer slot (a 128-B line at the memory) per chain step: its time "
-                            "is its line transactions (~122 M per launch at ~48 G lines/s, the rate of uniformly random line "
-                            "fetches on this chip) — `frac` prices SURVEY 8d's algorithmic bytes (query bytes + one pass over the "
-                            "reference-layout ESA), `traffic` is what the HBM interface carried (PMC); pileup_pairs moves far "
-                            "fewer HBM bytes than the reference layout's algorithmic 2 B/site"}
+                    "note": "anchor_spec fetches one random 16-byte k-mer slot per chain step, a memory request each: the chip serves "
+                            "~55 G uniformly random rows a second whatever their size (profiles/r04_gather_bench.jsonl), and `requests` "
+                            "prices the kernel against that — `frac` prices SURVEY 8d's algorithmic bytes (query bytes + one pass over "
+                            "the reference-layout ESA), `traffic` is what the HBM interface carried (PMC)",
+                    # the request-granular view: memory-side read requests per launch (PMC, the same profile) over this run's launch
+                    # time, against the random-row rate the chip delivers to a pure gather
+                    "requests": (lambda rq: {"per_launch": rq, "achieved_G_per_s": round(rq / (avg_ms * 1e-3) / 1e9, 2), "peak_G_per_s": 55.0,
+                                             "frac": round(rq / (avg_ms * 1e-3) / 1e9 / 55.0, 4),
+                                             "peak_source": "profiles/r04_gather_bench.jsonl: 16-byte rows, 128 MB - 1 GB tables, 55-57 G rows/s"}
+                                 if rq else None)(pj.get("read_requests_" + args.workload, {}).get(dom) if traffic else None)}
         # the pair kernel against the vector ALUs: 16 x 6 instructions per window and wavefront for its 16 x 64 pairs
         # (2 xor, and, bitop3, 2 popcount-accumulate) + 8 of loop and address work, one wavefront per tile of
         # 16 x 64 genomes holding a pair i < j; peak = CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction

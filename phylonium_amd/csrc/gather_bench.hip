@@ -42,6 +42,65 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint8_t *__restrict__
 	out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
+// the cache-policy bits of a load (gfx950: sc0, sc1, nt) decide how a miss is fetched: does any of them bring a 16-byte
+// row in with less than a 128-byte line, and does the row rate rise with it?  Four independent 16-byte rows a trip.
+#define POLICY_LOAD(bits)                                                                                               \
+	asm volatile("global_load_dwordx4 %0, %4, off " bits "\n\tglobal_load_dwordx4 %1, %5, off " bits                   \
+				 "\n\tglobal_load_dwordx4 %2, %6, off " bits "\n\tglobal_load_dwordx4 %3, %7, off " bits               \
+				 "\n\ts_waitcnt vmcnt(0)"                                                                               \
+				 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)                                                            \
+				 : "v"(p0), "v"(p1), "v"(p2), "v"(p3)                                                                    \
+				 : "memory")
+template <int POL>
+__global__ __launch_bounds__(256) void policy_kernel(const uint8_t *__restrict__ table, uint64_t rows, uint32_t iters,
+													 uint32_t *__restrict__ out)
+{
+	uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
+	x *= 0x9E3779B97F4A7C15ull;
+	uint32_t acc = 0;
+	for (uint32_t it = 0; it < iters; it += 4) {
+		const uint8_t *pp[4];
+		for (int j = 0; j < 4; j++) {
+			x ^= x << 13;
+			x ^= x >> 7;
+			x ^= x << 17;
+			pp[j] = table + (x % rows) * 16;
+		}
+		const uint8_t *p0 = pp[0], *p1 = pp[1], *p2 = pp[2], *p3 = pp[3];
+		uint4 v0, v1, v2, v3;
+		if constexpr (POL == 0) POLICY_LOAD("");
+		if constexpr (POL == 1) POLICY_LOAD("nt");
+		if constexpr (POL == 2) POLICY_LOAD("sc0");
+		if constexpr (POL == 3) POLICY_LOAD("sc1");
+		if constexpr (POL == 4) POLICY_LOAD("sc0 sc1");
+		if constexpr (POL == 5) POLICY_LOAD("sc0 sc1 nt");
+		if constexpr (POL == 6) POLICY_LOAD("sc1 nt");
+		if constexpr (POL == 7) POLICY_LOAD("sc0 nt");
+		acc ^= v0.x ^ v1.y ^ v2.z ^ v3.w;
+	}
+	out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+template <int POL> static float run_policy(const uint8_t *table, uint64_t bytes, int blocks, uint32_t iters, uint32_t *out)
+{
+	hipEvent_t a, b;
+	hipEventCreate(&a);
+	hipEventCreate(&b);
+	float best = 1e30f;
+	for (int rep = 0; rep < 4; rep++) {
+		hipEventRecord(a, 0);
+		hipLaunchKernelGGL((policy_kernel<POL>), dim3(blocks), dim3(256), 0, 0, table, bytes / 16, iters, out);
+		hipEventRecord(b, 0);
+		hipEventSynchronize(b);
+		float ms;
+		hipEventElapsedTime(&ms, a, b);
+		if (rep && ms < best) best = ms;
+	}
+	hipEventDestroy(a);
+	hipEventDestroy(b);
+	return best;
+}
+
 template <int ROW, bool CHASE> static float run(const uint8_t *table, uint64_t bytes, int blocks, uint32_t iters, uint32_t *out)
 {
 	hipEvent_t a, b;
@@ -69,7 +128,8 @@ int main(int argc, char **argv)
 	const int cus = prop.multiProcessorCount;
 	uint32_t *out;
 	hipMalloc((void **)&out, (size_t)cus * 8 * 256 * 4);
-	for (int ai = 1; ai < argc; ai++) {
+	const bool policy = argc > 1 && !strcmp(argv[1], "policy"); // gather_bench policy <MB>...: the cache-policy experiment
+	for (int ai = policy ? 2 : 1; ai < argc; ai++) {
 		const uint64_t bytes = strtoull(argv[ai], 0, 10) << 20;
 		uint8_t *table;
 		if (hipMalloc((void **)&table, bytes) != hipSuccess) {
@@ -79,6 +139,22 @@ int main(int argc, char **argv)
 		hipMemset(table, 1, bytes);
 		hipDeviceSynchronize();
 		printf("{\"table_MB\": %llu", (unsigned long long)(bytes >> 20));
+		if (policy) {
+			const int blocks = cus * 4;
+			const uint32_t iters = 512;
+			const double n = (double)blocks * 256 * iters;
+			static const char *names[8] = {"plain", "nt", "sc0", "sc1", "sc0_sc1", "sc0_sc1_nt", "sc1_nt", "sc0_nt"};
+#define POL_(P)                                                                                                         \
+	{                                                                                                                   \
+		const float ms = run_policy<P>(table, bytes, blocks, iters, out);                                               \
+		printf(", \"row16_x4_%s_Grows_s\": %.2f", names[P], n / (ms * 1e-3) / 1e9);                                     \
+	}
+			POL_(0) POL_(1) POL_(2) POL_(3) POL_(4) POL_(5) POL_(6) POL_(7)
+			printf("}\n");
+			fflush(stdout);
+			hipFree(table);
+			continue;
+		}
 		const int bpcs[] = {3, 4, 8};
 		for (int bi = 0; bi < 3; bi++) {
 			const int bpc = bpcs[bi], blocks = cus * bpc;

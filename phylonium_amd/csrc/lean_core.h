@@ -619,6 +619,8 @@ struct VisDirect { // finished words of the visited bitmap go straight to memory
 	uint32_t *visited;
 	PHY_HD void put(uint32_t idx, uint32_t bits) { visited[idx] = bits; }
 	PHY_HD void close() {}
+	PHY_HD bool cheap(uint32_t) const { return true; }
+	PHY_HD void put_cheap(uint32_t idx, uint32_t bits) { put(idx, bits); }
 };
 
 PHY_HD uint32_t lean_visited_word(const LeanLane &ln, uint32_t q)
@@ -667,6 +669,22 @@ struct LeanSpec {
 		const uint32_t w = lean_visited_word(ln, ln.q);
 		if (w != vis_idx) {
 			vis.put(vis_idx, vis_word);
+			vis_idx = w;
+			vis_word = 0;
+		}
+		vis_word |= 1u << (ln.q & 31);
+		ln.qbad_seek(X);
+		return true;
+	}
+	// begin_step where it costs next to nothing — inside the chunk, the finished word of the visited bitmap in the group
+	// the sink is collecting — for the chain kernel's STEP-only trips; false: nothing was done, begin_step has to be
+	template <class Vis> PHY_HD bool begin_step_fast(const LeanIndex &X, Vis &vis)
+	{
+		if (ln.q >= q_end) return false;
+		const uint32_t w = lean_visited_word(ln, ln.q);
+		if (w != vis_idx) {
+			if (!vis.cheap(vis_idx)) return false;
+			vis.put_cheap(vis_idx, vis_word);
 			vis_idx = w;
 			vis_word = 0;
 		}

@@ -411,6 +411,13 @@ struct VisLds {
 		buf[idx & 15u][tid] = bits;
 	}
 	__device__ void close() { flush(); }
+	// a word of the group being collected (or the first word at all): no flush
+	__device__ bool cheap(uint32_t idx) const { return group == NO_BAD || (idx >> 4) == group; }
+	__device__ void put_cheap(uint32_t idx, uint32_t bits)
+	{
+		group = idx >> 4;
+		buf[idx & 15u][tid] = bits;
+	}
 };
 
 struct LeanAlloc {
@@ -583,8 +590,9 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 		// lanes are, up to PHY_FAST_TRIPS trips are taken here that know nothing else: window, the slot's 16 bytes (and
 		// the lucky window), lean_step, and a finished step's bookkeeping.  The few lanes in another phase (an extension,
 		// a bucket walk, a refill, the slow resolver) sit these out and have their turn in the full trip that follows.
+		bool need_bs = false; // a lane whose step has finished and whose begin_step is still owed
 		for (int f = 0; f < PHY_FAST_TRIPS; f++) {
-			bool go = active && ln.ph == LP_STEP && !X.force_slow;
+			bool go = active && !need_bs && ln.ph == LP_STEP && !X.force_slow;
 			if (go) go = lean_step_phase(ln, X) == LP_STEP;
 			const uint32_t n_go = (uint32_t)__popcll(__ballot(go)), n_act = (uint32_t)__popcll(__ballot(active));
 			if (!n_go || n_go * PHY_FAST_DEN < n_act * PHY_FAST_NUM) break;
@@ -604,11 +612,19 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 					if constexpr (MODE == 0) L.step_done(A);
 					else L.step_done(A, alloc);
 					ln.fin = false;
-					if constexpr (MODE == 0) active = L.begin_step(A, X, vis);
+					// (the speculative chains' rarer bookkeeping — a group of visited words to flush, the chunk's end —
+					// waits for the end of the fast trips: once per lane that needs it instead of its code in every trip)
+					if constexpr (MODE == 0) need_bs = !L.begin_step_fast(X, vis);
 					else active = L.begin_step(A, X, R);
 				}
 			}
 			trip++;
+		}
+		if constexpr (MODE == 0) {
+			if (__any(need_bs)) {
+				if (need_bs) active = L.begin_step(A, X, vis);
+				need_bs = false;
+			}
 		}
 		if (__all(done && !active)) break;
 #endif

@@ -1,3 +1,5 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r4m
-(time PHY_FUZZ_SEEDS=300 timeout 2800 python -m pytest tests -m gpu -q -x) > gpurun_out/r4m/gputests.log 2>&1; tail -5 gpurun_out/r4m/gputests.log | head -3; grep -a "^E \|^FAILED\|Memory access" gpurun_out/r4m/gputests.log | head
-(time timeout 2000 python -m pytest tests -m gpu -q -x) > gpurun_out/r4m/gputests2.log 2>&1; tail -5 gpurun_out/r4m/gputests2.log | head -3; grep -a "^E \|^FAILED\|Memory access" gpurun_out/r4m/gputests2.log | head
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+bash tools/tools_ab2.sh "--workload c5 --steps 5 --warmup 2 --check" "anchor_spec,anchor_bridge" base nt1 nt2
+bash tools/tools_ab2.sh "--workload c3 --steps 30 --warmup 3 --check" "anchor_spec,anchor_bridge" base nt1 nt2
+bash tools/tools_ab2.sh "--workload c4 --steps 10 --warmup 2" "anchor_spec,anchor_bridge" base nt1 nt2

@@ -19,6 +19,7 @@ for k, v in pmc.items():
     det[k] = {"read_bytes": rd, "write_bytes": wr, "bytes": rd + wr, "fetch_size_kb": v.get("FETCH_SIZE")}
 cur[wl] = tot
 cur["detail_" + wl] = det
+cur["read_requests_" + wl] = {k: v.get("TCC_EA0_RDREQ_sum", 0) for k, v in pmc.items()}  # memory-side read requests per launch
 cur["method"] = ("HBM-side bytes per launch from rocprofv3 PMC (separate passes): reads = TCC_EA0_RDREQ_128B*128 + _64B*64 "
                  "+ _32B*32 (FETCH_SIZE tallies every request at 64 B, i.e. half the bytes of the 128-B requests, as "
                  "MI355X_MICROARCH.md warns); writes = WRITE_SIZE KB. Sources: the source_<workload> entries")
