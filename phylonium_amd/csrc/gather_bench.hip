@@ -81,6 +81,58 @@ __global__ __launch_bounds__(256) void policy_kernel(const uint8_t *__restrict__
 	out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
+// The same rows through the scalar path: a lane's address goes to SGPRs (readlane), the row comes in by s_load_dwordx4
+// — the scalar cache is a 64-byte client of the L2: does a miss then cost a 64-byte fetch, and what is the rate?
+__global__ __launch_bounds__(256) void scalar_kernel(const uint8_t *__restrict__ table, uint64_t rows, uint32_t iters,
+													 uint32_t *__restrict__ out)
+{
+	typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+	uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
+	x *= 0x9E3779B97F4A7C15ull;
+	uint32_t acc = 0;
+	for (uint32_t it = 0; it < iters; it++) {
+		x ^= x << 13;
+		x ^= x >> 7;
+		x ^= x << 17;
+		const uint64_t off = (x % rows) * 16;
+		const uint32_t lo = (uint32_t)off, hi = (uint32_t)(off >> 32);
+		uint32_t sacc = 0;
+#pragma unroll
+		for (int b = 0; b < 4; b++) {
+			v4u v[16];
+#pragma unroll
+			for (int l = 0; l < 16; l++) {
+				const uint64_t o = (uint64_t)__builtin_amdgcn_readlane((int)lo, b * 16 + l) |
+								   (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, b * 16 + l) << 32;
+				v[l] = *(const v4u __attribute__((address_space(4))) *)(uintptr_t)(table + o);
+			}
+#pragma unroll
+			for (int l = 0; l < 16; l++) sacc ^= v[l].x ^ v[l].w;
+		}
+		acc ^= sacc;
+	}
+	out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+static float run_scalar(const uint8_t *table, uint64_t bytes, int blocks, uint32_t iters, uint32_t *out)
+{
+	hipEvent_t a, b;
+	hipEventCreate(&a);
+	hipEventCreate(&b);
+	float best = 1e30f;
+	for (int rep = 0; rep < 4; rep++) {
+		hipEventRecord(a, 0);
+		hipLaunchKernelGGL(scalar_kernel, dim3(blocks), dim3(256), 0, 0, table, bytes / 16, iters, out);
+		hipEventRecord(b, 0);
+		hipEventSynchronize(b);
+		float ms;
+		hipEventElapsedTime(&ms, a, b);
+		if (rep && ms < best) best = ms;
+	}
+	hipEventDestroy(a);
+	hipEventDestroy(b);
+	return best;
+}
+
 template <int POL> static float run_policy(const uint8_t *table, uint64_t bytes, int blocks, uint32_t iters, uint32_t *out)
 {
 	hipEvent_t a, b;
@@ -150,6 +202,11 @@ int main(int argc, char **argv)
 		printf(", \"row16_x4_%s_Grows_s\": %.2f", names[P], n / (ms * 1e-3) / 1e9);                                     \
 	}
 			POL_(0) POL_(1) POL_(2) POL_(3) POL_(4) POL_(5) POL_(6) POL_(7)
+			for (int bpc = 2; bpc <= 8; bpc *= 2) {
+				const uint32_t it2 = 128;
+				const float ms = run_scalar(table, bytes, cus * bpc, it2, out);
+				printf(", \"row16_scalar_b%d_Grows_s\": %.2f", bpc, (double)cus * bpc * 256 * it2 / (ms * 1e-3) / 1e9);
+			}
 			printf("}\n");
 			fflush(stdout);
 			hipFree(table);

@@ -9,7 +9,7 @@
 //         are only needed for repeats >= 64 kbp and then come from the host (Kasai)
 //   T     k-mer bucket bounds (replaces the 6-mer interval cache, esa.cxx:90-228)
 //   SAX   one 16-byte record per rank (anchor_core.h: sax_record)
-// SLOT is assembled from T and SAX by build_slots_kernel in phylo_abi.hip.
+// SLOT is assembled from T and SAX by build_slots_kernel in abi_reference.hip.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

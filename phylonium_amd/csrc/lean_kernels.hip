@@ -1,10 +1,8 @@
 // lean_kernels.hip — phase A's chain kernels on 2-bit packed operands (lean_core.h),
 // plus the kernels that make the packed tables.
 //
-// Replaces chain_kernel<0|1> of anchor_kernels.hip as the default for the speculative
-// chunk chains and the bridges (same logs, exits and bridge records: fold_kernel and
-// everything after it are unchanged).  Reference: anchor_homologies + the ESA match
-// under it, /root/reference/src/process.cxx:198-295, src/esa.cxx:361-563.
+// The speculative chunk chains, their overruns and the bridges; their logs, exits and bridge
+// records are what fold_kernel (anchor_kernels.hip) reads.  Reference: anchor_homologies + the ESA match under it, /root/reference/src/process.cxx:198-295, src/esa.cxx:361-563.
 //
 // One loop trip = one batch of loads for all 64 lanes whatever phase each is in
 // (32 B at pA, 32 B at pB, 8 B at pY), then the per-phase digest.  Steps the packed
