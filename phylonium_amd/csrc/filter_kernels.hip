@@ -513,160 +513,168 @@ __global__ __launch_bounds__(FILT_THREADS) void sort_filter_seg_kernel(const Raw
 
 
 // ── lists of more than FILT_MAX entries (queries of tens of Mbp: ~330 homologies per Mbp) ──
-// The same stretch-wise filter with the list in global memory.  The keys are sorted by a bitonic network spread over
-// the whole device: a list takes a scratch slot (a list that finds none goes to the host), and every stage of the
-// network is one launch over (slot, tile of FILT_MAX keys) — the passes whose partners lie inside a tile run in LDS
-// on that tile, the passes with partners a whole number of tiles apart on a *transposed* tile (the same columns of
-// every tile row), so a merge level k is two launches whatever its depth.  Then one block per list: prefix maximum
-// of the ends, cuts, stretches and output tile by tile with a carry.  (Round 2 sorted inside that one block: 2000
-// barrier-separated passes for C5's 33 k entries per list, 1.2 of the kernel's 1.7 ms on 64 of the 256 CUs.)
+// The same stretch-wise filter with the list in global memory.  A list takes a scratch slot (a list that finds none
+// goes to the host); its keys are sorted by an LSD radix sort spread over the whole device — four passes over the bits
+// a projected start can have, a pass is two launches over (slot, tile of FILT_MAX keys): the tiles' digit counts, then
+// every tile ranks its keys (stable: a wavefront's keys by ballot, the wavefronts in index order) and scatters them
+// behind the smaller digits of the list and the same digit of the tiles before it.  Then one block per list: prefix
+// maximum of the ends, cuts, stretches and output tile by tile with a carry.  (Round 2 sorted inside that one block:
+// 2000 barrier-separated passes for C5's 33 k entries per list; round 3 ran a bitonic network over the device, eleven
+// launches over lists padded to a power of two: 0.46 of the filter's 0.74 ms on C5.)
 struct LongMeta {
-	uint32_t n, n2, j, pad;
-};
-struct LongScratch {
-	uint64_t *keys; // [LONG_SLOTS][LONG_MAX_N] start << 32 | raw index
-	uint32_t *ends; // [LONG_SLOTS][LONG_MAX_N] end of the entry at that pile position
-	uint8_t *keep;  // [LONG_SLOTS][LONG_MAX_N] bit 0 kept, bit 1 a stretch starts here
-	LongMeta *meta; // [LONG_SLOTS] the list in the slot: entries, power of two the network runs over, query
-	uint32_t *next_slot;
+	uint32_t n, j, pad0, pad1;
 };
 static const uint32_t LONG_TILES = LONG_MAX_N / FILT_MAX; // tiles per slot
+static const uint32_t RADIX_BINS = 256;
+struct LongScratch {
+	uint64_t *keys;   // [LONG_SLOTS][LONG_MAX_N] start << 32 | raw index; sorted when the passes are through
+	uint64_t *keys2;  // the passes' other buffer
+	uint32_t *counts; // [LONG_SLOTS][LONG_TILES][RADIX_BINS] a pass's digit counts by tile
+	uint32_t *ends;   // [LONG_SLOTS][LONG_MAX_N] end of the entry at that pile position
+	LongMeta *meta;   // [LONG_SLOTS] the list in the slot: entries, query
+	uint32_t *next_slot;
+};
 
-// a slot for every long list, its keys (reverseEh, process.h:72-80) padded to a power of two; rng[2j] holds the slot
-__global__ __launch_bounds__(FILT_THREADS) void long_prepare_kernel(const RawHom *__restrict__ raw, const uint64_t *__restrict__ raw_base,
-																	 const uint32_t *__restrict__ raw_cnt, uint32_t j0, uint32_t border,
-																	 uint32_t *__restrict__ rng, uint32_t *__restrict__ flag, LongScratch S)
+// a slot for every long list (rng[2j] holds it)
+__global__ __launch_bounds__(64) void long_slots_kernel(const uint32_t *__restrict__ raw_cnt, uint32_t j0, uint32_t nq, uint32_t *__restrict__ rng,
+														 uint32_t *__restrict__ flag, LongScratch S)
 {
-	__shared__ uint32_t s_slot;
-	const uint32_t j = j0 + blockIdx.x, tid = threadIdx.x;
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= nq) return;
+	const uint32_t j = j0 + t;
 	if (flag[j] != FLAG_LONG) return;
-	const RawHom *r = raw + raw_base[j];
-	const uint32_t n = raw_cnt[j];
-	if (tid == 0) s_slot = atomicAdd(S.next_slot, 1u);
-	__syncthreads();
-	if (s_slot >= LONG_SLOTS) {
-		if (tid == 0) flag[j] = FLAG_HOST;
+	const uint32_t slot = atomicAdd(S.next_slot, 1u);
+	if (slot >= LONG_SLOTS) {
+		flag[j] = FLAG_HOST;
 		return;
 	}
-	uint64_t *K = S.keys + (size_t)s_slot * LONG_MAX_N;
-	uint32_t n2 = FILT_MAX;
-	while (n2 < n) n2 <<= 1;
-	for (uint32_t t = tid; t < n2; t += FILT_THREADS) {
-		uint64_t key = ~0ull;
-		if (t < n) {
-			const RawHom h = r[t];
-			const uint32_t start = h.iref >= border ? 2u * border + 1u - h.len - h.iref : h.iref;
-			key = (uint64_t)start << 32 | t;
-		}
-		K[t] = key;
-	}
-	if (tid == 0) {
-		S.meta[s_slot] = LongMeta{n, n2, j, 0u};
-		rng[2 * j] = s_slot;
-	}
+	S.meta[slot] = LongMeta{raw_cnt[j], j, 0u, 0u};
+	rng[2 * j] = slot;
 }
-
-// merge levels k_lo .. k_hi (powers of two), the passes with partners less than a tile apart: block = (slot, tile).
-// A thread holds four consecutive keys in registers: partners 1 or 2 apart are its own, partners 4 .. 128 apart sit in
-// another lane of the same wavefront (a shuffle, no barrier), only partners 256 or more apart go through LDS — 10 of
-// the first sweep's 78 passes, 4 of the 12 of every later one.
-static __device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int mask)
+// the keys (reverseEh, process.h:72-80): block = (slot, tile)
+__global__ __launch_bounds__(FILT_THREADS) void long_keys_kernel(const RawHom *__restrict__ raw, const uint64_t *__restrict__ raw_base,
+																  uint32_t border, LongScratch S)
 {
-	const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, mask, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), mask, 64);
-	return (uint64_t)hi << 32 | lo;
-}
-__global__ __launch_bounds__(FILT_THREADS) void long_sort_low_kernel(LongScratch S, uint32_t k_lo, uint32_t k_hi)
-{
-	__shared__ uint64_t tile[FILT_MAX];
 	const uint32_t slot = blockIdx.x / LONG_TILES, base = (blockIdx.x % LONG_TILES) * FILT_MAX, tid = threadIdx.x;
 	const uint32_t used = *S.next_slot < LONG_SLOTS ? *S.next_slot : LONG_SLOTS;
 	if (slot >= used) return;
-	const uint32_t n2 = S.meta[slot].n2;
-	if (base >= n2 || k_lo > n2) return;
-	uint64_t *K = S.keys + (size_t)slot * LONG_MAX_N + base;
-	uint64_t v[4];
-	{
-		const ulonglong2 a = *(const ulonglong2 *)(K + 4 * tid), b = *(const ulonglong2 *)(K + 4 * tid + 2);
-		v[0] = a.x, v[1] = a.y, v[2] = b.x, v[3] = b.y;
-	}
-	const uint32_t e0 = base + 4u * tid; // list index of v[0]
-	auto cx = [](uint64_t &lo_el, uint64_t &hi_el, bool asc) { // the pair in order: ascending when asc
-		if ((lo_el > hi_el) == asc) {
-			const uint64_t t = lo_el;
-			lo_el = hi_el;
-			hi_el = t;
-		}
-	};
-	for (uint32_t kk = k_lo; kk <= k_hi && kk <= n2; kk <<= 1) {
-		for (uint32_t j2 = (kk > FILT_MAX ? FILT_MAX : kk) >> 1; j2 > 0; j2 >>= 1) {
-			if (j2 == 2u) {
-				cx(v[0], v[2], (e0 & kk) == 0);
-				cx(v[1], v[3], ((e0 + 1u) & kk) == 0);
-			} else if (j2 == 1u) {
-				cx(v[0], v[1], (e0 & kk) == 0);
-				cx(v[2], v[3], ((e0 + 2u) & kk) == 0);
-			} else {
-				// the partner of key e0 + i is key (e0 + i) ^ j2: key i of thread tid ^ (j2 / 4); kk >= 8 here, so the four
-				// keys of a thread share their direction
-				const uint32_t d = j2 >> 2;
-				const bool asc = (e0 & kk) == 0, lower = (tid & d) == 0;
-				uint64_t o[4];
-				if (d < 64u) {
+	const LongMeta M = S.meta[slot];
+	if (base >= M.n) return;
+	const RawHom *r = raw + raw_base[M.j];
+	uint64_t *K = S.keys + (size_t)slot * LONG_MAX_N;
 #pragma unroll
-					for (int i = 0; i < 4; i++) o[i] = shfl_xor64(v[i], (int)d);
-				} else {
-					__syncthreads(); // (the partners' reads of the pass before)
-					*(ulonglong2 *)(tile + 4 * tid) = ulonglong2{v[0], v[1]};
-					*(ulonglong2 *)(tile + 4 * tid + 2) = ulonglong2{v[2], v[3]};
-					__syncthreads();
-					const ulonglong2 a = *(const ulonglong2 *)(tile + 4 * (tid ^ d)), b = *(const ulonglong2 *)(tile + 4 * (tid ^ d) + 2);
-					o[0] = a.x, o[1] = a.y, o[2] = b.x, o[3] = b.y;
-				}
-#pragma unroll
-				for (int i = 0; i < 4; i++) {
-					const bool take_min = lower == asc; // the lower index keeps the smaller key of an ascending pair
-					const uint64_t mn = v[i] < o[i] ? v[i] : o[i], mx = v[i] < o[i] ? o[i] : v[i];
-					v[i] = take_min ? mn : mx;
-				}
-			}
+	for (uint32_t u = 0; u < FILT_MAX / FILT_THREADS; u++) {
+		const uint32_t t = base + u * FILT_THREADS + tid;
+		if (t < M.n) {
+			const RawHom h = r[t];
+			const uint32_t start = h.iref >= border ? 2u * border + 1u - h.len - h.iref : h.iref;
+			K[t] = (uint64_t)start << 32 | t;
 		}
 	}
-	*(ulonglong2 *)(K + 4 * tid) = ulonglong2{v[0], v[1]};
-	*(ulonglong2 *)(K + 4 * tid + 2) = ulonglong2{v[2], v[3]};
 }
-
-// merge level k > FILT_MAX, the passes with partners a whole number of tiles apart: the list as rows of FILT_MAX keys,
-// block = (slot, group of columns) holds those columns of every row
-__global__ __launch_bounds__(FILT_THREADS) void long_sort_high_kernel(LongScratch S, uint32_t k)
+// a pass's digit counts: block = (slot, tile); `from2`: the pass reads keys2
+__global__ __launch_bounds__(FILT_THREADS) void long_radix_count_kernel(LongScratch S, uint32_t shift, uint32_t mask, uint32_t from2)
 {
-	__shared__ uint64_t tile[FILT_MAX];
-	const uint32_t slot = blockIdx.x / LONG_TILES, grp = blockIdx.x % LONG_TILES, tid = threadIdx.x;
+	__shared__ uint32_t hist[RADIX_BINS];
+	const uint32_t slot = blockIdx.x / LONG_TILES, tile = blockIdx.x % LONG_TILES, base = tile * FILT_MAX, tid = threadIdx.x;
 	const uint32_t used = *S.next_slot < LONG_SLOTS ? *S.next_slot : LONG_SLOTS;
 	if (slot >= used) return;
-	const uint32_t n2 = S.meta[slot].n2;
-	if (k > n2) return;
-	const uint32_t rows = n2 / FILT_MAX; // >= 2, a power of two
-	if (grp >= rows) return;
-	const uint32_t cols = FILT_MAX / rows, col0 = grp * cols; // (rows * cols = FILT_MAX keys per block)
-	uint64_t *K = S.keys + (size_t)slot * LONG_MAX_N;
-	for (uint32_t t = tid; t < FILT_MAX; t += FILT_THREADS) tile[t] = K[(t / cols) * FILT_MAX + col0 + (t % cols)];
+	const uint32_t n = S.meta[slot].n;
+	if (base >= n) return;
+	if (tid < RADIX_BINS) hist[tid] = 0;
 	__syncthreads();
-	for (uint32_t jj = k >> 1; jj >= FILT_MAX; jj >>= 1) {
-		const uint32_t rr = jj / FILT_MAX;
-		for (uint32_t t = tid; t < FILT_MAX; t += FILT_THREADS) {
-			const uint32_t row = t / cols, c = t % cols;
-			if ((row ^ rr) > row) {
-				const uint32_t x = (row ^ rr) * cols + c;
-				const uint64_t u = tile[t], v = tile[x];
-				if ((u > v) == (((row * FILT_MAX) & k) == 0)) {
-					tile[t] = v;
-					tile[x] = u;
-				}
-			}
-		}
-		__syncthreads();
+	const uint64_t *K = (from2 ? S.keys2 : S.keys) + (size_t)slot * LONG_MAX_N;
+	for (uint32_t t = base + tid; t < base + FILT_MAX && t < n; t += FILT_THREADS)
+		atomicAdd(&hist[(uint32_t)(K[t] >> (32u + shift)) & mask], 1u);
+	__syncthreads();
+	if (tid < RADIX_BINS) S.counts[((size_t)slot * LONG_TILES + tile) * RADIX_BINS + tid] = hist[tid];
+}
+// ... and the scatter: key i of the tile (index order: round r = i / 1024, wavefront, lane) goes behind the list's
+// smaller digits, the same digit of the tiles before, and the same digit of the keys before it in this tile
+__global__ __launch_bounds__(FILT_THREADS) void long_radix_scatter_kernel(LongScratch S, uint32_t shift, uint32_t mask, uint32_t from2)
+{
+	constexpr uint32_t ROUNDS = FILT_MAX / FILT_THREADS;
+	// counts, then offsets inside the tile's keys of that digit, of a (round, wavefront)'s digits (16-bit: 32 KB, so that
+	// every tile of C5's 64 lists is resident at once)
+	__shared__ uint16_t cnt[ROUNDS][FILT_WAVES][RADIX_BINS];
+	__shared__ uint32_t gbase[RADIX_BINS], wsum4[RADIX_BINS / 64];
+	const uint32_t slot = blockIdx.x / LONG_TILES, tile = blockIdx.x % LONG_TILES, base = tile * FILT_MAX, tid = threadIdx.x;
+	const uint32_t lane = tid & 63u, wave = tid >> 6;
+	const uint32_t used = *S.next_slot < LONG_SLOTS ? *S.next_slot : LONG_SLOTS;
+	if (slot >= used) return;
+	const uint32_t n = S.meta[slot].n;
+	if (base >= n) return;
+	const uint32_t ntiles = (n + FILT_MAX - 1) / FILT_MAX;
+	const uint64_t *K = (from2 ? S.keys2 : S.keys) + (size_t)slot * LONG_MAX_N;
+	uint64_t *D = (from2 ? S.keys : S.keys2) + (size_t)slot * LONG_MAX_N;
+	uint64_t key[ROUNDS];
+#pragma unroll
+	for (uint32_t r = 0; r < ROUNDS; r++) { // (on their way while the counts are read)
+		const uint32_t i = base + r * FILT_THREADS + tid;
+		key[r] = i < n ? K[i] : 0ull;
 	}
-	for (uint32_t t = tid; t < FILT_MAX; t += FILT_THREADS) K[(t / cols) * FILT_MAX + col0 + (t % cols)] = tile[t];
+	for (uint32_t t = tid; t < ROUNDS * FILT_WAVES * RADIX_BINS / 2; t += FILT_THREADS) ((uint32_t *)&cnt[0][0][0])[t] = 0;
+	// where this tile's keys of digit `tid` begin: the list's smaller digits (an exclusive scan over the 256 digits: four
+	// wavefronts, then their sums) and the same digit of the tiles before
+	uint32_t mine = 0;
+	if (tid < RADIX_BINS) {
+		const uint32_t *C = S.counts + (size_t)slot * LONG_TILES * RADIX_BINS + tid;
+		uint32_t before = 0, all = 0, v[LONG_TILES];
+#pragma unroll
+		for (uint32_t t2 = 0; t2 < LONG_TILES; t2++) v[t2] = t2 < ntiles ? C[(size_t)t2 * RADIX_BINS] : 0u; // (all in flight at once)
+#pragma unroll
+		for (uint32_t t2 = 0; t2 < LONG_TILES; t2++) {
+			if (t2 < tile) before += v[t2];
+			all += v[t2];
+		}
+		uint32_t incl = all;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t u = (uint32_t)__shfl_up((int)incl, d, 64);
+			if ((int)lane >= d) incl += u;
+		}
+		mine = incl - all + before;
+		if (lane == 63) wsum4[wave] = incl;
+	}
+	__syncthreads();
+	if (tid < RADIX_BINS) {
+		for (uint32_t w2 = 0; w2 < wave; w2++) mine += wsum4[w2];
+		gbase[tid] = mine;
+	}
+	uint32_t rank[ROUNDS];
+#pragma unroll
+	for (uint32_t r = 0; r < ROUNDS; r++) {
+		const bool valid = base + r * FILT_THREADS + tid < n;
+		const uint32_t dg = (uint32_t)(key[r] >> (32u + shift)) & mask;
+		unsigned long long peers = __ballot(valid);
+#pragma unroll
+		for (uint32_t bit = 0; bit < 8; bit++) {
+			const unsigned long long m = __ballot((dg >> bit) & 1u);
+			peers &= ((dg >> bit) & 1u) ? m : ~m;
+		}
+		rank[r] = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+		if (valid && rank[r] == 0) cnt[r][wave][dg] = (uint16_t)__popcll(peers);
+	}
+	__syncthreads();
+	if (tid < RADIX_BINS) {
+		uint32_t run = 0;
+#pragma unroll
+		for (uint32_t r = 0; r < ROUNDS; r++)
+#pragma unroll
+			for (uint32_t w2 = 0; w2 < FILT_WAVES; w2++) {
+				const uint32_t u = cnt[r][w2][tid];
+				cnt[r][w2][tid] = (uint16_t)run;
+				run += u;
+			}
+	}
+	__syncthreads();
+#pragma unroll
+	for (uint32_t r = 0; r < ROUNDS; r++) {
+		if (base + r * FILT_THREADS + tid < n) {
+			const uint32_t dg = (uint32_t)(key[r] >> (32u + shift)) & mask;
+			D[gbase[dg] + cnt[r][wave][dg] + rank[r]] = key[r];
+		}
+	}
 }
 
 __global__ __launch_bounds__(FILT_THREADS) void sort_filter_long_kernel(const RawHom *__restrict__ raw,
@@ -678,6 +686,7 @@ __global__ __launch_bounds__(FILT_THREADS) void sort_filter_long_kernel(const Ra
 {
 	__shared__ uint32_t wmax[FILT_WAVES], wsum[FILT_WAVES];
 	__shared__ uint32_t s_tie, s_general, s_carry, s_base;
+	__shared__ uint8_t s_keep[LONG_MAX_N];
 	const uint32_t j = j0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	if (flag[j] != FLAG_LONG) return;
 	const RawHom *r = raw + raw_base[j];
@@ -686,7 +695,7 @@ __global__ __launch_bounds__(FILT_THREADS) void sort_filter_long_kernel(const Ra
 	if (tid == 0) s_tie = s_general = 0;
 	uint64_t *K = S.keys + (size_t)slot * LONG_MAX_N;
 	uint32_t *E = S.ends + (size_t)slot * LONG_MAX_N;
-	uint8_t *KP = S.keep + (size_t)slot * LONG_MAX_N;
+	uint8_t *KP = s_keep; // bit 0 kept, bit 1 a stretch starts here — by pile position, the whole list in LDS
 	// ends, equal starts, prefix maximum of the ends and the cuts, tile by tile
 	if (tid == 0) s_carry = 0;
 	__syncthreads();
@@ -824,7 +833,10 @@ __global__ __launch_bounds__(FILT_THREADS) void sort_filter_long_kernel(const Ra
 	}
 }
 
-size_t long_filter_scratch_bytes() { return (size_t)LONG_SLOTS * LONG_MAX_N * (8 + 4 + 1) + LONG_SLOTS * sizeof(LongMeta) + 64; }
+size_t long_filter_scratch_bytes()
+{
+	return (size_t)LONG_SLOTS * LONG_MAX_N * (8 + 8 + 4) + (size_t)LONG_SLOTS * LONG_TILES * RADIX_BINS * 4 + LONG_SLOTS * sizeof(LongMeta) + 64;
+}
 uint32_t long_filter_min_entries() { return FILT_MAX; }
 
 void launch_sort_filter_long(const RawHom *raw, const uint64_t *raw_base, const uint32_t *raw_cnt, uint32_t j0, uint32_t j1,
@@ -834,16 +846,23 @@ void launch_sort_filter_long(const RawHom *raw, const uint64_t *raw_base, const 
 	if (j1 <= j0) return;
 	LongScratch S;
 	S.keys = (uint64_t *)scratch;
-	S.ends = (uint32_t *)(S.keys + (size_t)LONG_SLOTS * LONG_MAX_N);
-	S.meta = (LongMeta *)(S.ends + (size_t)LONG_SLOTS * LONG_MAX_N);
-	S.keep = (uint8_t *)(S.meta + LONG_SLOTS);
+	S.keys2 = S.keys + (size_t)LONG_SLOTS * LONG_MAX_N;
+	S.ends = (uint32_t *)(S.keys2 + (size_t)LONG_SLOTS * LONG_MAX_N);
+	S.counts = S.ends + (size_t)LONG_SLOTS * LONG_MAX_N;
+	S.meta = (LongMeta *)(S.counts + (size_t)LONG_SLOTS * LONG_TILES * RADIX_BINS);
 	S.next_slot = slot_counter;
-	hipLaunchKernelGGL(long_prepare_kernel, dim3(j1 - j0), dim3(FILT_THREADS), 0, st, raw, raw_base, raw_cnt, j0, border, rng, flag, S);
+	hipLaunchKernelGGL(long_slots_kernel, dim3((j1 - j0 + 63) / 64), dim3(64), 0, st, raw_cnt, j0, j1 - j0, rng, flag, S);
 	const dim3 grid(LONG_SLOTS * LONG_TILES);
-	hipLaunchKernelGGL(long_sort_low_kernel, grid, dim3(FILT_THREADS), 0, st, S, 2u, FILT_MAX);
-	for (uint32_t k = 2 * FILT_MAX; k <= LONG_MAX_N; k <<= 1) {
-		hipLaunchKernelGGL(long_sort_high_kernel, grid, dim3(FILT_THREADS), 0, st, S, k);
-		hipLaunchKernelGGL(long_sort_low_kernel, grid, dim3(FILT_THREADS), 0, st, S, k, k);
+	hipLaunchKernelGGL(long_keys_kernel, grid, dim3(FILT_THREADS), 0, st, raw, raw_base, border, S);
+	// projected starts lie below 2 * border + 2: four passes (an even number: the sorted keys are back in `keys`) over
+	// that many bits
+	uint32_t bits = 1;
+	while (bits < 32 && ((2ull * border + 1ull) >> bits)) bits++;
+	const uint32_t per = (bits + 3) / 4;
+	for (uint32_t p = 0; p < 4; p++) {
+		const uint32_t shift = p * per, mask = (1u << per) - 1u;
+		hipLaunchKernelGGL(long_radix_count_kernel, grid, dim3(FILT_THREADS), 0, st, S, shift, mask, p & 1u);
+		hipLaunchKernelGGL(long_radix_scatter_kernel, grid, dim3(FILT_THREADS), 0, st, S, shift, mask, p & 1u);
 	}
 	hipLaunchKernelGGL(sort_filter_long_kernel, dim3(j1 - j0), dim3(FILT_THREADS), 0, st, raw, raw_base, raw_cnt, j0, border, out, rng,
 					   total, flag, S);
