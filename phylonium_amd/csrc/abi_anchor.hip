@@ -86,6 +86,9 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, bool defer)
 		HIPOK(c, c->a_qlen.ensure(nq));
 		HIPOK(c, c->a_qchunk0.ensure(nq + 1));
 		HIPOK(c, c->a_items.ensure(nchp + 1));
+		HIPOK(c, c->a_work.ensure(nchp + 1));
+		HIPOK(c, c->a_qdesc.ensure(nq + 1));
+		c->work_stale = true;
 		HIPOK(c, c->a_chunk_query.ensure(nchp + 1));
 		HIPOK(c, c->a_spec_cnt.ensure(nchp + 1));
 		// one visited bit per byte of the genome buffer (chains address it by buffer offset)
@@ -135,6 +138,8 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, bool defer)
 	A.qchunk0 = c->a_qchunk0.p;
 	A.items = c->a_items.p;
 	A.chunk_query = c->a_chunk_query.p;
+	A.work = c->a_work.p;
+	A.qdesc = c->a_qdesc.p;
 	A.nchunks = nch;
 	A.C = P.C;
 	A.cap = P.cap;
@@ -158,6 +163,11 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, bool defer)
 	// are a few kbp in several contigs; option "cache_quirk" = 0 computes the true longest matches instead).
 	LeanIndex X = {c->d_S2.p, c->d_SBAD.p, c->nsb, c->ns, c->sb_first, c->d_Q2.p, c->d_QBAD.p, c->d_qbad_off.p + q_begin,
 				   (uint32_t)(c->lean_force_slow || quirk_mode), nullptr, quirk_mode ? c->d_quirk.p : nullptr, quirk_mode ? c->nquirk : 0u};
+	if (c->work_stale && nch) { // the plan is new: its work order as items and descriptors
+		launch_lean_work(A, X, c->a_work.p, c->a_qdesc.p, (uint32_t)nq, st);
+		HIPOK(c, hipGetLastError());
+		c->work_stale = false;
+	}
 #ifdef PHY_LEAN_TIMING
 	static unsigned long long *dbg_buf = nullptr;
 	const size_t dbg_words = 16 + 4 * 8192 + 64 + 16;

@@ -93,6 +93,8 @@ void phylo_ctx_destroy(phylo_ctx *c)
 	c->a_qchunk0.release();
 	c->a_qanc0.release();
 	c->a_items.release();
+	c->a_work.release();
+	c->a_qdesc.release();
 	c->a_chunk_query.release();
 	c->a_spec_cnt.release();
 	c->a_visited.release();

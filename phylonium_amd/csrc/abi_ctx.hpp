@@ -227,6 +227,9 @@ struct phylo_ctx {
 	// phase A scratch
 	DevBuf<uint64_t> a_qoff;
 	DevBuf<uint32_t> a_qlen, a_qchunk0, a_qanc0, a_items, a_chunk_query, a_spec_cnt, a_visited, a_misc;
+	DevBuf<WorkItem> a_work; // the plan's work order as items to start from, and the queries' descriptors (lean_work_kernel)
+	DevBuf<QDesc> a_qdesc;
+	bool work_stale = true;
 	DevBuf<Anchor> a_spec_anchors;
 	DevBuf<SpecExit> a_spec_exit;
 	DevBuf<BridgeRec> a_bridge;

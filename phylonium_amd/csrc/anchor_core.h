@@ -288,6 +288,17 @@ struct PoolBlock {
 	uint32_t pad;
 };
 
+// The speculative kernel's work queue, ready to start from (lean_kernels.hip: lean_work_kernel makes both with the plan):
+// an item = a chunk, its query and where the query's list of non-ACGT positions stands at the chunk's first position;
+// a query's descriptor = everything LeanSpec::start needs of it — so that a lane takes its next chunk without a chain
+// of dependent loads (item -> query -> six tables -> a binary search), which stalls the other 63 lanes of its wavefront.
+struct WorkItem {
+	uint32_t chunk, j, qb_idx, qb_next;
+};
+struct QDesc {
+	uint32_t qchunk0, qlen, qword0, qanc0, qb_end, pad0, pad1, pad2;
+};
+
 struct PhaseA {
 	// inputs
 	const uint8_t *qbase;      // all genomes, each followed by >= 64 zero bytes
@@ -296,6 +307,8 @@ struct PhaseA {
 	const uint32_t *qchunk0;   // [nq+1] first global chunk id of each query
 	const uint32_t *items;     // [nchunks] work order: global chunk ids, runs of one query (hostlogic.hpp: plan_chunks)
 	const uint32_t *chunk_query; // [nchunks] query id of each global chunk
+	const WorkItem *work;      // [nchunks] the work order as items to start from
+	const QDesc *qdesc;        // [nq]
 	uint32_t nchunks;
 	uint32_t C;                // positions per chunk (a multiple of 64; a query's last chunk is cut by its length)
 	uint32_t cap;              // anchor slots per chunk

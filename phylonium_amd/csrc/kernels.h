@@ -14,6 +14,8 @@ int lean_spec_resident_blocks(int n_cu);
 void launch_lean_spec(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st, int max_blocks = 0); // max_blocks > 0: no more blocks than that
 void launch_lean_overruns(const PhaseA &A, const RefIndex &R, uint32_t nq, hipStream_t st); // between spec and bridge
 void launch_lean_bridge(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st);
+// the speculative kernel's work queue as items and query descriptors (anchor_core.h), once per plan
+void launch_lean_work(const PhaseA &A, const LeanIndex &X, WorkItem *work, QDesc *qdesc, uint32_t nq, hipStream_t st);
 void launch_pack2(const uint8_t *src, uint64_t bytes, uint32_t *dst, hipStream_t st); // bytes: a multiple of 16
 // Q2 → byte arena (bytes: the whole arena, a multiple of 16), then '!' at the nbad listed positions; code bits of Q2
 // outside the genomes or under a separator are cleared on the way

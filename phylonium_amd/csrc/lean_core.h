@@ -633,22 +633,47 @@ struct LeanSpec {
 	uint32_t gc, q_end, cnt, log0, cap, vis_word, vis_idx;
 	uint32_t q_end_full; // the chunk's end on the grid (not clipped to the query's length)
 
+	// the work item of a chunk and the descriptor of a query, as lean_work_kernel stores them
+	static PHY_HD WorkItem make_item(const PhaseA &A, const LeanIndex &X, uint32_t chunk)
+	{
+		const uint32_t j = A.chunk_query[chunk], q0 = (chunk - A.qchunk0[j]) * A.C;
+		uint32_t lo = X.qbad_off[j], hi = X.qbad_off[j + 1];
+		const uint32_t end = hi;
+		while (lo < hi) { // first entry >= q0
+			const uint32_t mid = lo + ((hi - lo) >> 1);
+			if (X.QBAD[mid] < q0) lo = mid + 1;
+			else hi = mid;
+		}
+		WorkItem w = {chunk, j, lo, lo < end ? X.QBAD[lo] : NO_BAD};
+		return w;
+	}
+	static PHY_HD QDesc make_qdesc(const PhaseA &A, const LeanIndex &X, uint32_t j)
+	{
+		QDesc d = {A.qchunk0[j], A.qlen[j], (uint32_t)(A.qoff[j] >> 4), A.qanc0[j], X.qbad_off[j + 1], 0u, 0u, 0u};
+		return d;
+	}
 	PHY_HD void start(const PhaseA &A, const LeanIndex &X, uint32_t chunk)
 	{
-		gc = chunk;
-		const uint32_t j = A.chunk_query[chunk];
-		const ChunkGeom g = chunk_geom(A, j, chunk - A.qchunk0[j]);
-		const uint32_t ql = A.qlen[j], e = g.q0 + g.len;
-		q_end = e < ql ? e : ql;
+		const WorkItem w = make_item(A, X, chunk);
+		start_desc(A, w, make_qdesc(A, X, w.j));
+	}
+	// ... without a load: everything comes with the item and the descriptor
+	PHY_HD void start_desc(const PhaseA &A, const WorkItem &w, const QDesc &d)
+	{
+		gc = w.chunk;
+		const uint32_t lc = w.chunk - d.qchunk0, q0 = lc * A.C, e = q0 + A.C;
+		q_end = e < d.qlen ? e : d.qlen;
 		q_end_full = e;
-		log0 = g.log0;
-		cap = g.cap;
-		ln.reset((uint32_t)(A.qoff[j] >> 4), ql, g.q0, 0, 0, 0);
-		ln.qbad_start(X, j);
-		ln.q_cap = e + g.len < e ? NO_BAD : e + g.len;
+		log0 = d.qanc0 + lc * A.cap;
+		cap = A.cap;
+		ln.reset(d.qword0, d.qlen, q0, 0, 0, 0);
+		ln.qb_idx = w.qb_idx;
+		ln.qb_end = d.qb_end;
+		ln.qb_next = w.qb_next;
+		ln.q_cap = e + A.C < e ? NO_BAD : e + A.C;
 		cnt = 0;
 		vis_word = 0;
-		vis_idx = lean_visited_word(ln, g.q0);
+		vis_idx = lean_visited_word(ln, q0);
 	}
 	// called when ln.ph == LP_STEP; false when the chunk is finished.  `vis` takes the finished words of the
 	// visited bitmap: put(word index, bits) for one that is complete, close() at the chunk's end.  (The GPU

@@ -427,6 +427,20 @@ struct LeanAlloc {
 	}
 };
 
+// The speculative kernel's work queue in the form a lane starts from (anchor_core.h: WorkItem, QDesc): made once per plan.
+__global__ __launch_bounds__(256) void lean_work_kernel(PhaseA A, LeanIndex X, WorkItem *__restrict__ work, QDesc *__restrict__ qdesc, uint32_t nq)
+{
+	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+	if (t < A.nchunks) work[t] = LeanSpec::make_item(A, X, A.items[t]);
+	if (t < nq) qdesc[t] = LeanSpec::make_qdesc(A, X, t);
+}
+void launch_lean_work(const PhaseA &A, const LeanIndex &X, WorkItem *work, QDesc *qdesc, uint32_t nq, hipStream_t st)
+{
+	const uint32_t n = A.nchunks > nq ? A.nchunks : nq;
+	if (!n) return;
+	hipLaunchKernelGGL(lean_work_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A, X, work, qdesc, nq);
+}
+
 // STEP-only trips between two full ones (0: none), taken while at least NUM / DEN of the wavefront's live lanes are in
 // STEP.  Same-box A/B on C3, anchor_spec / anchor_bridge: none 3.14 / 0.45 ms; 1 trip at 3/4 2.79 / 0.36; 2 at 1/2
 // 2.78 / 0.36; 4 at 1/2 2.76 / 0.345; 4 at 1/4 2.75 / 0.344; 8 at 1/4 2.91 / 0.37 (C5: 19.1 -> 16.4 / 0.74 -> 0.50;
@@ -485,6 +499,16 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 	}
 	bool active = false, done = false;
 	uint32_t trip = 0;
+	// The next work item, fetched ahead (MODE 0).  A lane that has run out of work and asks the queue then — counter, item,
+	// the query's descriptor: three dependent loads — keeps the other 63 lanes of its wavefront waiting, sixty-four times
+	// a round.  Instead a lane claims its next item when it is an eighth of a chunk from the end of this one, and the
+	// trips that follow bring the item and the descriptor in beside their own loads; at the chunk's end it starts from
+	// registers.  (pf: 0 nothing claimed, 1 the counter's answer is on its way, 2 the item, 3 the descriptor — ready,
+	// 4 the queue is empty.)  queue_empty: a lane of this wavefront has seen the end of the queue.
+	uint32_t pf = 0, nx_it = 0;
+	WorkItem nx_w = {0, 0, 0, 0};
+	QDesc nx_d = {0, 0, 0, 0, 0, 0, 0, 0};
+	bool queue_empty = false;
 #if PHY_PRIO_ROT
 	const uint32_t prio_pass = (uint32_t)(((uint64_t)blockIdx.x * 4u) / gridDim.x);
 #endif
@@ -544,15 +568,54 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 			}
 #endif
 		}
+		if constexpr (MODE == 0) {
+			// the next item on its way: one stage a trip
+			if (__any(pf == 1u || pf == 2u)) {
+				if (pf == 2u) {
+					const U4 *dp = (const U4 *)(A.qdesc + nx_w.j);
+					const U4 d0 = dp[0], d1 = dp[1];
+					nx_d = QDesc{d0.x, d0.y, d0.z, d0.w, d1.x, 0u, 0u, 0u};
+					pf = 3u;
+				} else if (pf == 1u) {
+					if (nx_it >= n_items) {
+						pf = 4u;
+					} else {
+						const U4 v = *(const U4 *)(A.work + nx_it);
+						nx_w = WorkItem{v.x, v.y, v.z, v.w};
+						pf = 2u;
+					}
+				}
+			}
+			if (active && pf == 0u && !queue_empty && ln.ph == LP_STEP && ln.q + (A.C >> 3) >= L.q_end) {
+				nx_it = atomicAdd(&A.fetch[0], 1u);
+				pf = 1u;
+			}
+		}
 		if (!active && !done) {
-			const uint32_t it = atomicAdd(&A.fetch[MODE], 1u);
+			uint32_t it = n_items;
+			if constexpr (MODE == 0) {
+				if (pf == 3u) it = nx_it;                                      // ready: no load below
+				else if (pf == 1u || pf == 2u) it = nx_it;                      // (claimed late: the rest of the chain now)
+				else if (pf == 0u && !queue_empty) it = atomicAdd(&A.fetch[0], 1u); // (the first item, or a chunk shorter than the lead)
+			} else {
+				if (!queue_empty) it = atomicAdd(&A.fetch[MODE], 1u);
+			}
 			done = it >= n_items;
 			if (!done) {
 				if constexpr (MODE == 0) {
-					const uint32_t item = A.items[it];
-					L.start(A, X, item);
+					if (pf != 3u) {
+						if (pf != 2u) {
+							const U4 v = *(const U4 *)(A.work + it);
+							nx_w = WorkItem{v.x, v.y, v.z, v.w};
+						}
+						const U4 *dp = (const U4 *)(A.qdesc + nx_w.j);
+						const U4 d0 = dp[0], d1 = dp[1];
+						nx_d = QDesc{d0.x, d0.y, d0.z, d0.w, d1.x, 0u, 0u, 0u};
+					}
+					pf = 0u;
+					L.start_desc(A, nx_w, nx_d);
 #ifdef PHY_LEAN_TIMING
-					if (first_query == ~0ull) first_query = A.chunk_query[item];
+					if (first_query == ~0ull) first_query = nx_w.j;
 #endif
 					vis.lo = L.vis_idx; // the chunk's words: from its first position to its end (chunks are multiples of 64 positions)
 					vis.hi = lean_visited_word(ln, L.q_end_full);
@@ -579,6 +642,7 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 				}
 			}
 		}
+		queue_empty = queue_empty || __any(done || pf == 4u);
 		if (__all(done && !active)) break;
 		LEAN_TICK(0)
 

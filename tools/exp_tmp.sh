@@ -1,5 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r4d
-( time python -m pytest tests -x -q -m gpu ) > gpurun_out/r4d/gputests.log 2>&1
-tail -5 gpurun_out/r4d/gputests.log
+mkdir -p gpurun_out/r4e
+( time python -m pytest tests -x -q -m gpu ) > gpurun_out/r4e/gputests.log 2>&1
+tail -5 gpurun_out/r4e/gputests.log
