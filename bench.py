@@ -656,10 +656,11 @@ def main():
                                       "entry names the profile; traffic_of_these_kernels says whether the chain and phase-B kernels' sources are the ones "
                                       "the profile was taken on (sha256 recorded by tools/tools_pmc_traffic.py); regenerate "
                                       "with tools/tools_prof.sh + tools/tools_pmc_traffic.py when the kernels change)",
-                    "note": "anchor_spec fetches one random 16-byte k-mer slot per chain step, a memory request each: the chip serves "
-                            "~55 G uniformly random rows a second whatever their size (profiles/r04_gather_bench.jsonl), and `requests` "
-                            "prices the kernel against that — `frac` prices SURVEY 8d's algorithmic bytes (query bytes + one pass over "
-                            "the reference-layout ESA), `traffic` is what the HBM interface carried (PMC)",
+                    "note": "anchor_spec fetches one random 16-byte k-mer slot per chain step, and every such fetch is a 128-byte "
+                            "line at the memory whatever the load's cache policy (profiles/r04_gather_bench.jsonl: ~55 G random rows/s "
+                            "= 7 TB/s of lines, the same out of the Infinity Cache): `traffic` (PMC) over the launch time — "
+                            "`traffic_GBps`, `traffic_frac` — is what the HBM interface carried, `requests` the same by count; "
+                            "`frac` prices SURVEY 8d's algorithmic bytes (query bytes + one pass over the reference-layout ESA)",
                     # the request-granular view: memory-side read requests per launch (PMC, the same profile) over this run's launch
                     # time, against the random-row rate the chip delivers to a pure gather
                     "requests": (lambda rq: {"per_launch": rq, "achieved_G_per_s": round(rq / (avg_ms * 1e-3) / 1e9, 2), "peak_G_per_s": 55.0,

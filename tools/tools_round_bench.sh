@@ -17,5 +17,13 @@ python tools/tools_wallclock.py --workload c3 --out gpurun_out/final/r04_wallclo
 python tools/tools_wallclock.py --workload c4 --gpus 1,2,8 --out gpurun_out/final/r04_wallclock_c4.json > /dev/null 2>&1
 python tools/tools_wallclock.py --workload c5 --out gpurun_out/final/r04_wallclock_c5.json > /dev/null 2>&1
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+# one process() as a timeline (kernel trace of a short bench run)
+( cd /tmp && export TMPDIR=/tmp && for wl in c3 c5; do
+  rm -rf $GRAFT_REPO_ROOT/gpurun_out/final/tl_$wl
+  timeout 300 rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/final/tl_$wl --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 4 --warmup 1 --cpu-sample 0 --no-profile --no-wallclock > /dev/null 2>&1
+  f=$(find $GRAFT_REPO_ROOT/gpurun_out/final/tl_$wl -name "*kernel_trace.csv" | head -1)
+  python3 $GRAFT_REPO_ROOT/tools/tools_timeline.py $f > $GRAFT_REPO_ROOT/gpurun_out/final/r04_timeline_$wl.txt
+  rm -rf $GRAFT_REPO_ROOT/gpurun_out/final/tl_$wl
+done )
 python tools/tools_round_summary.py gpurun_out/final
 grep -h "emulated\|check" gpurun_out/final/*.err | head
