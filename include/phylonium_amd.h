@@ -68,6 +68,8 @@ const char *phylo_last_error(const phylo_ctx *ctx);
  *                      ties is libstdc++'s), 1 on the host cores
  *   "filter_kernel"    the device filter: 0 stretch by stretch, 1 the general dependent scan only
  *   "fold_blocks"      blocks per query of the fold kernel (0: the library chooses)
+ *   "spec_blocks"      at most that many blocks of the speculative chain kernel (0: the library's plan); with a few,
+ *                      every lane takes chunk after chunk from the work queue
  *   "lean_force_slow"  1: every step of the chain kernels through their wave-cooperative slow resolver
  *   "cache_quirk"      1 (default): a subject on which the reference's 6-mer cache holds over-deep intervals is matched
  *                      as the reference matches it; 0: true longest matches (results then differ from the reference's)

@@ -191,7 +191,7 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, bool defer)
 	if (nch) {
 		{
 			KernelSpan s(c, "anchor_spec");
-			launch_lean_spec(A, R, X, c->n_cu, st, c->plan_spec_per_cu * c->n_cu);
+			launch_lean_spec(A, R, X, c->n_cu, st, c->opt_spec_blocks ? (int)c->opt_spec_blocks : c->plan_spec_per_cu * c->n_cu);
 		}
 		dbg_sync("anchor_spec");
 		{

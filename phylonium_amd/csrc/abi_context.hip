@@ -160,6 +160,9 @@ int phylo_set_option(phylo_ctx *c, const char *key, long value)
 		c->opt_cache_quirk = (int)value;
 		c->plan_valid = false;
 		c->homs_staged = false;
+	} else if (k == "spec_blocks") {
+		if (value < 0 || value > 65536) return c->fail("spec_blocks must be in 0..65536");
+		c->opt_spec_blocks = (uint32_t)value;
 	} else if (k == "fold_blocks") {
 		if (value < 0 || value > 64) return c->fail("fold_blocks must be in 0..64");
 		c->opt_fold_blocks = (uint32_t)value;

@@ -46,6 +46,7 @@ BUNDLES = [
     ("host-filter+valu-pairs", {"filter": 1, "pairs_kernel": 1, "fold_blocks": 8, "recheck": 1}),
     ("general-filter-kernel", {"filter": 2, "filter_kernel": 1, "packed": 1, "fold_blocks": 1}),
     ("device-filter+valu-pairs", {"filter": 2, "pairs_kernel": 1}),
+    ("few-chain-blocks", {"spec_blocks": 2, "fold_blocks": 2}),
 ]
 BUNDLE_NAMES = [b[0] for b in BUNDLES]
 _calls = {}
@@ -74,6 +75,7 @@ def check_process(ctx, gs, ref, chunk=0, kmer=0, backend=0, complete_deletion=Fa
     ctx.set_option("filter_kernel", opts.get("filter_kernel", 0))
     ctx.set_option("pairs_kernel", opts.get("pairs_kernel", 0))
     ctx.set_option("fold_blocks", opts.get("fold_blocks", 0))
+    ctx.set_option("spec_blocks", opts.get("spec_blocks", 0))
     ctx.set_option("chunk", chunk)
     ctx.set_option("kmer", kmer)
     ctx.set_option("compare_backend", backend)
@@ -114,7 +116,7 @@ def check_process(ctx, gs, ref, chunk=0, kmer=0, backend=0, complete_deletion=Fa
                 a, b = api.estimate("jc", s[i, j], h[i, j]), O.estimate("jc", so[i, j], ho[i, j])
                 assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= 1e-12, tag
     finally:
-        for key in ("chunk", "kmer", "compare_backend", "filter", "filter_kernel", "pairs_kernel", "fold_blocks"):
+        for key in ("chunk", "kmer", "compare_backend", "filter", "filter_kernel", "pairs_kernel", "fold_blocks", "spec_blocks"):
             ctx.set_option(key, 0)
     return s, h
 
@@ -186,7 +188,19 @@ def _five_sets():
             (bang, 0), (near, 4)]
 
 
-@pytest.mark.parametrize("bundle", ["default", "host-filter+valu-pairs", "general-filter-kernel"])
+def test_lanes_that_take_chunk_after_chunk(ctx):
+    """Two blocks of the speculative chain kernel (option spec_blocks) for thousands of chunks: every lane works through
+    chunk after chunk, claiming the next one an eighth of a chunk ahead — its work item and its query's descriptor come
+    in beside the trips' loads (lean_kernels.hip) — from chunks of a few steps, at whose end the claim is still on its
+    way, to chunks of thousands of positions; contigs, so that where the query's list of '!' stands travels with the item."""
+    gs = synth.make_genomes(6, 150000, seed=77, d_range=(0.01, 0.25), indel_per_mbp=300, inv_frac=0.05, contigs=5,
+                            inv_len=(300, 3000))
+    for chunk in (64, 256, 1024, 4096):
+        check_process(ctx, gs, 0, chunk=chunk, bundle="few-chain-blocks")
+    check_process(ctx, gs, 3, chunk=512, bundle="few-chain-blocks")
+
+
+@pytest.mark.parametrize("bundle", ["default", "host-filter+valu-pairs", "general-filter-kernel", "few-chain-blocks"])
 def test_named_bundles_over_the_same_five_sets(ctx, bundle):
     """The library's default configuration and two named non-default bundles over the same five input sets: whatever
     the per-test rotation picks elsewhere, these combinations are always exercised on these inputs."""

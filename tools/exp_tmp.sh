@@ -1,7 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-bash tools/tools_prof.sh f3 c3 > /dev/null 2>&1
-bash tools/tools_prof.sh f4 c4 > /dev/null 2>&1
-bash tools/tools_prof.sh f5 c5 > /dev/null 2>&1
-bash tools/tools_prof.sh frank c4 --emulate-rank 0/8 --emulate-exchange > /dev/null 2>&1
-ls gpurun_out/prof_f3 gpurun_out/prof_f5 | head -30
+mkdir -p gpurun_out/r4f
+( time python -m pytest tests -x -q -m gpu ) > gpurun_out/r4f/gputests.log 2>&1
+tail -5 gpurun_out/r4f/gputests.log
