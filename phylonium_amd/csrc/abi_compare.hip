@@ -116,7 +116,7 @@ static int compare_segments(phylo_ctx *c, size_t part, size_t nparts, uint64_t *
 // dev_out: leave the tallies in the caller's device buffers (subst / homologs are device pointers)
 // The result on its way to the host: both matrices as symmetric u32 (a tally is at most the reference's length,
 // below 2^31) — half the bytes of the u64 matrices across PCIe; the host widens them row by row, which is a streaming
-// pass.  (Mirroring on the host instead is a strided walk over 16 MB: measured 0.5-2 ms at N = 1024)
+// pass.  (Mirroring on the host instead is a strided walk over 16 MB: measured 0.5-2 ms at N = 1024, round 3.)
 __global__ __launch_bounds__(256) void sym32_from_matrices_kernel(uint32_t N, const unsigned long long *__restrict__ s,
 																   const unsigned long long *__restrict__ h, uint32_t *__restrict__ out)
 {

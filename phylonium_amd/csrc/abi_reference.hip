@@ -107,7 +107,7 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 		HIPOK(c, c->d_LCP.ensure((size_t)ns + 1 + 4));
 		HIPOK(c, c->d_T.ensure(codes + 1 + 4 + kmer_table_scratch(k)));
 		HIPOK(c, c->d_SLOT.ensure(codes + 8)); // (+8: the chain kernels' load batch reads up to 64 bytes from a slot's address)
-		c->stats["ms:ref_alloc"] += now_ms() - ta; // hipMalloc of tens of GB stalls when other processes have just released as much
+		c->stats["ms:ref_alloc"] += now_ms() - ta; // hipMalloc of tens of GB stalls when other processes have just released as much (round 2: one C5 run waited 2.4 s there)
 	}
 	HIPOK(c, hipMemsetAsync(c->a_misc.p, 0, 64, st));
 	HIPOK(c, hipMemsetAsync(c->d_LCP.p, 0, ((size_t)ns + 1 + 4) * 4, st));

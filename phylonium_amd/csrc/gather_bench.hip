@@ -6,7 +6,7 @@
 //   chase — the next index depends on the loaded row (a dependent chain per lane, as a
 //           chain step's slot fetch is): the time of one hop under full load.
 // usage: gather_bench <table MB> [<table MB> ...]   (one JSON line per size)
-// DESIGN.md §3.1, §13; profiles/r01_gather_bench.jsonl (round 1: 1–16 GB, 64/128-byte rows),
+// DESIGN.md §3.1; profiles/r01_gather_bench.jsonl (round 1: 1–16 GB, 64/128-byte rows),
 // profiles/r04_gather_bench.jsonl (32 MB–16 GB, 8–128-byte rows).
 #include <hip/hip_runtime.h>
 #include <stdint.h>

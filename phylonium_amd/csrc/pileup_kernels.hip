@@ -415,7 +415,7 @@ __global__ __launch_bounds__(64) void pairs_kernel(Pileup P, const uint32_t *__r
 // the cycles of the bf16 32x32x16 form.  The f32 accumulators hold integers exactly below 2^24 (a wavefront's
 // window chunk contributes at most 3 x 32 x wchunk to one of them).  (seqcmp counts byte mismatches,
 // libs/seqcmp.c:13-28; on the planes that is this sum.  The north star kept the matrix cores out of the merge-join
-// formulation; with the pileup the work IS a contraction — measured: tools/microbench/mfma_pairs.hip, DESIGN §12.)
+// formulation; with the pileup the work IS a contraction — measured: tools/microbench/mfma_pairs.hip, DESIGN §4.)
 //
 // Operands are made in registers from the plane words.  A plane word holds 32 positions; its position class d
 // (positions = d mod 4) becomes one dword of 8 nibbles by one shift and one mask, V landing on nibble bit 1 and the
