@@ -223,12 +223,12 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, bool defer)
 		HIPOK(c, c->b_hom_rng.ensure(2 * std::max(nq, c->n)));
 		HIPOK(c, c->a_flt.ensure(nq + 1));
 		HIPOK(c, c->h_rng.ensure(3 * nq + 16));
-		HIPOK(c, hipMemsetAsync(c->a_flt.p, 0, 4, st));
+		if (!nch) HIPOK(c, hipMemsetAsync(c->a_flt.p, 0, 4, st)); // (else: the bridges' prepare kernel zeroes it, below)
 		if (tail_eager) {
 			if (make_pileup(c, 0, 1, &TP)) return 1;
 			HIPOK(c, c->b_flag.ensure(4));
 			HIPOK(c, c->b_first.ensure(project_index_entries(TP) + 1));
-			HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 16, st));
+			if (!nch) HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 16, st));
 			c->eager_five = c->pileup_five && c->opt_pairs_kernel != 0; // (the matrix-core path lists the '!' instead: compare_pileup)
 			HIPOK(c, c->b_bang.ensure(2 * (size_t)c->bang_cap + 2));
 		}
@@ -238,7 +238,10 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, bool defer)
 		const uint32_t j0 = 0, j1 = (uint32_t)nq;
 		if (nch) {
 			KernelSpan s(c, "anchor_bridge", sg);
-			launch_lean_bridge(A, R, X, c->n_cu, st);
+			// (the counters of what follows are zeroed on the way: the fold's list lengths, the filter's total, the projection's flags)
+			BridgeZero Z = {{c->a_out_cnt.p + j0, device_filter ? c->a_flt.p : nullptr, (device_filter && tail_eager) ? c->b_flag.p : nullptr},
+							{j1 - j0, device_filter ? 1u : 0u, (device_filter && tail_eager) ? 4u : 0u}};
+			launch_lean_bridge(A, R, X, c->n_cu, st, Z);
 		}
 		{
 			KernelSpan s(c, "anchor_fold", sg);
@@ -248,7 +251,7 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, bool defer)
 			// the idle CUs take a part each (c2like's 29 queries: 0.167 -> 0.100 ms; C5's 64: 2.65 -> 2.28 ms)
 			uint32_t fold_nb = c->opt_fold_blocks;
 			if (!fold_nb) fold_nb = 2 * (j1 - j0) <= (uint32_t)c->n_cu ? (uint32_t)std::min<size_t>(8, (size_t)c->n_cu / (j1 - j0)) : 1u;
-			launch_fold(A, j0, j1, c->L, c->threshold, c->a_raw.p, c->a_out_base.p, c->a_out_cap.p, c->a_out_cnt.p, sg, fold_nb);
+			launch_fold(A, j0, j1, c->L, c->threshold, c->a_raw.p, c->a_out_base.p, c->a_out_cap.p, c->a_out_cnt.p, sg, fold_nb, nch == 0);
 		}
 		if (device_filter) {
 			// reverseEh + sort + filter_overlaps_max on the device (filter_kernels.hip).  The lists stay

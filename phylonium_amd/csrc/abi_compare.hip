@@ -298,15 +298,18 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		acc_s = (unsigned long long *)subst;
 		acc_h = (unsigned long long *)homologs;
 	} else {
-		HIPOK(c, c->b_subst.ensure(N * N));
-		HIPOK(c, c->b_homologs.ensure(N * N));
+		HIPOK(c, c->b_subst.ensure(2 * N * N)); // both tallies in one buffer: one fill
 		acc_s = c->b_subst.p;
-		acc_h = c->b_homologs.p;
+		acc_h = c->b_subst.p + N * N;
 	}
 	HIPOK(c, c->h_mat.ensure(2 * N * N + 8));
 	if (out_mode == 0) HIPOK(c, c->b_sym32.ensure(2 * N * N + 4));
-	HIPOK(c, hipMemsetAsync(acc_s, 0, N * N * 8, st));
-	HIPOK(c, hipMemsetAsync(acc_h, 0, N * N * 8, st));
+	auto zero_tallies = [&]() -> hipError_t {
+		if (acc_h == acc_s + N * N) return hipMemsetAsync(acc_s, 0, 2 * N * N * 8, st);
+		const hipError_t e = hipMemsetAsync(acc_s, 0, N * N * 8, st);
+		return e != hipSuccess ? e : hipMemsetAsync(acc_h, 0, N * N * 8, st);
+	};
+	HIPOK(c, zero_tallies());
 	const DevHom *dev_homs = c->att_homs ? c->att_homs : c->b_homs.p;
 	// phase A may have projected the lists already (whole reference, i.e. part 0 of 1)
 	const bool projected = c->homs_staged && c->eager_valid && part == 0 && nparts == 1;
@@ -331,10 +334,9 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 			if ((uint64_t)ig * PAIR_IG >= (uint64_t)jt * PAIR_JT + PAIR_JT - 1) continue; // no i<j inside
 			tiles.push_back((ig << 16) | jt);
 		}
-	if (!tiles.empty()) {
-		HIPOK(c, c->b_tiles.ensure(tiles.size() + (N / 64 + 2) * (N / 64 + 2))); // room for the matrix-core kernel's tiles behind them
-		HIPOK(c, hipMemcpyAsync(c->b_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, st));
-	}
+	// (the tile lists depend on the number of genomes and the pair kernel only: uploaded when those change)
+	const uint64_t tiles_key = (uint64_t)N * 2u + (c->opt_pairs_kernel == 0 ? 1u : 0u) + 1u;
+	if (!tiles.empty()) HIPOK(c, c->b_tiles.ensure(tiles.size() + (N / 64 + 2) * (N / 64 + 2))); // room for the matrix-core kernel's tiles behind them
 	// tiles of the matrix-core kernel: 64 x 64 genomes, ti <= tj
 	std::vector<uint32_t> mtiles;
 	if (c->opt_pairs_kernel == 0) {
@@ -342,7 +344,13 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		for (uint32_t a = 0; a < nt; a++)
 			for (uint32_t b = a; b < nt; b++) mtiles.push_back((a << 16) | b);
 		HIPOK(c, c->b_tiles.ensure(tiles.size() + mtiles.size()));
+	}
+	if (c->tiles_key != tiles_key || c->tiles_at != c->b_tiles.p) {
+		if (!tiles.empty()) HIPOK(c, hipMemcpyAsync(c->b_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, st));
 		if (!mtiles.empty()) HIPOK(c, hipMemcpyAsync(c->b_tiles.p + tiles.size(), mtiles.data(), mtiles.size() * 4, hipMemcpyHostToDevice, st));
+		if (sync_stream(c)) return 1; // (the vectors are this call's)
+		c->tiles_key = tiles_key;
+		c->tiles_at = c->b_tiles.p;
 	}
 	bool do_correct = false; // three planes under the matrix-core kernel: the listed '!' are settled before the tallies leave
 	auto finish_tallies = [&]() { // the packed triangle for the wire; mirror images for the matrices (u32 on the way to the host)
@@ -456,8 +464,7 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 	do_correct = false;
 	if (flag && !bang) { // '!' among the projected positions, and the plain kernel ran: once more with all five planes
 		c->stats["count:compare_repeated_with_five_planes"] += 1;
-		HIPOK(c, hipMemsetAsync(acc_s, 0, N * N * 8, st));
-		HIPOK(c, hipMemsetAsync(acc_h, 0, N * N * 8, st));
+		HIPOK(c, zero_tallies());
 		HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 4, st));
 		bang = true;
 		if (project(true) || pairs(true) || fetch()) return 1;

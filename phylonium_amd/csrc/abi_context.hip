@@ -113,11 +113,12 @@ void phylo_ctx_destroy(phylo_ctx *c)
 	c->b_planes.release();
 	c->b_hom_rng.release();
 	c->b_tiles.release();
+	c->tiles_key = 0;
+	c->tiles_at = nullptr;
 	c->b_flag.release();
 	c->b_first.release();
 	c->b_homs.release();
 	c->b_subst.release();
-	c->b_homologs.release();
 	c->b_sym32.release();
 	c->b_bang.release();
 	c->s_segs.release();

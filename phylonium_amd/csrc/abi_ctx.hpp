@@ -266,7 +266,9 @@ struct phylo_ctx {
 	hipStream_t own_stream = nullptr; // the stream this context created (phylo_ctx_set_stream may lend it another)
 	bool pileup_five = false; // the last projection met '!': start with five planes next time
 	DevBuf<DevHom> b_homs;
-	DevBuf<unsigned long long> b_subst, b_homologs;
+	DevBuf<unsigned long long> b_subst; // both tallies, N x N each
+	uint64_t tiles_key = 0;         // what b_tiles holds (compare_pileup)
+	const uint32_t *tiles_at = nullptr;
 	DevBuf<uint32_t> b_sym32; // both result matrices as symmetric u32, on their way to the host
 	DevBuf<uint32_t> b_bang;  // the projected '!' of the three-plane projection: {genome | reverse << 31, position} each
 	uint32_t bang_cap = 0;    // as many as the genomes hold separators (a separator is projected at most once)

@@ -607,11 +607,12 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j
 
 // queries [j0, j1)
 void launch_fold(const PhaseA &A, uint32_t j0, uint32_t j1, uint32_t border, uint32_t thr, RawHom *out,
-				 const uint64_t *out_base, const uint32_t *out_cap, uint32_t *out_cnt, hipStream_t st, uint32_t blocks_per_query)
+				 const uint64_t *out_base, const uint32_t *out_cap, uint32_t *out_cnt, hipStream_t st, uint32_t blocks_per_query,
+				 bool zero_cnt)
 {
 	if (j1 <= j0) return;
 	const uint32_t nb = blocks_per_query ? blocks_per_query : 1u;
-	(void)hipMemsetAsync(out_cnt + j0, 0, (size_t)(j1 - j0) * 4, st); // the list lengths are counted up by the blocks
+	if (zero_cnt) (void)hipMemsetAsync(out_cnt + j0, 0, (size_t)(j1 - j0) * 4, st); // the list lengths are counted up by the blocks
 	hipLaunchKernelGGL(fold_kernel, dim3((j1 - j0) * nb), dim3(FOLD_THREADS), 0, st, A, j0, j1, nb, border, thr, out, out_base, out_cap, out_cnt);
 }
 

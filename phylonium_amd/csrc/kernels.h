@@ -13,7 +13,13 @@ namespace phy {
 int lean_spec_resident_blocks(int n_cu);
 void launch_lean_spec(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st, int max_blocks = 0); // max_blocks > 0: no more blocks than that
 void launch_lean_overruns(const PhaseA &A, const RefIndex &R, uint32_t nq, hipStream_t st); // between spec and bridge
-void launch_lean_bridge(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st);
+// Z: up to three short arrays of counters that the kernels behind the bridges start from zero (p[0] of any length, p[1] and
+// p[2] of at most a block's worth of words): the prepare kernel zeroes them on its way
+struct BridgeZero {
+	uint32_t *p[3];
+	uint32_t n[3];
+};
+void launch_lean_bridge(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st, const BridgeZero &Z = BridgeZero{{nullptr, nullptr, nullptr}, {0, 0, 0}});
 // the speculative kernel's work queue as items and query descriptors (anchor_core.h), once per plan
 void launch_lean_work(const PhaseA &A, const LeanIndex &X, WorkItem *work, QDesc *qdesc, uint32_t nq, hipStream_t st);
 void launch_pack2(const uint8_t *src, uint64_t bytes, uint32_t *dst, hipStream_t st); // bytes: a multiple of 16
@@ -31,7 +37,8 @@ void launch_bad_positions(const uint8_t *base, const uint64_t *off, const uint32
 // queries [j0, j1), blocks_per_query blocks each (with more than one a query's homologies leave in the order its
 // blocks got their slots, not in query order)
 void launch_fold(const PhaseA &A, uint32_t j0, uint32_t j1, uint32_t border, uint32_t thr, RawHom *out,
-				 const uint64_t *out_base, const uint32_t *out_cap, uint32_t *out_cnt, hipStream_t st, uint32_t blocks_per_query = 1);
+				 const uint64_t *out_base, const uint32_t *out_cap, uint32_t *out_cnt, hipStream_t st, uint32_t blocks_per_query = 1,
+				 bool zero_cnt = true); // zero_cnt = false: out_cnt[j0, j1) is zero already (launch_lean_bridge's BridgeZero)
 
 // filter_kernels.hip: reverseEh + sort + filter_overlaps_max per query on the device; flag[j] = 1
 // leaves query j to the host (two entries share a projected start, or the list is too long)

@@ -460,9 +460,14 @@ void launch_lean_work(const PhaseA &A, const LeanIndex &X, WorkItem *work, QDesc
 // chunk's last match ran on into the next chunk and that chunk's chain found the same match — there is nothing to
 // walk: one thread per chunk finds out, writes those bridges' records, and leaves the others started and packed
 // (LeanBridge::pack + the first words of the query) for the lanes of lean_chain_kernel<1>.
-__global__ __launch_bounds__(256) void lean_bridge_prepare_kernel(PhaseA A, RefIndex R, LeanIndex X)
+__global__ __launch_bounds__(256) void lean_bridge_prepare_kernel(PhaseA A, RefIndex R, LeanIndex X, BridgeZero Z)
 {
 	const uint32_t gc = blockIdx.x * 256u + threadIdx.x;
+	// (counters of the kernels that follow — the fold's list lengths, the filter's total, the projection's flags —, zeroed
+	// here instead of by a fill each)
+	for (uint32_t i = gc; i < Z.n[0]; i += gridDim.x * 256u) Z.p[0][i] = 0;
+	if (gc < Z.n[1]) Z.p[1][gc] = 0;
+	if (gc < Z.n[2]) Z.p[2][gc] = 0;
 	if (gc >= A.nchunks) return;
 	LeanBridge L;
 	L.start(A, X, gc);
@@ -1137,9 +1142,9 @@ static int lean_bridge_blocks(uint32_t count, int n_cu, uint32_t k)
 	if (const char *e = getenv("PHY_BRIDGE_BLOCKS")) blocks = std::max(1, std::min(std::max(need, 1), atoi(e))); // experiments
 	return blocks;
 }
-void launch_lean_bridge(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st)
+void launch_lean_bridge(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st, const BridgeZero &Z)
 {
-	hipLaunchKernelGGL(lean_bridge_prepare_kernel, dim3((A.nchunks + 255u) / 256u), dim3(256), 0, st, A, R, X);
+	hipLaunchKernelGGL(lean_bridge_prepare_kernel, dim3((A.nchunks + 255u) / 256u), dim3(256), 0, st, A, R, X, Z);
 	hipLaunchKernelGGL(lean_chain_kernel<1>, dim3(lean_bridge_blocks(A.nchunks, n_cu, R.k)), dim3(256), 0, st, A, R, X);
 }
 
