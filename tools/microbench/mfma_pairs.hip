@@ -437,6 +437,21 @@ __global__ __launch_bounds__(64, 2) void pairs_mfma3(Planes P, const uint32_t *_
 	else pairs_mfma3_body<GI, GJ, false, NB, SCHED>(P, ti, tj, wc, wchunk, subst, homologs);
 }
 
+// the same body with a wavefront per SIMD (512 registers): the room a 64 x 128 tile's 256 accumulators need — a quarter
+// fewer vector instructions per matrix instruction than 64 x 64
+template <int GI, int GJ, int NB, int SCHED>
+__global__ __launch_bounds__(64, 1) void pairs_mfma3w(Planes P, const uint32_t *__restrict__ tiles, uint32_t ntiles, uint32_t wchunk,
+													   uint32_t nwc, unsigned long long *__restrict__ subst,
+													   unsigned long long *__restrict__ homologs)
+{
+	const uint32_t xcd = blockIdx.x & 7u, local = blockIdx.x >> 3;
+	const uint32_t tile = local % ntiles;
+	const uint32_t wc = (local / ntiles) * 8u + xcd;
+	if (wc >= nwc) return;
+	const uint32_t ti = tiles[tile] >> 16, tj = tiles[tile] & 0xffffu;
+	pairs_mfma3_body<GI, GJ, false, NB, SCHED>(P, ti, tj, wc, wchunk, subst, homologs);
+}
+
 // the product's kernel (csrc/pileup_kernels.hip: pairs_kernel<false>), for the same-box comparison
 static const uint32_t PAIR_IG = 16, PAIR_JT = 64;
 __global__ __launch_bounds__(64) void pairs_valu(Planes P, const uint32_t *__restrict__ tiles, uint32_t ntiles, uint32_t wchunk,
@@ -662,6 +677,8 @@ int main(int argc, char **argv)
 		ok &= check_kernel(R, pairs_mfma3<2, 2, 3, 0>, make_tiles(R.N, 64, 64), 126, rs, rh, "MFMA v3 nb3 c126");
 		ok &= check_kernel(R, pairs_mfma3<2, 2, 3, 1>, make_tiles(R.N, 64, 64), 1008, rs, rh, "MFMA v3 nb3 sched c1008");
 		ok &= check_kernel(R, pairs_mfma3<2, 2, 2, 1>, make_tiles(R.N, 64, 64), 1008, rs, rh, "MFMA v3 nb2 sched c1008");
+		ok &= check_kernel(R, pairs_mfma3w<2, 4, 3, 1>, make_tiles(R.N, 64, 128), 1008, rs, rh, "MFMA v3 64x128 nb3 sched");
+		ok &= check_kernel(R, pairs_mfma3w<2, 4, 2, 0>, make_tiles(R.N, 64, 128), 60, rs, rh, "MFMA v3 64x128 nb2 c60");
 		ok &= check_kernel(R, pairs_mfma3<2, 2, 3, 4>, make_tiles(R.N, 64, 64), 252, rs, rh, "MFMA v3 nb3 phases c252");
 		ok &= check_kernel(R, pairs_mfma3<2, 2, 2, 5>, make_tiles(R.N, 64, 64), 252, rs, rh, "MFMA v3 nb2 phases+ c252");
 		CK(hipFree(R.dV));
@@ -735,6 +752,16 @@ int main(int argc, char **argv)
 			printf("  the same shape, expansion alone / matrix instructions alone (nb3; results meaningless)\n");
 			time_kernel(R, pairs_mfma3<2, 2, 3, 2>, t, wch, reps);
 			time_kernel(R, pairs_mfma3<2, 2, 3, 3>, t, wch, reps);
+		}
+		for (uint32_t slots : {4u, 8u, 16u}) {
+			auto t = make_tiles(R.N, 64, 128);
+			const uint32_t wch = choose_wchunk(R, (uint32_t)t.size(), slots);
+			printf("  MFMA v3 64x128, one wavefront per SIMD, %u wave slots per CU: nb2 / nb3 / nb2 sched / nb3 sched\n", slots);
+			float m1 = time_kernel(R, pairs_mfma3w<2, 4, 2, 0>, t, wch, reps);
+			float m2 = time_kernel(R, pairs_mfma3w<2, 4, 3, 0>, t, wch, reps);
+			float m3 = time_kernel(R, pairs_mfma3w<2, 4, 2, 1>, t, wch, reps);
+			float m4 = time_kernel(R, pairs_mfma3w<2, 4, 3, 1>, t, wch, reps);
+			printf("    -> %.3f / %.3f / %.3f / %.3f ms\n", m1, m2, m3, m4);
 		}
 		for (uint32_t slots : {16u, 32u}) {
 			auto t = make_tiles(R.N, 32, 64);
