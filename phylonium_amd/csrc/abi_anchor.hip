@@ -345,10 +345,9 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, bool defer)
 	c->att_rng_on_device = false;
 	c->host_stale.clear();
 	if (device_filter) {
-		uint32_t *hr = c->h_rng.p; // [0, 2nq) ranges, [2nq, 3nq) flags, then total and the four misc words
+		uint32_t *hr = c->h_rng.p; // [0, 2nq) ranges, [2nq] the lists' total, [2nq + 1, 3nq + 1) flags (a_flt as it lies), then the misc words
 		HIPOK(c, hipMemcpyAsync(hr, c->b_hom_rng.p, 2 * nq * 4, hipMemcpyDeviceToHost, st));
-		HIPOK(c, hipMemcpyAsync(hr + 2 * nq, c->a_flt.p + 1, nq * 4, hipMemcpyDeviceToHost, st));
-		HIPOK(c, hipMemcpyAsync(hr + 3 * nq, c->a_flt.p, 4, hipMemcpyDeviceToHost, st));
+		HIPOK(c, hipMemcpyAsync(hr + 2 * nq, c->a_flt.p, (nq + 1) * 4, hipMemcpyDeviceToHost, st));
 		HIPOK(c, hipMemcpyAsync(hr + 3 * nq + 1, c->a_misc.p, 32, hipMemcpyDeviceToHost, st));
 		HIPOK(c, hipGetLastError());
 		if (defer && tail_eager) { // (tail_eager: all genomes, device filter, projection queued)
@@ -364,7 +363,7 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, bool defer)
 		const uint32_t *dmisc = hr + 3 * nq + 1;
 		if (dmisc[3]) return c->fail("phase A scratch overflow (code %u: 1 chunk log, 2 bridge pool, 3 homology buffer)", dmisc[3]);
 		size_t flagged = 0;
-		for (size_t j = 0; j < nq; j++) flagged += hr[2 * nq + j] != 0;
+		for (size_t j = 0; j < nq; j++) flagged += hr[2 * nq + 1 + j] != 0;
 		if (!flagged) {
 			const size_t N = c->n;
 			c->att_homs = c->b_homs.p;
@@ -387,7 +386,7 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, bool defer)
 			c->stats["n:anchor_calls"] += 1;
 			c->stats["count:query_bases"] += (double)total;
 			c->stats["count:chunks"] += nch;
-			c->stats["count:filtered_homologies"] += (double)hr[3 * nq];
+			c->stats["count:filtered_homologies"] += (double)hr[2 * nq];
 			c->stats["count:pool_blocks_used"] += dmisc[2];
 			c->stats["count:overrun_runs"] += dmisc[5];
 			c->stats["count:overrun_bytes_compared"] += dmisc[6];

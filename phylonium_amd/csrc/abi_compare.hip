@@ -645,7 +645,7 @@ static int anchor_finish(phylo_ctx *c)
 	const uint32_t *hr = c->h_rng.p, *dmisc = hr + 3 * N + 1;
 	c->anchor_pending = false;
 	size_t flagged = 0;
-	for (size_t j = 0; j < N; j++) flagged += hr[2 * N + j] != 0;
+	for (size_t j = 0; j < N; j++) flagged += hr[2 * N + 1 + j] != 0;
 	if (dmisc[3] || flagged) {
 		c->homs_staged = false;
 		c->eager_valid = false;
@@ -671,7 +671,7 @@ static int anchor_finish(phylo_ctx *c)
 	c->stats["n:anchor_calls_without_a_wait"] += 1;
 	c->stats["count:query_bases"] += c->pend_total;
 	c->stats["count:chunks"] += c->pend_nch;
-	c->stats["count:filtered_homologies"] += (double)hr[3 * N];
+	c->stats["count:filtered_homologies"] += (double)hr[2 * N];
 	c->stats["count:pool_blocks_used"] += dmisc[2];
 	c->stats["count:overrun_runs"] += dmisc[5];
 	c->stats["count:overrun_bytes_compared"] += dmisc[6];

@@ -1,5 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/mb
-./build/mb/mfma_pairs 1024 > gpurun_out/mb/mfma_pairs_n1024.txt 2>&1
-grep -A2 "64x128\|v3 64x64, 8 wave\|v3 64x64, 16 wave\|check MFMA v3 64x128" gpurun_out/mb/mfma_pairs_n1024.txt | head -40
+mkdir -p gpurun_out/r4j
+( time python -m pytest tests -x -q -m gpu ) > gpurun_out/r4j/gputests.log 2>&1
+tail -4 gpurun_out/r4j/gputests.log
+python bench.py --steps 100 --warmup 5 --cpu-sample 0 --no-wallclock 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['ms_per_step_noprofile'])"
