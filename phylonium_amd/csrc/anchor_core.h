@@ -49,6 +49,7 @@ struct RefIndex {
 
 struct Anchor {
 	uint32_t q, s, len; // this_pos_Q, this_pos_S, this_length of an accepted anchor
+	uint32_t pad;       // (16 bytes: four of them are a 64-byte store — the speculative chains write their logs that way)
 };
 
 PHY_HD U4 load16(const uint8_t *p)

@@ -814,7 +814,7 @@ static inline ChunkPlan plan_chunks(const std::vector<uint32_t> &qlen, uint32_t 
 	C = (C + 63) / 64 * 64;
 	while (C <= 2 * threshold + 32) C += 64; // chunk starts must be lucky-ineligible from (0,0,0)
 	P.C = C;
-	P.cap = C / (threshold + 1) + 2;
+	P.cap = (C / (threshold + 1) + 2 + 3u) & ~3u; // (a multiple of four: a chunk's log starts on a 64-byte boundary)
 	size_t nq = qlen.size();
 	P.qchunk0.resize(nq + 1);
 	P.qanc0.resize(nq);

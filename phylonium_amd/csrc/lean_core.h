@@ -630,8 +630,12 @@ PHY_HD uint32_t lean_visited_word(const LeanLane &ln, uint32_t q)
 
 struct LeanSpec {
 	LeanLane ln;
-	uint32_t gc, q_end, cnt, log0, cap, vis_word, vis_idx;
+	uint32_t gc, q_end, cnt, log0, vis_word, vis_idx; // (the log's capacity is the plan's A.cap)
 	uint32_t q_end_full; // the chunk's end on the grid (not clipped to the query's length)
+	// The log is written two anchors — 32 bytes, what the memory writes without reading first; a chunk's log starts on
+	// such a boundary — at a time: an anchor on its own is a partial write there (the line has left the L2 long before
+	// the chain's next anchor, 14 trips on), eleven million of them a pass on C3.  The one that waits:
+	Anchor pend;
 
 	// the work item of a chunk and the descriptor of a query, as lean_work_kernel stores them
 	static PHY_HD WorkItem make_item(const PhaseA &A, const LeanIndex &X, uint32_t chunk)
@@ -665,7 +669,6 @@ struct LeanSpec {
 		q_end = e < d.qlen ? e : d.qlen;
 		q_end_full = e;
 		log0 = d.qanc0 + lc * A.cap;
-		cap = A.cap;
 		ln.reset(d.qword0, d.qlen, q0, 0, 0, 0);
 		ln.qb_idx = w.qb_idx;
 		ln.qb_end = d.qb_end;
@@ -685,6 +688,7 @@ struct LeanSpec {
 		if (ln.q >= q_end) {
 			vis.put(vis_idx, vis_word);
 			vis.close();
+			log_close(A);
 			A.spec_cnt[gc] = cnt | (ln.ovr ? LEAN_OVERRUN_BIT : 0u); // only a chunk's last step can be cut
 			if (ln.ovr) *A.overrun = 1;
 			SpecExit x = {ln.q, ln.lq, ln.ls, ln.ll};
@@ -717,12 +721,24 @@ struct LeanSpec {
 		ln.qbad_seek(X);
 		return true;
 	}
+	// the anchor still waiting when the chunk ends
+	PHY_HD void log_close(const PhaseA &A)
+	{
+		const uint32_t n = cnt < A.cap ? cnt : A.cap;
+		if (n & 1u) A.spec_anchors[(size_t)log0 + (n - 1u)] = pend;
+	}
 	PHY_HD void step_done(const PhaseA &A)
 	{
 		if (ln.r_accepted) {
-			if (cnt < cap) {
-				Anchor a = {ln.r_q, ln.r_s, ln.r_len};
-				A.spec_anchors[(size_t)log0 + cnt] = a;
+			if (cnt < A.cap) {
+				const Anchor a = {ln.r_q, ln.r_s, ln.r_len, 0u};
+				if ((cnt & 1u) == 0u) {
+					pend = a;
+				} else {
+					U4 *dst = (U4 *)(A.spec_anchors + (size_t)log0 + (cnt - 1u));
+					dst[0] = U4{pend.q, pend.s, pend.len, 0u};
+					dst[1] = U4{a.q, a.s, a.len, 0u};
+				}
 			} else {
 				*A.error = 1;
 			}

@@ -1,8 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-run() { python bench.py --cpu-sample 0 --no-wallclock --workload c3 --steps 30 --warmup 3 --check "$@" 2>gpurun_out/e.err | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$PHY_CHUNK_WEIGHTS_FILE $*', d['ms_per_step'], d['phase_a_plan'], {k:v['avg_ms'] for k,v in d['kernels'].items() if k in ('anchor_spec','anchor_bridge','anchor_fold')})"; grep -c "check vs oracle.*OK" gpurun_out/e.err; }
-run
-PHY_CHUNK_WEIGHTS_FILE=tools/scratch/weights_life.txt run
-PHY_CHUNK_WEIGHTS_FILE=tools/scratch/weights_trips.txt run
-run
-PHY_CHUNK_WEIGHTS_FILE=tools/scratch/weights_life.txt run
+mkdir -p gpurun_out/r4k
+( time PHY_FUZZ_SEEDS=150 python -m pytest tests -x -q -m gpu ) > gpurun_out/r4k/gputests.log 2>&1
+tail -4 gpurun_out/r4k/gputests.log
