@@ -387,9 +387,19 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 			wchunk = std::min(wchunk, pairs_mfma_max_wchunk() & ~1u);
 			// (the kernel addresses a chunk's rows with 32-bit byte offsets, the loads it issues ahead included)
 			wchunk = std::min<uint32_t>(wchunk, (uint32_t)((0xffffffffull / ((uint64_t)P.Npad * 4u)) & ~1ull) - 16u);
+			// A wavefront flushes its 64 x 64 tallies with 64-bit atomics: with many chunks (N = 1024: 592 of the 264 windows
+			// the L2 holds the rows of) that is a fifth of the kernel — so a wavefront takes up to four chunks of its XCD in
+			// a row, as long as that leaves the chip some sixty wavefronts per CU to balance with.
+			uint32_t cpw = 1;
+			{
+				const uint64_t nwc = (P.W + wchunk - 1) / wchunk, waves = nwc * mtiles.size();
+				cpw = (uint32_t)std::min<uint64_t>(4, std::max<uint64_t>(1, waves / ((uint64_t)c->n_cu * 64u)));
+				cpw = std::min<uint32_t>(cpw, std::max<uint32_t>(1u, pairs_mfma_max_wchunk() / wchunk));
+				if (const char *e = getenv("PHY_PAIRS_CPW")) cpw = std::max(1, atoi(e)); // experiments
+			}
 			{
 				KernelSpan s(c, "pileup_pairs_mfma");
-				launch_pairs_mfma(P, c->b_tiles.p + tiles.size(), (uint32_t)mtiles.size(), wchunk, acc_s, acc_h, st);
+				launch_pairs_mfma(P, c->b_tiles.p + tiles.size(), (uint32_t)mtiles.size(), wchunk, acc_s, acc_h, st, cpw);
 			}
 			HIPOK(c, hipGetLastError());
 			finish_tallies();

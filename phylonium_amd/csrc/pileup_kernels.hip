@@ -453,21 +453,17 @@ struct PmWords {
 	uint32_t v, a, b;
 };
 // DIAG: a tile on the diagonal of the pair grid — its sub-tile below the diagonal is left out
+// The wavefront takes `cpw` window chunks of its XCD one after the other (chunk wc0, wc0 + 8, ...: the chunks are dealt
+// round-robin over the XCDs) and keeps the tallies in its accumulators across them: one flush of 64-bit atomics at the end
+// instead of one per chunk — with 592 chunks of 264 windows (C4, the length the L2 holds the rows of) the flushes were a
+// fifth of the kernel (4.7 ms; 6.7 with chunks half as long, 4.4 with twice — where the rows no longer fit).
 template <bool DIAG>
-static __device__ __forceinline__ void pairs_mfma_body(const Pileup &P, uint32_t ti, uint32_t tj, uint32_t w0, uint32_t w1,
-														unsigned long long *__restrict__ subst, unsigned long long *__restrict__ homologs)
+static __device__ __forceinline__ void pairs_mfma_body(const Pileup &P, uint32_t ti, uint32_t tj, uint32_t wc0, uint32_t cpw, uint32_t wchunk,
+														uint32_t nwc, unsigned long long *__restrict__ subst, unsigned long long *__restrict__ homologs)
 {
 	constexpr int G = PM_G, NG = 2 * PM_G;
 	const uint32_t lane = threadIdx.x & 63u, gl = lane & 31u, half = lane >> 5;
-	// the chunk's rows as buffers: an offset beyond the chunk reads 0, so the last step's odd window and the
-	// loads issued ahead need no guard (and offsets stay 32-bit whatever the planes' size)
-	const uint32_t chunk_bytes = (w1 - w0) * P.Npad * 4u;
-	const size_t row0 = (size_t)w0 * P.Npad;
-	const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(P.plane[0] + row0), 0, chunk_bytes, 0x00020000);
-	const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)(P.plane[1] + row0), 0, chunk_bytes, 0x00020000);
-	const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(P.plane[2] + row0), 0, chunk_bytes, 0x00020000);
 	const uint32_t so_i = ti * G * 128u, so_j = tj * G * 128u; // byte offset of the tile's first i / j genome in a row
-	uint32_t off = (half * P.Npad + gl) * 4u;                  // this lane's word of its window's row
 	const uint32_t step = 2u * P.Npad * 4u;
 	pm_v16f acc_h[G][G], acc_t[G][G];
 #pragma unroll
@@ -477,6 +473,10 @@ static __device__ __forceinline__ void pairs_mfma_body(const Pileup &P, uint32_t
 #pragma unroll
 			for (int r = 0; r < 16; r++) acc_h[a][b][r] = acc_t[a][b][r] = 0.f;
 #define PM_NEED(a, b) (!DIAG || (a) <= (b))
+	// the current chunk's rows as buffers: an offset beyond the chunk reads 0, so the last step's odd window and the
+	// loads issued ahead need no guard (and offsets stay 32-bit whatever the planes' size)
+	__amdgpu_buffer_rsrc_t rv, ra, rb;
+	uint32_t off = 0; // this lane's word of its window's row
 	auto load = [&](PmWords (&x)[NG]) {
 #pragma unroll
 		for (int g = 0; g < NG; g++) {
@@ -518,11 +518,22 @@ static __device__ __forceinline__ void pairs_mfma_body(const Pileup &P, uint32_t
 		}
 	};
 	PmWords x[PM_NB][NG];
+	for (uint32_t u = 0; u < cpw; u++) {
+		const uint32_t wc = wc0 + 8u * u;
+		if (wc >= nwc) break;
+		const uint32_t w0 = wc * wchunk, w1 = (w0 + wchunk < P.W) ? w0 + wchunk : P.W;
+		const uint32_t chunk_bytes = (w1 - w0) * P.Npad * 4u;
+		const size_t row0 = (size_t)w0 * P.Npad;
+		rv = __builtin_amdgcn_make_buffer_rsrc((void *)(P.plane[0] + row0), 0, chunk_bytes, 0x00020000);
+		ra = __builtin_amdgcn_make_buffer_rsrc((void *)(P.plane[1] + row0), 0, chunk_bytes, 0x00020000);
+		rb = __builtin_amdgcn_make_buffer_rsrc((void *)(P.plane[2] + row0), 0, chunk_bytes, 0x00020000);
+		off = (half * P.Npad + gl) * 4u;
 #pragma unroll
-	for (int k = 0; k < PM_NB; k++) load(x[k]);
-	for (uint32_t w = w0; w < w1; w += 2 * PM_NB) {
+		for (int k = 0; k < PM_NB; k++) load(x[k]);
+		for (uint32_t w = w0; w < w1; w += 2 * PM_NB) {
 #pragma unroll
-		for (int k = 0; k < PM_NB; k++) compute(x[k]);
+			for (int k = 0; k < PM_NB; k++) compute(x[k]);
+		}
 	}
 	// C/D layout of the 32x32 forms: column = lane & 31 (the B operand's row: genome j), row = (r & 3) + 8 (r >> 2)
 	// + 4 (lane >> 5) (the A operand's row: genome i)
@@ -547,27 +558,29 @@ static __device__ __forceinline__ void pairs_mfma_body(const Pileup &P, uint32_t
 }
 // One wavefront per (tile of 64 x 64 genomes, window chunk); the same XCD-aware order as pairs_kernel.
 __global__ __launch_bounds__(64, 2) void pairs_mfma_kernel(Pileup P, const uint32_t *__restrict__ tiles, uint32_t ntiles,
-															uint32_t wchunk, uint32_t nwc, unsigned long long *__restrict__ subst,
+															uint32_t wchunk, uint32_t nwc, uint32_t cpw, unsigned long long *__restrict__ subst,
 															unsigned long long *__restrict__ homologs)
 {
 	const uint32_t xcd = blockIdx.x & 7u, local = blockIdx.x >> 3;
 	const uint32_t tile = local % ntiles;
-	const uint32_t wc = (local / ntiles) * 8u + xcd;
-	if (wc >= nwc) return;
+	const uint32_t wc0 = (local / ntiles) * cpw * 8u + xcd; // this wavefront's chunks: wc0, wc0 + 8, ... (cpw of them)
+	if (wc0 >= nwc) return;
 	const uint32_t ti = tiles[tile] >> 16, tj = tiles[tile] & 0xffffu;
-	const uint32_t w0 = wc * wchunk, w1 = (w0 + wchunk < P.W) ? w0 + wchunk : P.W;
-	if (ti == tj) pairs_mfma_body<true>(P, ti, tj, w0, w1, subst, homologs);
-	else pairs_mfma_body<false>(P, ti, tj, w0, w1, subst, homologs);
+	if (ti == tj) pairs_mfma_body<true>(P, ti, tj, wc0, cpw, wchunk, nwc, subst, homologs);
+	else pairs_mfma_body<false>(P, ti, tj, wc0, cpw, wchunk, nwc, subst, homologs);
 }
 uint32_t pairs_mfma_tile() { return PM_G * 32u; }
 uint32_t pairs_mfma_max_wchunk() { return (1u << 24) / (3u * 32u) - 8u; } // exact integers in the f32 accumulators
+// cpw: window chunks a wavefront takes in a row (>= 1; cpw x wchunk must stay within pairs_mfma_max_wchunk())
 void launch_pairs_mfma(const Pileup &P, const uint32_t *tiles, uint32_t ntiles, uint32_t wchunk, unsigned long long *subst,
-					   unsigned long long *homologs, hipStream_t st)
+					   unsigned long long *homologs, hipStream_t st, uint32_t cpw)
 {
 	if (!ntiles || !P.W) return;
+	if (!cpw) cpw = 1;
 	const uint32_t nwc = (P.W + wchunk - 1) / wchunk;
-	dim3 grid(((nwc + 7) / 8) * 8 * ntiles);
-	hipLaunchKernelGGL(pairs_mfma_kernel, grid, dim3(64), 0, st, P, tiles, ntiles, wchunk, nwc, subst, homologs);
+	const uint32_t groups = ((nwc + 7) / 8 + cpw - 1) / cpw; // per XCD
+	dim3 grid(groups * 8 * ntiles);
+	hipLaunchKernelGGL(pairs_mfma_kernel, grid, dim3(64), 0, st, P, tiles, ntiles, wchunk, nwc, cpw, subst, homologs);
 }
 
 // The three planes carry '!' as 'A' (code 00), which is what revseqcmp's ((c ^ d) & 6) == 4 test sees
