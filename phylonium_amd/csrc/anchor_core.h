@@ -129,7 +129,7 @@ PHY_HD uint32_t clz32(uint32_t x)
 // in 16 bytes — x: SA[r]; y: 2-bit codes of the suffix's first 16 bytes (bits
 // beyond the valid length are 0); z: number of leading A,C,G,T bytes (<= 16);
 // w: min(LCP[r],LCP_CLIP) | min(LCP[r+1],LCP_CLIP) << 16.  The clip is 13 bits so
-// that a record also fits the 12 bytes a slot has for it (slot_pack).
+// that z and w also fit the one dword a k-mer slot has for them (slot_make, lean_core.h: meta_of_sax).
 static const uint32_t LCP_CLIP = 0x1fffu;
 PHY_HD U4 sax_record(const uint8_t *S, uint32_t sa, uint32_t lcp_r, uint32_t lcp_r1)
 {

@@ -132,7 +132,7 @@ PHY_HD void rec_cmp(uint32_t qcode, uint32_t code, uint32_t sv, uint32_t *len, u
 	*less = sv < 16u ? (code <= qcode ? 1u : 0u) : (code < qcode ? 1u : 0u);
 }
 
-PHY_HD uint32_t meta_of_sax(const U4 &r) // a SAX record's z, w in the slot's one-dword form (slot_pack)
+PHY_HD uint32_t meta_of_sax(const U4 &r) // a SAX record's z, w in the slot's one-dword form (anchor_core.h: slot_make)
 {
 	return (r.z & 31u) | ((r.w & LCP_CLIP) << 5) | (((r.w >> 16) & LCP_CLIP) << 18);
 }
