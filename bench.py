@@ -368,6 +368,8 @@ def main():
                     "the reference's row recomputed through the B0 kernels, and a sub-matrix of up to 32 genomes (the first genome of every "
                     "rank's block among them) against a one-context run of those genomes alone — and prints the verdict with every rank's "
                     "timings as one JSON line on stderr; exit status 3 when a check fails")
+    ap.add_argument("--test-corrupt-rank", type=int, default=-1, help="tests of --verify-ranks: this rank sends one damaged record — its first "
+                    "homology's query position moved by one base, a list as valid as any — into the exchange")
     ap.add_argument("--chunk", type=int, default=0, help="dev: force the phase-A chunk length")
     ap.add_argument("--filter", type=int, default=0, help="dev: sort + chain filter 1 on the host, 2 on the device (0: the library chooses)")
     ap.add_argument("--host-threads", type=int, default=0, help="dev: size of the library's host worker pool")
@@ -488,6 +490,19 @@ def main():
         seg[name] = seg.get(name, 0.0) + (t - t_prev)
         return t
 
+    tamper = {}
+    if args.test_corrupt_rank == rank:  # tests of --verify-ranks (the record's query position is word 1 of the 16-byte record)
+        def damage_block(block, maxq):
+            words = block.view(torch.int32)
+            words[4 + maxq + 1] += (words[0] > 0).to(torch.int32)  # (block: 4 header words, the lengths, the records)
+
+        def damage_records(flat):
+            if flat.size:
+                flat = flat.copy()
+                flat["index_query"][0] += 1
+            return flat
+        tamper = {"on_block": damage_block, "on_records": damage_records}
+
     def step():
         if emu:
             bounds = [dist.query_shard(n, r, emu[1], lens)[0] for r in range(emu[1])] + [n]
@@ -515,7 +530,7 @@ def main():
                 return r
             return ctx.compare(emu[0], emu[1])
         return dist.process_sharded(ctx, ref_idx, rank, world, device=None if shared else device, lengths=lens,
-                                    set_reference=False, out=out_mats, copy=False, result_rank=0 if world > 1 else None)
+                                    set_reference=False, out=out_mats, copy=False, result_rank=0 if world > 1 else None, **tamper)
 
     if emu:  # the other ranks' lists must exist for the projection: compute them once, untimed
         if args.emulate_exchange:
@@ -701,11 +716,16 @@ def main():
             roof_mfma = {"kernel": "pileup_pairs_mfma", "bound": "mfma", "achieved": round(flop_alg / (t_ms * 1e-3) / 1e12, 1), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(flop_alg / (t_ms * 1e-3) / 1e12 / peak, 4), "avg_launch_ms": round(t_ms, 4),
                          "issued_TFLOPs": round(flop_issued / (t_ms * 1e-3) / 1e12, 1),
+                         # the clock the chip held under this kernel (its wavefronts' shader cycles over their 100 MHz ticks, stamped
+                         # inside the kernel on profiled launches), and the peak at that clock: instruction-mix loss apart from DVFS
+                         "clock_ghz": round(stats.get("clock:pairs_mfma_mhz", 0.0) / 1e3, 3) or None,
+                         "frac_at_held_clock": (round(flop_alg / (t_ms * 1e-3) / 1e12 / (peak * stats["clock:pairs_mfma_mhz"] / 2400.0), 4)
+                                                if stats.get("clock:pairs_mfma_mhz") else None),
                          "note": "algorithmic work: pairs x reference positions x 4 channels x 2 (v_mfma_f32_32x32x64_f8f6f4, both operands "
                                  "FP4, f32 accumulators exact below 2^24); `issued` adds the halves of the diagonal 32 x 32 sub-tiles "
                                  "and the padding of the last window.  The operands are expanded from the bit planes in registers "
                                  "(~7 vector instructions per matrix instruction): the kernel runs at the sum of the two, the chip "
-                                 "holding ~1.4-2.1 GHz under it (tools/microbench/mfma_pairs.hip, DESIGN section 12)"}
+                                 "holding ~1.4-2.1 GHz under it (`clock_ghz`: measured in this run; the peak is quoted at 2.4 GHz; tools/microbench/mfma_pairs.hip, DESIGN section 4)"}
         phase_b_traffic = None
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload, {})
@@ -784,7 +804,7 @@ def main():
                                                  "note": "achieved/frac price the reference layout's 2 B per compared site (above 1: "
                                                          "see roofline_path); traffic = HBM-side bytes of these kernels from the "
                                                          "PMC profile: the pair kernel is bound by its matrix and vector instructions "
-                                                         "(roofline_mfma; DESIGN.md, section 12.1), not by HBM"} if tb > 0 else None)(
+                                                         "(roofline_mfma; DESIGN.md, section 4), not by HBM"} if tb > 0 else None)(
                 sum(kern[k] for k in kern if k.startswith("pileup_")) / K, phase_b_traffic),
             "phase_a_plan": {"chunk": stats.get("anchor:chunk"), "chunks": (stats.get("count:chunks") or 0) / max(1.0, stats.get("n:anchor_calls") or 1.0)},
             "setup_s": {"generate": round(t_gen, 2), "reference_index": round(t_ref, 2),

@@ -64,7 +64,9 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, bool defer)
 		uint64_t plan_bases = 0;
 		for (size_t j = 0; j < nq; j++) plan_bases += qlen[j];
 		int per_cu_cap = (c->k >= 14 || plan_bases > 2500000000ull) ? 4 : 3;
+#ifdef PHY_DEV_HOOKS
 		if (const char *e = getenv("PHY_SPEC_PER_CU")) per_cu_cap = std::max(1, atoi(e)); // experiments
+#endif
 		c->plan_spec_per_cu = per_cu_cap;
 		const int resident = std::min(lean_spec_resident_blocks(c->n_cu), per_cu_cap * c->n_cu);
 		c->plan = plan_chunks(qlen, c->threshold, c->opt_chunk, (uint32_t)resident * 256u, (uint32_t)c->n_cu * 256u);
@@ -176,7 +178,11 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, bool defer)
 	X.dbg = dbg_buf;
 #endif
 	double t1 = now_ms();
+#ifdef PHY_DEV_HOOKS
 	const bool dbg = getenv("PHY_DEBUG_SYNC") != nullptr; // name the kernel a hang is in
+#else
+	const bool dbg = false;
+#endif
 	if (dbg) {
 		hipError_t e = hipStreamSynchronize(st);
 		fprintf(stderr, "[phylonium_amd] phase A set up (%s): %zu queries, %u chunks of %u, cap %u, k %u, |S| %u, threshold %u\n",

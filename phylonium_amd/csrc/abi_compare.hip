@@ -394,12 +394,20 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 			{
 				const uint64_t nwc = (P.W + wchunk - 1) / wchunk, waves = nwc * mtiles.size();
 				cpw = (uint32_t)std::min<uint64_t>(4, std::max<uint64_t>(1, waves / ((uint64_t)c->n_cu * 64u)));
+#ifdef PHY_DEV_HOOKS
+				if (const char *e = getenv("PHY_PAIRS_CPW")) cpw = (uint32_t)std::max(1, atoi(e)); // experiments
+#endif
+				// (the f32 accumulators are flushed once per cpw chunks and are exact below 2^24: the clamp comes last)
 				cpw = std::min<uint32_t>(cpw, std::max<uint32_t>(1u, pairs_mfma_max_wchunk() / wchunk));
-				if (const char *e = getenv("PHY_PAIRS_CPW")) cpw = std::max(1, atoi(e)); // experiments
+			}
+			if (c->profile && !c->b_clk.p) { // (stat "clock:pairs_mfma_mhz")
+				HIPOK(c, c->b_clk.ensure(2));
+				HIPOK(c, hipMemsetAsync(c->b_clk.p, 0, 16, st));
+				c->stats["clock:pairs_mfma_mhz"] = 0;
 			}
 			{
 				KernelSpan s(c, "pileup_pairs_mfma");
-				launch_pairs_mfma(P, c->b_tiles.p + tiles.size(), (uint32_t)mtiles.size(), wchunk, acc_s, acc_h, st, cpw);
+				launch_pairs_mfma(P, c->b_tiles.p + tiles.size(), (uint32_t)mtiles.size(), wchunk, acc_s, acc_h, st, cpw, c->profile ? c->b_clk.p : nullptr);
 			}
 			HIPOK(c, hipGetLastError());
 			finish_tallies();

@@ -36,7 +36,9 @@ int phylo_ctx_create(phylo_ctx **out, int device)
 		return 4;
 	}
 	c->own_stream = c->stream;
+#ifdef PHY_DEV_HOOKS
 	if (const char *e = getenv("PHYLONIUM_AMD_ZERO_COPY")) c->opt_result_zero_copy = atoi(e) != 0; // experiments
+#endif
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
 	*out = c;
@@ -121,6 +123,7 @@ void phylo_ctx_destroy(phylo_ctx *c)
 	c->b_subst.release();
 	c->b_sym32.release();
 	c->b_bang.release();
+	c->b_clk.release();
 	c->s_segs.release();
 	c->s_out.release();
 	for (TimedSpan &s : c->spans) {
@@ -202,6 +205,13 @@ int phylo_set_option(phylo_ctx *c, const char *key, long value)
 int phylo_get_stat(phylo_ctx *c, const char *key, double *out)
 {
 	if (!c || !key || !out) return 1;
+	if (c->b_clk.p && !strcmp(key, "clock:pairs_mfma_mhz")) { // the clock the chip held under the matrix-core pair kernel (profiled launches since the last reset)
+		unsigned long long h[2] = {0, 0};
+		HIPOK(c, hipSetDevice(c->device));
+		HIPOK(c, hipStreamSynchronize(c->stream));
+		HIPOK(c, hipMemcpy(h, c->b_clk.p, 16, hipMemcpyDeviceToHost));
+		c->stats["clock:pairs_mfma_mhz"] = h[1] ? 100.0 * (double)h[0] / (double)h[1] : 0.0;
+	}
 	auto it = c->stats.find(key);
 	if (it == c->stats.end()) return 1;
 	*out = it->second;
@@ -212,6 +222,11 @@ int phylo_reset_stats(phylo_ctx *c)
 {
 	if (!c) return 1;
 	c->stats.clear();
+	if (c->b_clk.p) {
+		HIPOK(c, hipSetDevice(c->device));
+		HIPOK(c, hipMemsetAsync(c->b_clk.p, 0, 16, c->stream));
+		c->stats["clock:pairs_mfma_mhz"] = 0;
+	}
 	return 0;
 }
 

@@ -271,6 +271,7 @@ struct phylo_ctx {
 	const uint32_t *tiles_at = nullptr;
 	DevBuf<uint32_t> b_sym32; // both result matrices as symmetric u32, on their way to the host
 	DevBuf<uint32_t> b_bang;  // the projected '!' of the three-plane projection: {genome | reverse << 31, position} each
+	DevBuf<unsigned long long> b_clk; // option "profile": the matrix-core pair kernel's wavefront lifetimes {shader cycles, 100 MHz ticks}
 	uint32_t bang_cap = 0;    // as many as the genomes hold separators (a separator is projected at most once)
 	DevBuf<Segment> s_segs;
 	DevBuf<uint64_t> s_out;

@@ -158,12 +158,15 @@ class Barrier
 	}
 };
 
-// tests of the hosts' self-check (phylonium-amd --verify-ranks): PHYLONIUM_AMD_TEST_CORRUPT_RANK=r makes rank r send one damaged
-// record — its first homology's query position moved by one base, a list as valid as any — into the exchange
+#ifdef PHY_DEV_HOOKS
+// (development builds only: `make dev`) tests of the hosts' self-check (phylonium-amd --verify-ranks):
+// PHYLONIUM_AMD_TEST_CORRUPT_RANK=r makes rank r send one damaged record — its first homology's query position moved
+// by one base, a list as valid as any — into the exchange
 __global__ void corrupt_block_kernel(uint32_t *block, uint32_t maxq)
 {
 	if (threadIdx.x == 0 && block[0] > 0) block[4 + maxq + 1] += 1u; // (block: 4 header words, the lengths, the records {start, iq, len, rev})
 }
+#endif
 
 __global__ __launch_bounds__(256) void add_u32_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, size_t n)
 {
@@ -178,6 +181,7 @@ double now_ms()
 
 thread_local std::string g_group_error;
 
+#ifdef PHY_DEV_HOOKS
 // PHY_DEBUG_ABORT=1 (experiments): the native stack of the thread that aborts, on stderr
 void abort_trace(int sig)
 {
@@ -189,6 +193,7 @@ void abort_trace(int sig)
 	signal(sig, SIG_DFL);
 	raise(sig);
 }
+#endif
 
 } // namespace
 
@@ -363,10 +368,12 @@ int phylo_group_create(phylo_group **out, size_t n_ranks, const int *devices)
 		g_group_error = "no usable HIP device";
 		return 2;
 	}
+#ifdef PHY_DEV_HOOKS
 	if (getenv("PHY_DEBUG_ABORT")) {
 		signal(SIGABRT, abort_trace);
 		signal(SIGSEGV, abort_trace);
 	}
+#endif
 	phylo_group *g = new phylo_group();
 	g->world = n_ranks;
 	for (size_t r = 0; r < n_ranks; r++) g->dev.push_back(devices ? devices[r] : (int)(r % (size_t)count));
@@ -391,8 +398,11 @@ int phylo_group_create(phylo_group **out, size_t n_ranks, const int *devices)
 	std::vector<int> sorted = g->dev;
 	std::sort(sorted.begin(), sorted.end());
 	const bool distinct = std::adjacent_find(sorted.begin(), sorted.end()) == sorted.end();
-	const char *force = getenv("PHYLONIUM_AMD_GROUP_BACKEND"); // "copies": tests
-	if (n_ranks > 1 && distinct && !(force && !strcmp(force, "copies")) && g->rccl.load()) {
+	bool copies_only = false;
+#ifdef PHY_DEV_HOOKS
+	if (const char *force = getenv("PHYLONIUM_AMD_GROUP_BACKEND")) copies_only = !strcmp(force, "copies"); // tests
+#endif
+	if (n_ranks > 1 && distinct && !copies_only && g->rccl.load()) {
 		g->comm.assign(n_ranks, nullptr);
 		if (g->rccl.CommInitAll(g->comm.data(), (int)n_ranks, g->dev.data()) == ncclSuccess) g->use_rccl = true;
 		else g->comm.clear();
@@ -611,11 +621,17 @@ int phylo_group_anchor(phylo_group *g)
 		// own block straight into its place of the gathered buffer; the all-gather fills the rest in place
 		if (!bad && phylo_export_block_device(g->ctx[r], qb, qe, (char *)g->d_all[r] + r * g->block_bytes, g->maxq, g->cap))
 			bad = g->fail("rank %zu: %s", r, phylo_last_error(g->ctx[r])) != 0;
+#ifdef PHY_DEV_HOOKS
 		if (!bad) {
 			const char *cr = getenv("PHYLONIUM_AMD_TEST_CORRUPT_RANK");
-			if (cr && *cr && (size_t)atoi(cr) == r)
+			char *end = nullptr;
+			const long want = cr && *cr ? strtol(cr, &end, 10) : -1;
+			if (want >= 0 && end && !*end && (size_t)want == r) {
+				fprintf(stderr, "[phylonium_amd] development hook: rank %zu sends a damaged record (PHYLONIUM_AMD_TEST_CORRUPT_RANK)\n", r);
 				hipLaunchKernelGGL(corrupt_block_kernel, dim3(1), dim3(64), 0, g->stream[r], (uint32_t *)((char *)g->d_all[r] + r * g->block_bytes), (uint32_t)g->maxq);
+			}
 		}
+#endif
 		if (all_gather(g, r, g->d_all, g->block_bytes, bad)) return;
 		if (phylo_attach_blocks_device(g->ctx[r], g->d_all[r], W, g->bounds.data(), g->maxq, g->cap, qb, qe))
 			g->fail("rank %zu: %s", r, phylo_last_error(g->ctx[r]));

@@ -127,7 +127,8 @@ void launch_pairs(const Pileup &P, bool with_bang, const uint32_t *tiles, uint32
 uint32_t pairs_mfma_tile();
 uint32_t pairs_mfma_max_wchunk();
 void launch_pairs_mfma(const Pileup &P, const uint32_t *tiles, uint32_t ntiles, uint32_t wchunk, unsigned long long *subst,
-					   unsigned long long *homologs, hipStream_t st, uint32_t cpw = 1); // cpw: window chunks (of one XCD) a wavefront takes in a row
+					   unsigned long long *homologs, hipStream_t st, uint32_t cpw = 1, // cpw: window chunks (of one XCD) a wavefront takes in a row
+					   unsigned long long *clk = nullptr); // profiling: clk[0] += the wavefronts' shader cycles, clk[1] += their 100 MHz ticks
 
 void launch_symmetrise(uint32_t N, unsigned long long *a, unsigned long long *b, hipStream_t st);
 // *bad = 1 unless every genome's list is sorted by projected start, disjoint and inside [0, L)

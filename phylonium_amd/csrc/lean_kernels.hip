@@ -1139,7 +1139,9 @@ static int lean_bridge_blocks(uint32_t count, int n_cu, uint32_t k)
 	if (need < blocks) blocks = need > 0 ? need : 1;
 	const int few = std::min(std::max(n_cu, need / 3), k >= 14u ? 2 * n_cu : 3 * n_cu / 2);
 	if (few < blocks) blocks = few;
+#ifdef PHY_DEV_HOOKS
 	if (const char *e = getenv("PHY_BRIDGE_BLOCKS")) blocks = std::max(1, std::min(std::max(need, 1), atoi(e))); // experiments
+#endif
 	return blocks;
 }
 void launch_lean_bridge(const PhaseA &A, const RefIndex &R, const LeanIndex &X, int n_cu, hipStream_t st, const BridgeZero &Z)

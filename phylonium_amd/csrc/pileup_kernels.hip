@@ -559,28 +559,40 @@ static __device__ __forceinline__ void pairs_mfma_body(const Pileup &P, uint32_t
 // One wavefront per (tile of 64 x 64 genomes, window chunk); the same XCD-aware order as pairs_kernel.
 __global__ __launch_bounds__(64, 2) void pairs_mfma_kernel(Pileup P, const uint32_t *__restrict__ tiles, uint32_t ntiles,
 															uint32_t wchunk, uint32_t nwc, uint32_t cpw, unsigned long long *__restrict__ subst,
-															unsigned long long *__restrict__ homologs)
+															unsigned long long *__restrict__ homologs, unsigned long long *__restrict__ clk)
 {
 	const uint32_t xcd = blockIdx.x & 7u, local = blockIdx.x >> 3;
 	const uint32_t tile = local % ntiles;
 	const uint32_t wc0 = (local / ntiles) * cpw * 8u + xcd; // this wavefront's chunks: wc0, wc0 + 8, ... (cpw of them)
 	if (wc0 >= nwc) return;
+	// clk (profiling only): the wavefronts' lifetimes in shader cycles and in ticks of the constant 100 MHz counter —
+	// their ratio is the clock the chip held under this kernel's mix of matrix and vector instructions
+	unsigned long long c0 = 0, r0 = 0;
+	if (clk) {
+		c0 = __builtin_amdgcn_s_memtime();
+		r0 = __builtin_amdgcn_s_memrealtime();
+	}
 	const uint32_t ti = tiles[tile] >> 16, tj = tiles[tile] & 0xffffu;
 	if (ti == tj) pairs_mfma_body<true>(P, ti, tj, wc0, cpw, wchunk, nwc, subst, homologs);
 	else pairs_mfma_body<false>(P, ti, tj, wc0, cpw, wchunk, nwc, subst, homologs);
+	if (clk && threadIdx.x == 0) {
+		atomicAdd(&clk[0], __builtin_amdgcn_s_memtime() - c0);
+		atomicAdd(&clk[1], __builtin_amdgcn_s_memrealtime() - r0);
+	}
 }
 uint32_t pairs_mfma_tile() { return PM_G * 32u; }
 uint32_t pairs_mfma_max_wchunk() { return (1u << 24) / (3u * 32u) - 8u; } // exact integers in the f32 accumulators
 // cpw: window chunks a wavefront takes in a row (>= 1; cpw x wchunk must stay within pairs_mfma_max_wchunk())
 void launch_pairs_mfma(const Pileup &P, const uint32_t *tiles, uint32_t ntiles, uint32_t wchunk, unsigned long long *subst,
-					   unsigned long long *homologs, hipStream_t st, uint32_t cpw)
+					   unsigned long long *homologs, hipStream_t st, uint32_t cpw, unsigned long long *clk)
 {
 	if (!ntiles || !P.W) return;
 	if (!cpw) cpw = 1;
+	while (cpw > 1 && (uint64_t)cpw * wchunk > pairs_mfma_max_wchunk()) cpw--; // (never beyond what the f32 accumulators hold exactly)
 	const uint32_t nwc = (P.W + wchunk - 1) / wchunk;
 	const uint32_t groups = ((nwc + 7) / 8 + cpw - 1) / cpw; // per XCD
 	dim3 grid(groups * 8 * ntiles);
-	hipLaunchKernelGGL(pairs_mfma_kernel, grid, dim3(64), 0, st, P, tiles, ntiles, wchunk, nwc, cpw, subst, homologs);
+	hipLaunchKernelGGL(pairs_mfma_kernel, grid, dim3(64), 0, st, P, tiles, ntiles, wchunk, nwc, cpw, subst, homologs, clk);
 }
 
 // The three planes carry '!' as 'A' (code 00), which is what revseqcmp's ((c ^ d) & 6) == 4 test sees

@@ -20,14 +20,6 @@ _FORCE_COLLECTIVES = False
 _LEGACY_DEVICE_EXCHANGE = False
 
 
-def _corrupt_rank():
-    """Tests of the self-check (bench.py --verify-ranks): PHYLONIUM_AMD_TEST_CORRUPT_RANK=r makes rank r send one damaged
-    record — its first homology's query position moved by one base, a list as valid as any — into the exchange."""
-    import os
-    v = os.environ.get("PHYLONIUM_AMD_TEST_CORRUPT_RANK", "")
-    return int(v) if v.isdigit() else -1
-
-
 def query_shard(n, rank, world, lengths=None):
     """Contiguous block of queries for this rank, balanced by total length."""
     if lengths is None:
@@ -49,7 +41,7 @@ def _dev(backend_device):
     return backend_device if backend_device is not None else torch.device("cpu")
 
 
-def exchange_homologies(ctx, n, rank, world, bounds, device=None, _n_pad=1):
+def exchange_homologies(ctx, n, rank, world, bounds, device=None, _n_pad=1, on_records=None):
     """After phase A every rank holds the lists of its own query block; afterwards
     every rank holds all of them.  Two collectives: the per-genome counts
     (all-reduce of a vector that is zero outside the own block) and the flat
@@ -57,9 +49,8 @@ def exchange_homologies(ctx, n, rank, world, bounds, device=None, _n_pad=1):
     dev = _dev(device)
     qb, qe = bounds[rank], bounds[rank + 1]
     counts, flat = ctx.export_packed(qb, qe)  # 16-byte wire records
-    if rank == _corrupt_rank() and flat.size:
-        flat = flat.copy()
-        flat["index_query"][0] += 1
+    if on_records is not None:  # (the self-check's tests damage a record here: bench.py --test-corrupt-rank)
+        flat = on_records(flat)
     call = np.zeros(n, np.int64)
     call[qb:qe] = counts.astype(np.int64)
     ct = torch.from_numpy(call).to(dev)
@@ -139,7 +130,7 @@ def _exchange_plan(ctx, n, rank, world, bounds, device):
             "tri": torch.empty(ctx.triangle_words(n), dtype=torch.int32, device=device)}
 
 
-def process_sharded_device(ctx, rank, world, bounds, device, out=None, result_rank=None):
+def process_sharded_device(ctx, rank, world, bounds, device, out=None, result_rank=None, on_block=None):
     """One step with the exchange left to the device: the context works on torch's current stream, so the library's
     kernels and the collectives are ordered by the stream and the host waits twice — at the end of phase A (its
     error and tie flags) and for the result.  Lists travel as fixed-shape blocks (one all-gather), tallies as a u32
@@ -155,18 +146,19 @@ def process_sharded_device(ctx, rank, world, bounds, device, out=None, result_ra
         plan = getattr(ctx, "_xplan", None)
         if plan is None or plan["bounds"] != tuple(bounds) or plan["tri"].numel() != ctx.triangle_words(n):
             plan = ctx._xplan = _exchange_plan(ctx, n, rank, world, bounds, device)
-        # everything from here to the result is queued on the stream: the block export, the all-gather, the attach, the
-        # comparison (its kernels and what it has to report ride in the triangle's last four words) and the reduction;
-        # the host waits once, for the result — or, on a rank that does not get it, for the 16 bytes of the report
-        ctx.export_block_device(qb, qe, plan["block"].data_ptr(), plan["maxq"], plan["cap"])
-        if rank == _corrupt_rank():
-            words = plan["block"].view(torch.int32)
-            words[4 + plan["maxq"] + 1] += (words[0] > 0).to(torch.int32)  # record 0's query position (block: 4 header words, the lengths, the records)
-        td.all_gather_into_tensor(plan["all"], plan["block"])
-        ctx.attach_blocks_device(plan["all"].data_ptr(), bounds, plan["maxq"], plan["cap"], qb, qe)
-        ctx.compare_triangle_device(rank, world, plan["tri"].data_ptr())
-        ctx._attached_records = plan["all"]  # still the source of the other ranks' lists should the caller ask for them
         try:
+            # everything from here to the result is queued on the stream: the block export, the all-gather, the attach, the
+            # comparison (its kernels and what it has to report ride in the triangle's last four words) and the reduction;
+            # the host waits once, for the result — or, on a rank that does not get it, for the 16 bytes of the report
+            ctx.export_block_device(qb, qe, plan["block"].data_ptr(), plan["maxq"], plan["cap"])
+            if on_block is not None:  # (the self-check's tests damage a record here: bench.py --test-corrupt-rank)
+                on_block(plan["block"], plan["maxq"])
+            td.all_gather_into_tensor(plan["all"], plan["block"])
+            ctx.attach_blocks_device(plan["all"].data_ptr(), bounds, plan["maxq"], plan["cap"], qb, qe)
+            ctx._attached_records = plan["all"]  # still the source of the other ranks' lists should the caller ask for them
+            # (the vector-ALU pair kernel, option pairs_kernel = 1, waits for its flags itself: a block that overflowed
+            # surfaces here, on every rank alike — all of them hold all blocks — and is planned again like the others)
+            ctx.compare_triangle_device(rank, world, plan["tri"].data_ptr())
             if result_rank is None:  # every rank gets the matrices
                 td.all_reduce(plan["tri"], op=td.ReduceOp.SUM)
                 return ctx.triangle_to_matrices(plan["tri"].data_ptr(), out)
@@ -192,7 +184,19 @@ def process_sharded_device(ctx, rank, world, bounds, device, out=None, result_ra
     raise RuntimeError("process_sharded_device: the exchange blocks overflowed twice")
 
 
-def process_sharded(ctx, ref_idx, rank, world, device=None, lengths=None, set_reference=True, out=None, copy=True, result_rank=None):
+def shard_bounds(ctx, world, lengths=None):
+    """bounds[r] .. bounds[r + 1]: rank r's block of queries (kept on the context: a thousand genomes' lengths are not
+    walked through again step after step)."""
+    lens = lengths or getattr(ctx, "lengths", None)
+    key = (ctx.n, world, id(lens), len(lens) if lens is not None else 0)
+    cached = getattr(ctx, "_shard_bounds", None)
+    if cached is None or cached[0] != key:
+        cached = ctx._shard_bounds = (key, [query_shard(ctx.n, r, world, lens)[0] for r in range(world)] + [ctx.n])
+    return cached[1]
+
+
+def process_sharded(ctx, ref_idx, rank, world, device=None, lengths=None, set_reference=True, out=None, copy=True, result_rank=None,
+                    on_block=None, on_records=None):
     """process() with queries and pair tiles sharded over `world` ranks.
     ctx: an api.Context (or any object with the same methods) holding all genomes.
     Returns (subst, homologs), two N x N uint64 arrays.  With `out` = (subst, homologs) the result is written
@@ -203,15 +207,14 @@ def process_sharded(ctx, ref_idx, rank, world, device=None, lengths=None, set_re
     returns the matrices; the other ranks return (None, None)."""
     if set_reference:
         ctx.set_reference(ref_idx)
-    lens = lengths or getattr(ctx, "lengths", None)
-    bounds = [query_shard(ctx.n, r, world, lens)[0] for r in range(world)] + [ctx.n]
+    bounds = shard_bounds(ctx, world, lengths)
     qb, qe = bounds[rank], bounds[rank + 1]
     if world == 1 and not _FORCE_COLLECTIVES and hasattr(ctx, "anchor_compare"):
         return ctx.anchor_compare(out=out)  # one rank: both phases as the one call they are in the reference
     on_gpu = device is not None and torch.device(device).type == "cuda" and hasattr(ctx, "attach_packed_device")
     if on_gpu and (world > 1 or _FORCE_COLLECTIVES) and hasattr(ctx, "export_block_device") and not _LEGACY_DEVICE_EXCHANGE:
         # (phase A is this path's own first step — on the caller's stream, and again should the exchange blocks overflow)
-        return process_sharded_device(ctx, rank, world, bounds, device, out=out, result_rank=result_rank)
+        return process_sharded_device(ctx, rank, world, bounds, device, out=out, result_rank=result_rank, on_block=on_block)
     ctx.anchor(qb, qe)
     if on_gpu and (world > 1 or _FORCE_COLLECTIVES):
         # device-resident: records and tallies never visit the host between the ranks
@@ -235,7 +238,7 @@ def process_sharded(ctx, ref_idx, rank, world, device=None, lengths=None, set_re
             return out[0], out[1]
         return (m[0].copy(), m[1].copy()) if copy else (m[0], m[1])
     if world > 1 or _FORCE_COLLECTIVES:
-        exchange_homologies(ctx, ctx.n, rank, world, bounds, device)
+        exchange_homologies(ctx, ctx.n, rank, world, bounds, device, on_records=on_records)
     s, h = ctx.compare(rank, world, out=out) if out is not None else ctx.compare(rank, world)
     if world > 1 or _FORCE_COLLECTIVES:
         s, h = allreduce_matrix(s, h, device)

@@ -281,8 +281,11 @@ __attribute__((target("avx2,bmi2"))) inline void pack_bytes_avx2(Packer &P, cons
 inline bool have_avx2_bmi2()
 {
 #if defined(__x86_64__)
-	// PHYLONIUM_AMD_NO_SIMD: the byte-wise loop only (tests compare the two)
-	static const bool yes = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && !getenv("PHYLONIUM_AMD_NO_SIMD");
+	static const bool yes = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2")
+#ifdef PHY_DEV_HOOKS
+							&& !getenv("PHYLONIUM_AMD_NO_SIMD") // the byte-wise loop only (tests compare the two)
+#endif
+		;
 	return yes;
 #else
 	return false;

@@ -192,7 +192,11 @@ def test_packed_fasta_reader_equals_the_byte_reader(lib, tmp_path):
             "pickle.dump(api.read_fasta_packed(%r, threads=2), sys.stdout.buffer)" % (ROOT, paths))
     import pickle
     import subprocess
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, env=dict(os.environ, PHYLONIUM_AMD_NO_SIMD="1"), check=True)
+    # (the switch exists in the development build only: `make dev`, -DPHY_DEV_HOOKS)
+    dev_lib = os.path.join(ROOT, "phylonium_amd", "libphylonium_amd_dev.so")
+    assert os.path.exists(dev_lib), "run __graft_entry__.build() (make dev) first"
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True,
+                         env=dict(os.environ, PHYLONIUM_AMD_NO_SIMD="1", PHYLONIUM_AMD_LIB=dev_lib), check=True)
     for a, b in zip(pk, pickle.loads(out.stdout)):
         assert a[1] == b[1] and np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])
     # something that cannot be mapped and has no size (a FIFO) still reads: it gets a place of its own in the arena

@@ -71,8 +71,7 @@ def test_verify_ranks_passes_and_catches_a_damaged_block(ranks):
     assert len(rep) == 1
     rep = json.loads(rep[0][len("# verify-ranks: "):])
     assert rep["n_ranks"] == ranks and len(rep["ranks"]) == ranks and all("kernels_ms" in x for x in rep["ranks"])
-    env = dict(_env(), PHYLONIUM_AMD_TEST_CORRUPT_RANK=str(ranks - 1))
-    r = subprocess.run(base, capture_output=True, text=True, timeout=800, env=env)
+    r = subprocess.run(base + ["--test-corrupt-rank", str(ranks - 1)], capture_output=True, text=True, timeout=800, env=_env())
     assert r.returncode == 3, (r.returncode, r.stderr[-3000:])
     line = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
     v = line["verify_ranks"]

@@ -15,6 +15,7 @@ from phylonium_amd import synth
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "phylonium_amd", "phylonium-amd")
+CLI_DEV = os.path.join(ROOT, "phylonium_amd", "phylonium-amd-dev")  # `make dev`: with the tests' switches (-DPHY_DEV_HOOKS)
 
 
 def run(args, cwd):
@@ -211,11 +212,13 @@ def test_several_gpus_print_the_same(tmp_path, backend):
     with a reference given or chosen, complete deletion, -p and the two-pass mode; on a box with fewer GPUs than
     ranks the ranks share them and the exchange is device-to-device copies."""
     env = dict(os.environ)
-    if backend == "copies":
+    exe = CLI
+    if backend == "copies":  # (a switch of the development build)
         env["PHYLONIUM_AMD_GROUP_BACKEND"] = "copies"
+        exe = CLI_DEV
 
     def run_env(args):
-        p = subprocess.run([CLI, *args], cwd=tmp_path, capture_output=True, text=True, env=env)
+        p = subprocess.run([exe, *args], cwd=tmp_path, capture_output=True, text=True, env=env)
         return p.returncode, p.stdout, p.stderr
 
     gs = synth.make_genomes(11, 30000, seed=83, d_range=(0.01, 0.25), indel_per_mbp=300, inv_frac=0.08, contigs=3,
@@ -246,7 +249,7 @@ def test_verify_ranks_of_the_driver(tmp_path, ranks):
     """`phylonium-amd --gpus N --verify-ranks`: after printing, the reference's row is recomputed through the B0 kernels and
     a sub-matrix of up to 32 genomes (the first genome of every rank's block among them) is compared with a one-GPU run of
     those genomes; one JSON line on stderr carries the verdict and every rank's timings.  Passes for 2 and 8 ranks sharing
-    the test box's GPU with the matrix unchanged; a rank that sends a damaged record (PHYLONIUM_AMD_TEST_CORRUPT_RANK) is
+    the test box's GPU with the matrix unchanged; a rank that sends a damaged record (PHYLONIUM_AMD_TEST_CORRUPT_RANK, development build) is
     caught — exit status 3, the damaged pairs named."""
     import json
     gs = synth.make_genomes(40, 20000, seed=97, d_range=(0.01, 0.2), indel_per_mbp=300, inv_frac=0.05, contigs=2, inv_len=(200, 1500))
@@ -263,7 +266,11 @@ def test_verify_ranks_of_the_driver(tmp_path, ranks):
     assert v["ok"] and v["n_ranks"] == ranks and len(v["ranks"]) == ranks and v["submatrix"]["identical"] and not v["reference_row"]["mismatching"]
     assert v["submatrix"]["genomes"] >= min(32, len(gs))
     env = dict(os.environ, PHYLONIUM_AMD_TEST_CORRUPT_RANK=str(ranks - 1))
+    # the shipped driver has no such switch: the matrix is unchanged and the check passes ...
     p = subprocess.run([CLI, "--gpus", str(ranks), "--verify-ranks", "-r", files[3], *files], cwd=tmp_path, capture_output=True, text=True, env=env)
+    assert (p.returncode, p.stdout) == plain[:2], p.stderr[-2000:]
+    # ... the development build's driver damages the record
+    p = subprocess.run([CLI_DEV, "--gpus", str(ranks), "--verify-ranks", "-r", files[3], *files], cwd=tmp_path, capture_output=True, text=True, env=env)
     assert p.returncode == 3, p.stderr[-2000:]
     v = json.loads([l for l in p.stderr.splitlines() if l.startswith("verify-ranks: ")][0][len("verify-ranks: "):])
     assert not v["ok"] and not v["submatrix"]["identical"] and v["submatrix"]["first_mismatching_pairs"]
