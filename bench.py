@@ -212,6 +212,9 @@ def wallclock_leg(torch, holder, offs, lens, contigs_sep, want_text, n_gpus, run
         cmd = [exe, "--timing", "-r", files[0]] + (["--gpus", str(n_gpus)] if n_gpus > 1 else []) + files
         res = []
         for _ in range(runs):
+            # (untimed: the driver clears the device memory the last process — this one, or the run before — gave back, and
+            # a hipMalloc issued before it is done waits for it; somebody who runs the program once does not see that)
+            time.sleep(2.0)
             t0 = time.perf_counter()
             pr = subprocess.run(cmd, capture_output=True)
             wall = time.perf_counter() - t0
@@ -421,6 +424,11 @@ def main():
         else:
             td.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
     coll_dev = torch.device("cpu") if shared else device  # where the barrier / timing tensors of the collectives live
+    if (world > 1 and not shared) or args.emulate_exchange:
+        # the library's kernels and torch's collectives on ONE stream of their own (the context is lent torch's current stream:
+        # dist.process_sharded_device; handle 0 — the legacy default stream — would mean "the context's own stream", ordered with
+        # torch's only by the default stream's implicit synchronisation)
+        torch.cuda.set_stream(torch.cuda.Stream(device=device))
 
     n, length, d_range, indel, inv, desc = WORKLOADS[args.workload]
     n = args.genomes or n
@@ -451,10 +459,6 @@ def main():
         ctx.set_option("host_threads", args.host_threads)
     if args.filter:
         ctx.set_option("filter", args.filter)
-    if world > 1 or args.emulate_rank:
-        # the result's rank keeps its two host matrices for the whole run and nothing forks while the context lives: the device
-        # may write them itself (phylo_triangle_to_matrices)
-        ctx.set_option("result_zero_copy", 1)
     ctx.set_genomes_device(buf.data_ptr(), offs, lens)
     print(f"# genomes generated in {t_gen:.1f} s", file=sys.stderr, flush=True)
     if world > 1:  # every rank must hold the same genomes (same seed, same generator): compare a checksum
@@ -505,38 +509,43 @@ def main():
 
     def step():
         if emu:
-            bounds = [dist.query_shard(n, r, emu[1], lens)[0] for r in range(emu[1])] + [n]
+            bounds = emu_state["bounds"]
             qb, qe = bounds[emu[0]], bounds[emu[0] + 1]
             tl = time.perf_counter()
-            ctx.anchor(qb, qe)
-            tl = lap("anchor", tl)
             if args.emulate_exchange:
-                # what rank emu[0] of emu[1] does around its kernels (dist.process_sharded_device), with a one-rank RCCL
-                # group standing in for the collectives and the other ranks' blocks prepared beforehand
+                # what rank emu[0] of emu[1] does (dist.process_sharded_device), with a one-rank RCCL group standing in for
+                # the collectives and the other ranks' blocks prepared beforehand: phase A with its block behind it, the
+                # all-gather, the attach, the rank's windows of phase B, the all-reduce, the rank's rows of the result
                 W = emu[1]
                 pl = emu_state["plan"]
                 own = pl["all"][emu[0] * pl["nbytes"]:(emu[0] + 1) * pl["nbytes"]]
-                ctx.export_block_device(qb, qe, pl["block"].data_ptr(), pl["maxq"], pl["cap"])
-                tl = lap("export (queued)", tl)
-                td.all_gather_into_tensor(own, pl["block"])
+                ctx.anchor_block_device(qb, qe, own.data_ptr(), pl["maxq"], pl["cap"])
+                tl = lap("anchor + export (queued)", tl)
+                td.all_gather_into_tensor(own, own)
                 tl = lap("all_gather (queued)", tl)
                 ctx.attach_blocks_device(pl["all"].data_ptr(), bounds, pl["maxq"], pl["cap"], qb, qe)
                 tl = lap("attach (queued)", tl)
                 ctx.compare_triangle_device(emu[0], W, pl["tri"].data_ptr())
                 tl = lap("compare (queued)", tl)
                 td.all_reduce(pl["tri"])
-                r = ctx.triangle_to_matrices(pl["tri"].data_ptr(), out_mats)
-                tl = lap("all_reduce + triangle to matrices", tl)
-                return r
+                rep = ctx.triangle_rows_to_result(pl["tri"].data_ptr(), n * emu[0] // W, n * (emu[0] + 1) // W, emu[0], 0)
+                if rep[0] or rep[1] or rep[2] or rep[4]:
+                    raise SystemExit(f"emulated rank: the pass reported {rep.tolist()}")
+                tl = lap("all_reduce + rows of the result + wait", tl)
+                return emu_state["views"]
+            ctx.anchor(qb, qe)
+            tl = lap("anchor", tl)
             return ctx.compare(emu[0], emu[1])
         return dist.process_sharded(ctx, ref_idx, rank, world, device=None if shared else device, lengths=lens,
-                                    set_reference=False, out=out_mats, copy=False, result_rank=0 if world > 1 else None, **tamper)
+                                    set_reference=False, out=out_mats if world == 1 or shared else None, copy=False,
+                                    result_rank=0 if world > 1 else None, **tamper)
 
     if emu:  # the other ranks' lists must exist for the projection: compute them once, untimed
+        emu_state["bounds"] = [dist.query_shard(n, r, emu[1], lens)[0] for r in range(emu[1])] + [n]
         if args.emulate_exchange:
             W = emu[1]
             ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
-            bounds = [dist.query_shard(n, r, W, lens)[0] for r in range(W)] + [n]
+            bounds = emu_state["bounds"]
             tot = []
             for r in range(W):
                 ctx.anchor(bounds[r], bounds[r + 1])
@@ -550,8 +559,9 @@ def main():
                 ctx.export_block_device(bounds[r], bounds[r + 1], allb.data_ptr() + r * nbytes, maxq, cap)
             torch.cuda.synchronize()
             emu_state["plan"] = {"maxq": maxq, "cap": cap, "nbytes": nbytes, "all": allb,
-                                 "block": torch.empty(nbytes, dtype=torch.uint8, device=device),
                                  "tri": torch.empty(ctx.triangle_words(n), dtype=torch.int32, device=device)}
+            ctx.result_open(None, ranks=W)  # (one process: the result's home is private; the rank writes its rows of it)
+            emu_state["views"] = ctx.result_matrices()
             print(f"# emulated exchange: blocks of {nbytes / 1e6:.2f} MB x {W} ranks, triangle {n * (n - 1) * 4 / 1e6:.2f} MB", file=sys.stderr)
         else:
             ctx.anchor(0, n)

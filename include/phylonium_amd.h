@@ -207,6 +207,16 @@ int phylo_export_block_device(phylo_ctx *ctx, size_t q_begin, size_t q_end, void
 							  size_t cap_records);
 int phylo_attach_blocks_device(phylo_ctx *ctx, const void *dev_all, size_t world, const size_t *bounds, size_t max_queries,
 							   size_t cap_records, size_t keep_begin, size_t keep_end);
+/* Phase A of a rank's block of queries with its exchange block written behind it — phylo_anchor(q_begin, q_end) +
+ * phylo_export_block_device without the host round trip between them (the loop of src/process.cxx:433-458 for this
+ * rank's queries, queued): nothing is waited for, the caller's all-gather goes straight behind it on the context's
+ * stream.  What phylo_anchor would have learnt at its wait — a list with tied projected starts, which only the host's
+ * std::sort orders as the reference does; scratch that overflowed — rides in the block's header to every rank and
+ * comes back in the summed triangle's report (word 4, below): the pass is then repeated with phylo_anchor +
+ * phylo_export_block_device.  Until phylo_attach_blocks_device has been given the gathered blocks, any call that asks
+ * for this context's lists waits for the queued phase A first. */
+int phylo_anchor_block_device(phylo_ctx *ctx, size_t q_begin, size_t q_end, void *dev_block, size_t max_queries,
+							  size_t cap_records);
 /* complete_delete over all genomes' lists, src/process.cxx:467-469,725-776 (host). */
 int phylo_complete_delete(phylo_ctx *ctx);
 
@@ -225,7 +235,8 @@ int phylo_compare_device(phylo_ctx *ctx, size_t part, size_t nparts, uint64_t *d
  * substitutions and tri[P + k] homologs of pair i < j, k = i (2n - i - 1) / 2 + (j - i - 1), P = n (n - 1) / 2 (a tally
  * is at most the reference's length, < 2^31; a quarter of the bytes of the two u64 matrices), followed by four words of
  * the part's own: what its comparison has to report ('!' list overflow, a gathered list out of order, a gathered block
- * beyond its capacity, 1) — phylo_triangle_words(n) = n (n - 1) + 4 words in all.  On the default (matrix-core) path the
+ * beyond its capacity, 1 per part, a rank's phase A needs the host (phylo_anchor_block_device), 0, 0, 0) —
+ * phylo_triangle_words(n) = n (n - 1) + 8 words in all.  On the default (matrix-core) path the
  * call queues its kernels and returns without waiting for them: the parts' triangles AND their reports add up (one
  * all-reduce / reduce of phylo_triangle_words(n) words on the context's stream), and phylo_triangle_to_matrices — on the
  * rank that wants the result — writes the two symmetric n x n matrices process() returns and fails if any part
@@ -236,6 +247,25 @@ int phylo_compare_device(phylo_ctx *ctx, size_t part, size_t nparts, uint64_t *d
 size_t phylo_triangle_words(size_t n);
 int phylo_compare_triangle_device(phylo_ctx *ctx, size_t part, size_t nparts, uint32_t *dev_tri);
 int phylo_triangle_to_matrices(phylo_ctx *ctx, const uint32_t *dev_tri, uint64_t *subst, uint64_t *homologs);
+
+/* The result's own home on the host: page-locked memory the library owns, which the device writes directly — no
+ * registration of the caller's pages (option "result_zero_copy"), no staging copy.  shm_name = NULL: private to this
+ * context; phylo_triangle_to_matrices (and phylo_compare*) recognise the two pointers phylo_result_matrices hands out
+ * and write there over PCIe.  shm_name = "/name": a POSIX shared-memory segment for the `ranks` ranks of one node (one
+ * process per GPU, or one thread per GPU): one rank creates it (create = 1), the others open it, the creator unlinks the
+ * name once all have (phylo_result_unlink; the memory lives as long as a mapping does).  Then, after the all-reduce
+ * of the parts' triangles, every rank's device writes ITS rows of both matrices over its own PCIe link:
+ * phylo_triangle_rows_to_result queues rows [row_begin, row_end), waits for this context's stream, records the
+ * delivery in the segment's header and — wait_ranks > 0: the rank(s) that want the result — returns when ranks
+ * 0 .. wait_ranks - 1 have recorded theirs (the ranks call it in step, once per pass).  report (8 words, may be NULL):
+ * the summed triangle's report as described above.  2 N^2 x 8 bytes cross eight links instead of one: at N = 1024 the
+ * result's way home shrinks from 0.32 ms to 0.05. */
+int phylo_result_open(phylo_ctx *ctx, const char *shm_name, int create, size_t n, size_t ranks);
+int phylo_result_unlink(phylo_ctx *ctx);
+void phylo_result_close(phylo_ctx *ctx);
+int phylo_result_matrices(phylo_ctx *ctx, uint64_t **subst, uint64_t **homologs);
+int phylo_triangle_rows_to_result(phylo_ctx *ctx, const uint32_t *dev_tri, size_t row_begin, size_t row_end, size_t rank,
+								  size_t wait_ranks, uint32_t *report);
 
 /* ── B2 in one call ── */
 int phylo_process(phylo_ctx *ctx, size_t ref_idx, int flags, uint64_t *subst, uint64_t *homologs);

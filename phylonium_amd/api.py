@@ -29,6 +29,7 @@ SYMBOLS = [
     "phylo_export_packed_device", "phylo_attach_packed_device", "phylo_compare_device",
     "phylo_ctx_set_stream", "phylo_ctx_device", "phylo_exchange_block_bytes", "phylo_export_block_device", "phylo_attach_blocks_device",
     "phylo_compare_triangle_device", "phylo_triangle_to_matrices", "phylo_triangle_words", "phylo_group_rank_begin", "phylo_host_device_count",
+    "phylo_anchor_block_device", "phylo_result_open", "phylo_result_unlink", "phylo_result_close", "phylo_result_matrices", "phylo_triangle_rows_to_result",
     "phylo_group_create", "phylo_group_destroy", "phylo_group_last_error", "phylo_group_size", "phylo_group_ctx", "phylo_group_backend",
     "phylo_group_set_option", "phylo_group_get_stat", "phylo_group_set_genomes_packed", "phylo_group_set_reference", "phylo_group_anchor",
     "phylo_group_compare", "phylo_group_process",
@@ -97,6 +98,13 @@ def load():
     L.phylo_triangle_to_matrices.argtypes = [vp, vp, vp, vp]
     L.phylo_triangle_words.restype = sz
     L.phylo_triangle_words.argtypes = [sz]
+    L.phylo_anchor_block_device.argtypes = [vp, sz, sz, vp, sz, sz]
+    L.phylo_result_open.argtypes = [vp, C.c_char_p, C.c_int, sz, sz]
+    L.phylo_result_unlink.argtypes = [vp]
+    L.phylo_result_close.argtypes = [vp]
+    L.phylo_result_close.restype = None
+    L.phylo_result_matrices.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.phylo_triangle_rows_to_result.argtypes = [vp, vp, sz, sz, sz, sz, vp]
     L.phylo_host_device_count.argtypes = [C.POINTER(C.c_int)]
     L.phylo_group_create.argtypes = [C.POINTER(vp), sz, vp]
     L.phylo_group_destroy.argtypes = [vp]
@@ -358,14 +366,47 @@ class Context:
         the context's stream, nothing is waited for."""
         self._chk(self.L.phylo_export_block_device(self.h, q_begin, q_end, C.c_void_p(dev_ptr), max_queries, cap_records))
 
+    def anchor_block_device(self, q_begin, q_end, dev_ptr, max_queries, cap_records):
+        """anchor(q_begin, q_end) with the exchange block written behind it, nothing waited for (phylo_anchor_block_device)."""
+        self._chk(self.L.phylo_anchor_block_device(self.h, q_begin, q_end, C.c_void_p(dev_ptr), max_queries, cap_records))
+
+    def result_open(self, shm_name=None, create=True, ranks=1):
+        """The result's page-locked home: private (shm_name None) or the node's shared segment (phylo_result_open)."""
+        self._chk(self.L.phylo_result_open(self.h, shm_name.encode() if shm_name else None, 1 if create else 0, self.n, ranks))
+
+    def result_unlink(self):
+        self._chk(self.L.phylo_result_unlink(self.h))
+
+    def result_close(self):
+        self.L.phylo_result_close(self.h)
+
+    def result_matrices(self):
+        """The two n x n uint64 matrices of the result's home as numpy views (valid until result_close / close)."""
+        ps, ph = C.c_void_p(), C.c_void_p()
+        self._chk(self.L.phylo_result_matrices(self.h, C.byref(ps), C.byref(ph)))
+        n = self.n
+        mk = lambda p: np.frombuffer((C.c_uint64 * (n * n)).from_address(p.value), dtype=np.uint64).reshape(n, n)
+        return mk(ps), mk(ph)
+
+    def triangle_rows_to_result(self, dev_tri_ptr, row_begin, row_end, rank, wait_ranks):
+        """This rank's rows of the summed triangle into the result's home; returns the triangle's 8 report words."""
+        rep = np.zeros(8, np.uint32)
+        self._chk(self.L.phylo_triangle_rows_to_result(self.h, C.c_void_p(dev_tri_ptr), row_begin, row_end, rank, wait_ranks,
+                                                       rep.ctypes.data_as(C.c_void_p)))
+        return rep
+
     def attach_blocks_device(self, dev_ptr, bounds, max_queries, cap_records, keep_begin, keep_end):
         """The gathered blocks of all ranks (rank r's genomes: bounds[r] .. bounds[r+1]) become the lists phase B reads."""
-        b = (C.c_size_t * len(bounds))(*[int(x) for x in bounds])
+        key = tuple(bounds)
+        b = self._bounds_cache[1] if getattr(self, "_bounds_cache", (None,))[0] == key else None
+        if b is None:
+            b = (C.c_size_t * len(bounds))(*[int(x) for x in bounds])
+            self._bounds_cache = (key, b)
         self._chk(self.L.phylo_attach_blocks_device(self.h, C.c_void_p(dev_ptr), len(bounds) - 1, b, max_queries, cap_records,
                                                     keep_begin, keep_end))
 
     def triangle_words(self, n=None):
-        """u32 words of a part's triangle: 2 x n (n - 1) / 2 tallies + the part's four report words."""
+        """u32 words of a part's triangle: 2 x n (n - 1) / 2 tallies + the part's eight report words."""
         return int(self.L.phylo_triangle_words(self.n if n is None else n))
 
     def compare_triangle_device(self, part, nparts, dev_tri_ptr):

@@ -20,11 +20,78 @@ __global__ void compact_raw_kernel(const RawHom *__restrict__ src, const uint64_
 }
 
 
-// defer: when this call covers every genome and leaves lists and projection on the device, do not wait for its flags —
+// What the device filter left for queries [q_begin, q_end), once the stream has been waited for and h_rng holds its ranges,
+// flags and counters (see anchor_impl): the lists stay in the context's device buffer, the host knows where.
+static void adopt_device_lists(phylo_ctx *c, size_t q_begin, size_t q_end, bool tail_eager)
+{
+	const size_t N = c->n, nq = q_end - q_begin;
+	const uint32_t *hr = c->h_rng.p, *dmisc = hr + 3 * nq + 1;
+	c->att_homs = c->b_homs.p;
+	c->att_rng_on_device = false;
+	if (c->att_begin.size() != N) {
+		c->att_begin.assign(N, 0);
+		c->att_count.assign(N, 0);
+	}
+	if (c->host_stale.size() != N) c->host_stale.assign(N, 0);
+	for (size_t j = 0; j < nq; j++) {
+		c->att_begin[q_begin + j] = hr[2 * j];
+		c->att_count[q_begin + j] = hr[2 * j + 1] - hr[2 * j];
+		c->host_stale[q_begin + j] = 1;
+	}
+	c->homs_staged = q_begin == 0 && q_end == N;
+	c->eager_valid = tail_eager;
+	c->stats["n:anchor_calls"] += 1;
+	c->stats["count:query_bases"] += c->pend_total;
+	c->stats["count:chunks"] += c->pend_nch;
+	c->stats["count:filtered_homologies"] += (double)hr[2 * nq];
+	c->stats["count:pool_blocks_used"] += dmisc[2];
+	c->stats["count:overrun_runs"] += dmisc[5];
+	c->stats["count:overrun_bytes_compared"] += dmisc[6];
+	c->stats["anchor:chunk"] = c->pend_C;
+}
+
+int phyabi::settle_anchor(phylo_ctx *c)
+{
+	if (!c->anchor_pending || !c->pend_range) return 0;
+	HIPOK(c, hipSetDevice(c->device));
+	if (sync_stream(c)) return 1;
+	const size_t qb = c->pend_qb, qe = c->pend_qe, nq = qe - qb;
+	const bool stats_only = c->pend_stats_only;
+	c->anchor_pending = c->pend_range = c->pend_stats_only = false;
+	const uint32_t *hr = c->h_rng.p, *dmisc = hr + 3 * nq + 1;
+	size_t flagged = 0;
+	for (size_t j = 0; j < nq; j++) flagged += hr[2 * nq + 1 + j] != 0;
+	c->stats["ms:anchor_setup"] += c->pend_t1 - c->pend_t0;
+	c->stats["ms:anchor_total"] += c->pend_t2 - c->pend_t0; // (the host's part: the device's time is in the wait for the result)
+	c->stats["n:anchor_calls_without_a_wait"] += 1;
+	if (stats_only) { // the gathered blocks have replaced this context's view of the lists; what the flags say went round with the blocks
+		c->stats["n:anchor_calls"] += 1;
+		c->stats["count:query_bases"] += c->pend_total;
+		c->stats["count:chunks"] += c->pend_nch;
+		c->stats["count:filtered_homologies"] += (double)hr[2 * nq];
+		c->stats["count:pool_blocks_used"] += dmisc[2];
+		c->stats["count:overrun_runs"] += dmisc[5];
+		c->stats["count:overrun_bytes_compared"] += dmisc[6];
+		c->stats["anchor:chunk"] = c->pend_C;
+		return 0;
+	}
+	if (dmisc[3]) return c->fail("phase A scratch overflow (code %u: 1 chunk log, 2 bridge pool, 3 homology buffer)", dmisc[3]);
+	if (flagged) { // a list needs the host's std::sort: the long way round
+		c->stats["count:anchor_block_calls_repeated"] += 1;
+		return anchor_impl(c, qb, qe, 0);
+	}
+	adopt_device_lists(c, qb, qe, false);
+	return 0;
+}
+
+// defer 1: when this call covers every genome and leaves lists and projection on the device, do not wait for its flags —
 // the caller queues phase B behind it and reads them with the result (phylo_anchor_compare); anchor_pending says so.
-int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, bool defer)
+// defer 2: a range of the queries on its way into the exchange between ranks (phylo_anchor_block_device): the block is
+// written behind the filter, nothing is waited for; pend_range says so, settle_anchor reads the flags when somebody asks.
+int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, int defer)
 {
 	if (!c) return 1;
+	if (settle_anchor(c)) return 1;
 	c->anchor_pending = false;
 	if (!c->have_ref) return c->fail("phylo_anchor: no reference set");
 	if (q_begin > q_end || q_end > c->n) return c->fail("phylo_anchor: bad query range");
@@ -94,7 +161,7 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, bool defer)
 		HIPOK(c, c->a_chunk_query.ensure(nchp + 1));
 		HIPOK(c, c->a_spec_cnt.ensure(nchp + 1));
 		// one visited bit per byte of the genome buffer (chains address it by buffer offset)
-		HIPOK(c, c->a_visited.ensure((c->goff[c->n - 1] + c->glen[c->n - 1]) / 32 + 8));
+		HIPOK(c, c->a_visited.ensure((c->goff[c->n - 1] + c->glen[c->n - 1]) / 32 + 8 + 128));
 		HIPOK(c, c->a_misc.ensure(32)); // counters and flags
 		HIPOK(c, c->a_spec_anchors.ensure(P.anchor_slots + 1));
 		HIPOK(c, c->a_qanc0.ensure(nq));
@@ -129,7 +196,8 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, bool defer)
 	for (size_t j = 0; j < nq; j++) total += c->glen[q_begin + j];
 	HIPOK(c, hipMemsetAsync(c->a_misc.p, 0, 32 * 4, st));
 	if (nch) { // the words of this call's queries (their genomes lie back to back in the buffer)
-		const uint64_t w0 = c->goff[q_begin] / 32, w1 = (c->goff[q_end - 1] + c->glen[q_end - 1]) / 32 + 1;
+		// (on 256-byte boundaries: one fill instead of head, body and tail; the neighbours' bits are nobody's between two calls)
+		const uint64_t w0 = c->goff[q_begin] / 32 / 64 * 64, w1 = ((c->goff[q_end - 1] + c->glen[q_end - 1]) / 32 + 1 + 63) / 64 * 64;
 		HIPOK(c, hipMemsetAsync(c->a_visited.p + w0, 0, (size_t)(w1 - w0) * 4, st));
 	}
 
@@ -232,7 +300,7 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, bool defer)
 		if (!nch) HIPOK(c, hipMemsetAsync(c->a_flt.p, 0, 4, st)); // (else: the bridges' prepare kernel zeroes it, below)
 		if (tail_eager) {
 			if (make_pileup(c, 0, 1, &TP)) return 1;
-			HIPOK(c, c->b_flag.ensure(4));
+			HIPOK(c, c->b_flag.ensure(8));
 			HIPOK(c, c->b_first.ensure(project_index_entries(TP) + 1));
 			if (!nch) HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 16, st));
 			c->eager_five = c->pileup_five && c->opt_pairs_kernel != 0; // (the matrix-core path lists the '!' instead: compare_pileup)
@@ -352,15 +420,31 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, bool defer)
 	c->host_stale.clear();
 	if (device_filter) {
 		uint32_t *hr = c->h_rng.p; // [0, 2nq) ranges, [2nq] the lists' total, [2nq + 1, 3nq + 1) flags (a_flt as it lies), then the misc words
-		HIPOK(c, hipMemcpyAsync(hr, c->b_hom_rng.p, 2 * nq * 4, hipMemcpyDeviceToHost, st));
-		HIPOK(c, hipMemcpyAsync(hr + 2 * nq, c->a_flt.p, (nq + 1) * 4, hipMemcpyDeviceToHost, st));
-		HIPOK(c, hipMemcpyAsync(hr + 3 * nq + 1, c->a_misc.p, 32, hipMemcpyDeviceToHost, st));
+		if (defer != 2) { // (defer 2: the kernel that writes the exchange block writes these words as well)
+			HIPOK(c, hipMemcpyAsync(hr, c->b_hom_rng.p, 2 * nq * 4, hipMemcpyDeviceToHost, st));
+			HIPOK(c, hipMemcpyAsync(hr + 2 * nq, c->a_flt.p, (nq + 1) * 4, hipMemcpyDeviceToHost, st));
+			HIPOK(c, hipMemcpyAsync(hr + 3 * nq + 1, c->a_misc.p, 32, hipMemcpyDeviceToHost, st));
+		}
 		HIPOK(c, hipGetLastError());
-		if (defer && tail_eager) { // (tail_eager: all genomes, device filter, projection queued)
-			c->pend_t0 = t0, c->pend_t1 = t1, c->pend_t2 = now_ms(), c->pend_total = (double)total, c->pend_nch = nch, c->pend_C = P.C;
+		c->pend_t0 = t0, c->pend_t1 = t1, c->pend_total = (double)total, c->pend_nch = nch, c->pend_C = P.C;
+		if (defer == 1 && tail_eager) { // (tail_eager: all genomes, device filter, projection queued)
+			c->pend_t2 = now_ms();
 			c->att_homs = c->b_homs.p;
 			c->homs_staged = true;
 			c->eager_valid = true;
+			c->anchor_pending = true;
+			return 0;
+		}
+		if (defer == 2) {
+			// the block behind the filter; what the filter's flags and the chains' counters say (a list that needs the host's
+			// std::sort, scratch that overflowed) rides in its header to every rank (block_export_kernel)
+			if (queue_block_export(c, nq, c->xb_block, c->xb_maxq, c->xb_cap, c->a_flt.p + 1, c->a_misc.p, hr)) return 1;
+			c->pend_t2 = now_ms();
+			c->att_homs = c->b_homs.p;
+			c->pend_range = true;
+			c->pend_stats_only = false;
+			c->pend_qb = q_begin;
+			c->pend_qe = q_end;
 			c->anchor_pending = true;
 			return 0;
 		}
@@ -371,32 +455,11 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, bool defer)
 		size_t flagged = 0;
 		for (size_t j = 0; j < nq; j++) flagged += hr[2 * nq + 1 + j] != 0;
 		if (!flagged) {
-			const size_t N = c->n;
-			c->att_homs = c->b_homs.p;
-			c->att_rng_on_device = false;
-			if (c->att_begin.size() != N) {
-				c->att_begin.assign(N, 0);
-				c->att_count.assign(N, 0);
-			}
-			c->host_stale.assign(N, 0);
-			for (size_t j = 0; j < nq; j++) {
-				c->att_begin[q_begin + j] = hr[2 * j];
-				c->att_count[q_begin + j] = hr[2 * j + 1] - hr[2 * j];
-				c->host_stale[q_begin + j] = 1;
-			}
-			c->homs_staged = full;
-			c->eager_valid = tail_eager;
+			c->host_stale.assign(c->n, 0);
+			adopt_device_lists(c, q_begin, q_end, tail_eager);
 			c->stats["ms:anchor_setup"] += t1 - t0;
 			c->stats["ms:anchor_gpu"] += t2d - t1;
 			c->stats["ms:anchor_total"] += now_ms() - t0;
-			c->stats["n:anchor_calls"] += 1;
-			c->stats["count:query_bases"] += (double)total;
-			c->stats["count:chunks"] += nch;
-			c->stats["count:filtered_homologies"] += (double)hr[2 * nq];
-			c->stats["count:pool_blocks_used"] += dmisc[2];
-			c->stats["count:overrun_runs"] += dmisc[5];
-			c->stats["count:overrun_bytes_compared"] += dmisc[6];
-			c->stats["anchor:chunk"] = P.C;
 			return 0;
 		}
 		c->stats["count:queries_left_to_the_host"] += (double)flagged;
@@ -476,7 +539,7 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, bool defer)
 		}
 		if (eager) {
 			if (make_pileup(c, 0, 1, &EP)) return 1;
-			HIPOK(c, c->b_flag.ensure(4));
+			HIPOK(c, c->b_flag.ensure(8));
 			HIPOK(c, c->b_first.ensure(project_index_entries(EP) + 1));
 			HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 16, st));
 			c->eager_five = c->pileup_five && c->opt_pairs_kernel != 0; // (the matrix-core path lists the '!' instead: compare_pileup)
@@ -583,6 +646,26 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, bool defer)
 	return 0;
 }
 
-int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end) { return anchor_impl(c, q_begin, q_end, false); }
+int phylo_anchor(phylo_ctx *c, size_t q_begin, size_t q_end) { return anchor_impl(c, q_begin, q_end, 0); }
+
+// Phase A of a rank's block of queries with its exchange block written behind it, nothing waited for: the caller's
+// all-gather goes straight behind it on the stream.  (With the host's sort + filter asked for, option "filter" = 1,
+// the lists pass through the host anyway: then this is phylo_anchor + phylo_export_block_device.)
+int phylo_anchor_block_device(phylo_ctx *c, size_t q_begin, size_t q_end, void *dev_block, size_t max_queries, size_t cap_records)
+{
+	if (!c) return 1;
+	if (q_begin > q_end || q_end > c->n || !dev_block) return c->fail("phylo_anchor_block_device: bad arguments");
+	const size_t nq = q_end - q_begin;
+	if (max_queries < nq || max_queries % 4 || max_queries == 0) return c->fail("phylo_anchor_block_device: max_queries must be a multiple of 4 and hold the block's queries");
+	if (4 + max_queries + 4 * cap_records >= 0xffffffffull) return c->fail("phylo_anchor_block_device: block too large");
+	if (c->filter_mode == 1 || nq == 0) {
+		if (anchor_impl(c, q_begin, q_end, 0)) return 1;
+		return phylo_export_block_device(c, q_begin, q_end, dev_block, max_queries, cap_records);
+	}
+	c->xb_block = dev_block;
+	c->xb_maxq = max_queries;
+	c->xb_cap = cap_records;
+	return anchor_impl(c, q_begin, q_end, 2);
+}
 
 } // extern "C"

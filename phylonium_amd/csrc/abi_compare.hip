@@ -69,7 +69,7 @@ static void pair_segments(const phylo_ctx *c, size_t i, size_t j, std::vector<Se
 
 static int compare_segments(phylo_ctx *c, size_t part, size_t nparts, uint64_t *subst, uint64_t *homologs)
 {
-	if (ensure_host_lists(c, 0, c->n)) return 1;
+	if (ensure_host_lists(c, 0, c->n)) return 1; // (settles a queued phase A first)
 	size_t N = c->n;
 	std::vector<Segment> segs;
 	std::vector<uint32_t> seg_pair; // pair index of each segment
@@ -85,19 +85,7 @@ static int compare_segments(phylo_ctx *c, size_t part, size_t nparts, uint64_t *
 			(void)before;
 		}
 	std::vector<uint64_t> out(segs.size());
-	if (!segs.empty()) {
-		HIPOK(c, c->s_segs.ensure(segs.size()));
-		HIPOK(c, c->s_out.ensure(segs.size()));
-		HIPOK(c, hipMemcpyAsync(c->s_segs.p, segs.data(), segs.size() * sizeof(Segment), hipMemcpyHostToDevice, c->stream));
-		int blocks = std::min<int>(c->n_cu * 8, (int)((segs.size() + 3) / 4));
-		{
-			KernelSpan s(c, "seqcmp_batch");
-			launch_seqcmp_batch(c->d_genomes, c->s_segs.p, (uint32_t)segs.size(), c->s_out.p, blocks, c->stream);
-		}
-		HIPOK(c, hipGetLastError());
-		HIPOK(c, hipMemcpyAsync(out.data(), c->s_out.p, segs.size() * 8, hipMemcpyDeviceToHost, c->stream));
-		if (sync_stream(c)) return 1;
-	}
+	if (!segs.empty() && run_segments(c, c->d_genomes, segs.data(), segs.size(), out.data(), "seqcmp_batch")) return 1;
 	double sites = 0;
 	for (size_t s = 0; s < segs.size(); s++) {
 		auto pr = pairs[seg_pair[s]];
@@ -162,30 +150,31 @@ static double widen_result(phylo_ctx *c, const uint32_t *sym, uint64_t *subst, u
 
 // u32 upper triangle: tri[k] = substitutions, tri[P + k] = homologs of pair (i < j), k = i (2N - i - 1) / 2 + (j - i - 1):
 // what crosses the wire between ranks (a tally is at most the reference's length, which is below 2^31)
+// flag (may be null): the TRI_TAIL words of the part's report go behind the triangle on the way — what this part's comparison
+// has to say, in a form that adds up over the parts like the tallies do: {the projection's list of '!' overflowed, a gathered
+// list is not sorted and disjoint, a gathered block overflowed its capacity, 1 per part, a rank's phase A needs the host
+// (phylo_anchor_block_device: the verdict rode in its block's header), 0, 0, 0}.  A rank queues its whole comparison and the
+// collective behind it without a host round trip; whoever reads the summed triangle reads the ranks' reports with it.
 __global__ __launch_bounds__(256) void pack_triangle_kernel(uint32_t N, const unsigned long long *__restrict__ s,
-															 const unsigned long long *__restrict__ h, uint32_t *__restrict__ tri)
+															 const unsigned long long *__restrict__ h, uint32_t *__restrict__ tri,
+															 const uint32_t *__restrict__ flag, int att)
 {
 	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (flag && t == 0) {
+		uint32_t *tail = tri + (uint64_t)N * (N - 1);
+		tail[0] = (flag[0] & 2u) ? 1u : 0u;
+		tail[1] = att && flag[1] ? 1u : 0u;
+		tail[2] = att && flag[2] ? 1u : 0u;
+		tail[3] = 1u;
+		tail[4] = att && flag[6] ? 1u : 0u;
+		tail[5] = tail[6] = tail[7] = 0u;
+	}
 	if (t >= (uint64_t)N * N) return;
 	const uint32_t i = (uint32_t)(t / N), j = (uint32_t)(t % N);
 	if (i >= j) return;
 	const uint64_t P = (uint64_t)N * (N - 1) / 2, k = (uint64_t)i * (2ull * N - i - 1) / 2 + (j - i - 1);
 	tri[k] = (uint32_t)s[t];
 	tri[P + k] = (uint32_t)h[t];
-}
-
-// The four words behind a part's triangle (phylo_triangle_words): what this part's comparison has to report, in a form
-// that adds up over the parts like the tallies do — {the projection's list of '!' overflowed, a gathered list is not
-// sorted and disjoint, a gathered block overflowed its capacity, 1 per part}.  A rank queues its whole comparison and
-// the collective behind it without a host round trip; whoever reads the summed triangle reads the ranks' flags with it.
-__global__ void triangle_flags_kernel(const uint32_t *__restrict__ flag, int att, uint32_t *__restrict__ tail)
-{
-	if (threadIdx.x == 0) {
-		tail[0] = (flag[0] & 2u) ? 1u : 0u;
-		tail[1] = att && flag[1] ? 1u : 0u;
-		tail[2] = att && flag[2] ? 1u : 0u;
-		tail[3] = 1u;
-	}
 }
 
 // A (summed) triangle straight into the caller's two n x n u64 matrices in host memory that the device can address
@@ -235,6 +224,8 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 	const bool dev_out = out_mode != 0;
 	size_t N = c->n;
 	hipStream_t st = c->stream;
+	// (a phase A queued by phylo_anchor_block_device whose blocks were never gathered and attached: its lists first)
+	if (c->anchor_pending && c->pend_range && !c->pend_stats_only && settle_anchor(c)) return 1;
 	Pileup P;
 	if (make_pileup(c, part, nparts, &P)) return 1;
 
@@ -291,7 +282,7 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		if (sync_stream(c)) return 1; // hom_rng goes out of scope
 		c->stats["ms:compare_hom_upload"] += now_ms() - t0;
 	}
-	HIPOK(c, c->b_flag.ensure(4));
+	HIPOK(c, c->b_flag.ensure(8));
 	HIPOK(c, c->b_first.ensure(project_index_entries(P) + 1));
 	unsigned long long *acc_s, *acc_h; // where the pair kernel accumulates
 	if (out_mode == 1) {
@@ -315,9 +306,12 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 	const bool projected = c->homs_staged && c->eager_valid && part == 0 && nparts == 1;
 	HIPOK(c, c->b_bang.ensure(2 * (size_t)c->bang_cap + 2));
 	if (!projected) {
-		HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 4, st)); // (words 1 and 2 belong to phylo_attach_blocks_device)
-		HIPOK(c, hipMemsetAsync(c->b_flag.p + 3, 0, 4, st)); // the count of listed '!'
-		launch_tile_index(P, query_src(c), dev_homs, c->b_hom_rng.p, c->b_first.p, 0, (uint32_t)N, st);
+		if (N && P.W) { // (the tile index zeroes the projection's flag words on the way: [0] its '!' flag, [3] the count of listed '!')
+			launch_tile_index(P, query_src(c), dev_homs, c->b_hom_rng.p, c->b_first.p, 0, (uint32_t)N, st, c->b_flag.p);
+		} else {
+			HIPOK(c, hipMemsetAsync(c->b_flag.p, 0, 4, st)); // (words 1 and 2 belong to phylo_attach_blocks_device)
+			HIPOK(c, hipMemsetAsync(c->b_flag.p + 3, 0, 4, st));
+		}
 	}
 	// Three planes and the plain pair kernel unless '!' turns up among the projected positions (the projection raises
 	// a flag); then all five planes and the kernel that reads D and B.  The context remembers the outcome of its last
@@ -353,13 +347,15 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		c->tiles_at = c->b_tiles.p;
 	}
 	bool do_correct = false; // three planes under the matrix-core kernel: the listed '!' are settled before the tallies leave
+	bool queued_report = false; // the part's report is written with the packed triangle (out_mode 2, matrix-core path)
 	auto finish_tallies = [&]() { // the packed triangle for the wire; mirror images for the matrices (u32 on the way to the host)
 		if (do_correct && c->bang_cap) {
 			KernelSpan s(c, "pileup_bang_correct");
 			launch_bang_correct(P, query_src(c), dev_homs, c->b_hom_rng.p, c->b_bang.p, c->b_flag.p + 3, c->bang_cap, acc_s, st);
 		}
-		if (out_mode == 2)
-			hipLaunchKernelGGL(pack_triangle_kernel, dim3((uint32_t)((N * N + 255) / 256)), dim3(256), 0, st, (uint32_t)N, acc_s, acc_h, (uint32_t *)subst);
+		if (out_mode == 2) // (the queued path: the part's report rides behind the triangle; the '!' corrections before it may have raised flag[0])
+			hipLaunchKernelGGL(pack_triangle_kernel, dim3((uint32_t)((N * N + 255) / 256)), dim3(256), 0, st, (uint32_t)N, acc_s, acc_h, (uint32_t *)subst,
+							   queued_report ? c->b_flag.p : (const uint32_t *)nullptr, c->att_unchecked ? 1 : 0);
 		else if (out_mode == 1)
 			launch_symmetrise((uint32_t)N, acc_s, acc_h, st);
 		else
@@ -445,7 +441,7 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 	uint64_t *hs = c->h_mat.p;
 	auto fetch = [&]() -> int { // the flag, and the result unless it stays on the device
 		HIPOK(c, hipGetLastError());
-		HIPOK(c, hipMemcpyAsync(flagp, c->b_flag.p, 12, hipMemcpyDeviceToHost, st));
+		HIPOK(c, hipMemcpyAsync(flagp, c->b_flag.p, 28, hipMemcpyDeviceToHost, st));
 		if (!dev_out) HIPOK(c, hipMemcpyAsync(hs, c->b_sym32.p, 2 * N * N * 4, hipMemcpyDeviceToHost, st));
 		return sync_stream(c);
 	};
@@ -456,15 +452,18 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 	const bool sparse = !mtiles.empty() && !(projected && c->eager_five);
 	const bool have_five = sparse ? false : (projected ? c->eager_five : c->pileup_five); // the planes this attempt works on
 	bool bang = !sparse && c->pileup_five && have_five;
-	if (!projected && project(have_five)) return 1;
+	if (!projected) {
+		c->eager_valid = false; // the planes now hold this call's projection (another part, other planes), not phase A's
+		if (project(have_five)) return 1;
+	}
 	double t1 = now_ms();
 	do_correct = sparse;
 	if (out_mode == 2 && sparse) {
 		// A part's triangle on the matrix-core path: everything is queued — pair kernel, the '!' corrections, the packed
-		// triangle and, behind it, what this part has to report (triangle_flags_kernel) — and the call returns without
+		// triangle with, behind it, what this part has to report (pack_triangle_kernel) — and the call returns without
 		// a host round trip: the caller's collective goes straight behind it on the stream.
+		queued_report = true;
 		if (pairs(bang)) return 1;
-		hipLaunchKernelGGL(triangle_flags_kernel, dim3(1), dim3(64), 0, st, c->b_flag.p, c->att_unchecked ? 1 : 0, (uint32_t *)subst + N * (N - 1));
 		HIPOK(c, hipGetLastError());
 		c->att_unchecked = false;
 		c->stats["ms:compare_project_phase"] += t1 - t0;
@@ -472,11 +471,12 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		return 0;
 	}
 	if (pairs(bang) || fetch()) return 1;
-	const bool att_bad = c->att_unchecked && (flagp[1] || flagp[2]);
+	const bool att_bad = c->att_unchecked && (flagp[1] || flagp[2] || flagp[6]);
 	c->att_unchecked = false;
 	if (att_bad)
-		return c->fail(flagp[2] ? "the lists gathered from the ranks overflowed their blocks' capacity (phylo_attach_blocks_device)"
-								: "a gathered list is not sorted by projected start, disjoint and inside the reference");
+		return c->fail(flagp[2]   ? "the lists gathered from the ranks overflowed their blocks' capacity (phylo_attach_blocks_device)"
+					   : flagp[6] ? "a rank's phase A needs the host (a list with tied starts, or scratch that overflowed): repeat the pass with phylo_anchor + phylo_export_block_device"
+								  : "a gathered list is not sorted by projected start, disjoint and inside the reference");
 	uint32_t flag = *flagp;
 	if (sparse) flag = (flag & 2u) ? 1u : 0u; // only a '!' list beyond its capacity sends this path to the five planes
 	do_correct = false;
@@ -490,8 +490,8 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 	}
 	if (!sparse) c->pileup_five = flag != 0;
 	if (out_mode == 2) { // (this path has looked at its flags itself: nothing to report but "a part")
-		const uint32_t tail[4] = {0, 0, 0, 1};
-		HIPOK(c, hipMemcpyAsync((uint32_t *)subst + N * (N - 1), tail, 16, hipMemcpyHostToDevice, st));
+		const uint32_t tail[TRI_TAIL] = {0, 0, 0, 1, 0, 0, 0, 0};
+		HIPOK(c, hipMemcpyAsync((uint32_t *)subst + N * (N - 1), tail, sizeof tail, hipMemcpyHostToDevice, st));
 		HIPOK(c, hipStreamSynchronize(st));
 	}
 	if (dev_out) {
@@ -574,7 +574,7 @@ int phylo_compare_triangle_device(phylo_ctx *c, size_t part, size_t nparts, uint
 	return rc;
 }
 
-size_t phylo_triangle_words(size_t n) { return n * (n - 1) + 4; }
+size_t phylo_triangle_words(size_t n) { return n * (n - 1) + TRI_TAIL; }
 
 // the caller's result matrix as the device sees it, when the caller keeps handing the same buffer over: registered
 // (mapped) the second time it is seen, for as long as the context lives
@@ -583,6 +583,10 @@ static void *host_matrix_on_device(phylo_ctx *c, void *p, size_t bytes)
 	// (a buffer of its own pages only: an allocation of a megabyte comes from mmap, while a small one shares its pages
 	// with whatever else the heap holds — and the runtime then takes copies to those neighbours for copies into the
 	// registered range)
+	if (c->res.map && c->res.n == c->n) { // the library's own page-locked home of the result (phylo_result_matrices): nothing to register
+		if (p == (void *)c->res.subst()) return (char *)c->res.dev + 4096;
+		if (p == (void *)c->res.homologs()) return (char *)c->res.dev + 4096 + c->res.matrix_words() * 8;
+	}
 	if (!c->opt_result_zero_copy || bytes < ((size_t)1 << 20)) return nullptr;
 	for (auto &r : c->host_regs)
 		if (r.ptr == p && r.bytes == bytes) {
@@ -616,7 +620,7 @@ int phylo_triangle_to_matrices(phylo_ctx *c, const uint32_t *dev_tri, uint64_t *
 	HIPOK(c, c->b_sym32.ensure(2 * N * N + 4));
 	const double t0 = now_ms();
 	uint32_t *tail = (uint32_t *)(c->h_mat.p + 2 * N * N); // the parts' flags (phylo_triangle_words), read with the result
-	unsigned long long *h_sites = (unsigned long long *)(c->h_mat.p + 2 * N * N + 2);
+	unsigned long long *h_sites = (unsigned long long *)(c->h_mat.p + 2 * N * N + 4);
 	void *ds = nullptr, *dh = nullptr;
 	if ((((uintptr_t)subst | (uintptr_t)homologs) & 15u) == 0) { // (the kernel stores 16 bytes at a time)
 		ds = host_matrix_on_device(c, subst, N * N * 8);
@@ -632,7 +636,7 @@ int phylo_triangle_to_matrices(phylo_ctx *c, const uint32_t *dev_tri, uint64_t *
 		hipLaunchKernelGGL(triangle_to_host_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, c->stream, (uint32_t)N, dev_tri,
 						   (unsigned long long *)ds, (unsigned long long *)dh, d_sites);
 		HIPOK(c, hipGetLastError());
-		HIPOK(c, hipMemcpyAsync(tail, dev_tri + N * (N - 1), 16, hipMemcpyDeviceToHost, c->stream));
+		HIPOK(c, hipMemcpyAsync(tail, dev_tri + N * (N - 1), TRI_TAIL * 4, hipMemcpyDeviceToHost, c->stream));
 		HIPOK(c, hipMemcpyAsync(h_sites, d_sites, 8, hipMemcpyDeviceToHost, c->stream));
 		if (sync_stream(c)) return 1;
 		sites = (double)*h_sites;
@@ -641,7 +645,7 @@ int phylo_triangle_to_matrices(phylo_ctx *c, const uint32_t *dev_tri, uint64_t *
 		hipLaunchKernelGGL(sym32_from_triangle_kernel, dim3((uint32_t)((N * N + 255) / 256)), dim3(256), 0, c->stream, (uint32_t)N, dev_tri, c->b_sym32.p);
 		HIPOK(c, hipGetLastError());
 		HIPOK(c, hipMemcpyAsync(c->h_mat.p, c->b_sym32.p, 2 * N * N * 4, hipMemcpyDeviceToHost, c->stream));
-		HIPOK(c, hipMemcpyAsync(tail, dev_tri + N * (N - 1), 16, hipMemcpyDeviceToHost, c->stream));
+		HIPOK(c, hipMemcpyAsync(tail, dev_tri + N * (N - 1), TRI_TAIL * 4, hipMemcpyDeviceToHost, c->stream));
 		if (sync_stream(c)) return 1;
 		const double t1 = now_ms();
 		sites = widen_result(c, (const uint32_t *)c->h_mat.p, subst, homologs);
@@ -649,6 +653,8 @@ int phylo_triangle_to_matrices(phylo_ctx *c, const uint32_t *dev_tri, uint64_t *
 		c->stats["ms:triangle_widen"] += now_ms() - t1;
 	}
 	c->stats["count:compare_sites"] += 0.5 * sites;
+	if (settle_anchor(c)) return 1; // (a phase A queued by phylo_anchor_block_device: its statistics)
+	if (tail[4]) return c->fail("a rank's phase A needs the host (a list with tied starts, or scratch that overflowed): repeat the pass with phylo_anchor + phylo_export_block_device");
 	if (tail[2]) return c->fail("the lists gathered from the ranks overflowed their blocks' capacity (phylo_attach_blocks_device)");
 	if (tail[1]) return c->fail("a gathered list is not sorted by projected start, disjoint and inside the reference");
 	if (tail[0]) return c->fail("more '!' inside homologies than the genomes hold separators (lists installed by a caller that overlap on the query): compare with option pairs_kernel = 1");
@@ -704,7 +710,7 @@ static int anchor_finish(phylo_ctx *c)
 int phylo_anchor_compare(phylo_ctx *c, uint64_t *subst, uint64_t *homologs)
 {
 	if (!c) return 1;
-	int rc = anchor_impl(c, 0, c->n, true);
+	int rc = anchor_impl(c, 0, c->n, 1);
 	if (rc) return rc;
 	if (!c->anchor_pending) return phylo_compare(c, 0, 1, subst, homologs);
 	rc = phylo_compare(c, 0, 1, subst, homologs); // (synchronises the stream whichever way it ends)
@@ -713,7 +719,7 @@ int phylo_anchor_compare(phylo_ctx *c, uint64_t *subst, uint64_t *homologs)
 	if (f == 1) return 1;
 	if (f == 0) return rc;
 	c->stats["count:anchor_compare_calls_repeated"] += 1;
-	rc = anchor_impl(c, 0, c->n, false);
+	rc = anchor_impl(c, 0, c->n, 0);
 	if (rc) return rc;
 	return phylo_compare(c, 0, 1, subst, homologs);
 }

@@ -63,6 +63,7 @@ void phylo_ctx_destroy(phylo_ctx *c)
 	(void)hipSetDevice(c->device);
 	(void)hipStreamSynchronize(c->stream);
 	c->pool.reset();
+	phylo_result_close(c);
 	c->h_cnt.release();
 	c->h_rng.release();
 	c->h_raw.release();
@@ -126,6 +127,8 @@ void phylo_ctx_destroy(phylo_ctx *c)
 	c->b_clk.release();
 	c->s_segs.release();
 	c->s_out.release();
+	c->s_piece0.release();
+	c->h_piece0.release();
 	for (TimedSpan &s : c->spans) {
 		(void)hipEventDestroy(s.a);
 		(void)hipEventDestroy(s.b);

@@ -7,6 +7,7 @@
 //   abi_anchor.hip     phase A: plan, chain kernels, fold, sort + filter (process.cxx:433-458)
 //   abi_lists.hip      homology lists in and out, the exchange between ranks, complete deletion
 //   abi_compare.hip    phase B: projection, pair tallies, results; both phases as one call (process.cxx:517-549)
+//   abi_result.hip     the result's home in page-locked memory, private or shared by the ranks of a node
 //   abi_host.hip       seam B0 (seqcmp / revseqcmp) and the host-side helpers (FASTA, suffix array, PHYLIP)
 // Mirrors process() of /root/reference/src/process.cxx:408-556.  There is no CPU compute fallback: every entry
 // point that does the path's arithmetic launches HIP kernels and fails if no device is usable.
@@ -253,6 +254,16 @@ struct phylo_ctx {
 	bool anchor_pending = false; // a deferred phase A is queued: its flags (h_rng) have not been read yet
 	double pend_t0 = 0, pend_t1 = 0, pend_t2 = 0, pend_total = 0;
 	uint32_t pend_nch = 0, pend_C = 0;
+	// ... for a range of the queries, its exchange block written behind it (phylo_anchor_block_device): the lists are described
+	// on the device only until phyabi::settle_anchor has read the flags — or the gathered blocks are attached, after which only
+	// its statistics are still to be collected (pend_stats_only)
+	bool pend_range = false, pend_stats_only = false;
+	size_t pend_qb = 0, pend_qe = 0;
+	void *xb_block = nullptr; // where anchor_impl (defer = 2) writes the block
+	size_t xb_maxq = 0, xb_cap = 0;
+	std::vector<uint32_t> xb_bounds;        // the ranks' bounds as phylo_attach_blocks_device uploaded them last ...
+	const uint32_t *xb_bounds_at = nullptr; // ... and where (skipped while both stay the same)
+	bool flags_zeroed = false;              // the block export of a queued phase A has zeroed b_flag for the attach that follows
 	bool homs_staged = false;
 	// ... and has projected them for the whole reference (part 0 of 1); with five planes or three
 	bool eager_valid = false, eager_five = false;
@@ -275,6 +286,8 @@ struct phylo_ctx {
 	uint32_t bang_cap = 0;    // as many as the genomes hold separators (a separator is projected at most once)
 	DevBuf<Segment> s_segs;
 	DevBuf<uint64_t> s_out;
+	DevBuf<uint32_t> s_piece0; // a batch of few, long segments: their pieces' prefix sums (seqcmp_kernels.hip)
+	PinBuf<uint32_t> h_piece0;
 
 	// host staging and workers
 	PinBuf<uint32_t> h_cnt;
@@ -294,6 +307,19 @@ struct phylo_ctx {
 	};
 	std::vector<HostReg> host_regs;
 	int opt_result_zero_copy = 0;
+	// the result's own home (abi_result.hip): page-locked host memory the library owns — private to this context, or a POSIX
+	// shared-memory segment every rank of a node maps, so that each rank's device writes its rows of the result itself
+	struct ResultHome {
+		void *map = nullptr;      // header (a 64-byte slot per rank: the steps it has delivered), then the two n x n u64 matrices
+		size_t bytes = 0, n = 0, ranks = 0;
+		void *dev = nullptr;      // the mapping as this context's device addresses it
+		bool shared = false, creator = false, linked = false;
+		std::string name;
+		uint64_t step = 0;        // deliveries so far (the ranks call in step)
+		size_t matrix_words() const { return (n * n + 7) / 8 * 8; } // (either matrix starts on a 64-byte boundary: the device stores 16 bytes at a time)
+		uint64_t *subst() const { return (uint64_t *)((char *)map + 4096); }
+		uint64_t *homologs() const { return subst() + matrix_words(); }
+	} res;
 	std::unique_ptr<WorkerPool> pool;
 	// cached phase-A plan
 	bool plan_valid = false;
@@ -385,6 +411,16 @@ int sync_stream(phylo_ctx *c)
 	return 0;
 }
 
+// a phase A queued by phylo_anchor_block_device that nobody will ask about any more (new genomes, another reference)
+void drop_pending_anchor(phylo_ctx *c)
+{
+	if (c->anchor_pending && c->pend_range) {
+		(void)hipSetDevice(c->device);
+		(void)sync_stream(c);
+	}
+	c->anchor_pending = c->pend_range = c->pend_stats_only = false;
+}
+
 QuerySrc query_src(const phylo_ctx *c) { return QuerySrc{c->d_Q2.p, c->d_goff.p, c->d_QBAD.p, c->d_qbad_off.p}; }
 
 WorkerPool &workers(phylo_ctx *c)
@@ -411,11 +447,22 @@ namespace phyabi {
 // abi_genomes.hip: sorted non-ACGT positions of `lens.size()` sequences (genomes, or S as one) into `out`
 PHYABI_LOCAL int bad_lists(phylo_ctx *c, const uint8_t *base, const uint64_t *d_off, const uint32_t *d_len, const std::vector<uint64_t> &lens,
 			  DevBuf<uint32_t> &out, std::vector<uint32_t> &off, size_t n);
-// abi_anchor.hip: phase A for queries [q_begin, q_end); defer: leave its flags for phylo_anchor_compare to read
-PHYABI_LOCAL int anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, bool defer);
+// abi_anchor.hip: phase A for queries [q_begin, q_end); defer 1: all genomes, the projection queued behind it, its flags left for
+// phylo_anchor_compare to read; defer 2: a range, its exchange block (c->xb_*) written behind it, its flags left for settle_anchor
+PHYABI_LOCAL int anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, int defer);
+// a phase A queued by phylo_anchor_block_device whose flags nobody has read yet: wait for it and take its lists in (repeating
+// it the long way when a list needs the host); after the gathered blocks were attached: its statistics only.  0, or 1 on error
+PHYABI_LOCAL int settle_anchor(phylo_ctx *c);
+// abi_lists.hip: the exchange block of queries [q_begin, q_end) from where phase A's device filter left the lists (queued);
+// flt_flags / misc: the filter's per-query flags and phase A's counters, whose verdict rides in the block's header (or null)
+// host_out (with them): page-locked words the kernel fills as anchor_impl's copies would (ranges, total, flags, counters)
+PHYABI_LOCAL int queue_block_export(phylo_ctx *c, size_t nq, void *dev_block, size_t max_queries, size_t cap_records, const uint32_t *flt_flags,
+								   const uint32_t *misc, uint32_t *host_out);
 // abi_lists.hip
 PHYABI_LOCAL int ensure_host_lists(phylo_ctx *c, size_t g0, size_t g1);
 PHYABI_LOCAL int fetch_att_ranges(phylo_ctx *c);
+// abi_host.hip: out[s] = seqcmp / revseqcmp of segment s of `base` (device), for n segments given on the host; waits for the result
+PHYABI_LOCAL int run_segments(phylo_ctx *c, const uint8_t *base, const phy::Segment *segs, size_t n, uint64_t *out, const char *span);
 // abi_compare.hip: the pileup of part `part` of `nparts` (a range of 64-window tiles of the reference)
 PHYABI_LOCAL int make_pileup(phylo_ctx *c, size_t part, size_t nparts, phy::Pileup *out);
 } // namespace phyabi

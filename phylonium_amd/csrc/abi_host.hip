@@ -25,16 +25,42 @@ int phylo_seqcmp_batch(phylo_ctx *c, size_t n, const uint32_t *ga, const uint64_
 		if (len[s] > 0xffffffffull) return c->fail("segment %zu too long", s);
 		segs[s] = Segment{c->goff[ga[s]] + offa[s], c->goff[gb[s]] + offb[s], (uint32_t)len[s], rev && rev[s] ? 1u : 0u};
 	}
+	return run_segments(c, c->d_genomes, segs.data(), n, out, "seqcmp_batch");
+}
+
+// A batch of segments through the byte kernels.  With fewer segments than a launch has wavefronts — one seqcmp() of
+// megabytes, a handful of long homologies — the segments' 4 KiB pieces are dealt out over all wavefronts instead of
+// a segment per wavefront (seqcmp_kernels.hip); the pieces' prefix sums are made here.
+int phyabi::run_segments(phylo_ctx *c, const uint8_t *base, const Segment *segs, size_t n, uint64_t *out, const char *span)
+{
+	if (!n) return 0;
+	if (n >= 0xffffffffull) return c->fail("more than 2^32 segments in one batch");
 	HIPOK(c, c->s_segs.ensure(n));
 	HIPOK(c, c->s_out.ensure(n));
-	HIPOK(c, hipMemcpyAsync(c->s_segs.p, segs.data(), n * sizeof(Segment), hipMemcpyHostToDevice, c->stream));
-	int blocks = std::min<int>(c->n_cu * 8, (int)((n + 3) / 4));
+	hipStream_t st = c->stream;
+	HIPOK(c, hipMemcpyAsync(c->s_segs.p, segs, n * sizeof(Segment), hipMemcpyHostToDevice, st));
+	const uint32_t *piece0 = nullptr;
+	uint64_t npieces = 0;
+	if (n < seqcmp_split_waves(c->n_cu)) {
+		HIPOK(c, c->h_piece0.ensure(n + 1));
+		for (size_t s = 0; s < n; s++) {
+			c->h_piece0.p[s] = (uint32_t)npieces;
+			npieces += (segs[s].len + SEQCMP_PIECE - 1) / SEQCMP_PIECE;
+		}
+		c->h_piece0.p[n] = (uint32_t)npieces;
+		if (npieces > 2 * n && npieces < 0xffffffffull) { // (else: nothing to deal out)
+			HIPOK(c, c->s_piece0.ensure(n + 1));
+			HIPOK(c, hipMemcpyAsync(c->s_piece0.p, c->h_piece0.p, (n + 1) * 4, hipMemcpyHostToDevice, st));
+			HIPOK(c, hipMemsetAsync(c->s_out.p, 0, n * 8, st));
+			piece0 = c->s_piece0.p;
+		}
+	}
 	{
-		KernelSpan s(c, "seqcmp_batch");
-		launch_seqcmp_batch(c->d_genomes, c->s_segs.p, (uint32_t)n, c->s_out.p, blocks, c->stream);
+		KernelSpan s(c, span);
+		launch_seqcmp_batch(base, c->s_segs.p, (uint32_t)n, piece0, (uint32_t)npieces, c->s_out.p, c->n_cu, st, n == 1 ? segs : nullptr);
 	}
 	HIPOK(c, hipGetLastError());
-	HIPOK(c, hipMemcpyAsync(out, c->s_out.p, n * 8, hipMemcpyDeviceToHost, c->stream));
+	HIPOK(c, hipMemcpyAsync(out, c->s_out.p, n * 8, hipMemcpyDeviceToHost, st));
 	return sync_stream(c);
 }
 
@@ -89,18 +115,12 @@ size_t b0_call(const char *a, const char *b, size_t length, int rev)
 		segs.push_back(Segment{o, stride + (rev ? length - o - m : o), (uint32_t)m, rev ? 1u : 0u});
 	}
 	std::vector<uint64_t> out(segs.size());
-	if (c->s_segs.ensure(segs.size()) != hipSuccess || c->s_out.ensure(segs.size()) != hipSuccess) return b0_fail("out of device memory");
 	hipStream_t st = c->stream;
 	if (hipMemcpyAsync(t.buf.p, a, length, hipMemcpyHostToDevice, st) != hipSuccess ||
-		hipMemcpyAsync(t.buf.p + stride, b, length, hipMemcpyHostToDevice, st) != hipSuccess ||
-		hipMemcpyAsync(c->s_segs.p, segs.data(), segs.size() * sizeof(Segment), hipMemcpyHostToDevice, st) != hipSuccess)
+		hipMemcpyAsync(t.buf.p + stride, b, length, hipMemcpyHostToDevice, st) != hipSuccess)
 		return b0_fail("upload failed");
-	const int blocks = std::max<int>(1, std::min<int>(c->n_cu * 8, (int)((length / 4096) + 1)));
-	launch_seqcmp_batch(t.buf.p, c->s_segs.p, (uint32_t)segs.size(), c->s_out.p, blocks, st);
-	if (hipGetLastError() != hipSuccess ||
-		hipMemcpyAsync(out.data(), c->s_out.p, segs.size() * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
-		hipStreamSynchronize(st) != hipSuccess)
-		return b0_fail("kernel launch or read-back failed");
+	// (one call = one segment per GiB: its pieces are dealt out over all wavefronts of the launch)
+	if (run_segments(c, t.buf.p, segs.data(), segs.size(), out.data(), "seqcmp_b0")) return b0_fail(nullptr);
 	uint64_t total = 0;
 	for (uint64_t v : out) total += v;
 	return (size_t)total;

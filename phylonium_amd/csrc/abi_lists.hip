@@ -14,6 +14,7 @@ static int unpack_lists(phylo_ctx *c, size_t q_begin, size_t q_end, const uint64
 // Host lists of genomes [g0, g1) that only exist as attached device records: fetch them.
 int phyabi::ensure_host_lists(phylo_ctx *c, size_t g0, size_t g1)
 {
+	if (settle_anchor(c)) return 1;
 	if (c->host_stale.empty()) return 0;
 	if (fetch_att_ranges(c)) return 1;
 	for (size_t g = g0; g < g1; g++) {
@@ -245,7 +246,7 @@ int phylo_attach_packed_device(phylo_ctx *c, const void *dev_records, const uint
 	HIPOK(c, hipMemcpyAsync(c->b_hom_rng.p, c->h_rng.p, 2 * N * 4, hipMemcpyHostToDevice, c->stream));
 	// the pileup needs every list sorted by projected start, disjoint and inside the reference (what phase A's
 	// filter leaves): a buffer that is anything else is refused here rather than tallied wrongly later
-	HIPOK(c, c->b_flag.ensure(4));
+	HIPOK(c, c->b_flag.ensure(8));
 	HIPOK(c, hipMemsetAsync(c->b_flag.p + 1, 0, 4, c->stream));
 	launch_check_lists((const DevHom *)dev_records, c->b_hom_rng.p, (uint32_t)N, c->L, c->b_flag.p + 1, c->stream);
 	uint32_t bad_lists = 0;
@@ -267,12 +268,17 @@ int phylo_attach_packed_device(phylo_ctx *c, const void *dev_records, const uint
 }
 
 // ── the exchange between ranks without the host in it ──
-// A rank's block: 4 header words {records in the block, overflow, queries, 0}, max_queries list lengths, then cap
-// records of 16 bytes.  Every rank's block has the same size, so one all-gather assembles all of them; the receiving
-// side works the per-genome ranges out on the device.
+// A rank's block: 4 header words {records in the block, overflow, queries, this rank's phase A needs the host},
+// max_queries list lengths, then cap records of 16 bytes.  Every rank's block has the same size, so one all-gather
+// assembles all of them; the receiving side works the per-genome ranges out on the device.
 static const uint32_t XB_HDR = 4;
+// flt_flags / misc (phylo_anchor_block_device: the block is written behind a phase A nobody has waited for): the filter's
+// per-query flags (a list with tied starts, which only the host's std::sort orders as the reference does) and the chains'
+// counters (misc[3]: scratch overflow) — either makes this block, and with it the pass, one to repeat the long way
 __global__ __launch_bounds__(256) void block_export_kernel(const DevHom *__restrict__ src, const uint32_t *__restrict__ rng, uint32_t nq,
-															 uint32_t maxq, uint32_t cap, uint32_t *__restrict__ block)
+															 uint32_t maxq, uint32_t cap, uint32_t *__restrict__ block,
+															 const uint32_t *__restrict__ flt_flags, const uint32_t *__restrict__ misc,
+															 uint32_t *__restrict__ host_out, uint32_t *__restrict__ zero8)
 {
 	const uint32_t j = blockIdx.x; // a slot of the header: the block's query j, or padding
 	__shared__ uint32_t part[256];
@@ -286,15 +292,31 @@ __global__ __launch_bounds__(256) void block_export_kernel(const DevHom *__restr
 	}
 	const uint32_t off = part[0];
 	const uint32_t cnt = j < nq ? rng[2 * j + 1] - rng[2 * j] : 0u;
-	if (threadIdx.x == 0) {
-		block[XB_HDR + j] = cnt;
-		if (j + 1 == maxq) {
-			block[0] = off + cnt;
-			block[2] = nq;
-			block[3] = 0;
+	if (j + 1 == maxq) { // the header (no memset before this kernel: every word of it is written here, once)
+		uint32_t needs_host = 0;
+		if (flt_flags) {
+			for (uint32_t t = threadIdx.x; t < nq; t += blockDim.x) needs_host |= flt_flags[t];
+			if (threadIdx.x == 0) needs_host |= misc[3];
 		}
-		if (off + cnt > cap) block[1] = 1; // (cleared by the caller's memset of the header)
+		needs_host = (uint32_t)__syncthreads_or((int)(needs_host != 0));
+		if (threadIdx.x == 0) {
+			block[0] = off + cnt;
+			block[1] = off + cnt > cap ? 1u : 0u; // (the slots' sums ascend: the last one holds the block's total)
+			block[2] = nq;
+			block[3] = needs_host ? 1u : 0u;
+		}
 	}
+	if (threadIdx.x == 0) block[XB_HDR + j] = cnt;
+	if (host_out) { // what anchor_impl's copies bring to the host on the path that waits (h_rng's layout)
+		if (threadIdx.x == 0 && j < nq) {
+			host_out[2 * j] = rng[2 * j];
+			host_out[2 * j + 1] = rng[2 * j + 1];
+			host_out[2 * nq + 1 + j] = flt_flags[j];
+		}
+		if (j == 0 && threadIdx.x < 8) host_out[3 * nq + 1 + threadIdx.x] = misc[threadIdx.x];
+		if (j == 0 && threadIdx.x == 8) host_out[2 * nq] = flt_flags[-1]; // (a_flt[0]: the lists' total)
+	}
+	if (zero8 && j == 0 && threadIdx.x < 8) zero8[threadIdx.x] = 0; // b_flag for the attach and the comparison that follow
 	if (off + cnt > cap) return;
 	DevHom *dst = (DevHom *)(block + XB_HDR + maxq) + off;
 	const DevHom *from = src + (j < nq ? rng[2 * j] : 0u);
@@ -312,6 +334,7 @@ __global__ __launch_bounds__(256) void block_attach_kernel(const uint32_t *__res
 	// its header reach beyond the records it holds, and the kernels that follow must not read there
 	const bool usable = !(blk[1] || blk[2] != nq || blk[0] > cap);
 	if (threadIdx.x == 0 && !usable) flags[2] = 1;
+	if (threadIdx.x == 0 && blk[3]) flags[6] = 1; // that rank's phase A needs the host: the pass is repeated (TRI_TAIL)
 	__shared__ uint32_t carry;
 	__shared__ uint32_t scan[256];
 	if (threadIdx.x == 0) carry = 0;
@@ -350,6 +373,7 @@ int phylo_export_block_device(phylo_ctx *c, size_t q_begin, size_t q_end, void *
 	const size_t nq = q_end - q_begin;
 	if (max_queries < nq || max_queries % 4 || max_queries == 0) return c->fail("phylo_export_block_device: max_queries must be a multiple of 4 and hold the block's queries");
 	if (XB_HDR + max_queries + 4 * cap_records >= 0xffffffffull) return c->fail("phylo_export_block_device: block too large");
+	if (settle_anchor(c)) return 1;
 	// the lists must be where phase A's device filter left them: this context's buffer, ranges by local query index
 	bool on_device = !c->host_stale.empty() && c->att_homs == c->b_homs.p && c->plan_valid && c->plan_qb == q_begin && c->plan_qe == q_end;
 	for (size_t j = q_begin; j < q_end && on_device; j++) on_device = c->host_stale[j] != 0;
@@ -379,15 +403,29 @@ int phylo_export_block_device(phylo_ctx *c, size_t q_begin, size_t q_end, void *
 		HIPOK(c, hipMemcpyAsync(dev_block, blk, words * 4, hipMemcpyHostToDevice, c->stream));
 		return sync_stream(c); // (the staging buffer is reused by other calls)
 	}
-	HIPOK(c, hipMemsetAsync(dev_block, 0, XB_HDR * 4, c->stream));
+	return queue_block_export(c, nq, dev_block, max_queries, cap_records, nullptr, nullptr, nullptr);
+}
+
+int phyabi::queue_block_export(phylo_ctx *c, size_t nq, void *dev_block, size_t max_queries, size_t cap_records, const uint32_t *flt_flags,
+							   const uint32_t *misc, uint32_t *host_out)
+{
+	uint32_t *host_dev = nullptr, *zero8 = nullptr;
+	if (host_out) { // (the queued pass: page-locked words as the device addresses them; b_flag zeroed on the way)
+		HIPOK(c, hipHostGetDevicePointer((void **)&host_dev, host_out, 0));
+		HIPOK(c, c->b_flag.ensure(8));
+		zero8 = c->b_flag.p;
+		c->flags_zeroed = true;
+	}
 	hipLaunchKernelGGL(block_export_kernel, dim3((uint32_t)max_queries), dim3(256), 0, c->stream, (const DevHom *)c->b_homs.p,
-					   (const uint32_t *)c->b_hom_rng.p, (uint32_t)nq, (uint32_t)max_queries, (uint32_t)cap_records, (uint32_t *)dev_block);
+					   (const uint32_t *)c->b_hom_rng.p, (uint32_t)nq, (uint32_t)max_queries, (uint32_t)cap_records, (uint32_t *)dev_block, flt_flags,
+					   misc, host_dev, zero8);
 	HIPOK(c, hipGetLastError());
 	return 0;
 }
 
 int phyabi::fetch_att_ranges(phylo_ctx *c)
 {
+	if (settle_anchor(c)) return 1;
 	if (!c->att_rng_on_device) return 0;
 	const size_t N = c->n;
 	std::vector<uint32_t> r(2 * N);
@@ -421,13 +459,27 @@ int phylo_attach_blocks_device(phylo_ctx *c, const void *dev_all, size_t world, 
 	HIPOK(c, hipSetDevice(c->device));
 	const size_t N = c->n;
 	HIPOK(c, c->b_hom_rng.ensure(2 * N + world + 2));
-	HIPOK(c, c->b_flag.ensure(4));
-	HIPOK(c, c->h_rng.ensure(3 * N + world + 16));
-	uint32_t *hb = c->h_rng.p; // pinned: the copy below must not wait for pageable staging
-	for (size_t r = 0; r <= world; r++) hb[r] = (uint32_t)bounds[r];
+	HIPOK(c, c->b_flag.ensure(8));
+	// (a phase A queued by phylo_anchor_block_device: its lists are in the gathered buffer now and what its flags say went
+	// round with its block; its statistics are collected at the next wait.  h_rng still receives its copies: the bounds go elsewhere)
+	const bool queued = c->anchor_pending && c->pend_range; // (then the host has none of this rank's own lists yet either)
+	if (queued) c->pend_stats_only = true;
 	uint32_t *d_bounds = c->b_hom_rng.p + 2 * N;
-	HIPOK(c, hipMemcpyAsync(d_bounds, hb, (world + 1) * 4, hipMemcpyHostToDevice, c->stream));
-	HIPOK(c, hipMemsetAsync(c->b_flag.p + 1, 0, 8, c->stream));
+	bool same = c->xb_bounds_at == d_bounds && c->xb_bounds.size() == world + 1;
+	for (size_t r = 0; r <= world && same; r++) same = c->xb_bounds[r] == (uint32_t)bounds[r];
+	if (!same) { // (the ranks' bounds change with the genomes, not from pass to pass)
+		HIPOK(c, c->h_cnt.ensure(world + 8));
+		uint32_t *hb = c->h_cnt.p; // pinned: the copy below must not wait for pageable staging
+		c->xb_bounds.resize(world + 1);
+		for (size_t r = 0; r <= world; r++) hb[r] = c->xb_bounds[r] = (uint32_t)bounds[r];
+		HIPOK(c, hipMemcpyAsync(d_bounds, hb, (world + 1) * 4, hipMemcpyHostToDevice, c->stream));
+		c->xb_bounds_at = d_bounds;
+	}
+	if (!(queued && c->flags_zeroed)) { // (a queued pass: its block export zeroed the flags)
+		HIPOK(c, hipMemsetAsync(c->b_flag.p + 1, 0, 8, c->stream));
+		HIPOK(c, hipMemsetAsync(c->b_flag.p + 6, 0, 4, c->stream));
+	}
+	c->flags_zeroed = false;
 	hipLaunchKernelGGL(block_attach_kernel, dim3((uint32_t)world), dim3(256), 0, c->stream, (const uint32_t *)dev_all, d_bounds,
 					   (uint32_t)max_queries, (uint32_t)cap_records, c->b_hom_rng.p, c->b_flag.p);
 	launch_check_lists((const DevHom *)dev_all, c->b_hom_rng.p, (uint32_t)N, c->L, c->b_flag.p + 1, c->stream);
@@ -439,7 +491,7 @@ int phylo_attach_blocks_device(phylo_ctx *c, const void *dev_all, size_t world, 
 	c->att_unchecked = true;
 	std::vector<uint8_t> was = c->host_stale;
 	c->host_stale.assign(N, 1);
-	for (size_t g = keep_begin; g < keep_end; g++) c->host_stale[g] = was.size() == N ? was[g] : 0;
+	for (size_t g = keep_begin; g < keep_end && !queued; g++) c->host_stale[g] = was.size() == N ? was[g] : 0;
 	c->homs_staged = true;
 	c->eager_valid = false;
 	return 0;

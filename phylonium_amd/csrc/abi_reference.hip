@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void build_slots_kernel(const uint32_t *__rest
 int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t threshold)
 {
 	if (!c) return 1;
+	drop_pending_anchor(c);
 	if (ref_idx >= c->n) return c->fail("reference index %zu out of range (n=%zu)", ref_idx, c->n);
 	HIPOK(c, hipSetDevice(c->device));
 	double t0 = now_ms();

@@ -77,8 +77,17 @@ struct Segment {
 	uint32_t len;
 	uint32_t rev; // 0: seqcmp, 1: revseqcmp
 };
-void launch_seqcmp_batch(const uint8_t *base, const Segment *segs, uint32_t nseg, uint64_t *out, int blocks,
-						 hipStream_t st);
+// words behind a part's u32 triangle (phylo_triangle_words): {the projection's list of '!' overflowed, a gathered list is not
+// sorted and disjoint, a gathered block overflowed its capacity, 1 per part, a rank's phase A needs the host, 0, 0, 0}
+static const uint32_t TRI_TAIL = 8;
+static const uint32_t SEQCMP_PIECE = 4096; // bytes a wavefront compares per round: four 16-byte chunks per lane and string
+uint32_t seqcmp_split_waves(int n_cu);     // wavefronts of a full launch: with fewer segments than that the pieces are dealt out instead
+// out[s] = seqcmp / revseqcmp of segment s.  piece0 = nullptr: a wavefront per segment.  piece0 = device array of nseg + 1
+// prefix sums of the segments' pieces (ceil(len / SEQCMP_PIECE)), npieces = piece0[nseg]: the pieces over all wavefronts,
+// which add to out[] (zeroed by the caller).
+// one: the batch's only segment, as the host holds it (split launches: spares the kernel its look-ups)
+void launch_seqcmp_batch(const uint8_t *base, const Segment *segs, uint32_t nseg, const uint32_t *piece0, uint32_t npieces, uint64_t *out,
+						 int n_cu, hipStream_t st, const Segment *one = nullptr);
 
 // pileup_kernels.hip
 struct DevHom {
@@ -105,8 +114,9 @@ struct QuerySrc {
 // hom_rng[2g], hom_rng[2g+1]: genome g's sorted, disjoint list is homs[begin, end).
 // Both take a range — genomes [g0, g1), genome tiles [tg0, tg1) of project_genomes_per_tile()
 // genomes — so that the projection can run for the genomes whose lists are ready.
+// zero_flags (may be null): the projection's flag words [0] and [3] of it are zeroed on the way (the kernel runs before the projection)
 void launch_tile_index(const Pileup &P, const QuerySrc &Q, const DevHom *homs, const uint32_t *hom_rng, uint32_t *first, uint32_t g0,
-					   uint32_t g1, hipStream_t st);
+					   uint32_t g1, hipStream_t st, uint32_t *zero_flags = nullptr);
 // five_planes = false: V, N0, N1 only; *bang_flag is raised when '!' was projected and D, B are needed after all
 // bang_list / bang_cap (three planes only; may be null / 0): the projected '!' are listed there — {genome | reverse << 31,
 // position} each, counted in bang_flag[3], bit 1 of bang_flag[0] on overflow — for launch_bang_correct

@@ -60,6 +60,9 @@ static const uint32_t PROJ_TW = 64; // words per tile
 #ifndef PHY_PROJ_TG
 #define PHY_PROJ_TG 32
 #endif
+#ifndef PHY_PROJ_V2
+#define PHY_PROJ_V2 1 // the projection's covering-homology look-up without a loop (0: rounds 1-4's searching loop only; A/B builds)
+#endif
 static const uint32_t PROJ_TG = PHY_PROJ_TG; // genomes per tile (LDS with three planes: 3*64*(TG+1)*4 = 25 KB at 32 → 5 blocks per CU)
 static const uint32_t PROJ_GPW = PROJ_TG / 4; // genomes per wavefront
 
@@ -88,10 +91,11 @@ static __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *__res
 }
 __global__ __launch_bounds__(256) void tile_index_kernel(Pileup P, QuerySrc Q, const DevHom *__restrict__ homs,
 														  const uint32_t *__restrict__ hom_rng,
-														  uint32_t *__restrict__ first, uint32_t g0, uint32_t g1)
+														  uint32_t *__restrict__ first, uint32_t g0, uint32_t g1, uint32_t *__restrict__ zero_flags)
 {
 	const uint32_t ntw = (P.W + PROJ_TW - 1) / PROJ_TW;
 	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (zero_flags && t == 0) zero_flags[0] = zero_flags[3] = 0; // the projection's '!' flag and its count of listed '!' (words 1, 2 are the attach's)
 	if (t >= (uint64_t)(g1 - g0) * ntw) return;
 	const uint32_t g = g0 + (uint32_t)(t / ntw), tw = (uint32_t)(t % ntw);
 	const uint64_t tid = (uint64_t)g * ntw + tw;
@@ -138,6 +142,7 @@ __global__ __launch_bounds__(256) void project_kernel(Pileup P, QuerySrc Q,
 	constexpr uint32_t NP = FIVE ? 5u : 3u;
 	__shared__ uint32_t tile[NP][PROJ_TW][PROJ_TG + 1];
 	__shared__ DevHom hcache[PROJ_TG][PROJ_HM];
+	__shared__ uint32_t hends[PROJ_TG][PROJ_HM]; // where the cached homologies end on the reference (0xffffffff: none)
 	__shared__ uint32_t hlo[PROJ_TG], hend[PROJ_TG], tbad[PROJ_TG];
 	__shared__ uint32_t below[33]; // below[t] = plane-order mask of the positions < t
 	const uint32_t ntw = (P.W + PROJ_TW - 1) / PROJ_TW;
@@ -162,6 +167,7 @@ __global__ __launch_bounds__(256) void project_kernel(Pileup P, QuerySrc Q,
 			if (lo + e < h1) hm = homs[lo + e];
 		}
 		hcache[gl][e] = hm;
+		hends[gl][e] = hm.start == 0xffffffffu ? 0xffffffffu : hm.start + hm.len;
 		if (e == 0) {
 			hlo[gl] = lo;
 			hend[gl] = h1;
@@ -268,6 +274,82 @@ __global__ __launch_bounds__(256) void project_kernel(Pileup P, QuerySrc Q,
 			}
 		}
 	};
+#if PHY_PROJ_V2
+	// Round 5.  The covering homology of a window without a loop: among the tile's cached descriptors (sorted, disjoint) it
+	// is the one whose index is the number of cached homologies that end at or before the window's first position — eight
+	// compares against wave-uniform LDS words.  A window takes that homology AND the one behind it (a window with a list
+	// boundary inside — one in fifty, but nearly every wavefront holds such a window — needs both; the second one's
+	// mask is empty otherwise and its load repeats the first's address), both loads of all the wavefront's genomes are
+	// issued together, and only what neither covers — a third piece in 32 positions, homologies beyond the cache —
+	// goes through the searching loop of rounds 1-4 below.
+	struct Fast {
+		uint32_t mask, rev, more; // more: first homology the searching loop still has to look at (h1: none)
+		int32_t rel;              // query index of the lowest position read (may be < 0)
+	};
+	auto fast_piece = [&](const DevHom &hm, bool usable, Fast &f) { // -> does this homology end inside the window?
+		const uint32_t he = hm.start + hm.len;
+		const bool ov = usable && hm.start < x1 && he > x0;
+		const uint32_t s = ov && hm.start > x0 ? hm.start - x0 : 0u, e = !ov ? 0u : he < x1 ? he - x0 : 32u;
+		f.mask = below[e] & ~below[s];
+		f.rev = hm.rev;
+		f.rel = (int32_t)(hm.rev ? hm.iq + he - x1 : hm.iq + x0 - hm.start);
+		return ov && he < x1;
+	};
+	// (the wavefront's genomes in two rounds of PROJ_GPW / 2: eight loads in flight per lane, and registers for five blocks per CU)
+	constexpr uint32_t HG = PROJ_GPW / 2;
+#pragma unroll 1
+	for (uint32_t half = 0; half < 2; half++) {
+	Fast fa[HG], fb[HG];
+	uint32_t a0[HG], a1[HG], a2[HG], b0[HG], b1[HG], b2[HG];
+#pragma unroll
+	for (uint32_t u = 0; u < HG; u++) {
+		const uint32_t gi = wave + 4 * (u + half * HG), g = tg * PROJ_TG + gi;
+		const bool valid = g < P.N && w < P.W;
+		const uint32_t lo = hlo[gi], h1 = hend[gi];
+		uint32_t idx = 0;
+#pragma unroll
+		for (uint32_t e = 0; e < PROJ_HM; e++) idx += hends[gi][e] <= x0 ? 1u : 0u;
+		const DevHom ha = hcache[gi][idx < PROJ_HM ? idx : PROJ_HM - 1], hb = hcache[gi][idx + 1 < PROJ_HM ? idx + 1 : PROJ_HM - 1];
+		const bool a_ends = fast_piece(ha, valid && idx < PROJ_HM, fa[u]);
+		const bool b_ends = fast_piece(hb, a_ends && idx + 1 < PROJ_HM, fb[u]);
+		// what is left for the searching loop: everything when the cache holds nothing that reaches the window; the homologies
+		// behind the second piece when that one ends inside the window too; the ones behind the cache
+		uint32_t more = h1;
+		if (valid) {
+			if (idx >= PROJ_HM) more = lo + PROJ_HM;
+			else if (a_ends && idx + 1 >= PROJ_HM) more = lo + PROJ_HM;
+			else if (b_ends) more = lo + idx + 2;
+		}
+		fa[u].more = more < h1 ? more : h1;
+		if (!fa[u].mask) fa[u].rel = 0;
+		if (!fb[u].mask) fb[u].rel = fa[u].rel;
+		const uint32_t *base = Q.q2 + (Q.goff[g < P.N ? g : 0] >> 4);
+		struct { uint32_t a, b, c; } v;
+		__builtin_memcpy(&v, (const uint8_t __attribute__((address_space(1))) *)(uintptr_t)(base + (fa[u].rel >> 4)), 12);
+		a0[u] = v.a, a1[u] = v.b, a2[u] = v.c;
+		__builtin_memcpy(&v, (const uint8_t __attribute__((address_space(1))) *)(uintptr_t)(base + (fb[u].rel >> 4)), 12);
+		b0[u] = v.a, b1[u] = v.b, b2[u] = v.c;
+	}
+#pragma unroll
+	for (uint32_t u = 0; u < HG; u++) {
+		const uint32_t gi = wave + 4 * (u + half * HG), g = tg * PROJ_TG + gi;
+		uint32_t V = 0, N0 = 0, N1 = 0, D = 0, B = 0;
+		const int64_t q = (int64_t)Q.goff[g < P.N ? g : 0];
+		if (fa[u].mask) add_piece(Piece{q + fa[u].rel, fa[u].mask, fa[u].rev, 0u}, gi, a0[u], a1[u], a2[u], V, N0, N1, D, B);
+		if (fb[u].mask) add_piece(Piece{q + fb[u].rel, fb[u].mask, fb[u].rev, 0u}, gi, b0[u], b1[u], b2[u], V, N0, N1, D, B);
+		{
+			const uint32_t lo = hlo[gi], h1 = hend[gi];
+			uint32_t h = fa[u].more;
+			while (h < h1) {
+				const Piece more = find_piece(gi, q, h, lo, h1);
+				if (!more.mask) break;
+				uint32_t e0, e1, e2;
+				fetch(more, e0, e1, e2);
+				add_piece(more, gi, e0, e1, e2, V, N0, N1, D, B);
+				h = more.next;
+			}
+		}
+#else
 	Piece pc[PROJ_GPW];
 	uint32_t d0[PROJ_GPW], d1[PROJ_GPW], d2[PROJ_GPW];
 #pragma unroll
@@ -297,6 +379,7 @@ __global__ __launch_bounds__(256) void project_kernel(Pileup P, QuerySrc Q,
 				h = more.next;
 			}
 		}
+#endif
 		any_bang |= B;
 		tile[0][lane][gi] = V;
 		tile[1][lane][gi] = N0;
@@ -306,6 +389,9 @@ __global__ __launch_bounds__(256) void project_kernel(Pileup P, QuerySrc Q,
 			tile[NP - 1][lane][gi] = B;
 		}
 	}
+#if PHY_PROJ_V2
+	} // half
+#endif
 	if (any_bang) atomicOr(bang_flag, 1u);
 	__syncthreads();
 	// rows [w][g0..g0+31] out: 128 contiguous bytes per row; a thread keeps its genome
@@ -568,6 +654,7 @@ __global__ __launch_bounds__(64, 2) void pairs_mfma_kernel(Pileup P, const uint3
 	// clk (profiling only): the wavefronts' lifetimes in shader cycles and in ticks of the constant 100 MHz counter —
 	// their ratio is the clock the chip held under this kernel's mix of matrix and vector instructions
 	unsigned long long c0 = 0, r0 = 0;
+	if ((blockIdx.x & 127u) != 0) clk = nullptr; // (a sample of the wavefronts: two atomics each on the same two words add up otherwise)
 	if (clk) {
 		c0 = __builtin_amdgcn_s_memtime();
 		r0 = __builtin_amdgcn_s_memrealtime();
@@ -683,14 +770,14 @@ void launch_symmetrise(uint32_t N, unsigned long long *a, unsigned long long *b,
 // genomes [g0, g1) / genome tiles [tg0, tg1) of PROJ_TG genomes: the whole pileup, or the part
 // of it whose lists are ready (phase A projects eagerly, group by group)
 void launch_tile_index(const Pileup &P, const QuerySrc &Q, const DevHom *homs, const uint32_t *hom_rng, uint32_t *first, uint32_t g0,
-					   uint32_t g1, hipStream_t st)
+					   uint32_t g1, hipStream_t st, uint32_t *zero_flags)
 {
 	uint32_t ntw = (P.W + PROJ_TW - 1) / PROJ_TW;
 	if (g1 > P.N) g1 = P.N;
 	if (!ntw || g0 >= g1) return;
 	uint64_t entries = (uint64_t)(g1 - g0) * ntw;
 	hipLaunchKernelGGL(tile_index_kernel, dim3((uint32_t)((entries + 255) / 256)), dim3(256), 0, st, P, Q, homs, hom_rng, first,
-					   g0, g1);
+					   g0, g1, zero_flags);
 }
 void launch_project(const Pileup &P, bool five_planes, const QuerySrc &Q, const DevHom *homs,
 					const uint32_t *hom_rng, const uint32_t *first, uint32_t *bang_flag, uint32_t tg0, uint32_t tg1,

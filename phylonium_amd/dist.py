@@ -18,6 +18,8 @@ from .api import PACKED
 _FORCE_COLLECTIVES = False
 # tests: round 2's exchange (counts through the host, u64 matrices on the wire) instead of the block exchange
 _LEGACY_DEVICE_EXCHANGE = False
+# tests: without the node's shared home of the result (one rank fetches it, as before round 5)
+_SHARED_RESULT = True
 
 
 def query_shard(n, rank, world, lengths=None):
@@ -113,7 +115,9 @@ def exchange_homologies_device(ctx, n, rank, world, bounds, device):
 def _exchange_plan(ctx, n, rank, world, bounds, device):
     """Shape of the exchange blocks (list lengths per rank, record capacity), from this step's counts: the one
     place where the ranks wait for each other's numbers on the host.  Kept on the context and reused while the
-    lists fit (their sizes repeat from step to step; an overflow is detected on the device and re-plans)."""
+    lists fit (their sizes repeat from step to step; an overflow is detected on the device and re-plans).  With it the
+    node's shared home of the result (phylo_result_open): every rank's device writes its rows of the two matrices over
+    its own PCIe link; when a rank cannot map or register the segment, all fall back to one rank fetching the result."""
     qb, qe = bounds[rank], bounds[rank + 1]
     own = int(ctx.hom_counts(qb, qe).sum())
     t = torch.tensor([own], dtype=torch.int64, device=device)
@@ -123,34 +127,91 @@ def _exchange_plan(ctx, n, rank, world, bounds, device):
     maxq = max(bounds[r + 1] - bounds[r] for r in range(world))
     maxq = (maxq + 3) // 4 * 4 or 4
     nbytes = ctx.exchange_block_bytes(maxq, cap)
-    P = n * (n - 1) // 2
-    return {"maxq": maxq, "cap": cap, "bounds": tuple(bounds),
-            "block": torch.empty(nbytes, dtype=torch.uint8, device=device),
-            "all": torch.empty(world * nbytes, dtype=torch.uint8, device=device),
+    shared = False
+    if _SHARED_RESULT:
+        import os
+        import time
+        name = [None]
+        ok = 1
+        if rank == 0:
+            name[0] = "/phylonium_amd_%d_%x" % (os.getpid(), int(time.time() * 1e6) & 0xffffffff)
+            try:
+                ctx.result_open(name[0], create=True, ranks=world)
+            except Exception:
+                ok = 0
+        if world > 1:
+            td.broadcast_object_list(name, src=0)
+        if rank != 0:
+            try:
+                ctx.result_open(name[0], create=False, ranks=world)
+            except Exception:
+                ok = 0
+        t = torch.tensor([ok], dtype=torch.int64, device=device)
+        td.all_reduce(t, op=td.ReduceOp.MIN)
+        if rank == 0 and ok:
+            ctx.result_unlink()
+        shared = bool(int(t.item()))
+        if not shared:
+            ctx.result_close()
+    all_blocks = torch.empty(world * nbytes, dtype=torch.uint8, device=device)
+    return {"maxq": maxq, "cap": cap, "bounds": tuple(bounds), "nbytes": nbytes, "shared_result": shared,
+            "views": ctx.result_matrices() if shared else None,
+            # a rank's own block lies in its place of the gathered buffer: the all-gather fills the rest in place
+            "block": all_blocks[rank * nbytes:(rank + 1) * nbytes], "all": all_blocks,
             "tri": torch.empty(ctx.triangle_words(n), dtype=torch.int32, device=device)}
 
 
-def process_sharded_device(ctx, rank, world, bounds, device, out=None, result_rank=None, on_block=None):
+class _Repeat(Exception):
+    """A pass that every rank repeats (all of them read the same summed report): `how` says in which way."""
+
+    def __init__(self, how, msg):
+        super().__init__(msg)
+        self.how = how
+
+
+def _check_report(rep):
+    if int(rep[2]):
+        raise _Repeat("plan", "the lists gathered from the ranks overflowed their blocks' capacity")
+    if int(rep[4]):
+        raise _Repeat("anchor", "a rank's phase A needs the host (a list with tied starts, or scratch that overflowed)")
+    if int(rep[0]):
+        raise _Repeat("pairs", "more '!' inside homologies than the genomes hold separators: the vector-ALU pair kernels take the pass")
+    if int(rep[1]):
+        raise RuntimeError("a gathered list is not sorted by projected start, disjoint and inside the reference")
+
+
+def process_sharded_device(ctx, rank, world, bounds, device, out=None, result_rank=None, on_block=None, copy=True):
     """One step with the exchange left to the device: the context works on torch's current stream, so the library's
-    kernels and the collectives are ordered by the stream and the host waits twice — at the end of phase A (its
-    error and tie flags) and for the result.  Lists travel as fixed-shape blocks (one all-gather), tallies as a u32
-    upper triangle (one all-reduce, a quarter of the bytes of the two u64 matrices)."""
+    kernels and the collectives are ordered by the stream and the host waits ONCE, for the result.  Phase A of the rank's
+    queries is queued with its exchange block behind it (phylo_anchor_block_device); lists travel as fixed-shape blocks
+    (one all-gather); tallies as a u32 upper triangle (one all-reduce, a quarter of the bytes of the two u64 matrices);
+    every rank's device writes its rows of the result into the node's shared page-locked segment
+    (phylo_triangle_rows_to_result).  What a rank would have learnt at a wait of its own — a list that needs the host's
+    std::sort, an overflowing block, a '!' list beyond its capacity — comes back in the summed triangle's report, which
+    every rank reads: the pass is then repeated, by all of them alike, the long way."""
     n = ctx.n
     qb, qe = bounds[rank], bounds[rank + 1]
     stream = torch.cuda.current_stream(device).cuda_stream
     if getattr(ctx, "_on_stream", None) != stream:
         ctx.set_stream(stream)
         ctx._on_stream = stream
-    for attempt in range(2):
-        ctx.anchor(qb, qe)
+    slow_anchor, valu_pairs = False, False
+    for attempt in range(4):
         plan = getattr(ctx, "_xplan", None)
-        if plan is None or plan["bounds"] != tuple(bounds) or plan["tri"].numel() != ctx.triangle_words(n):
-            plan = ctx._xplan = _exchange_plan(ctx, n, rank, world, bounds, device)
+        usable = plan is not None and plan["bounds"] == tuple(bounds) and plan["tri"].numel() == ctx.triangle_words(n)
         try:
-            # everything from here to the result is queued on the stream: the block export, the all-gather, the attach, the
-            # comparison (its kernels and what it has to report ride in the triangle's last four words) and the reduction;
-            # the host waits once, for the result — or, on a rank that does not get it, for the 16 bytes of the report
-            ctx.export_block_device(qb, qe, plan["block"].data_ptr(), plan["maxq"], plan["cap"])
+            if valu_pairs:
+                ctx.set_option("pairs_kernel", 1)
+            # everything from here to the result is queued on the stream: phase A with the block export behind it, the
+            # all-gather, the attach, the comparison (its kernels and what it has to report ride in the triangle's last
+            # words), the all-reduce and the rows of the result
+            if usable and not slow_anchor:
+                ctx.anchor_block_device(qb, qe, plan["block"].data_ptr(), plan["maxq"], plan["cap"])
+            else:  # no plan yet (the blocks are sized from this pass's own lists), or a pass repeated the long way
+                ctx.anchor(qb, qe)
+                if not usable:
+                    plan = ctx._xplan = _exchange_plan(ctx, n, rank, world, bounds, device)
+                ctx.export_block_device(qb, qe, plan["block"].data_ptr(), plan["maxq"], plan["cap"])
             if on_block is not None:  # (the self-check's tests damage a record here: bench.py --test-corrupt-rank)
                 on_block(plan["block"], plan["maxq"])
             td.all_gather_into_tensor(plan["all"], plan["block"])
@@ -159,29 +220,57 @@ def process_sharded_device(ctx, rank, world, bounds, device, out=None, result_ra
             # (the vector-ALU pair kernel, option pairs_kernel = 1, waits for its flags itself: a block that overflowed
             # surfaces here, on every rank alike — all of them hold all blocks — and is planned again like the others)
             ctx.compare_triangle_device(rank, world, plan["tri"].data_ptr())
+            wants = result_rank is None or rank == result_rank
+            if plan["shared_result"]:
+                td.all_reduce(plan["tri"], op=td.ReduceOp.SUM)
+                rep = ctx.triangle_rows_to_result(plan["tri"].data_ptr(), n * rank // world, n * (rank + 1) // world, rank,
+                                                  world if wants else 0)
+                _check_report(rep)
+                if not wants:
+                    return None, None
+                s, h = plan["views"]
+                if out is not None:
+                    np.copyto(out[0], s)
+                    np.copyto(out[1], h)
+                    return out[0], out[1]
+                return (s.copy(), h.copy()) if copy else (s, h)
             if result_rank is None:  # every rank gets the matrices
                 td.all_reduce(plan["tri"], op=td.ReduceOp.SUM)
                 return ctx.triangle_to_matrices(plan["tri"].data_ptr(), out)
             # the job's one result, on one rank (as the reference prints one matrix): a reduce instead of the all-reduce, and
             # the other ranks neither copy 2 N^2 words home nor widen them on host cores the result's rank could use; the
-            # parts' reports are all-reduced beside it (16 bytes), so that every rank learns of a pass to repeat
-            report = plan["tri"][-4:].clone()
+            # parts' reports are all-reduced beside it (32 bytes), so that every rank learns of a pass to repeat
+            report = plan["tri"][-8:].clone()
             td.reduce(plan["tri"], dst=result_rank, op=td.ReduceOp.SUM)
             td.all_reduce(report, op=td.ReduceOp.SUM)
+            _check_report(report.cpu().numpy())
             if rank == result_rank:
                 return ctx.triangle_to_matrices(plan["tri"].data_ptr(), out)
-            rep = report.cpu()
-            if int(rep[2]):
-                raise RuntimeError("the lists gathered from the ranks overflowed their blocks' capacity")
-            if int(rep[0]) or int(rep[1]):
-                raise RuntimeError("a part of the comparison reported unusable lists")
             return None, None
-        except Exception as e:  # a block overflowed its capacity (every rank learns of it): plan again
-            if attempt == 0 and "overflow" in str(e):
-                ctx._xplan = None
-                continue
-            raise
-    raise RuntimeError("process_sharded_device: the exchange blocks overflowed twice")
+        except _Repeat as e:
+            how = e.how
+        except Exception as e:  # the library's own words for the same verdicts (the paths that wait for their flags themselves)
+            msg = str(e)
+            how = "plan" if "overflow" in msg and "scratch" not in msg else "anchor" if "needs the host" in msg else \
+                "pairs" if "pairs_kernel = 1" in msg else None
+            if how is None:
+                raise
+        finally:
+            if valu_pairs:
+                ctx.set_option("pairs_kernel", 0)
+        if how == "plan":
+            if getattr(ctx, "_xplan", None) is None:
+                raise RuntimeError("process_sharded_device: the exchange blocks overflowed twice")
+            ctx._xplan = None
+        elif how == "anchor":
+            if slow_anchor:
+                raise RuntimeError("process_sharded_device: phase A failed on the host's route as well")
+            slow_anchor = True
+        else:
+            if valu_pairs:
+                raise RuntimeError("process_sharded_device: the vector-ALU pair kernels reported a '!' list overflow")
+            valu_pairs = True
+    raise RuntimeError("process_sharded_device: the pass was repeated three times without a result")
 
 
 def shard_bounds(ctx, world, lengths=None):
@@ -214,7 +303,7 @@ def process_sharded(ctx, ref_idx, rank, world, device=None, lengths=None, set_re
     on_gpu = device is not None and torch.device(device).type == "cuda" and hasattr(ctx, "attach_packed_device")
     if on_gpu and (world > 1 or _FORCE_COLLECTIVES) and hasattr(ctx, "export_block_device") and not _LEGACY_DEVICE_EXCHANGE:
         # (phase A is this path's own first step — on the caller's stream, and again should the exchange blocks overflow)
-        return process_sharded_device(ctx, rank, world, bounds, device, out=out, result_rank=result_rank, on_block=on_block)
+        return process_sharded_device(ctx, rank, world, bounds, device, out=out, result_rank=result_rank, on_block=on_block, copy=copy)
     ctx.anchor(qb, qe)
     if on_gpu and (world > 1 or _FORCE_COLLECTIVES):
         # device-resident: records and tallies never visit the host between the ranks

@@ -404,6 +404,8 @@ bool verify_group_result(Run &r, const std::vector<PackedGenome> &pk, const std:
 		"                       genomes against a one-GPU run of those genomes), print the verdict and\n"
 		"                       every rank's timings as one JSON line on stderr; exit status 3 on failure\n"
 		"  -d, --device=N       GPU ordinal (default 0; with --gpus: the first of them)\n"
+		"      --teardown       Release the device context(s) before exiting (default: exit as soon\n"
+		"                       as the output is written)\n"
 		"      --gpus=N         Shard the queries (phase A) and the reference's windows (phase B) over N\n"
 		"                       GPUs: one host thread and one context per GPU, RCCL between them\n"
 		"                       (ranks share GPUs when the machine has fewer)\n"
@@ -424,7 +426,7 @@ int main(int argc, char *argv[])
 	std::random_device rd;
 	const char *seed_env = getenv("PHYLONIUM_AMD_SEED");
 	std::mt19937 prng(seed_env ? (std::mt19937::result_type)strtoul(seed_env, nullptr, 10) : rd());
-	int version_flag = 0, timing = 0, verify_ranks = 0, flags = 0, device = 0, gpus = 0;
+	int version_flag = 0, timing = 0, verify_ranks = 0, teardown = 0, flags = 0, device = 0, gpus = 0;
 	bool packed_ingest = true, host_sa = false;
 	long threads = 0;
 	bool two_pass = false;
@@ -442,6 +444,7 @@ int main(int argc, char *argv[])
 										   {"verbose", no_argument, NULL, 'v'},
 										   {"version", no_argument, &version_flag, 1},
 										   {"timing", no_argument, &timing, 1},
+										   {"teardown", no_argument, &teardown, 1},
 										   {"verify-ranks", no_argument, &verify_ranks, 1},
 										   {"ingest", required_argument, NULL, 0},
 										   {"sa", required_argument, NULL, 0},
@@ -617,6 +620,7 @@ int main(int argc, char *argv[])
 		ref_idx = pick_second_pass(q.size(), m);
 		m = process(r, ref_idx);
 	}
+	const double t_proc = now_s();
 	print_matrix(q, m, flags, bootstrap, ref_idx, prng);
 	t_done = now_s();
 	if (verify_ranks && r.grp && !(flags & (F_COMPLETE_DELETION | F_POSITIONS)) && !verify_group_result(r, pk, pk_q2, ref_idx, m, device)) RETURN_CODE = 3;
@@ -631,11 +635,11 @@ int main(int argc, char *argv[])
 		fprintf(stderr,
 				"timing: genomes %zu  bases %.0f  total %.3f s | read %.3f (%zu threads, %s)  wait-for-device %.3f  upload %.3f (device memory %.3f  copies %.3f  "
 				"install %.3f)  "
-				"wait-for-suffix-array %.3f (%s)  process+print %.3f  "
+				"wait-for-suffix-array %.3f (%s)  process+print %.3f (print %.3f)  "
 				"[suffix array %.3f  rest of the index %.3f (device allocations %.3f)  anchor %.3f  compare %.3f]\n",
 				q.size(), bases, t_done - t_start, t_read - t_start, read_threads, packed_ingest ? "packed" : "bytes", t_ctx - t_read, t_upload - t_ctx, stat("ms:genomes_alloc"), stat("ms:genomes_copy"),
 				stat("ms:genomes_install"),
-				t_sa - t_upload, host_sa ? "built on a host thread since the files were read" : "built on the device with the index", t_done - t_sa, stat("ms:ref_suffix_array"), stat("ms:ref_total") - stat("ms:ref_suffix_array"), stat("ms:ref_alloc"),
+				t_sa - t_upload, host_sa ? "built on a host thread since the files were read" : "built on the device with the index", t_done - t_sa, t_done - t_proc, stat("ms:ref_suffix_array"), stat("ms:ref_total") - stat("ms:ref_suffix_array"), stat("ms:ref_alloc"),
 				stat("ms:anchor_total"), stat("ms:compare_total"));
 	}
 	if (timing && r.grp) {
@@ -651,6 +655,13 @@ int main(int argc, char *argv[])
 		}
 		fprintf(stderr, "\n");
 	}
+	// The matrix is out: leave.  Taking the HIP runtime down in an orderly way (contexts, code objects, the driver's
+	// queues) costs a tenth of a second that nobody waits for a result in (tools/microbench/startup.hip: the same for an
+	// empty program); --teardown does it all the same.
+	std::cout.flush();
+	fflush(stdout);
+	fflush(stderr);
+	if (!teardown) _exit(RETURN_CODE);
 	if (r.grp) phylo_group_destroy(r.grp);
 	else phylo_ctx_destroy(r.ctx);
 	if (timing) fprintf(stderr, "timing: releasing the device context%s %.3f s\n", r.grp ? "s" : "", now_s() - t_done);

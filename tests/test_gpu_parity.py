@@ -149,14 +149,45 @@ def test_seqcmp_batch_all_lengths_and_alignments(ctx):
     assert got.tolist() == want
 
 
+def test_seqcmp_batch_few_long_segments_are_split_over_the_wavefronts(ctx):
+    """Fewer segments than the launch has wavefronts, and long ones: their 4 KiB pieces are dealt out over all wavefronts
+    (seqcmp_split_kernel) — lengths around the piece size, an empty segment between others, every alignment, both
+    directions, a segment of megabytes beside one of a byte; and one call with a single segment (one seqcmp())."""
+    rng = np.random.default_rng(11)
+    alpha = np.frombuffer(b"ACGT!", np.uint8)
+    L = 3_600_000
+    a = rng.choice(alpha, L, p=[.24, .24, .24, .24, .04])
+    b = a.copy()
+    idx = rng.random(L) < 0.15
+    b[idx] = rng.choice(alpha, int(idx.sum()))
+    ctx.set_genomes([a, b])
+    ga, oa, gb, ob, ln, rv, want = [], [], [], [], [], [], []
+    for k, n in enumerate([1, 0, 17, 4095, 4096, 4097, 8191, 12288, 70001, 1_000_003, 0, 2_500_000, 5, 3_599_990]):
+        for rev in (0, 1):
+            offa, offb = (3 * k + rev) % 11, (7 * k) % 13
+            if max(offa, offb) + n > L:
+                offa = offb = 0
+            ga.append(k % 2); gb.append(1 - k % 2); oa.append(offa); ob.append(offb); ln.append(n); rv.append(rev)
+            x, y = (a, b)[k % 2][offa:offa + n], (a, b)[1 - k % 2][offb:offb + n]
+            want.append(O.revseqcmp(x, y, n) if rev else O.seqcmp(x, y, n))
+    got = ctx.seqcmp_batch(ga, oa, gb, ob, ln, rv)
+    assert got.tolist() == want
+    for rev in (0, 1):
+        got = ctx.seqcmp_batch([0], [5], [1], [2], [L - 5], [rev])
+        assert got.tolist() == [(O.revseqcmp if rev else O.seqcmp)(a[5:], b[2:L - 3], L - 5)]
+
+
 def test_b0_reference_signatures(ctx):
     rng = np.random.default_rng(2)
     a = rng.integers(0, 256, 100000, dtype=np.uint8)  # arbitrary bytes, like any char*
     b = a.copy()
     b[rng.random(100000) < 0.3] = 7
-    for n in (0, 1, 15, 16, 17, 99999, 100000):
+    for n in (0, 1, 15, 16, 17, 4096, 8193, 99999, 100000):
         assert api.seqcmp(a, b, n) == O.seqcmp(a, b, n)
         assert api.revseqcmp(a, b, n) == O.revseqcmp(a, b, n)
+    # unaligned starts, as a caller's char* may be
+    assert api.seqcmp(a[3:], b[7:], 90001) == O.seqcmp(a[3:], b[7:], 90001)
+    assert api.revseqcmp(a[5:], b[1:], 90001) == O.revseqcmp(a[5:], b[1:], 90001)
 
 
 # ── the path ──
@@ -825,9 +856,10 @@ def test_block_exchange_between_three_contexts():
                 t = torch.empty(nw, dtype=torch.int32, device=dev)
                 c.compare_triangle_device(r, world, t.data_ptr())  # queued: what the part has to report rides behind its tallies
                 total += t
-            assert int(total[-1].item()) == world
+            tail = total[-8:].cpu().numpy()  # the parts' reports: {'!' overflow, unsorted list, block overflow, parts, phase A needs the host, 0, 0, 0}
+            assert int(tail[3]) == world and not tail[4:].any()
             if not fits:  # every rank saw every block's overflow mark; whoever reads the summed triangle learns of it
-                assert int(total[-2].item()) == world
+                assert int(tail[2]) == world
                 with pytest.raises(api.PhyloniumError, match="overflow"):
                     ctxs[1].triangle_to_matrices(total.data_ptr())
                 continue
@@ -847,6 +879,105 @@ def test_block_exchange_between_three_contexts():
                     assert hom_tuples_gpu(c.homologies(j)) == want, j
         s2, h2 = ctxs[2].compare()
         assert (s2 == so).all() and (h2 == ho).all()
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_queued_rank_pass_and_the_results_shared_home():
+    """A rank's pass without a host round trip (round 5): phase A of the rank's queries with its exchange block written
+    behind it (phylo_anchor_block_device — nothing waited for), the blocks attached, the parts' triangles summed, and every
+    rank's device writing ITS rows of the two matrices into one shared page-locked segment (phylo_result_open /
+    phylo_triangle_rows_to_result; three contexts stand for three ranks of a node).  Matrices and lists equal the
+    oracle's.  A query whose list has tied starts — only the host's std::sort orders those as the reference does — makes
+    its rank's block say so: the summed report tells every rank (word 4), and the pass repeated the long way is right.
+    A context that is asked for its lists before any block was attached waits for the queued phase A itself."""
+    import torch
+    gs = synth.make_genomes(13, 25000, seed=86, d_range=(0.01, 0.25), indel_per_mbp=300, inv_frac=0.08, contigs=2)
+    dup = np.concatenate([gs[5][1000:9000], synth.random_base(300, np.random.default_rng(1)), gs[5][1000:9000]])
+    dev = torch.device("cuda", 0)
+    world, bounds_of = 3, lambda n: [0, 3, 9, n]
+    # one stream for the three contexts and torch's own work, as a rank's context shares its stream with the collectives: what
+    # orders a rank's queued phase A before the others' reads of its block is the stream (handle 0 would mean "the context's own")
+    side = torch.cuda.Stream(device=dev)
+    stream = side.cuda_stream
+    assert stream != 0
+    ctxs = [api.Context(0) for _ in range(world)]
+    name = "/phylonium_amd_test_%d" % os.getpid()
+    try:
+      with torch.cuda.stream(side):
+        for tied in (False, True):
+                g2 = gs + ([dup] if tied else [])
+                n, ref = len(g2), 5
+                bounds = bounds_of(n)
+                r_orc = O.Run(g2, ref).process()
+                so, ho = r_orc.matrix()
+                for r, c in enumerate(ctxs):
+                    c.set_stream(stream)
+                    c.set_genomes(g2)
+                    c.set_reference(ref)
+                ctxs[0].result_open(name, create=True, ranks=world)
+                for c in ctxs[1:]:
+                    c.result_open(name, create=False, ranks=world)
+                ctxs[0].result_unlink()
+                maxq, cap = 8, 100000
+                nbytes = ctxs[0].exchange_block_bytes(maxq, cap)
+                nw = ctxs[0].triangle_words()
+                for attempt in ("queued", "long way"):
+                    gathered = torch.zeros(world * nbytes, dtype=torch.uint8, device=dev)
+                    total = torch.zeros(nw, dtype=torch.int32, device=dev)
+                    for r, c in enumerate(ctxs):
+                        if attempt == "queued":
+                            c.anchor_block_device(bounds[r], bounds[r + 1], gathered.data_ptr() + r * nbytes, maxq, cap)
+                        else:
+                            c.anchor(bounds[r], bounds[r + 1])
+                            c.export_block_device(bounds[r], bounds[r + 1], gathered.data_ptr() + r * nbytes, maxq, cap)
+                    for r, c in enumerate(ctxs):
+                        c.attach_blocks_device(gathered.data_ptr(), bounds, maxq, cap, bounds[r], bounds[r + 1])
+                        t = torch.empty(nw, dtype=torch.int32, device=dev)
+                        c.compare_triangle_device(r, world, t.data_ptr())
+                        total += t
+                    reps = [c.triangle_rows_to_result(total.data_ptr(), n * r // world, n * (r + 1) // world, r, world if r == world - 1 else 0)
+                            for r, c in enumerate(ctxs)]
+                    assert all((rep == reps[0]).all() for rep in reps) and int(reps[0][3]) == world
+                    if tied and attempt == "queued":  # the last rank's block said its phase A needs the host: every part reports it
+                        assert int(reps[0][4]) == world
+                        with pytest.raises(api.PhyloniumError, match="needs the host"):
+                            ctxs[1].triangle_to_matrices(total.data_ptr())
+                        continue
+                    assert not reps[0][[0, 1, 2, 4]].any(), (tied, attempt, reps[0])
+                    for c in ctxs:  # every context maps the same segment
+                        s, h = c.result_matrices()
+                        assert (s == so).all() and (h == ho).all(), (tied, attempt)
+                    for j in range(n):
+                        want = hom_tuples_orc(r_orc.homologies(j))
+                        for c in ctxs:
+                            assert hom_tuples_gpu(c.homologies(j)) == want, (tied, attempt, j)
+                    assert ctxs[0].stat("n:anchor_calls_without_a_wait", 0) >= (1 if attempt == "queued" else 0)
+                    if not tied:
+                        break
+                # asked for its lists with the queued phase A still unread and nothing attached: the context settles it itself
+                # (with the tied list: by repeating phase A the long way)
+                c = ctxs[2]
+                blk = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+                c.anchor_block_device(bounds[2], n, blk.data_ptr(), maxq, cap)
+                for j in range(bounds[2], n):
+                    assert hom_tuples_gpu(c.homologies(j)) == hom_tuples_orc(r_orc.homologies(j)), (tied, j)
+                words = blk.cpu().numpy().view(np.uint32)
+                assert int(words[3]) == (1 if tied else 0) and int(words[2]) == n - bounds[2]
+                # a private home: phylo_triangle_to_matrices writes the matrices phylo_result_matrices hands out directly
+                c = ctxs[1]
+                c.anchor()
+                c.result_open(None, ranks=1)
+                views = c.result_matrices()
+                views[0][:] = 7
+                tri = torch.empty(nw, dtype=torch.int32, device=dev)
+                c.compare_triangle_device(0, 1, tri.data_ptr())
+                c.reset_stats()
+                s, h = c.triangle_to_matrices(tri.data_ptr(), views)
+                assert (s == so).all() and (h == ho).all() and c.stat("ms:triangle_zero_copy") is not None
+                for c in ctxs:
+                    c.result_close()
     finally:
         for c in ctxs:
             c.close()
@@ -1026,6 +1157,14 @@ def _nccl_one_rank_worker(rank, world, port, out):
     assert (s3 == s).all() and (h3 == h).all()
     s4, h4 = dist.process_sharded(c, 1, rank, world, device=dev, result_rank=0)  # a reduce to the result's rank (bench.py --gpus N)
     assert (s4 == s).all() and (h4 == h).all()
+    assert c.stat("n:anchor_calls_without_a_wait", 0) >= 2 and c.stat("ms:result_rows") is not None  # queued passes, the shared home
+    dist._SHARED_RESULT = False  # a node whose ranks cannot share a segment: one rank fetches the result
+    c._xplan = None
+    for rr in (None, 0):
+        s5, h5 = dist.process_sharded(c, 1, rank, world, device=dev, result_rank=rr)
+        assert (s5 == s).all() and (h5 == h).all()
+    dist._SHARED_RESULT = True
+    c._xplan = None
     dist._LEGACY_DEVICE_EXCHANGE = True  # round 2's exchange: counts through the host, u64 matrices on the wire
     s2, h2 = dist.process_sharded(c, 1, rank, world, device=dev)
     assert (s2 == s).all() and (h2 == h).all()
@@ -1107,6 +1246,16 @@ def test_many_queries_default_options(ctx):
     assert (s == so).all() and (h == ho).all()
     for j in (0, 7, 63, 139):  # read back on demand
         assert hom_tuples_gpu(ctx.homologies(j)) == hom_tuples_orc(r.homologies(j))
+    # parts of the comparison project their window ranges into the planes phase A's projection left: a whole
+    # comparison afterwards must project again (round 5: it took the planes for phase A's still)
+    s2, h2 = np.zeros_like(s), np.zeros_like(h)
+    for part in range(3):
+        a, b = ctx.compare(part, 3)
+        s2 += a
+        h2 += b
+    assert (s2 == so).all() and (h2 == ho).all()
+    s3, h3 = ctx.compare()
+    assert (s3 == so).all() and (h3 == ho).all()
 
 
 @pytest.mark.timeout(900)
@@ -1155,7 +1304,7 @@ def test_full_size_properties_and_reference_row(workload):
         # and the two genomes only, so the small run must reproduce the sub-matrix
         # (every workload: c4 checks a pair kernel tile table of 1024 genomes, c5 — three genomes of 100 Mbp in 100
         # contigs, 10 % inverted — the five-plane kernels and the long-list filter at full length)
-        if True:
+        if workload != "c5":  # (c5's 100 Mbp genomes go through the oracle once: the drawn sample below)
             idx = {"c2like": [0, 1, n - 1], "c3dup": [0, 2, 10, n - 1], "c5": [0, 1, n - 1],
                    "c4": [0, 1, n // 2 + 1, n - 1]}.get(workload, [0, 1, n // 2, n - 1])
             gs = [buf[offs[j]:offs[j] + lens[j]].cpu().numpy() for j in idx]
@@ -1170,6 +1319,56 @@ def test_full_size_properties_and_reference_row(workload):
             s2 += a
             h2 += b
         assert (s2 == s).all() and (h2 == h).all()
+        # the whole matrix once more with the vector-ALU pair kernels (five planes, popcounts): a second implementation
+        # of the tallies over the same planes — a wrong tile of the matrix-core kernel shows here
+        c.set_option("pairs_kernel", 1)
+        try:
+            sv, hv = c.compare()
+        finally:
+            c.set_option("pairs_kernel", 0)
+        assert (sv == s).all() and (hv == h).all(), "matrix-core and vector-ALU pair kernels disagree: " + \
+            str([(int(i), int(j)) for i, j in zip(*np.nonzero((sv != s) | (hv != h)))][:8])
+        # Pairs off the reference's row, by routes that share nothing with the pileup.  A sample of genomes drawn anew
+        # every run (PHY_SAMPLE_SEED pins it; every assertion message names the seed): always the reference, one genome
+        # of the last 64-genome tile, and two of one and the same tile; their sub-matrix AND their lists
+        #   (i)  against the oracle run on those genomes alone (a pair's tallies depend on the reference and the two
+        #        genomes only), and
+        #   (ii) against the literal route: the big context's lists installed in a second context (phylo_set_homologies),
+        #        compare_backend = 1 — the reference's merge-join restated on the host (pair_segments, process.cxx:566-658)
+        #        + the byte kernels (seqcmp_batch_kernel) over the resident bytes.
+        seed = int(os.environ.get("PHY_SAMPLE_SEED") or int.from_bytes(os.urandom(4), "little"))
+        srng = np.random.default_rng(seed)
+        want = {"c5": 4, "c5s": 6}.get(workload, 10)
+        ntile = (n + 63) // 64
+        pick = {0, int(srng.integers(64 * (ntile - 1), n))}
+        t2 = int(srng.integers(0, ntile))
+        lo2, hi2 = 64 * t2, min(n, 64 * t2 + 64)
+        for v in srng.choice(np.arange(lo2, hi2), size=min(2, hi2 - lo2), replace=False):
+            pick.add(int(v))
+        while len(pick) < min(want, n):
+            pick.add(int(srng.integers(1, n)))
+        idx2 = sorted(pick)
+        tag = f"[workload {workload}, PHY_SAMPLE_SEED={seed}, genomes {idx2}]"
+        gs2 = [buf[offs[j]:offs[j] + lens[j]].cpu().numpy() for j in idx2]
+        refb = bytes(gs2[0])
+        sa = api.host_suffix_array(refb + b"#" + O.revcomp(refb))
+        r2 = O.Run(gs2, 0).process(sa=sa, threads=8)
+        so2, ho2 = r2.matrix()
+        sub_s, sub_h = s[np.ix_(idx2, idx2)], h[np.ix_(idx2, idx2)]
+        assert (sub_h == ho2).all() and (sub_s == so2).all(), "sub-matrix differs from the oracle " + tag
+        lists = [c.homologies(j).copy() for j in idx2]
+        for t, j in enumerate(idx2):
+            assert hom_tuples_gpu(lists[t]) == hom_tuples_orc(r2.homologies(t)), f"list of genome {j} differs from the oracle " + tag
+        r2.close()
+        with api.Context(0) as c2:
+            c2.set_genomes_device(buf.data_ptr(), [offs[j] for j in idx2], [lens[j] for j in idx2])
+            c2.set_reference(0)
+            for t in range(len(idx2)):
+                c2.set_homologies(t, lists[t])
+            c2.set_option("compare_backend", 1)
+            s3, h3 = c2.compare()
+            assert c2.stat("count:segments", 0) > 0
+        assert (s3 == sub_s).all() and (h3 == sub_h).all(), "sub-matrix differs from the segment route (merge-join + byte kernels) " + tag
 
 
 def test_b0_under_the_reference_names_from_eight_threads():

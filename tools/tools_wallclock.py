@@ -70,11 +70,40 @@ def main():
     json.dump({"bases": float(sum(lens)), "fasta_write_s": round(t_write, 2), "devices": torch.cuda.device_count()}, open(args.prepare, "w"))
 
 
+# Between two runs: the driver clears the device memory a process gives back and hands none of it out before it has — a
+# run started right behind another one's exit (5-50 GB each) waits for that inside its first hipMalloc, up to a second
+# (tools/microbench/alloc.hip shows it without any of this code).  Somebody who runs the program once does not see it.
+PAUSE_S = 2.0
+
+
+def floor_runs():
+    """The floor: tools/microbench/startup.hip (hipInit, a stream, hipMalloc of 1 MB, an empty kernel) start to exit on this
+    box, with the runtime's orderly teardown and leaving through _exit."""
+    exe = os.path.join(ROOT, "build", "startup")
+    if not os.path.exists(exe):
+        return None
+    out = {}
+    for mode in ("orderly", "quick"):
+        walls, notes = [], []
+        for _ in range(5):
+            time.sleep(0.5)
+            t0 = time.perf_counter()
+            p = subprocess.run([exe] + (["quick"] if mode == "quick" else []), capture_output=True)
+            walls.append(round(time.perf_counter() - t0, 4))
+            notes.append(p.stderr.decode().strip()[-160:])
+        out[mode] = {"wall_s": sorted(walls), "median_s": sorted(walls)[2], "inside": notes[2]}
+    t0 = time.perf_counter()
+    subprocess.run(["/bin/true"])
+    out["spawn_of_an_empty_process_s"] = round(time.perf_counter() - t0, 4)
+    return out
+
+
 def drive(args, n, desc, files, want, meta):
     exe = os.path.join(ROOT, "phylonium_amd", "phylonium-amd")
     runs = []
     for label, extra in (("first run", []), ("files in page cache", []), ("files in page cache, --ingest=bytes", ["--ingest=bytes"]),
-                         ("files in page cache, again", [])):
+                         ("files in page cache, again", []), ("files in page cache, a third time", [])):
+        time.sleep(PAUSE_S)
         t0 = time.time()
         p = subprocess.run([exe, "--timing", "-r", files[0]] + extra + files, capture_output=True)
         wall = time.time() - t0
@@ -84,6 +113,7 @@ def drive(args, n, desc, files, want, meta):
                      "matrix_identical": p.stdout.decode() == want, "exit": p.returncode})
     for ranks in [int(x) for x in args.gpus.split(",") if x]:
         for rep in range(2):
+            time.sleep(PAUSE_S)
             t0 = time.time()
             p = subprocess.run([exe, "--timing", "--gpus", str(ranks), "-r", files[0]] + files, capture_output=True)
             wall = time.time() - t0
@@ -95,6 +125,7 @@ def drive(args, n, desc, files, want, meta):
                          "ranks": m2.group(1) if m2 else None, "matrix_identical": p.stdout.decode() == want, "exit": p.returncode})
     out = {"workload": f"{args.workload}: {desc}", "genomes": n, "bases": meta["bases"],
            "fasta_bytes": sum(os.path.getsize(f) for f in files), "fasta_write_s": meta["fasta_write_s"], "runs": runs,
+           "floor": floor_runs(), "pause_between_runs_s": PAUSE_S,
            "note": "exit 1 is the reference's soft-warning status (io.cxx:106-139): this workload has pairs with less than "
                    "20 % homology; the matrix is printed all the same"}
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
