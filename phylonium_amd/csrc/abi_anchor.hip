@@ -227,7 +227,7 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, int defer)
 	A.pool_next = c->a_misc.p + 2;
 	A.error = c->a_misc.p + 3;
 	A.overrun = c->a_misc.p + 4;
-	RefIndex R = {c->d_S.p, c->d_SAX.p, c->d_LCP.p, c->d_SLOT.p, c->d_T.p, c->ns, c->k, c->threshold};
+	RefIndex R = {c->d_S.p, c->d_SAX.p, c->d_LCP.p, c->slot_at, c->d_T.p, c->ns, c->k, c->threshold};
 	// A subject on which the reference's 6-mer cache holds over-deep intervals (esa.cxx:174-199): the reference's
 	// answers there are reproduced by the lean chains' slow resolver, so every step goes through it (such subjects
 	// are a few kbp in several contigs; option "cache_quirk" = 0 computes the true longest matches instead).

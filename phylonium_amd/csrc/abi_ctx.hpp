@@ -32,6 +32,7 @@
 
 #include "../../include/phylonium_amd.h"
 #include "../host/fasta_reader.hpp"
+#include "../host/fmt_e4.hpp"
 #include "hostlogic.hpp"
 #include "kernels.h"
 
@@ -214,6 +215,7 @@ struct phylo_ctx {
 	uint32_t L = 0, ns = 0, k = 0, threshold = 0;
 	DevBuf<uint8_t> d_S;
 	DevBuf<U4> d_SAX, d_SLOT;
+	U4 *slot_at = nullptr; // the slot table inside d_SLOT (development builds can place it on a 1 GiB boundary: PHY_SLOT_ALIGN_GB)
 	DevBuf<uint32_t> d_SA;
 	DevBuf<uint32_t> d_LCP, d_T;
 	// 2-bit packed companions for the lean chain kernels (lean_core.h): genomes and S, 16 bases per

@@ -185,37 +185,13 @@ int phylo_set_genomes_packed(phylo_ctx *c, size_t n, const uint32_t *const *q2, 
 	HIPOK(c, hipMemsetAsync(c->d_Q2.p, 0, (words + 64) * 4, c->stream));
 	HIPOK(c, hipStreamSynchronize(c->stream));
 	double t1 = now_ms();
-	{
-		// The codes come out of pageable memory (the reader's arena): the runtime stages such a copy through page-locked
-		// buffers of its own, at what one host thread copies (~12 GB/s measured: 0.10 s for C4's 1.3 GB).  Several threads,
-		// each with a stream of its own and the genomes dealt round-robin, stage side by side.
-		uint64_t total_bytes = 0;
-		for (size_t j = 0; j < n; j++) total_bytes += (len[j] + 15) / 16 * 4;
-		const size_t nt = total_bytes < (64u << 20) ? 1 : std::min<size_t>(6, std::max<size_t>(1, workers(c).size()));
-		if (nt <= 1) {
-			for (size_t j = 0; j < n; j++)
-				if (len[j])
-					HIPOK(c, hipMemcpyAsync(c->d_Q2.p + c->goff[j] / 16, q2[j], (len[j] + 15) / 16 * 4, hipMemcpyHostToDevice, c->stream));
-			HIPOK(c, hipStreamSynchronize(c->stream));
-		} else {
-			std::vector<hipStream_t> st(nt, nullptr);
-			std::atomic<int> bad{0};
-			std::vector<std::thread> th;
-			for (size_t t = 0; t < nt; t++)
-				th.emplace_back([&, t] {
-					if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&st[t], hipStreamNonBlocking) != hipSuccess) {
-						bad = 1;
-						return;
-					}
-					for (size_t j = t; j < n; j += nt)
-						if (len[j] && hipMemcpyAsync(c->d_Q2.p + c->goff[j] / 16, q2[j], (len[j] + 15) / 16 * 4, hipMemcpyHostToDevice, st[t]) != hipSuccess) bad = 1;
-					if (hipStreamSynchronize(st[t]) != hipSuccess) bad = 1;
-					(void)hipStreamDestroy(st[t]);
-				});
-			for (auto &x : th) x.join();
-			if (bad) return c->fail("upload of the packed genomes failed");
-		}
-	}
+	// (the codes come out of pageable memory — the reader's arena — and the runtime stages them through page-locked buffers
+	// of its own at ~12 GB/s; several host threads with a stream each staging side by side were measured and are slower:
+	// C3 0.075 s against 0.026, C4 0.08-0.14 against 0.09-0.10)
+	for (size_t j = 0; j < n; j++)
+		if (len[j])
+			HIPOK(c, hipMemcpyAsync(c->d_Q2.p + c->goff[j] / 16, q2[j], (len[j] + 15) / 16 * 4, hipMemcpyHostToDevice, c->stream));
+	HIPOK(c, hipStreamSynchronize(c->stream));
 	double t2 = now_ms();
 	c->d_genomes = c->genomes_store.p;
 	c->own_genomes = true;

@@ -327,7 +327,6 @@ size_t phylo_format_phylip(size_t n, const char *const *names, const uint64_t *s
 {
 	// just_print, io.cxx:141-163: precision 4 with std::scientific ("%.4e"), or the default float format for ANI
 	// (std::dec does not touch it: "%.4g").  Row blocks are formatted on the host threads and joined in order.
-	const char *fmt = kind == 2 ? "  %.4g" : "  %.4e";
 	unsigned hw = std::thread::hardware_concurrency();
 	const size_t nt = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(hw ? hw : 1, 16), n / 16 + 1));
 	std::vector<std::string> part(nt);
@@ -341,7 +340,8 @@ size_t phylo_format_phylip(size_t n, const char *const *names, const uint64_t *s
 			o += names[i];
 			for (size_t j = 0; j < n; j++) {
 				const double d = (i == j) ? 0.0 : phylo_estimate(kind, subst[i * n + j], homologs[i * n + j], 0);
-				o.append(buf, (size_t)snprintf(buf, sizeof buf, fmt, d));
+				buf[0] = buf[1] = ' ';
+				o.append(buf, 2 + (kind == 2 ? (size_t)snprintf(buf + 2, sizeof buf - 2, "%.4g", d) : phyfmt::e4(buf + 2, d)));
 			}
 			o += '\n';
 		}

@@ -107,7 +107,13 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 		HIPOK(c, c->d_SAX.ensure((size_t)ns + 4));
 		HIPOK(c, c->d_LCP.ensure((size_t)ns + 1 + 4));
 		HIPOK(c, c->d_T.ensure(codes + 1 + 4 + kmer_table_scratch(k)));
-		HIPOK(c, c->d_SLOT.ensure(codes + 8)); // (+8: the chain kernels' load batch reads up to 64 bytes from a slot's address)
+		size_t slot_pad = 0;
+#ifdef PHY_DEV_HOOKS
+		if (const char *e = getenv("PHY_SLOT_ALIGN_GB")) slot_pad = ((size_t)std::max(0, atoi(e)) << 30) / sizeof(U4); // experiments: the table on that boundary
+#endif
+		HIPOK(c, c->d_SLOT.ensure(codes + 8 + slot_pad)); // (+8: the chain kernels' load batch reads up to 64 bytes from a slot's address)
+		c->slot_at = c->d_SLOT.p;
+		if (slot_pad) c->slot_at = (U4 *)(((uintptr_t)c->d_SLOT.p + slot_pad * sizeof(U4) - 1) / (slot_pad * sizeof(U4)) * (slot_pad * sizeof(U4)));
 		c->stats["ms:ref_alloc"] += now_ms() - ta; // hipMalloc of tens of GB stalls when other processes have just released as much (round 2: one C5 run waited 2.4 s there)
 	}
 	HIPOK(c, hipMemsetAsync(c->a_misc.p, 0, 64, st));
@@ -131,7 +137,7 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 	launch_sax(c->d_S.p, c->d_SA.p, c->d_LCP.p, ns, c->d_SAX.p, st);
 	{
 		hipLaunchKernelGGL(build_slots_kernel, dim3((uint32_t)((codes + 255) / 256)), dim3(256), 0, st, c->d_T.p,
-						   c->d_SAX.p, ns, k, codes, c->d_SLOT.p);
+						   c->d_SAX.p, ns, k, codes, c->slot_at);
 	}
 	HIPOK(c, hipGetLastError());
 	HIPOK(c, hipStreamSynchronize(st));

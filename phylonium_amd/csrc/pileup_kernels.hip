@@ -60,6 +60,9 @@ static const uint32_t PROJ_TW = 64; // words per tile
 #ifndef PHY_PROJ_TG
 #define PHY_PROJ_TG 32
 #endif
+#ifndef PHY_PROJ_MINB
+#define PHY_PROJ_MINB 1 // blocks per CU the projection is compiled for (A/B builds: 5 caps the registers at 96 and spills)
+#endif
 #ifndef PHY_PROJ_V2
 #define PHY_PROJ_V2 1 // the projection's covering-homology look-up without a loop (0: rounds 1-4's searching loop only; A/B builds)
 #endif
@@ -132,11 +135,11 @@ static const uint32_t PROJ_HM = 256 / PROJ_TG; // homology descriptors cached pe
 // bang_list (FIVE = false only, may be null): every projected '!' as {genome | reverse << 31, reference position},
 // appended through the counter bang_flag[3]; more than bang_cap of them raise bit 1 of bang_flag[0].
 template <bool FIVE>
-__global__ __launch_bounds__(256) void project_kernel(Pileup P, QuerySrc Q,
+__global__ __launch_bounds__(256, PHY_PROJ_MINB) void project_kernel(Pileup P, QuerySrc Q,
 													   const DevHom *__restrict__ homs,
 													   const uint32_t *__restrict__ hom_rng,
 													   const uint32_t *__restrict__ first,
-													   uint32_t *__restrict__ bang_flag, uint32_t tg0,
+													   uint32_t *__restrict__ bang_flag, uint32_t tg0, uint32_t ntiles,
 													   uint32_t *__restrict__ bang_list, uint32_t bang_cap)
 {
 	constexpr uint32_t NP = FIVE ? 5u : 3u;
@@ -146,38 +149,60 @@ __global__ __launch_bounds__(256) void project_kernel(Pileup P, QuerySrc Q,
 	__shared__ uint32_t hlo[PROJ_TG], hend[PROJ_TG], tbad[PROJ_TG];
 	__shared__ uint32_t below[33]; // below[t] = plane-order mask of the positions < t
 	const uint32_t ntw = (P.W + PROJ_TW - 1) / PROJ_TW;
-	const uint32_t tw = blockIdx.x % ntw, tg = tg0 + blockIdx.x / ntw;
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	if (threadIdx.x < 33) {
 		uint32_t m = 0;
 		for (uint32_t pp = 0; pp < threadIdx.x; pp++) m |= 1u << plane_bit(pp);
 		below[threadIdx.x] = m;
 	}
-	// the tile's homology descriptors: two dependent rounds for the whole block
-	{
-		const uint32_t gl = threadIdx.x / PROJ_HM, e = threadIdx.x % PROJ_HM; // PROJ_TG * PROJ_HM == 256
-		const uint32_t g = tg * PROJ_TG + gl;
-		DevHom hm = {0xffffffffu, 0, 0, 0};
-		uint32_t lo = 0, h1 = 0, bad = 0;
-		if (g < P.N) {
-			lo = first[(size_t)g * ntw + tw];
-			bad = lo & TILE_BAD;
-			lo &= ~TILE_BAD;
-			h1 = hom_rng[2 * g + 1];
-			if (lo + e < h1) hm = homs[lo + e];
+	// Round 5: a block takes tile after tile (tile t, t + gridDim.x, ...: the launch is as many blocks as the chip holds at once)
+	// and keeps the NEXT tile's homology descriptors — and the tile index entry of the one after that — on their way while
+	// it works on this one: what used to be three dependent fetches per tile (tile index, descriptors, codes) is one.
+	// A thread's part in that: descriptor pe of genome pgl of the tile.
+	const uint32_t pgl = threadIdx.x / PROJ_HM, pe = threadIdx.x % PROJ_HM; // PROJ_TG * PROJ_HM == 256
+	struct Ahead {
+		uint32_t f, h1; // the tile index entry (first homology | TILE_BAD) and the end of the genome's list
+	};
+	auto index_of = [&](uint32_t t) {
+		Ahead a = {0u, 0u};
+		if (t < ntiles) {
+			const uint32_t g = (tg0 + t / ntw) * PROJ_TG + pgl;
+			if (g < P.N) {
+				a.f = first[(size_t)g * ntw + t % ntw];
+				a.h1 = hom_rng[2 * g + 1];
+			}
 		}
-		hcache[gl][e] = hm;
-		hends[gl][e] = hm.start == 0xffffffffu ? 0xffffffffu : hm.start + hm.len;
-		if (e == 0) {
-			hlo[gl] = lo;
-			hend[gl] = h1;
-			tbad[gl] = bad;
+		return a;
+	};
+	auto descriptor_of = [&](uint32_t t, const Ahead &a) {
+		DevHom hm = {0xffffffffu, 0, 0, 0};
+		const uint32_t lo = a.f & ~TILE_BAD;
+		if (t < ntiles && lo + pe < a.h1) hm = homs[lo + pe];
+		return hm;
+	};
+	uint32_t any_bang = 0;
+	const uint32_t stride = gridDim.x;
+	Ahead a_cur = index_of(blockIdx.x), a_next = index_of(blockIdx.x + stride);
+	DevHom hm_cur = descriptor_of(blockIdx.x, a_cur);
+	for (uint32_t t = blockIdx.x; t < ntiles; t += stride) {
+	const uint32_t tw = t % ntw, tg = tg0 + t / ntw;
+	if (t != blockIdx.x) __syncthreads(); // the tile before has left LDS
+	{
+		hcache[pgl][pe] = hm_cur;
+		hends[pgl][pe] = hm_cur.start == 0xffffffffu ? 0xffffffffu : hm_cur.start + hm_cur.len;
+		if (pe == 0) {
+			hlo[pgl] = a_cur.f & ~TILE_BAD;
+			hend[pgl] = a_cur.h1;
+			tbad[pgl] = a_cur.f & TILE_BAD;
 		}
 	}
+	// on their way while this tile is worked on: the next tile's descriptors (its index entry came in a tile ago) and the
+	// index entry of the tile after it
+	const DevHom hm_next = descriptor_of(t + stride, a_next);
+	const Ahead a_next2 = index_of(t + 2 * stride);
 	__syncthreads();
 	const uint32_t w = tw * PROJ_TW + lane; // row of this part; reference window P.w0 + w
 	const uint32_t x0 = (P.w0 + w) * 32u, x1 = x0 + 32u;
-	uint32_t any_bang = 0;
 	// A wavefront owns PROJ_GPW genomes of the tile.  The covering homology of each is
 	// looked up first (LDS only), then the PROJ_GPW 12-byte reads (32 codes at any 2-bit
 	// offset) are issued together — one read per genome in flight at a time left the kernel
@@ -392,7 +417,6 @@ __global__ __launch_bounds__(256) void project_kernel(Pileup P, QuerySrc Q,
 #if PHY_PROJ_V2
 	} // half
 #endif
-	if (any_bang) atomicOr(bang_flag, 1u);
 	__syncthreads();
 	// rows [w][g0..g0+31] out: 128 contiguous bytes per row; a thread keeps its genome
 	// column and walks down the rows
@@ -408,6 +432,11 @@ __global__ __launch_bounds__(256) void project_kernel(Pileup P, QuerySrc Q,
 				if (tw * PROJ_TW + wl0 + RPP * k < P.W) dst[(size_t)(RPP * k) * P.Npad] = tile[p][wl0 + RPP * k][gl];
 		}
 	}
+	hm_cur = hm_next;
+	a_cur = a_next;
+	a_next = a_next2;
+	} // tiles
+	if (any_bang) atomicOr(bang_flag, 1u);
 }
 
 // One wavefront per (tile, window chunk): lane = genome j of the tile's 64,
@@ -786,11 +815,23 @@ void launch_project(const Pileup &P, bool five_planes, const QuerySrc &Q, const 
 	uint32_t ntw = (P.W + PROJ_TW - 1) / PROJ_TW, ntg = P.Npad / PROJ_TG;
 	if (tg1 > ntg) tg1 = ntg;
 	if (!ntw || tg0 >= tg1) return;
-	dim3 grid(ntw * (tg1 - tg0));
+	const uint32_t ntiles = ntw * (tg1 - tg0);
+	// as many blocks as the chip holds at once (LDS: five per CU with three planes), each taking tile after tile
+	static int resident[2] = {0, 0};
+	int &res = resident[five_planes ? 1 : 0];
+	if (!res) {
+		int per_cu = 0, dev = 0;
+		hipDeviceProp_t prop;
+		const void *fn = five_planes ? (const void *)project_kernel<true> : (const void *)project_kernel<false>;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+		if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
+		res = per_cu * prop.multiProcessorCount;
+	}
+	dim3 grid(std::min<uint32_t>(ntiles, (uint32_t)res));
 	if (five_planes)
-		hipLaunchKernelGGL(project_kernel<true>, grid, dim3(256), 0, st, P, Q, homs, hom_rng, first, bang_flag, tg0, (uint32_t *)nullptr, 0u);
+		hipLaunchKernelGGL(project_kernel<true>, grid, dim3(256), 0, st, P, Q, homs, hom_rng, first, bang_flag, tg0, ntiles, (uint32_t *)nullptr, 0u);
 	else
-		hipLaunchKernelGGL(project_kernel<false>, grid, dim3(256), 0, st, P, Q, homs, hom_rng, first, bang_flag, tg0, bang_list, bang_cap);
+		hipLaunchKernelGGL(project_kernel<false>, grid, dim3(256), 0, st, P, Q, homs, hom_rng, first, bang_flag, tg0, ntiles, bang_list, bang_cap);
 }
 uint32_t project_genomes_per_tile() { return PROJ_TG; }
 size_t project_index_entries(const Pileup &P) { return (size_t)P.N * ((P.W + PROJ_TW - 1) / PROJ_TW); }

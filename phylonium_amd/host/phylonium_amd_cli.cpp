@@ -31,6 +31,7 @@
 
 #include "../../include/phylonium_amd.h"
 #include "fasta_reader.hpp"
+#include "fmt_e4.hpp"
 
 namespace {
 
@@ -80,7 +81,7 @@ size_t PRINT_THREADS = 1;
 void print_phylip(const std::vector<Genome> &q, const std::vector<double> &d, int flags)
 {
 	size_t N = q.size();
-	const char *fmt = (flags & F_ANI) ? "  %.4g" : "  %.4e";
+	const bool ani = (flags & F_ANI) != 0;
 	const size_t nt = std::max<size_t>(1, std::min(PRINT_THREADS, N / 16 + 1));
 	std::vector<std::string> part(nt);
 	auto work = [&](size_t t) {
@@ -90,7 +91,11 @@ void print_phylip(const std::vector<Genome> &q, const std::vector<double> &d, in
 		char buf[64];
 		for (size_t i = i0; i < i1; i++) {
 			o += q[i].name;
-			for (size_t j = 0; j < N; j++) o.append(buf, (size_t)snprintf(buf, sizeof buf, fmt, i == j ? 0.0 : d[i * N + j]));
+			for (size_t j = 0; j < N; j++) {
+				const double v = i == j ? 0.0 : d[i * N + j];
+				buf[0] = buf[1] = ' ';
+				o.append(buf, 2 + (ani ? (size_t)snprintf(buf + 2, sizeof buf - 2, "%.4g", v) : phyfmt::e4(buf + 2, v)));
+			}
 			o += '\n';
 		}
 	};
@@ -109,29 +114,42 @@ void print_matrix(const std::vector<Genome> &q, const Matrix &m, int flags, unsi
 {
 	size_t N = q.size();
 	std::vector<double> d(N * N);
-	for (size_t k = 0; k < N * N; k++) d[k] = dist_of(m[k], flags);
-	// warnings first (io.cxx:106-139)
-	for (size_t i = 0; i < N; i++)
-		for (size_t j = 0; j < i; j++) {
-			double v = d[i * N + j];
-			char buf[1024];
-			if (std::isnan(v)) {
-				snprintf(buf, sizeof buf,
-						 "For the two sequences '%s' and '%s' the distance computation failed and is reported as nan.",
-						 q[i].name.c_str(), q[j].name.c_str());
-				soft_err(buf);
-			} else {
-				double c1 = (double)m[i * N + j].homologs / GLEN[i];
-				double c2 = (double)m[i * N + j].homologs / GLEN[j];
-				if (c1 < 0.2 || c2 < 0.2) {
-					snprintf(buf, sizeof buf,
-							 "For the two sequences '%s' and '%s' less than 20%% homology were found (%f and %f, "
-							 "respectively).",
-							 q[i].name.c_str(), q[j].name.c_str(), c1, c2);
-					soft_err(buf);
+	// The distances (a logarithm each) and the warnings (io.cxx:106-139: they come first, row by row) are worked out on
+	// the host threads — a million pairs at N = 1024 — and the warnings then leave in the reference's order.
+	std::vector<std::vector<std::string>> warn(N);
+	{
+		const size_t nt = std::max<size_t>(1, std::min(PRINT_THREADS, N / 16 + 1));
+		auto work = [&](size_t t) {
+			for (size_t i = t; i < N; i += nt) // (row i checks i pairs: dealt round-robin the threads get the same share)
+				for (size_t j = 0; j < N; j++) {
+					const double v = d[i * N + j] = dist_of(m[i * N + j], flags);
+					if (j >= i) continue;
+					char buf[1024];
+					if (std::isnan(v)) {
+						snprintf(buf, sizeof buf,
+								 "For the two sequences '%s' and '%s' the distance computation failed and is reported as nan.",
+								 q[i].name.c_str(), q[j].name.c_str());
+						warn[i].push_back(buf);
+					} else {
+						double c1 = (double)m[i * N + j].homologs / GLEN[i];
+						double c2 = (double)m[i * N + j].homologs / GLEN[j];
+						if (c1 < 0.2 || c2 < 0.2) {
+							snprintf(buf, sizeof buf,
+									 "For the two sequences '%s' and '%s' less than 20%% homology were found (%f and %f, "
+									 "respectively).",
+									 q[i].name.c_str(), q[j].name.c_str(), c1, c2);
+							warn[i].push_back(buf);
+						}
+					}
 				}
-			}
-		}
+		};
+		std::vector<std::thread> pool;
+		for (size_t t = 1; t < nt; t++) pool.emplace_back(work, t);
+		work(0);
+		for (auto &t : pool) t.join();
+	}
+	for (size_t i = 0; i < N; i++)
+		for (const std::string &w : warn[i]) soft_err(w);
 	print_phylip(q, d, flags);
 	for (unsigned long k = 0; k < bootstrap; k++) { // evo_model::bootstrap, evo_model.cxx:136-147
 		std::vector<double> b(N * N);

@@ -219,3 +219,14 @@ def test_packed_fasta_reader_equals_the_byte_reader(lib, tmp_path):
         api.read_fasta_packed([str(tmp_path / "none.fa")])
     with pytest.raises(api.PhyloniumError, match="nope.fa"):
         api.read_fasta_packed([str(tmp_path / "nope.fa")])
+
+
+def test_hand_rolled_e4_format_equals_printf(tmp_path):
+    """The matrix cells are written by phyfmt::e4 (host/fmt_e4.hpp) instead of printf("%.4e") (src/io.cxx:141-163's
+    std::scientific, precision 4): ten million values — raw and Jukes-Cantor distances, powers of two times [0.5, 1.5),
+    every decimal tie d.dddd5e+-x with three representable neighbours on either side, the specials — format the same."""
+    import subprocess
+    exe = str(tmp_path / "fmt_e4_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "emul", "fmt_e4_check.cpp")], check=True)
+    r = subprocess.run([exe, "3000000"], capture_output=True, text=True)
+    assert r.returncode == 0 and int(r.stdout.strip()) > 10_000_000, r.stdout[-500:]

@@ -894,7 +894,18 @@ def test_queued_rank_pass_and_the_results_shared_home():
     A context that is asked for its lists before any block was attached waits for the queued phase A itself."""
     import torch
     gs = synth.make_genomes(13, 25000, seed=86, d_range=(0.01, 0.25), indel_per_mbp=300, inv_frac=0.08, contigs=2)
-    dup = np.concatenate([gs[5][1000:9000], synth.random_base(300, np.random.default_rng(1)), gs[5][1000:9000]])
+    # a query that carries stretches of the reference once forward and once reverse-complemented between random flanks: the
+    # two homologies of a stretch project onto the same reference interval, and with 20 stretches some pairs begin at the
+    # same base (asserted on the oracle's raw list) — equal starts, the host's case
+    rng = np.random.default_rng(7)
+    clean = gs[5][gs[5] != ord("!")]
+    pieces = []
+    for x in range(1000, 21000, 1000):
+        seg = clean[x:x + 500]
+        pieces += [synth.random_base(100, rng), seg, synth.random_base(100, rng), synth.revcomp(seg)]
+    dup = np.concatenate(pieces + [synth.random_base(200, rng)])
+    starts = [int(x["iproj"]) for x in O.Run(gs + [dup], 5).process(compare=False).homologies(13, filtered=False)]
+    assert len(set(starts)) < len(starts)
     dev = torch.device("cuda", 0)
     world, bounds_of = 3, lambda n: [0, 3, 9, n]
     # one stream for the three contexts and torch's own work, as a rank's context shares its stream with the collectives: what
