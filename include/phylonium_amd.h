@@ -79,7 +79,8 @@ const char *phylo_last_error(const phylo_ctx *ctx);
  *   "pairs_wchunk"     windows per chunk of the pair kernels (0: chosen from the L2 size)
  *   "result_zero_copy" 0 (default) / 1: see phylo_triangle_to_matrices
  *   "host_threads"     size of the context's host worker pool
- *   "profile"          1: time every kernel with HIP events ("ms:<kernel>" stats) */
+ *   "profile"          1: time every kernel with HIP events ("ms:<kernel>" stats; two events and ~4 us a kernel),
+ *                      2: the speculative chain kernel only */
 int phylo_set_option(phylo_ctx *ctx, const char *key, long value);
 /* Accumulated since the last phylo_reset_stats: "ms:<kernel>", "n:<kernel>"
  * (HIP-event time and launch count per kernel when profiling is on),

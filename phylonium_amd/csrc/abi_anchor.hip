@@ -20,6 +20,18 @@ __global__ void compact_raw_kernel(const RawHom *__restrict__ src, const uint64_
 }
 
 
+// What the host wants to know of a phase A, written by the device straight into page-locked memory (one launch instead of
+// three copies in front of phase B): h_rng's layout — [0, 2nq) the lists' ranges, [2nq] their total, [2nq + 1, 3nq + 1) the
+// filter's flags, then eight of the chains' counters.
+__global__ __launch_bounds__(256) void phase_a_report_kernel(const uint32_t *__restrict__ rng, const uint32_t *__restrict__ flt,
+															  const uint32_t *__restrict__ misc, uint32_t nq, uint32_t *__restrict__ host_out)
+{
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t < 2 * nq) host_out[t] = rng[t];
+	else if (t < 3 * nq + 1) host_out[t] = flt[t - 2 * nq];
+	else if (t < 3 * nq + 9) host_out[t] = misc[t - (3 * nq + 1)];
+}
+
 // What the device filter left for queries [q_begin, q_end), once the stream has been waited for and h_rng holds its ranges,
 // flags and counters (see anchor_impl): the lists stay in the context's device buffer, the host knows where.
 static void adopt_device_lists(phylo_ctx *c, size_t q_begin, size_t q_end, bool tail_eager)
@@ -188,6 +200,7 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, int defer)
 		c->plan_qb = q_begin;
 		c->plan_qe = q_end;
 		c->plan_valid = true;
+		c->vis_clean_w0 = c->vis_clean_w1 = 0; // (another layout: nothing is known to be clean)
 	}
 	const ChunkPlan &P = c->plan;
 	const uint32_t nch = P.nchunks;
@@ -198,7 +211,12 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, int defer)
 	if (nch) { // the words of this call's queries (their genomes lie back to back in the buffer)
 		// (on 256-byte boundaries: one fill instead of head, body and tail; the neighbours' bits are nobody's between two calls)
 		const uint64_t w0 = c->goff[q_begin] / 32 / 64 * 64, w1 = ((c->goff[q_end - 1] + c->glen[q_end - 1]) / 32 + 1 + 63) / 64 * 64;
-		HIPOK(c, hipMemsetAsync(c->a_visited.p + w0, 0, (size_t)(w1 - w0) * 4, st));
+		if (c->vis_clean_w0 == w0 && c->vis_clean_w1 == w1 && c->vis_ev_clean) {
+			HIPOK(c, hipStreamWaitEvent(st, c->vis_ev_clean, 0)); // cleared behind the last pass's bridges, beside its phase B
+		} else {
+			HIPOK(c, hipMemsetAsync(c->a_visited.p + w0, 0, (size_t)(w1 - w0) * 4, st));
+		}
+		c->vis_clean_w0 = c->vis_clean_w1 = 0;
 	}
 
 	PhaseA A;
@@ -316,6 +334,19 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, int defer)
 			BridgeZero Z = {{c->a_out_cnt.p + j0, device_filter ? c->a_flt.p : nullptr, (device_filter && tail_eager) ? c->b_flag.p : nullptr},
 							{j1 - j0, device_filter ? 1u : 0u, (device_filter && tail_eager) ? 4u : 0u}};
 			launch_lean_bridge(A, R, X, c->n_cu, st, Z);
+			// the bridges were the visited bits' last readers: clear them for the next pass on the copy stream, beside the
+			// fold, the filter and phase B (160 MB at C3: 22 us that stood in front of every pass's chain kernel)
+			if (!c->vis_ev_bridges) {
+				HIPOK(c, hipEventCreateWithFlags(&c->vis_ev_bridges, hipEventDisableTiming));
+				HIPOK(c, hipEventCreateWithFlags(&c->vis_ev_clean, hipEventDisableTiming));
+			}
+			const uint64_t w0 = c->goff[q_begin] / 32 / 64 * 64, w1 = ((c->goff[q_end - 1] + c->glen[q_end - 1]) / 32 + 1 + 63) / 64 * 64;
+			HIPOK(c, hipEventRecord(c->vis_ev_bridges, st));
+			HIPOK(c, hipStreamWaitEvent(c->copy_stream, c->vis_ev_bridges, 0));
+			HIPOK(c, hipMemsetAsync(c->a_visited.p + w0, 0, (size_t)(w1 - w0) * 4, c->copy_stream));
+			HIPOK(c, hipEventRecord(c->vis_ev_clean, c->copy_stream));
+			c->vis_clean_w0 = w0;
+			c->vis_clean_w1 = w1;
 		}
 		{
 			KernelSpan s(c, "anchor_fold", sg);
@@ -421,9 +452,10 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, int defer)
 	if (device_filter) {
 		uint32_t *hr = c->h_rng.p; // [0, 2nq) ranges, [2nq] the lists' total, [2nq + 1, 3nq + 1) flags (a_flt as it lies), then the misc words
 		if (defer != 2) { // (defer 2: the kernel that writes the exchange block writes these words as well)
-			HIPOK(c, hipMemcpyAsync(hr, c->b_hom_rng.p, 2 * nq * 4, hipMemcpyDeviceToHost, st));
-			HIPOK(c, hipMemcpyAsync(hr + 2 * nq, c->a_flt.p, (nq + 1) * 4, hipMemcpyDeviceToHost, st));
-			HIPOK(c, hipMemcpyAsync(hr + 3 * nq + 1, c->a_misc.p, 32, hipMemcpyDeviceToHost, st));
+			uint32_t *hr_dev = nullptr;
+			HIPOK(c, hipHostGetDevicePointer((void **)&hr_dev, hr, 0));
+			hipLaunchKernelGGL(phase_a_report_kernel, dim3((uint32_t)((3 * nq + 9 + 255) / 256)), dim3(256), 0, st, (const uint32_t *)c->b_hom_rng.p,
+							   (const uint32_t *)c->a_flt.p, (const uint32_t *)c->a_misc.p, (uint32_t)nq, hr_dev);
 		}
 		HIPOK(c, hipGetLastError());
 		c->pend_t0 = t0, c->pend_t1 = t1, c->pend_total = (double)total, c->pend_nch = nch, c->pend_C = P.C;

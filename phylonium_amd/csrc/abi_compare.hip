@@ -125,6 +125,39 @@ __global__ __launch_bounds__(256) void sym32_from_triangle_kernel(uint32_t N, co
 	out[t] = i == j ? 0u : tri[k];
 	out[NN + t] = i == j ? 0u : tri[P + k];
 }
+// The tallies (upper triangles of two N x N u64 matrices on the device) straight into the result's page-locked home
+// (phylo_result_matrices) as the two symmetric matrices process() returns: 16-byte stores over PCIe, no staging copy and
+// no pass on the host cores.  A thread takes two neighbouring columns of one row.
+__global__ __launch_bounds__(256) void matrices_to_home_kernel(uint32_t N, const unsigned long long *__restrict__ s, const unsigned long long *__restrict__ h,
+																unsigned long long *__restrict__ ds, unsigned long long *__restrict__ dh)
+{
+	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, half = ((uint64_t)N + 1) / 2;
+	if (t >= (uint64_t)N * half) return;
+	const uint32_t i = (uint32_t)(t / half), j0 = (uint32_t)(t % half) * 2u;
+	unsigned long long vs[2] = {0, 0}, vh[2] = {0, 0};
+#pragma unroll
+	for (uint32_t e = 0; e < 2; e++) {
+		const uint32_t j = j0 + e;
+		if (j < N && j != i) {
+			const uint64_t src = i < j ? (uint64_t)i * N + j : (uint64_t)j * N + i;
+			vs[e] = s[src];
+			vh[e] = h[src];
+		}
+	}
+	const uint64_t o = (uint64_t)i * N + j0;
+	if (j0 + 1 < N && (o & 1) == 0) {
+		*(ulonglong2 *)(ds + o) = ulonglong2{vs[0], vs[1]};
+		*(ulonglong2 *)(dh + o) = ulonglong2{vh[0], vh[1]};
+	} else {
+		ds[o] = vs[0];
+		dh[o] = vh[0];
+		if (j0 + 1 < N) {
+			ds[o + 1] = vs[1];
+			dh[o + 1] = vh[1];
+		}
+	}
+}
+
 // sym (2 N^2 u32 in pinned memory) -> the caller's two N x N u64 matrices; returns the sum of the homologs matrix
 static double widen_result(phylo_ctx *c, const uint32_t *sym, uint64_t *subst, uint64_t *homologs)
 {
@@ -294,7 +327,9 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 		acc_h = c->b_subst.p + N * N;
 	}
 	HIPOK(c, c->h_mat.ensure(2 * N * N + 8));
-	if (out_mode == 0) HIPOK(c, c->b_sym32.ensure(2 * N * N + 4));
+	// the caller's matrices are the result's page-locked home (phylo_result_matrices): the device writes them itself
+	const bool to_home = out_mode == 0 && c->res.map && c->res.n == N && subst == c->res.subst() && homologs == c->res.homologs();
+	if (out_mode == 0 && !to_home) HIPOK(c, c->b_sym32.ensure(2 * N * N + 4));
 	auto zero_tallies = [&]() -> hipError_t {
 		if (acc_h == acc_s + N * N) return hipMemsetAsync(acc_s, 0, 2 * N * N * 8, st);
 		const hipError_t e = hipMemsetAsync(acc_s, 0, N * N * 8, st);
@@ -358,6 +393,9 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 							   queued_report ? c->b_flag.p : (const uint32_t *)nullptr, c->att_unchecked ? 1 : 0);
 		else if (out_mode == 1)
 			launch_symmetrise((uint32_t)N, acc_s, acc_h, st);
+		else if (to_home)
+			hipLaunchKernelGGL(matrices_to_home_kernel, dim3((uint32_t)((N * ((N + 1) / 2) + 255) / 256)), dim3(256), 0, st, (uint32_t)N, acc_s, acc_h,
+							   (unsigned long long *)((char *)c->res.dev + 4096), (unsigned long long *)((char *)c->res.dev + 4096) + c->res.matrix_words());
 		else
 			hipLaunchKernelGGL(sym32_from_matrices_kernel, dim3((uint32_t)((N * N + 255) / 256)), dim3(256), 0, st, (uint32_t)N, acc_s, acc_h, c->b_sym32.p);
 	};
@@ -396,14 +434,14 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 				// (the f32 accumulators are flushed once per cpw chunks and are exact below 2^24: the clamp comes last)
 				cpw = std::min<uint32_t>(cpw, std::max<uint32_t>(1u, pairs_mfma_max_wchunk() / wchunk));
 			}
-			if (c->profile && !c->b_clk.p) { // (stat "clock:pairs_mfma_mhz")
+			if (c->profile == 1 && !c->b_clk.p) { // (stat "clock:pairs_mfma_mhz")
 				HIPOK(c, c->b_clk.ensure(2));
 				HIPOK(c, hipMemsetAsync(c->b_clk.p, 0, 16, st));
 				c->stats["clock:pairs_mfma_mhz"] = 0;
 			}
 			{
 				KernelSpan s(c, "pileup_pairs_mfma");
-				launch_pairs_mfma(P, c->b_tiles.p + tiles.size(), (uint32_t)mtiles.size(), wchunk, acc_s, acc_h, st, cpw, c->profile ? c->b_clk.p : nullptr);
+				launch_pairs_mfma(P, c->b_tiles.p + tiles.size(), (uint32_t)mtiles.size(), wchunk, acc_s, acc_h, st, cpw, c->profile == 1 ? c->b_clk.p : nullptr);
 			}
 			HIPOK(c, hipGetLastError());
 			finish_tallies();
@@ -442,7 +480,7 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 	auto fetch = [&]() -> int { // the flag, and the result unless it stays on the device
 		HIPOK(c, hipGetLastError());
 		HIPOK(c, hipMemcpyAsync(flagp, c->b_flag.p, 28, hipMemcpyDeviceToHost, st));
-		if (!dev_out) HIPOK(c, hipMemcpyAsync(hs, c->b_sym32.p, 2 * N * N * 4, hipMemcpyDeviceToHost, st));
+		if (!dev_out && !to_home) HIPOK(c, hipMemcpyAsync(hs, c->b_sym32.p, 2 * N * N * 4, hipMemcpyDeviceToHost, st));
 		return sync_stream(c);
 	};
 	// The matrix-core path (option "pairs_kernel" = 0) works on three planes whatever the genomes hold: the projection
@@ -502,7 +540,7 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 	}
 	double t2 = now_ms();
 	// out of the pinned buffer into the caller's matrices, widened (16 MB at N = 1024: worth several threads)
-	double sites = widen_result(c, (const uint32_t *)hs, subst, homologs);
+	double sites = to_home ? 0.0 : widen_result(c, (const uint32_t *)hs, subst, homologs);
 	sites *= 0.5;
 	c->stats["ms:compare_project_phase"] += t1 - t0;
 	c->stats["ms:compare_pairs_phase"] += t2 - t1;

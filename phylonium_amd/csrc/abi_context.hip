@@ -135,6 +135,8 @@ void phylo_ctx_destroy(phylo_ctx *c)
 	}
 	for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
 	for (hipEvent_t e : c->copy_events) (void)hipEventDestroy(e);
+	if (c->vis_ev_bridges) (void)hipEventDestroy(c->vis_ev_bridges);
+	if (c->vis_ev_clean) (void)hipEventDestroy(c->vis_ev_clean);
 	if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
 	(void)hipStreamDestroy(c->own_stream);
 	delete c;
@@ -189,7 +191,8 @@ int phylo_set_option(phylo_ctx *c, const char *key, long value)
 	} else if (k == "lean_force_slow") {
 		c->lean_force_slow = value != 0;
 	} else if (k == "profile") {
-		c->profile = value != 0;
+		if (value < 0 || value > 2) return c->fail("profile must be 0 (off), 1 (every kernel) or 2 (the chain kernel only)");
+		c->profile = (int)value;
 	} else if (k == "filter") {
 		if (value < 0 || value > 2) return c->fail("filter must be 0 (auto), 1 (host) or 2 (device)");
 		c->filter_mode = (int)value;

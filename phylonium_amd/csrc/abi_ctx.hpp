@@ -20,6 +20,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <condition_variable>
 #include <functional>
 #include <map>
@@ -196,7 +197,7 @@ struct phylo_ctx {
 	// options
 	uint32_t opt_chunk = 0, opt_kmer = 0;
 	int plan_spec_per_cu = 4; // blocks of the speculative chain kernel per CU the plan was made for
-	bool profile = false;
+	int profile = 0; // option "profile": 0 no kernel timing, 1 every kernel (two HIP events each: ~4 us a kernel), 2 the chain kernel only (the bench's timed loop)
 	int backend = 0;
 	int host_threads = 0;
 
@@ -266,6 +267,10 @@ struct phylo_ctx {
 	std::vector<uint32_t> xb_bounds;        // the ranks' bounds as phylo_attach_blocks_device uploaded them last ...
 	const uint32_t *xb_bounds_at = nullptr; // ... and where (skipped while both stay the same)
 	bool flags_zeroed = false;              // the block export of a queued phase A has zeroed b_flag for the attach that follows
+	// the visited bits of the last phase A's queries are cleared again behind its bridges, on the copy stream beside phase B:
+	// the next phase A over the same queries waits for that event instead of filling 160 MB in front of its chains
+	uint64_t vis_clean_w0 = 0, vis_clean_w1 = 0;
+	hipEvent_t vis_ev_bridges = nullptr, vis_ev_clean = nullptr;
 	bool homs_staged = false;
 	// ... and has projected them for the whole reference (part 0 of 1); with five planes or three
 	bool eager_valid = false, eager_five = false;
@@ -374,9 +379,11 @@ struct KernelSpan {
 	hipEvent_t a = nullptr, b = nullptr;
 	const char *name;
 	hipStream_t st;
+	bool on_ = false;
 	KernelSpan(phylo_ctx *ctx, const char *nm, hipStream_t on = nullptr) : c(ctx), name(nm), st(on ? on : ctx->stream)
 	{
-		if (c->profile) {
+		on_ = c->profile == 1 || (c->profile == 2 && !strcmp(nm, "anchor_spec"));
+		if (on_) {
 			a = get_event(c);
 			b = get_event(c);
 			(void)hipEventRecord(a, st);
@@ -384,7 +391,7 @@ struct KernelSpan {
 	}
 	~KernelSpan()
 	{
-		if (c->profile) {
+		if (on_) {
 			(void)hipEventRecord(b, st);
 			c->spans.push_back(TimedSpan{name, a, b});
 		}

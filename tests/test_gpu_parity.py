@@ -1124,6 +1124,57 @@ def test_two_process_sharded_run_on_gpu(tmp_path):
     assert (np.load(out + ".h.npy") == ho).all()
 
 
+def _shared_home_worker(rank, world, name, out):
+    import time
+    import torch
+    gs = synth.make_genomes(9, 20000, seed=72, d_range=(0.01, 0.2), indel_per_mbp=300, inv_frac=0.05)
+    n = len(gs)
+    c = api.Context(0)
+    c.set_genomes(gs)
+    c.set_reference(2)
+    c.anchor()
+    if rank == 0:
+        c.result_open(name, create=True, ranks=world)
+    else:
+        for _ in range(200):  # (the tests have no collective to wait with: the segment appears when rank 0 has made it)
+            try:
+                c.result_open(name, create=False, ranks=world)
+                break
+            except api.PhyloniumError:
+                time.sleep(0.05)
+        else:
+            raise RuntimeError("the shared segment never appeared")
+    tri = torch.empty(c.triangle_words(), dtype=torch.int32, device="cuda:0")
+    for step in range(3):  # deliveries are counted: the ranks stay in step from pass to pass
+        c.compare_triangle_device(0, 1, tri.data_ptr())
+        rep = c.triangle_rows_to_result(tri.data_ptr(), n * rank // world, n * (rank + 1) // world, rank, world if rank == 0 else 0)
+        assert int(rep[3]) == 1 and not rep[[0, 1, 2, 4]].any()
+        if rank == 0:
+            s, h = c.result_matrices()
+            np.save(out + ".s%d.npy" % step, s)
+            np.save(out + ".h%d.npy" % step, h)
+    if rank == 0:
+        c.result_unlink()
+    c.close()
+
+
+def test_two_processes_write_their_rows_of_one_shared_result(tmp_path):
+    """The result's shared page-locked home across processes (phylo_result_open with a POSIX shared-memory name): two
+    processes on the test box's one GPU map and register the same segment, each one's device writes its half of the rows
+    of both matrices, rank 0 waits for both deliveries (a counter per rank in the segment's header) and reads the whole
+    result — three passes (in the library's own use the collectives of the next pass keep a rank from writing rows the
+    result's rank is still reading; here nothing is written between passes that differs)."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "res")
+    name = "/phylonium_amd_test2_%d" % os.getpid()
+    mp.spawn(_shared_home_worker, args=(2, name, out), nprocs=2, join=True)
+    gs = synth.make_genomes(9, 20000, seed=72, d_range=(0.01, 0.2), indel_per_mbp=300, inv_frac=0.05)
+    so, ho = O.Run(gs, 2).process().matrix()
+    for step in range(3):
+        assert (np.load(out + ".s%d.npy" % step) == so).all() and (np.load(out + ".h%d.npy" % step) == ho).all(), step
+    assert not os.path.exists("/dev/shm" + name)
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("PHY_FUZZ_SEEDS", "48"))))  # a long sweep: PHY_FUZZ_SEEDS=300
 def test_fuzz_small_random_sets(ctx, seed):
     """Randomised shapes: genome count, lengths, divergence, structure, contigs, chunk
@@ -1267,6 +1318,18 @@ def test_many_queries_default_options(ctx):
     assert (s2 == so).all() and (h2 == ho).all()
     s3, h3 = ctx.compare()
     assert (s3 == so).all() and (h3 == ho).all()
+    # the result's page-locked home as the caller's matrices: the device writes them itself (both phases as one call, and a
+    # comparison alone), an odd number of genomes included (the second matrix then starts on a boundary of its own)
+    ctx.result_open(None, ranks=1)
+    try:
+        views = ctx.result_matrices()
+        for call in (ctx.anchor_compare, lambda out: ctx.compare(0, 1, out=out)):
+            views[0][:] = 7
+            views[1][:] = 7
+            s4, h4 = call(out=views)
+            assert (s4 == so).all() and (h4 == ho).all()
+    finally:
+        ctx.result_close()
 
 
 @pytest.mark.timeout(900)
