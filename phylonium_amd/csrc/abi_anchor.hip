@@ -200,7 +200,6 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, int defer)
 		c->plan_qb = q_begin;
 		c->plan_qe = q_end;
 		c->plan_valid = true;
-		c->vis_clean_w0 = c->vis_clean_w1 = 0; // (another layout: nothing is known to be clean)
 	}
 	const ChunkPlan &P = c->plan;
 	const uint32_t nch = P.nchunks;
@@ -211,12 +210,10 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, int defer)
 	if (nch) { // the words of this call's queries (their genomes lie back to back in the buffer)
 		// (on 256-byte boundaries: one fill instead of head, body and tail; the neighbours' bits are nobody's between two calls)
 		const uint64_t w0 = c->goff[q_begin] / 32 / 64 * 64, w1 = ((c->goff[q_end - 1] + c->glen[q_end - 1]) / 32 + 1 + 63) / 64 * 64;
-		if (c->vis_clean_w0 == w0 && c->vis_clean_w1 == w1 && c->vis_ev_clean) {
-			HIPOK(c, hipStreamWaitEvent(st, c->vis_ev_clean, 0)); // cleared behind the last pass's bridges, beside its phase B
-		} else {
-			HIPOK(c, hipMemsetAsync(c->a_visited.p + w0, 0, (size_t)(w1 - w0) * 4, st));
-		}
-		c->vis_clean_w0 = c->vis_clean_w1 = 0;
+		// (Clearing them for the next pass on a second stream behind this pass's bridges — beside the fold, or behind the
+		// projection beside the pair kernel — was measured: the fill then costs the kernel it runs beside what it saved in
+		// front of the chains, C3 fold 0.18 -> 0.21 ms or pairs 0.345 -> 0.364; not kept.)
+		HIPOK(c, hipMemsetAsync(c->a_visited.p + w0, 0, (size_t)(w1 - w0) * 4, st));
 	}
 
 	PhaseA A;
@@ -334,19 +331,6 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, int defer)
 			BridgeZero Z = {{c->a_out_cnt.p + j0, device_filter ? c->a_flt.p : nullptr, (device_filter && tail_eager) ? c->b_flag.p : nullptr},
 							{j1 - j0, device_filter ? 1u : 0u, (device_filter && tail_eager) ? 4u : 0u}};
 			launch_lean_bridge(A, R, X, c->n_cu, st, Z);
-			// the bridges were the visited bits' last readers: clear them for the next pass on the copy stream, beside the
-			// fold, the filter and phase B (160 MB at C3: 22 us that stood in front of every pass's chain kernel)
-			if (!c->vis_ev_bridges) {
-				HIPOK(c, hipEventCreateWithFlags(&c->vis_ev_bridges, hipEventDisableTiming));
-				HIPOK(c, hipEventCreateWithFlags(&c->vis_ev_clean, hipEventDisableTiming));
-			}
-			const uint64_t w0 = c->goff[q_begin] / 32 / 64 * 64, w1 = ((c->goff[q_end - 1] + c->glen[q_end - 1]) / 32 + 1 + 63) / 64 * 64;
-			HIPOK(c, hipEventRecord(c->vis_ev_bridges, st));
-			HIPOK(c, hipStreamWaitEvent(c->copy_stream, c->vis_ev_bridges, 0));
-			HIPOK(c, hipMemsetAsync(c->a_visited.p + w0, 0, (size_t)(w1 - w0) * 4, c->copy_stream));
-			HIPOK(c, hipEventRecord(c->vis_ev_clean, c->copy_stream));
-			c->vis_clean_w0 = w0;
-			c->vis_clean_w1 = w1;
 		}
 		{
 			KernelSpan s(c, "anchor_fold", sg);

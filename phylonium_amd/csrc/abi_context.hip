@@ -135,8 +135,6 @@ void phylo_ctx_destroy(phylo_ctx *c)
 	}
 	for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
 	for (hipEvent_t e : c->copy_events) (void)hipEventDestroy(e);
-	if (c->vis_ev_bridges) (void)hipEventDestroy(c->vis_ev_bridges);
-	if (c->vis_ev_clean) (void)hipEventDestroy(c->vis_ev_clean);
 	if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
 	(void)hipStreamDestroy(c->own_stream);
 	delete c;

@@ -267,10 +267,6 @@ struct phylo_ctx {
 	std::vector<uint32_t> xb_bounds;        // the ranks' bounds as phylo_attach_blocks_device uploaded them last ...
 	const uint32_t *xb_bounds_at = nullptr; // ... and where (skipped while both stay the same)
 	bool flags_zeroed = false;              // the block export of a queued phase A has zeroed b_flag for the attach that follows
-	// the visited bits of the last phase A's queries are cleared again behind its bridges, on the copy stream beside phase B:
-	// the next phase A over the same queries waits for that event instead of filling 160 MB in front of its chains
-	uint64_t vis_clean_w0 = 0, vis_clean_w1 = 0;
-	hipEvent_t vis_ev_bridges = nullptr, vis_ev_clean = nullptr;
 	bool homs_staged = false;
 	// ... and has projected them for the whole reference (part 0 of 1); with five planes or three
 	bool eager_valid = false, eager_five = false;
