@@ -4,6 +4,7 @@
 # (files land in gpurun_out/final; the ones kept are copied to profiles/ by hand).
 set -x
 cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests -x -q -m gpu > gpurun_out/final_pytest.log 2>&1; tail -3 gpurun_out/final_pytest.log
 R=r05
 mkdir -p gpurun_out/final
 python bench.py > gpurun_out/final/${R}_bench_c3.json 2> gpurun_out/final/c3.err
