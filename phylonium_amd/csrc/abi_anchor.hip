@@ -142,6 +142,8 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, int defer)
 		// 16.0 against 18.7 ms; five: 16.4).
 		uint64_t plan_bases = 0;
 		for (size_t j = 0; j < nq; j++) plan_bases += qlen[j];
+		c->plan_nq_real = 0; // queries that have chunks (the subject among the queries has none)
+		for (size_t j = 0; j < nq; j++) c->plan_nq_real += qlen[j] > 0;
 		int per_cu_cap = (c->k >= 14 || plan_bases > 2500000000ull) ? 4 : 3;
 #ifdef PHY_DEV_HOOKS
 		if (const char *e = getenv("PHY_SPEC_PER_CU")) per_cu_cap = std::max(1, atoi(e)); // experiments
@@ -338,8 +340,12 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, int defer)
 			// repeats) plus its share of the anchors; with a block per CU or more there is nothing to gain from
 			// splitting (measured, C3's 256 queries with two blocks each: 0.17 -> 0.21 ms), with a handful of queries
 			// the idle CUs take a part each (c2like's 29 queries: 0.167 -> 0.100 ms; C5's 64: 2.65 -> 2.28 ms)
+			// (counted without the queries that have no chunks — the subject among its queries: their blocks leave at once.  A
+			// rank of eight with the subject in its block has 129 queries, 128 of them real: two blocks each fit the 256 CUs,
+			// 0.12 ms; counted with the subject it was one block each, 0.19 ms — on the rank that also fetches the result.)
 			uint32_t fold_nb = c->opt_fold_blocks;
-			if (!fold_nb) fold_nb = 2 * (j1 - j0) <= (uint32_t)c->n_cu ? (uint32_t)std::min<size_t>(8, (size_t)c->n_cu / (j1 - j0)) : 1u;
+			const uint32_t nq_real = std::max<uint32_t>(1, (uint32_t)c->plan_nq_real);
+			if (!fold_nb) fold_nb = 2 * nq_real <= (uint32_t)c->n_cu ? (uint32_t)std::min<size_t>(8, (size_t)c->n_cu / nq_real) : 1u;
 			launch_fold(A, j0, j1, c->L, c->threshold, c->a_raw.p, c->a_out_base.p, c->a_out_cap.p, c->a_out_cnt.p, sg, fold_nb, nch == 0);
 		}
 		if (device_filter) {

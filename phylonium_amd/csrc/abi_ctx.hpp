@@ -330,6 +330,7 @@ struct phylo_ctx {
 	ChunkPlan plan;
 	std::vector<uint64_t> plan_out_base;
 	uint64_t plan_raw_total = 0;
+	size_t plan_nq_real = 0; // the plan's queries that have chunks
 
 	// stats
 	std::map<std::string, double> stats;
