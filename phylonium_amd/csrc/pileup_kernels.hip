@@ -63,6 +63,12 @@ static const uint32_t PROJ_TW = 64; // words per tile
 #ifndef PHY_PROJ_MINB
 #define PHY_PROJ_MINB 1 // blocks per CU the projection is compiled for (A/B builds: 5 caps the registers at 96 and spills)
 #endif
+#ifndef PHY_PROJ_SCALAR_BAD
+#define PHY_PROJ_SCALAR_BAD 0 // A/B builds
+#endif
+#ifndef PHY_PROJ_ALWAYS_A
+#define PHY_PROJ_ALWAYS_A 0 // A/B builds
+#endif
 #ifndef PHY_PROJ_V2
 #define PHY_PROJ_V2 1 // the projection's covering-homology look-up without a loop (0: rounds 1-4's searching loop only; A/B builds)
 #endif
@@ -275,7 +281,11 @@ __global__ __launch_bounds__(256, PHY_PROJ_MINB) void project_kernel(Pileup P, Q
 		V |= pc.mask;
 		N0 |= lo & pc.mask;
 		N1 |= hi & pc.mask;
+#if PHY_PROJ_SCALAR_BAD
+		if (__builtin_amdgcn_readfirstlane((int)tbad[gi])) { // (the same for the whole wavefront: a scalar branch)
+#else
 		if (tbad[gi]) {
+#endif
 			// '!' among the 32 query positions [pc.pos, pc.pos + 32)?  (the tile index found one in this tile)
 			const uint32_t g = tg * PROJ_TG + gi;
 			const uint32_t b0 = Q.qbad_off[g], nb = Q.qbad_off[g + 1] - b0;
@@ -360,7 +370,11 @@ __global__ __launch_bounds__(256, PHY_PROJ_MINB) void project_kernel(Pileup P, Q
 		const uint32_t gi = wave + 4 * (u + half * HG), g = tg * PROJ_TG + gi;
 		uint32_t V = 0, N0 = 0, N1 = 0, D = 0, B = 0;
 		const int64_t q = (int64_t)Q.goff[g < P.N ? g : 0];
+#if PHY_PROJ_ALWAYS_A
+		add_piece(Piece{q + fa[u].rel, fa[u].mask, fa[u].rev, 0u}, gi, a0[u], a1[u], a2[u], V, N0, N1, D, B); // (an empty mask adds nothing)
+#else
 		if (fa[u].mask) add_piece(Piece{q + fa[u].rel, fa[u].mask, fa[u].rev, 0u}, gi, a0[u], a1[u], a2[u], V, N0, N1, D, B);
+#endif
 		if (fb[u].mask) add_piece(Piece{q + fb[u].rel, fb[u].mask, fb[u].rev, 0u}, gi, b0[u], b1[u], b2[u], V, N0, N1, D, B);
 		{
 			const uint32_t lo = hlo[gi], h1 = hend[gi];
