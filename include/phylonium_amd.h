@@ -234,7 +234,7 @@ int phylo_compare_device(phylo_ctx *ctx, size_t part, size_t nparts, uint64_t *d
 
 /* The tallies of a part as a u32 upper triangle in device memory — what crosses the wire between ranks: tri[k]
  * substitutions and tri[P + k] homologs of pair i < j, k = i (2n - i - 1) / 2 + (j - i - 1), P = n (n - 1) / 2 (a tally
- * is at most the reference's length, < 2^31; a quarter of the bytes of the two u64 matrices), followed by four words of
+ * is at most the reference's length, < 2^31; a quarter of the bytes of the two u64 matrices), followed by eight words of
  * the part's own: what its comparison has to report ('!' list overflow, a gathered list out of order, a gathered block
  * beyond its capacity, 1 per part, a rank's phase A needs the host (phylo_anchor_block_device), 0, 0, 0) —
  * phylo_triangle_words(n) = n (n - 1) + 8 words in all.  On the default (matrix-core) path the

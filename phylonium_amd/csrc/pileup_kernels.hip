@@ -63,12 +63,15 @@ static const uint32_t PROJ_TW = 64; // words per tile
 #ifndef PHY_PROJ_MINB
 #define PHY_PROJ_MINB 1 // blocks per CU the projection is compiled for (A/B builds: 5 caps the registers at 96 and spills)
 #endif
-#ifndef PHY_PROJ_SCALAR_BAD
-#define PHY_PROJ_SCALAR_BAD 0 // A/B builds
-#endif
+// Branches the projection is better off without (same-box A/B, profiles/r05_ab_projection_micro*.txt; 0 restores them):
 #ifndef PHY_PROJ_ALWAYS_A
-#define PHY_PROJ_ALWAYS_A 0 // A/B builds
+#define PHY_PROJ_ALWAYS_A 1 // a window's first piece is added without a test of its mask (an empty mask adds nothing): C3 -4 %, C4 -6 %, C5 -8 %
 #endif
+#ifndef PHY_PROJ_REV_SELECT
+#define PHY_PROJ_REV_SELECT 1 // a reverse piece by selects instead of a branch: C3 -5 %, C4 -4 %, C5 -4 %
+#endif
+// (measured and left: the second piece without its test +1...5 %; v_alignbit instead of the 64-bit shifts 0...+2 %; the '!'
+// look-up's test as a scalar branch 0 %, or hoisted out of the pieces into one test per genome 0...+1 %)
 #ifndef PHY_PROJ_V2
 #define PHY_PROJ_V2 1 // the projection's covering-homology look-up without a loop (0: rounds 1-4's searching loop only; A/B builds)
 #endif
@@ -267,6 +270,19 @@ __global__ __launch_bounds__(256, PHY_PROJ_MINB) void project_kernel(Pileup P, Q
 		uint32_t a = (uint32_t)(((((uint64_t)w0 << 32) | w1) << sh) >> 32);
 		uint32_t b = (uint32_t)(((((uint64_t)w1 << 32) | w2) << sh) >> 32);
 		uint32_t hi, lo;
+#if PHY_PROJ_REV_SELECT
+		{
+			// a reverse piece: all 64 bits reversed — the codes run backwards and every code's two bits have changed places —
+			// and complemented.  Without a branch (nearly every wavefront holds a reverse piece somewhere and then runs both
+			// sides of one): the operands selected, both planes formed, swapped and flipped by the flag.
+			const bool rv = pc.rev != 0;
+			const uint32_t x = rv ? __builtin_bitreverse32(b) : a, y = rv ? __builtin_bitreverse32(a) : b;
+			const uint32_t pt = code_plane<true>(x, y), pf = code_plane<false>(x, y), flip = rv ? 0xffffffffu : 0u;
+			hi = (rv ? pf : pt) ^ flip;
+			lo = (rv ? pt : pf) ^ flip;
+			if (FIVE) D |= rv ? pc.mask : 0u;
+		}
+#else
 		if (pc.rev) {
 			// all 64 bits reversed: the codes run backwards and every code's two bits have changed places;
 			// the complement flips both
@@ -278,14 +294,11 @@ __global__ __launch_bounds__(256, PHY_PROJ_MINB) void project_kernel(Pileup P, Q
 			hi = code_plane<true>(a, b);
 			lo = code_plane<false>(a, b);
 		}
+#endif
 		V |= pc.mask;
 		N0 |= lo & pc.mask;
 		N1 |= hi & pc.mask;
-#if PHY_PROJ_SCALAR_BAD
-		if (__builtin_amdgcn_readfirstlane((int)tbad[gi])) { // (the same for the whole wavefront: a scalar branch)
-#else
 		if (tbad[gi]) {
-#endif
 			// '!' among the 32 query positions [pc.pos, pc.pos + 32)?  (the tile index found one in this tile)
 			const uint32_t g = tg * PROJ_TG + gi;
 			const uint32_t b0 = Q.qbad_off[g], nb = Q.qbad_off[g + 1] - b0;
