@@ -1220,6 +1220,21 @@ def _nccl_one_rank_worker(rank, world, port, out):
     s4, h4 = dist.process_sharded(c, 1, rank, world, device=dev, result_rank=0)  # a reduce to the result's rank (bench.py --gpus N)
     assert (s4 == s).all() and (h4 == h).all()
     assert c.stat("n:anchor_calls_without_a_wait", 0) >= 2 and c.stat("ms:result_rows") is not None  # queued passes, the shared home
+    # exchange blocks that have become too small (the lists grew since the plan was made): the overflow mark of the block comes
+    # back in the summed report — or, with the vector-ALU pair kernels, as the comparison's own error — and the pass is
+    # planned again and repeated, by every rank alike
+    import torch
+    for pairs_kernel in (0, 1):
+        p = c._xplan
+        nbytes = c.exchange_block_bytes(p["maxq"], 16)
+        small = dict(p)
+        blocks = torch.empty(world * nbytes, dtype=torch.uint8, device=dev)
+        small.update({"cap": 16, "nbytes": nbytes, "all": blocks, "block": blocks[rank * nbytes:(rank + 1) * nbytes]})
+        c._xplan = small
+        c.set_option("pairs_kernel", pairs_kernel)
+        s6, h6 = dist.process_sharded(c, 1, rank, world, device=dev, result_rank=0)
+        c.set_option("pairs_kernel", 0)
+        assert (s6 == s).all() and (h6 == h).all() and c._xplan["cap"] > 16, pairs_kernel
     dist._SHARED_RESULT = False  # a node whose ranks cannot share a segment: one rank fetches the result
     c._xplan = None
     for rr in (None, 0):
