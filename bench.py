@@ -490,10 +490,14 @@ def main():
     # one rank: the two N x N result matrices are the library's own page-locked home of the result (phylo_result_open,
     # private to this context): the device writes them itself, nothing is staged or widened on the host (the N-rank path
     # has the node's shared segment)
+    out_mats = None
     if world == 1 and not emu:
-        ctx.result_open(None, ranks=1)
-        out_mats = ctx.result_matrices()
-    else:
+        try:
+            ctx.result_open(None, ranks=1)
+            out_mats = ctx.result_matrices()
+        except Exception as e:  # (no page-locked memory to be had: the caller's own matrices, staged and widened by the library)
+            print(f"# result home unavailable ({e}): plain host matrices", file=sys.stderr)
+    if out_mats is None:
         out_mats = (np.empty((n, n), np.uint64), np.empty((n, n), np.uint64))
 
     seg = {}
