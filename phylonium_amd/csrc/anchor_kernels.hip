@@ -85,9 +85,11 @@ struct FoldShared {
 	uint8_t live[FOLD_WCH + 1];
 	uint32_t scan_s[FOLD_WAVES], scan_a[FOLD_WAVES];
 	// per-iteration exchange between the four waves
-	uint32_t wl_q[FOLD_WAVES], wl_s[FOLD_WAVES], wl_len[FOLD_WAVES], wl_r[FOLD_WAVES]; // last anchor of each wave and its right flag
-	uint32_t st_has[FOLD_WAVES], st_s[FOLD_WAVES], st_q[FOLD_WAVES]; // latest non-right anchor of each wave
-	uint32_t ecnt[FOLD_WAVES];
+	// (two sets, taken in turn by the iterations: the next iteration writes the other set, so no barrier has to keep it from
+	// overtaking the slowest wavefront's reads of this one — three barriers an iteration instead of four)
+	uint32_t wl_q[2][FOLD_WAVES], wl_s[2][FOLD_WAVES], wl_len[2][FOLD_WAVES], wl_r[2][FOLD_WAVES]; // last anchor of each wave and its right flag
+	uint32_t st_has[2][FOLD_WAVES], st_s[2][FOLD_WAVES], st_q[2][FOLD_WAVES]; // latest non-right anchor of each wave
+	uint32_t ecnt[2][FOLD_WAVES];
 	// several blocks per query: a block's homologies wait here until FOLD_STAGE of them go out behind one atomic
 	RawHom stage[FOLD_STAGE];
 	uint32_t stage_base;
@@ -362,13 +364,13 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j
 						fl = sh.scan_s[w2];
 					}
 				if (fw < FOLD_WAVES && wave == fw && lane == fl) {
-					sh.st_s[0] = ak.s;
-					sh.st_q[0] = ak.q;
+					sh.st_s[0][0] = ak.s;
+					sh.st_q[0][0] = ak.q;
 				}
 				__syncthreads();
 				if (fw < FOLD_WAVES) {
-					cs = sh.st_s[0];
-					cq = sh.st_q[0];
+					cs = sh.st_s[0][0];
+					cq = sh.st_q[0][0];
 					__syncthreads();
 					break;
 				}
@@ -419,6 +421,7 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j
 		if (base0 < base1) fetch(base0);
 		for (uint32_t base = base0; base < base1; base += FOLD_ITER) {
 			const uint32_t k0 = base + tid * FOLD_APT;
+			const uint32_t pb = ((base - base0) / FOLD_ITER) & 1u; // this iteration's set of the exchange arrays
 			Anchor a[FOLD_APT];
 #pragma unroll
 			for (uint32_t e = 0; e < FOLD_APT; e++) a[e] = an[e];
@@ -431,11 +434,14 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j
 				if (e < ev) tl = a[e];
 			const bool wave_last = ev > 0 && (lane == 63 || k0 + ev == total);
 			if (wave_last) {
-				sh.wl_q[wave] = tl.q;
-				sh.wl_s[wave] = tl.s;
-				sh.wl_len[wave] = tl.len;
+				sh.wl_q[pb][wave] = tl.q;
+				sh.wl_s[pb][wave] = tl.s;
+				sh.wl_len[pb][wave] = tl.len;
 			}
 			lds_barrier();
+			// (Measured and left: every thread fetching its first anchor's predecessor itself — one more 16-byte load beside
+			// its four — makes this barrier and the shuffle below unnecessary; the iteration then has two barriers and is
+			// slower all the same: C3 0.159 -> 0.168 ms, C4 0.475 -> 0.500, C5 0.875 -> 0.905.)
 			Anchor prev0;
 			prev0.q = (uint32_t)__shfl_up((int)tl.q, 1, 64);
 			prev0.s = (uint32_t)__shfl_up((int)tl.s, 1, 64);
@@ -446,9 +452,9 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j
 					prev0.s = ls;
 					prev0.len = ll;
 				} else {
-					prev0.q = sh.wl_q[wave - 1];
-					prev0.s = sh.wl_s[wave - 1];
-					prev0.len = sh.wl_len[wave - 1];
+					prev0.q = sh.wl_q[pb][wave - 1];
+					prev0.s = sh.wl_s[pb][wave - 1];
+					prev0.len = sh.wl_len[pb][wave - 1];
 				}
 			}
 			// r: bit e = anchor e is a right anchor of its predecessor
@@ -468,15 +474,15 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j
 					tq = a[e].q;
 				}
 			const uint64_t sm = __ballot(has_t);
-			if (wave_last) sh.wl_r[wave] = rl;
-			if (lane == 0) sh.st_has[wave] = sm ? 1u : 0u;
+			if (wave_last) sh.wl_r[pb][wave] = rl;
+			if (lane == 0) sh.st_has[pb][wave] = sm ? 1u : 0u;
 			if (sm && (int)lane == 63 - __clzll((long long)sm)) {
-				sh.st_s[wave] = ts;
-				sh.st_q[wave] = tq;
+				sh.st_s[pb][wave] = ts;
+				sh.st_q[pb][wave] = tq;
 			}
 			lds_barrier();
 			uint32_t prev_right0 = (uint32_t)__shfl_up((int)rl, 1, 64);
-			if (lane == 0) prev_right0 = wave == 0 ? lr : sh.wl_r[wave - 1];
+			if (lane == 0) prev_right0 = wave == 0 ? lr : sh.wl_r[pb][wave - 1];
 			// a homology ends at every non-right anchor; it is emitted iff the anchor before it
 			// was a right anchor or long enough (process.cxx:261)
 			uint32_t em = (ev > 0 && !(r & 1u) && (prev_right0 || prev0.len / 2 >= thr)) ? 1u : 0u;
@@ -490,7 +496,7 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j
 				uint32_t t1 = (uint32_t)__shfl_up((int)pe, d, 64);
 				if ((int)lane >= d) pe += t1;
 			}
-			if (lane == 63) sh.ecnt[wave] = pe;
+			if (lane == 63) sh.ecnt[pb][wave] = pe;
 			// the run that is open when this thread's first anchor arrives started at the latest
 			// non-right anchor of an earlier thread / wave / iteration
 			const uint64_t below = sm & ((1ull << lane) - 1ull);
@@ -501,9 +507,9 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j
 				rs = cs;
 				rq = cq;
 				for (int w2 = (int)wave - 1; w2 >= 0; w2--)
-					if (sh.st_has[w2]) {
-						rs = sh.st_s[w2];
-						rq = sh.st_q[w2];
+					if (sh.st_has[pb][w2]) {
+						rs = sh.st_s[pb][w2];
+						rq = sh.st_q[pb][w2];
 						break;
 					}
 			}
@@ -515,8 +521,8 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j
 			// anchors already requested — into every iteration: 21 us instead of 10.  The block's homologies are staged in
 			// LDS instead and leave FOLD_STAGE at a time behind one atomic.
 			uint32_t slot = pe - ne, tot = 0;
-			for (uint32_t w2 = 0; w2 < wave; w2++) slot += sh.ecnt[w2];
-			for (uint32_t w2 = 0; w2 < FOLD_WAVES; w2++) tot += sh.ecnt[w2];
+			for (uint32_t w2 = 0; w2 < wave; w2++) slot += sh.ecnt[pb][w2];
+			for (uint32_t w2 = 0; w2 < FOLD_WAVES; w2++) tot += sh.ecnt[pb][w2];
 			bool staged = false;
 			if (nb == 1) {
 				slot += cnt;
@@ -554,17 +560,18 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j
 			}
 			// carry out (same values in every thread)
 			const uint32_t lw = ((m - 1) / FOLD_APT) >> 6;
-			lq = sh.wl_q[lw];
-			ls = sh.wl_s[lw];
-			ll = sh.wl_len[lw];
-			lr = sh.wl_r[lw];
+			lq = sh.wl_q[pb][lw];
+			ls = sh.wl_s[pb][lw];
+			ll = sh.wl_len[pb][lw];
+			lr = sh.wl_r[pb][lw];
 			for (int w2 = (int)FOLD_WAVES - 1; w2 >= 0; w2--)
-				if (sh.st_has[w2]) {
-					cs = sh.st_s[w2];
-					cq = sh.st_q[w2];
+				if (sh.st_has[pb][w2]) {
+					cs = sh.st_s[pb][w2];
+					cq = sh.st_q[pb][w2];
 					break;
 				}
-			lds_barrier(); // the exchange arrays are rewritten next iteration
+			// (no barrier here: the next iteration writes the other set of the exchange arrays, and the set after that is
+			// three barriers away)
 		}
 		// the carry behind the window's last anchor: every block needs it for the next window (and block 0 for the
 		// query's last homology); the block that folded the window's end has it already
