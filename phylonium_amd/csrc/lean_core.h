@@ -113,10 +113,20 @@ PHY_HD uint32_t popc32(uint32_t x)
 // number of leading bases two 16-base codes share
 PHY_HD uint32_t lead_eq(uint32_t x) { return x ? clz32(x) >> 1 : 16u; }
 
+#ifndef PHY_CODE_WINDOW_BRANCHY
+#define PHY_CODE_WINDOW_BRANCHY 0 // A/B builds
+#endif
 // 16 bases starting `o` bases into w0 (o in 0..15), continuing in w1
 PHY_HD uint32_t code_window(uint32_t w0, uint32_t w1, uint32_t o)
 {
+#if PHY_CODE_WINDOW_BRANCHY
 	return o ? (w0 << (2u * o)) | (w1 >> (32u - 2u * o)) : w0;
+#else
+	// (one 64-bit shift, no case for o = 0: with the case the compiler puts the second word's read — an LDS read of the
+	// lane's ring in the chain kernels — under a branch that costs every wavefront more than the sixteenth of its lanes
+	// that could skip the read saves)
+	return (uint32_t)(((((uint64_t)w0 << 32) | w1) << (2u * o)) >> 32);
+#endif
 }
 
 // A pure-ACGT 16-base query window against a suffix record (code of its first 16 bytes with
@@ -516,6 +526,73 @@ PHY_HD LeanAddr lean_addr(const LeanLane &ln, const RefIndex &R)
 }
 
 // STEP, part 2: d[0..4) = the slot, y0/y1 = the two S2 words of the lucky window
+#ifndef PHY_STEP_FLAT
+#define PHY_STEP_FLAT 0 // 1: the outcomes side by side (A/B builds)
+#endif
+#if PHY_STEP_FLAT
+// The step's outcomes side by side — lucky_anchor (process.cxx:227-242) hit or running on, else anchor() (process.cxx:219-225)
+// on the slot: an empty bucket, one or two members decided by their codes, one of them to extend, a long bucket to walk, the
+// bytes to decide — and the lane's state written with selects.  A wavefront's lanes take all of these in any mix: as cases
+// (below) every trip runs every case's code once, each behind its own exec mask and with the lane's fields copied at every
+// join; written flat the same arithmetic is a third of the instructions.  (The fields of another phase — e_*, s_*, p_* — and
+// r_* are dead while the lane is in STEP: they are written whatever the outcome.)
+PHY_HD void lean_step(LeanLane &ln, const RefIndex &R, const LeanIndex &X, const uint32_t *d, uint32_t y0, uint32_t y1)
+{
+	const uint32_t thr = R.threshold, q = ln.q;
+	const bool lucky = ln.lucky_ok(R);
+	const uint32_t try_s = ln.ls + (q - ln.lq);
+	if (lucky && !(try_s >= ln.sb_lo && try_s < ln.sb_hi)) ln.sbad_next(X, try_s); // (seldom: the next '#' of S behind try_s changes)
+	const uint32_t dcode = lead_eq(ln.qcode ^ code_window(y0, y1, try_s & 15u));
+	const uint32_t ds = ln.sb_hi - try_s;
+	const uint32_t lw = lucky ? (dcode < ds ? dcode : ds) : 0u;
+	const bool l_ext = lw >= 16u, l_fin = lucky && !l_ext && lw >= thr, l_any = l_ext || l_fin;
+	// the slot (lean_search)
+	const uint32_t w0 = d[0], w1 = d[1], w2 = d[2], w3 = d[3];
+	const uint32_t type = w0 & 7u;
+	const bool one = type == SLOT_ONE, two = type == SLOT_TWO, empty = type == SLOT_EMPTY, many = type == SLOT_MANY;
+	const uint32_t tmask = 0xffffffffu >> (2u * R.k);
+	const uint32_t qt = ln.qcode & tmask;
+	const uint32_t x1 = one ? ln.qcode ^ w2 : qt ^ (w2 & 0xffffu);
+	const uint32_t x2 = qt ^ (w2 >> 16);
+	const uint32_t sv1 = one ? w3 & 31u : (w0 >> 3) & 31u, sv2 = (w0 >> 8) & 31u;
+	const uint32_t d1 = lead_eq(x1), d2 = lead_eq(x2);
+	const uint32_t l1 = d1 < sv1 ? d1 : sv1;
+	const uint32_t l2 = two ? (d2 < sv2 ? d2 : sv2) : 0u;
+	const uint32_t c12 = two ? (w0 >> 13) & LCP_CLIP : 0u;
+	const bool pend1 = l1 == 16u, pend2 = l2 == 16u, reg = one || two;
+	const uint32_t le = (w0 >> 3) & 31u; // an empty bucket: what its neighbours share with the window
+	const bool first = l1 > l2;
+	const uint32_t l = first ? l1 : l2;
+	const bool s_fin = (empty && le < thr) || (reg && !pend1 && !pend2);
+	const bool s_ext = reg && (pend1 != pend2);
+	// what the step comes to
+	const bool fin = l_fin || (!l_any && s_fin), ext = l_ext || (!l_any && s_ext), scan = !l_any && many;
+	const uint32_t pos = l_fin ? try_s : empty ? 0u : first ? w1 : w3;
+	const uint32_t len = l_fin ? lw : empty ? le : l;
+	const bool acc = l_fin || (fin && reg && l >= thr && l > c12);
+	ln.r_q = q; // LeanLane::finish
+	ln.r_s = pos;
+	ln.r_len = len;
+	ln.r_accepted = acc;
+	ln.lq = acc ? q : ln.lq;
+	ln.ls = acc ? pos : ln.ls;
+	ln.ll = acc ? len : ln.ll;
+	ln.q = fin ? q + len + 1u : q;
+	ln.fin = fin;
+	ln.ph = fin ? (uint32_t)LP_STEP : ext ? (uint32_t)LP_EXT : scan ? (uint32_t)LP_SCAN : (uint32_t)LP_SLOW;
+	ln.e_kind = l_ext ? (uint32_t)EXT_LUCKY : (uint32_t)EXT_CAND; // LeanLane::start_ext
+	ln.e_pos = 16;
+	ln.e_p = l_ext ? try_s : pend1 ? w1 : w3;
+	ln.e_meta = l_ext ? 0u : one ? w3 : pend1 ? (sv1 | (c12 << 18)) : (sv2 | (c12 << 5));
+	ln.p_len = ln.p_pos = ln.p_meta = 0; // a bucket walk's start (lean_search)
+	ln.npend = 0;
+	ln.s_rank = w1;
+	ln.s_last = w2 - 1u;
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(LEAN_COUNT_WHY)
+	if (!fin && !ext && !scan) LEAN_WHY(!l_any && reg && pend1 && pend2 ? SW_PEND_MANY : SW_BUCKET);
+#endif
+}
+#else
 PHY_HD void lean_step(LeanLane &ln, const RefIndex &R, const LeanIndex &X, const uint32_t *d, uint32_t y0, uint32_t y1)
 {
 	if (ln.lucky_ok(R)) { // lucky_anchor, process.cxx:227-242
@@ -534,6 +611,7 @@ PHY_HD void lean_step(LeanLane &ln, const RefIndex &R, const LeanIndex &X, const
 	}
 	lean_search(ln, R, d[0], d[1], d[2], d[3]);
 }
+#endif
 
 // ───────────────── the slow resolver's definition, in plain loops (CPU emulation) ─────────────────
 // One whole step from the raw bytes: lucky_anchor, else the longest match at the query suffix's
