@@ -527,7 +527,7 @@ PHY_HD LeanAddr lean_addr(const LeanLane &ln, const RefIndex &R)
 
 // STEP, part 2: d[0..4) = the slot, y0/y1 = the two S2 words of the lucky window
 #ifndef PHY_STEP_FLAT
-#define PHY_STEP_FLAT 0 // 1: the outcomes side by side (A/B builds)
+#define PHY_STEP_FLAT 1 // 0: lean_step as the cases read (A/B builds)
 #endif
 #if PHY_STEP_FLAT
 // The step's outcomes side by side — lucky_anchor (process.cxx:227-242) hit or running on, else anchor() (process.cxx:219-225)
@@ -583,7 +583,8 @@ PHY_HD void lean_step(LeanLane &ln, const RefIndex &R, const LeanIndex &X, const
 	ln.e_kind = l_ext ? (uint32_t)EXT_LUCKY : (uint32_t)EXT_CAND; // LeanLane::start_ext
 	ln.e_pos = 16;
 	ln.e_p = l_ext ? try_s : pend1 ? w1 : w3;
-	ln.e_meta = l_ext ? 0u : one ? w3 : pend1 ? (sv1 | (c12 << 18)) : (sv2 | (c12 << 5));
+	const uint32_t m_two = (pend1 ? sv1 : sv2) | (c12 << (pend1 ? 18u : 5u)); // the other member's LCP on the candidate's other side
+	ln.e_meta = l_ext ? 0u : one ? w3 : m_two;
 	ln.p_len = ln.p_pos = ln.p_meta = 0; // a bucket walk's start (lean_search)
 	ln.npend = 0;
 	ln.s_rank = w1;
