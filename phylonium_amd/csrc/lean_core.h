@@ -834,6 +834,11 @@ struct LeanBridge {
 	// what every step would otherwise fetch again: the query's chunk grid, the position of the
 	// speculative log's next anchor, the word of the visited bitmap last looked at
 	uint32_t g_anc0, g_chunk0, nx_q, vw_idx, vw_word;
+	// two words of the visited bitmap fetched ahead (the chain kernel brings them in beside the step's slot: a walker's next
+	// position is 13 bases on on average, so two steps in five cross into the next word — a load the next slot's address
+	// would have to wait for, in a kernel whose length is its longest walk's dependent loads): words pv_base, pv_base + 1
+	static const uint32_t PV_NONE = 0x80000000u; // (no word index comes near: the bitmap has a bit per byte of a 32-bit arena)
+	uint32_t pv_base, pv0, pv1;
 
 	PHY_HD void start(const PhaseA &A, const LeanIndex &X, uint32_t chunk)
 	{
@@ -852,6 +857,8 @@ struct LeanBridge {
 		nx_q = 0xffffffffu;
 		vw_idx = 0xffffffffu;
 		vw_word = 0;
+		pv_base = PV_NONE;
+		pv0 = pv1 = 0;
 		n = 0;
 		first_block = cur_block = NO_BLOCK;
 	}
@@ -884,6 +891,8 @@ struct LeanBridge {
 		cur_log = g_anc0 + lc * A.cap;
 		n = 0;
 		first_block = cur_block = NO_BLOCK;
+		pv_base = PV_NONE;
+		pv0 = pv1 = 0;
 		ln.wb = ln.q >> 4; // the ring as the record's last eight words fill it
 		ln.we = ln.wb + PACKED_RING;
 	}
@@ -914,8 +923,10 @@ struct LeanBridge {
 		}
 		const uint32_t wi = lean_visited_word(ln, ln.q);
 		if (wi != vw_idx) {
+			const uint32_t ahead = wi - pv_base;
 			vw_idx = wi;
-			vw_word = A.visited[wi];
+			if (ahead < 2u) vw_word = ahead ? pv1 : pv0;
+			else vw_word = A.visited[wi];
 		}
 		if ((vw_word >> (ln.q & 31)) & 1u) {
 			// The chunk's own chain stood here too: the same chain from here on iff the two are in equivalent states,

@@ -663,15 +663,20 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 			if (go) go = lean_step_phase(ln, X) == LP_STEP;
 			const uint32_t n_go = (uint32_t)__popcll(__ballot(go)), n_act = (uint32_t)__popcll(__ballot(active));
 			if (!n_go || n_go * PHY_FAST_DEN < n_act * PHY_FAST_NUM) break;
-			const uint8_t *fA = s2_b, *fY = s2_b;
+			const uint8_t *fA = s2_b, *fY = s2_b, *fV = s2_b;
 			if (go) {
 				const uint32_t w = ln.q >> 4;
 				ln.qcode = code_window(ring[w & 15u][tid], ring[(w + 1u) & 15u][tid], ln.q & 15u);
 				fA = slot_b + (uint64_t)(ln.qcode >> (2u * (16u - R.k))) * 16u;
 				if (ln.lucky_ok(R)) fY = s2_b + (uint64_t)((ln.ls + (ln.q - ln.lq)) >> 4) * 4u;
+				if constexpr (MODE == 1) fV = (const uint8_t *)(A.visited + L.vw_idx + 1u); // (LeanBridge: pv_base)
 			}
 			const U4 fx = lg16(fA);
 			const U2 fy = lg8(fY);
+			if constexpr (MODE == 1) {
+				const U2 fv = lg8(fV);
+				if (go) L.pv_base = L.vw_idx + 1u, L.pv0 = fv.x, L.pv1 = fv.y;
+			}
 			if (go) {
 				const uint32_t fd[4] = {fx.x, fx.y, fx.z, fx.w};
 				lean_step(ln, R, X, fd, fy.x, fy.y);
@@ -768,8 +773,10 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 		if (ph == LP_STEP || ph == LP_SEARCH || ph == LP_LOOK) {
 			pA = slot_b + (uint64_t)(ln.qcode >> (2u * (16u - R.k))) * 16u;
 			if (ph == LP_STEP && ln.lucky_ok(R)) pY = s2_b + (uint64_t)((ln.ls + (ln.q - ln.lq)) >> 4) * 4u;
-			if constexpr (MODE == 1) // the walker that is looked ahead for: the visited bits of the positions ahead of it
-				if ((int)lane64() == look_leader) pB = (const uint8_t *)(A.visited + look_vis0);
+			if constexpr (MODE == 1) { // the visited bits of the positions ahead: for the walker's next begin_step (LeanBridge: pv_base) ...
+				if (ph == LP_STEP) pB = (const uint8_t *)(A.visited + L.vw_idx);
+				if ((int)lane64() == look_leader) pB = (const uint8_t *)(A.visited + look_vis0); // ... and for the one that is looked ahead for
+			}
 		} else if (ph == LP_EXT) {
 			const uint32_t e0 = ln.e_pos - ((ln.q + ln.e_pos) & 15u);
 			pA = q2_b + ((uint64_t)ln.qw0 + ((ln.q + e0) >> 4)) * 4u;
@@ -807,6 +814,7 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 		LEAN_TICK(2)
 		// digest
 		if (ph == LP_STEP) {
+			if constexpr (MODE == 1) L.pv_base = L.vw_idx + 1u, L.pv0 = d[9], L.pv1 = d[10];
 			lean_step(ln, R, X, d, y[0], y[1]);
 		} else if (ph == LP_SEARCH || ph == LP_LOOK) {
 			lean_search(ln, R, d[0], d[1], d[2], d[3]);
