@@ -536,10 +536,12 @@ PHY_HD LeanAddr lean_addr(const LeanLane &ln, const RefIndex &R)
 // (below) every trip runs every case's code once, each behind its own exec mask and with the lane's fields copied at every
 // join; written flat the same arithmetic is a third of the instructions.  (The fields of another phase — e_*, s_*, p_* — and
 // r_* are dead while the lane is in STEP: they are written whatever the outcome.)
-PHY_HD void lean_step(LeanLane &ln, const RefIndex &R, const LeanIndex &X, const uint32_t *d, uint32_t y0, uint32_t y1)
+// with_lucky = false: the slot's part alone (lean_search: SEARCH, and the bridge kernel's look-ahead) — one body for the lanes
+// of a trip that are in either
+PHY_HD void lean_step_any(LeanLane &ln, const RefIndex &R, const LeanIndex &X, const uint32_t *d, uint32_t y0, uint32_t y1, bool with_lucky)
 {
 	const uint32_t thr = R.threshold, q = ln.q;
-	const bool lucky = ln.lucky_ok(R);
+	const bool lucky = with_lucky && ln.lucky_ok(R);
 	const uint32_t try_s = ln.ls + (q - ln.lq);
 	if (lucky && !(try_s >= ln.sb_lo && try_s < ln.sb_hi)) ln.sbad_next(X, try_s); // (seldom: the next '#' of S behind try_s changes)
 	const uint32_t dcode = lead_eq(ln.qcode ^ code_window(y0, y1, try_s & 15u));
@@ -592,6 +594,10 @@ PHY_HD void lean_step(LeanLane &ln, const RefIndex &R, const LeanIndex &X, const
 #if !defined(__HIP_DEVICE_COMPILE__) && defined(LEAN_COUNT_WHY)
 	if (!fin && !ext && !scan) LEAN_WHY(!l_any && reg && pend1 && pend2 ? SW_PEND_MANY : SW_BUCKET);
 #endif
+}
+PHY_HD void lean_step(LeanLane &ln, const RefIndex &R, const LeanIndex &X, const uint32_t *d, uint32_t y0, uint32_t y1)
+{
+	lean_step_any(ln, R, X, d, y0, y1, true);
 }
 #else
 PHY_HD void lean_step(LeanLane &ln, const RefIndex &R, const LeanIndex &X, const uint32_t *d, uint32_t y0, uint32_t y1)
@@ -808,21 +814,19 @@ struct LeanSpec {
 	}
 	PHY_HD void step_done(const PhaseA &A)
 	{
-		if (ln.r_accepted) {
-			if (cnt < A.cap) {
-				const Anchor a = {ln.r_q, ln.r_s, ln.r_len, 0u};
-				if ((cnt & 1u) == 0u) {
-					pend = a;
-				} else {
-					U4 *dst = (U4 *)(A.spec_anchors + (size_t)log0 + (cnt - 1u));
-					dst[0] = U4{pend.q, pend.s, pend.len, 0u};
-					dst[1] = U4{a.q, a.s, a.len, 0u};
-				}
-			} else {
-				*A.error = 1;
-			}
-			cnt++;
+		// (the anchor that waits for its pair, kept with selects: as cases the three words are copied at every join)
+		const bool acc = ln.r_accepted, room = cnt < A.cap, second = (cnt & 1u) != 0u;
+		if (acc && room && second) {
+			U4 *dst = (U4 *)(A.spec_anchors + (size_t)log0 + (cnt - 1u));
+			dst[0] = U4{pend.q, pend.s, pend.len, 0u};
+			dst[1] = U4{ln.r_q, ln.r_s, ln.r_len, 0u};
 		}
+		if (acc && !room) *A.error = 1;
+		const bool keep = acc && room && !second;
+		pend.q = keep ? ln.r_q : pend.q;
+		pend.s = keep ? ln.r_s : pend.s;
+		pend.len = keep ? ln.r_len : pend.len;
+		cnt += acc ? 1u : 0u;
 	}
 };
 

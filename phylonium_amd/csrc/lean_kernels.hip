@@ -813,12 +813,21 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 		}
 		LEAN_TICK(2)
 		// digest
+#if PHY_STEP_FLAT
+		if (ph == LP_STEP || ph == LP_SEARCH || ph == LP_LOOK) { // (one body for the three: lean_step_any)
+			if constexpr (MODE == 1) {
+				if (ph == LP_STEP) L.pv_base = L.vw_idx + 1u, L.pv0 = d[9], L.pv1 = d[10];
+			}
+			lean_step_any(ln, R, X, d, y[0], y[1], ph == LP_STEP);
+		} else if (ph == LP_EXT) {
+#else
 		if (ph == LP_STEP) {
 			if constexpr (MODE == 1) L.pv_base = L.vw_idx + 1u, L.pv0 = d[9], L.pv1 = d[10];
 			lean_step(ln, R, X, d, y[0], y[1]);
 		} else if (ph == LP_SEARCH || ph == LP_LOOK) {
 			lean_search(ln, R, d[0], d[1], d[2], d[3]);
 		} else if (ph == LP_EXT) {
+#endif
 			uint32_t sw[9];
 			ln.wb = (ln.q + (ln.e_pos - ((ln.q + ln.e_pos) & 15u))) >> 4;
 			ln.we = ln.wb + 8;
