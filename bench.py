@@ -338,6 +338,11 @@ def launch_ranks(n_ranks):
                 break
             if live:
                 time.sleep(0.05)
+        # (a rank has failed: the others a moment to fail the same way and say so themselves — all of them without a GPU,
+        # say — before the ones stuck in a collective are ended)
+        t_grace = time.time() + 2.0
+        while rc != 124 and any(p.poll() is None for p in procs) and time.time() < t_grace:
+            time.sleep(0.05)
     finally:
         for p in procs:
             if p.poll() is None:

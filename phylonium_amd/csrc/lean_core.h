@@ -1087,7 +1087,11 @@ inline void lean_trip_cpu(LeanLane &ln, uint32_t *ring, const uint8_t *qbase, co
 	memcpy(y, lean_ptr(T, a.baseY, a.offY), 8);
 	switch (ln.ph) {
 		case LP_STEP: lean_step(ln, R, X, d, y[0], y[1]); break;
+#if PHY_STEP_FLAT
+		case LP_SEARCH: lean_step_any(ln, R, X, d, y[0], y[1], false); break; // (as the kernels digest it)
+#else
 		case LP_SEARCH: lean_search(ln, R, d[0], d[1], d[2], d[3]); break;
+#endif
 		case LP_SCAN: {
 			U4 r[4];
 			memcpy(r, d, 64);
