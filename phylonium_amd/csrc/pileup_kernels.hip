@@ -566,6 +566,9 @@ __global__ __launch_bounds__(64) void pairs_kernel(Pileup P, const uint32_t *__r
 // i side and the j side.  Lane l holds genome l & 31 of a group of 32 genomes; lanes 0..31 take window w, lanes
 // 32..63 window w + 1: the instruction's two K blocks of 32.  A wavefront owns a tile of 64 x 64 genomes (2 x 2
 // instructions per channel and step) and a chunk of windows; two wavefronts per SIMD.
+#ifndef PHY_PAIRS_FENCE
+#define PHY_PAIRS_FENCE 1 // 0: the pair kernel's first loads in the scheduler's order (A/B builds)
+#endif
 typedef int pm_v8i __attribute__((ext_vector_type(8)));
 typedef float pm_v16f __attribute__((ext_vector_type(16)));
 static const int PM_G = 2;  // groups of 32 genomes per tile side
@@ -671,7 +674,16 @@ static __device__ __forceinline__ void pairs_mfma_body(const Pileup &P, uint32_t
 		rb = __builtin_amdgcn_make_buffer_rsrc((void *)(P.plane[2] + row0), 0, chunk_bytes, 0x00020000);
 		off = (half * P.Npad + gl) * 4u;
 #pragma unroll
-		for (int k = 0; k < PM_NB; k++) load(x[k]);
+		for (int k = 0; k < PM_NB; k++) {
+			load(x[k]);
+#if PHY_PAIRS_FENCE
+			// The sets are asked for one after the other, as the loop refills them.  Left to itself the scheduler sorts these 36
+			// loads by plane, the set the loop starts with has words among the last — and where the loop's first trip has to wait
+			// for every load in flight (s_waitcnt vmcnt(0)), the compiler makes every trip wait so: the two sets just asked for
+			// with it, a load's whole latency every three steps.  In order the waits count: vmcnt(35) ... (24), (12).
+			__builtin_amdgcn_sched_barrier(0);
+#endif
+		}
 		for (uint32_t w = w0; w < w1; w += 2 * PM_NB) {
 #pragma unroll
 			for (int k = 0; k < PM_NB; k++) compute(x[k]);
