@@ -62,6 +62,9 @@ static const uint32_t FOLD_THREADS = 1024; // per block (= per query)
 static const uint32_t FOLD_WAVES = FOLD_THREADS / 64;
 static const uint32_t FOLD_PPT = FOLD_WCH / FOLD_THREADS; // chain positions per thread when segments are laid out
 static const uint32_t FOLD_ITER = FOLD_THREADS * FOLD_APT;
+#ifndef PHY_FOLD_WAIT_FIRST
+#define PHY_FOLD_WAIT_FIRST 1 // 0: the compiler's own waits in the fold's iteration (A/B builds)
+#endif
 
 // Workgroup barrier that orders LDS traffic only: global loads issued before it may
 // still be in flight afterwards (__syncthreads would wait for them).
@@ -426,6 +429,13 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j
 #pragma unroll
 			for (uint32_t e = 0; e < FOLD_APT; e++) a[e] = an[e];
 			const uint32_t ev = evn; // valid anchors of this thread (the invalid ones are at the very end)
+#if PHY_FOLD_WAIT_FIRST
+			// This iteration's anchors were asked for an iteration ago: they are waited for HERE, before the next ones are
+			// asked for.  The compiler cannot count the loads fetch() issues under its conditions, and where the iteration
+			// first looks at its own anchors it waited for everything in flight (s_waitcnt vmcnt(0)) — the anchors just asked
+			// for with them, their whole latency in every iteration: the fetch ahead hid nothing.
+			__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+#endif
 			if (base + FOLD_ITER < base1) fetch(base + FOLD_ITER);
 			const uint32_t m = total - base < FOLD_ITER ? total - base : FOLD_ITER; // valid anchors this iteration
 			Anchor tl = a[0]; // this thread's last valid anchor
