@@ -572,7 +572,10 @@ __global__ __launch_bounds__(64) void pairs_kernel(Pileup P, const uint32_t *__r
 typedef int pm_v8i __attribute__((ext_vector_type(8)));
 typedef float pm_v16f __attribute__((ext_vector_type(16)));
 static const int PM_G = 2;  // groups of 32 genomes per tile side
-static const int PM_NB = 3; // register sets of plane words in flight (a set is refilled right after its step has expanded it)
+#ifndef PHY_PAIRS_NB
+#define PHY_PAIRS_NB 3 // (A/B builds; with the waits counting: 2 sets C4 4.71 ms, 3 sets 4.36, 4 sets 4.41 — profiles/r05_ab_pairs_nb.txt)
+#endif
+static const int PM_NB = PHY_PAIRS_NB; // register sets of plane words in flight (a set is refilled right after its step has expanded it)
 
 static __device__ __forceinline__ void pm_expand_v(uint32_t V, uint32_t o[4])
 {
