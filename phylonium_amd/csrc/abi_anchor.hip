@@ -214,7 +214,9 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, int defer)
 		const uint64_t w0 = c->goff[q_begin] / 32 / 64 * 64, w1 = ((c->goff[q_end - 1] + c->glen[q_end - 1]) / 32 + 1 + 63) / 64 * 64;
 		// (Clearing them for the next pass on a second stream behind this pass's bridges — beside the fold, or behind the
 		// projection beside the pair kernel — was measured: the fill then costs the kernel it runs beside what it saved in
-		// front of the chains, C3 fold 0.18 -> 0.21 ms or pairs 0.345 -> 0.364; not kept.)
+		// front of the chains, C3 fold 0.18 -> 0.21 ms or pairs 0.345 -> 0.364; not kept.  Nor behind the pass's result, with
+		// the host waiting for an event recorded in front of the fill — the device clearing while the host turns around:
+		// the same to a hundredth of a millisecond, profiles/r05_ab_visited_clear_behind_result.txt.)
 		HIPOK(c, hipMemsetAsync(c->a_visited.p + w0, 0, (size_t)(w1 - w0) * 4, st));
 	}
 
