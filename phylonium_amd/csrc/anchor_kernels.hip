@@ -54,17 +54,11 @@ static __device__ __forceinline__ Anchor gload_anchor(const Anchor *p)
 
 static const uint32_t FOLD_WCH = 1024;  // chunks of metadata per window
 static const uint32_t FOLD_SEGS = 5120; // anchor segments per window (a chunk contributes 1-3; 5 per chunk on average would overflow, reported as error 4)
-#ifndef PHY_FOLD_APT
-#define PHY_FOLD_APT 4
-#endif
-static const uint32_t FOLD_APT = PHY_FOLD_APT; // anchors per thread and iteration
+static const uint32_t FOLD_APT = 4; // anchors per thread and iteration
 static const uint32_t FOLD_THREADS = 1024; // per block (= per query)
 static const uint32_t FOLD_WAVES = FOLD_THREADS / 64;
 static const uint32_t FOLD_PPT = FOLD_WCH / FOLD_THREADS; // chain positions per thread when segments are laid out
 static const uint32_t FOLD_ITER = FOLD_THREADS * FOLD_APT;
-#ifndef PHY_FOLD_WAIT_FIRST
-#define PHY_FOLD_WAIT_FIRST 1 // 0: the compiler's own waits in the fold's iteration (A/B builds)
-#endif
 
 // Workgroup barrier that orders LDS traffic only: global loads issued before it may
 // still be in flight afterwards (__syncthreads would wait for them).
@@ -192,6 +186,8 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j
 			if (tid == 0) sh.dist[0] = (uint16_t)wn;
 			__syncthreads();
 		} else {
+		// (neither loop over the levels unrolled: eleven levels' LDS addresses held in registers took the kernel past its 128)
+#pragma unroll 1
 		for (uint32_t k = 0; k < 10; k++) {
 			uint32_t nd[FOLD_WCH / FOLD_THREADS + 1], nj[FOLD_WCH / FOLD_THREADS + 1], c = 0;
 			for (uint32_t t = tid; t <= wn; t += FOLD_THREADS, c++) {
@@ -210,6 +206,7 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j
 		const uint32_t entry = gc - wbeg;
 		if (tid == 0) sh.live[entry] = 1;
 		__syncthreads();
+#pragma unroll 1
 		for (int k = 10; k >= 0; k--) {
 			for (uint32_t t = tid; t < wn; t += FOLD_THREADS)
 				if (sh.live[t]) {
@@ -429,13 +426,11 @@ __global__ __launch_bounds__(FOLD_THREADS) void fold_kernel(PhaseA A, uint32_t j
 #pragma unroll
 			for (uint32_t e = 0; e < FOLD_APT; e++) a[e] = an[e];
 			const uint32_t ev = evn; // valid anchors of this thread (the invalid ones are at the very end)
-#if PHY_FOLD_WAIT_FIRST
 			// This iteration's anchors were asked for an iteration ago: they are waited for HERE, before the next ones are
 			// asked for.  The compiler cannot count the loads fetch() issues under its conditions, and where the iteration
 			// first looks at its own anchors it waited for everything in flight (s_waitcnt vmcnt(0)) — the anchors just asked
 			// for with them, their whole latency in every iteration: the fetch ahead hid nothing.
 			__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
-#endif
 			if (base + FOLD_ITER < base1) fetch(base + FOLD_ITER);
 			const uint32_t m = total - base < FOLD_ITER ? total - base : FOLD_ITER; // valid anchors this iteration
 			Anchor tl = a[0]; // this thread's last valid anchor

@@ -144,10 +144,7 @@ void launch_symmetrise(uint32_t N, unsigned long long *a, unsigned long long *b,
 // *bad = 1 unless every genome's list is sorted by projected start, disjoint and inside [0, L)
 void launch_check_lists(const DevHom *homs, const uint32_t *hom_rng, uint32_t N, uint32_t L, uint32_t *bad, hipStream_t st);
 
-#ifndef PHY_PAIR_IG
-#define PHY_PAIR_IG 16
-#endif
-static const uint32_t PAIR_IG = PHY_PAIR_IG; // i-genomes per block (scalar side)
+static const uint32_t PAIR_IG = 16; // i-genomes per block (scalar side)
 static const uint32_t PAIR_JT = 64; // j-genomes per block (one per lane)
 
 } // namespace phy

@@ -79,10 +79,7 @@ PHY_HD uint32_t lean_quirk_lookup(const LeanIndex &X, const uint8_t *Q, uint32_t
 
 enum LeanPhase : uint32_t { LP_STEP = 0, LP_SEARCH, LP_SCAN, LP_EXT, LP_REFILL, LP_SLOW, LP_SLOWEXT,
 							 LP_LOOK }; // (LP_LOOK: a lane of the bridge kernel working out a position ahead of a walker, lean_kernels.hip)
-#ifndef PHY_LOOK_MAX_LIVE
-#define PHY_LOOK_MAX_LIVE 8
-#endif
-static const uint32_t LEAN_LOOK_MAX_LIVE = PHY_LOOK_MAX_LIVE; // the bridge kernel looks ahead when a wavefront has at most this many walkers left
+static const uint32_t LEAN_LOOK_MAX_LIVE = 8; // the bridge kernel looks ahead when a wavefront has at most this many walkers left
 
 static const uint32_t LEAN_RING_WORDS = 16;         // dwords of the query a lane keeps at hand (256 bases)
 static const uint32_t LEAN_EXT_BASES = 128;         // bases per EXT trip
@@ -113,20 +110,13 @@ PHY_HD uint32_t popc32(uint32_t x)
 // number of leading bases two 16-base codes share
 PHY_HD uint32_t lead_eq(uint32_t x) { return x ? clz32(x) >> 1 : 16u; }
 
-#ifndef PHY_CODE_WINDOW_BRANCHY
-#define PHY_CODE_WINDOW_BRANCHY 0 // A/B builds
-#endif
 // 16 bases starting `o` bases into w0 (o in 0..15), continuing in w1
 PHY_HD uint32_t code_window(uint32_t w0, uint32_t w1, uint32_t o)
 {
-#if PHY_CODE_WINDOW_BRANCHY
-	return o ? (w0 << (2u * o)) | (w1 >> (32u - 2u * o)) : w0;
-#else
 	// (one 64-bit shift, no case for o = 0: with the case the compiler puts the second word's read — an LDS read of the
 	// lane's ring in the chain kernels — under a branch that costs every wavefront more than the sixteenth of its lanes
 	// that could skip the read saves)
 	return (uint32_t)(((((uint64_t)w0 << 32) | w1) << (2u * o)) >> 32);
-#endif
 }
 
 // A pure-ACGT 16-base query window against a suffix record (code of its first 16 bytes with
@@ -526,10 +516,6 @@ PHY_HD LeanAddr lean_addr(const LeanLane &ln, const RefIndex &R)
 }
 
 // STEP, part 2: d[0..4) = the slot, y0/y1 = the two S2 words of the lucky window
-#ifndef PHY_STEP_FLAT
-#define PHY_STEP_FLAT 1 // 0: lean_step as the cases read (A/B builds)
-#endif
-#if PHY_STEP_FLAT
 // The step's outcomes side by side — lucky_anchor (process.cxx:227-242) hit or running on, else anchor() (process.cxx:219-225)
 // on the slot: an empty bucket, one or two members decided by their codes, one of them to extend, a long bucket to walk, the
 // bytes to decide — and the lane's state written with selects.  A wavefront's lanes take all of these in any mix: as cases
@@ -599,26 +585,6 @@ PHY_HD void lean_step(LeanLane &ln, const RefIndex &R, const LeanIndex &X, const
 {
 	lean_step_any(ln, R, X, d, y0, y1, true);
 }
-#else
-PHY_HD void lean_step(LeanLane &ln, const RefIndex &R, const LeanIndex &X, const uint32_t *d, uint32_t y0, uint32_t y1)
-{
-	if (ln.lucky_ok(R)) { // lucky_anchor, process.cxx:227-242
-		const uint32_t try_s = ln.ls + (ln.q - ln.lq);
-		const uint32_t dcode = lead_eq(ln.qcode ^ code_window(y0, y1, try_s & 15u));
-		const uint32_t ds = ln.sbad_next(X, try_s) - try_s;
-		const uint32_t lw = dcode < ds ? dcode : ds;
-		if (lw >= 16u) {
-			ln.start_ext(EXT_LUCKY, try_s, 0);
-			return;
-		}
-		if (lw >= R.threshold) {
-			ln.finish(try_s, lw, true);
-			return;
-		}
-	}
-	lean_search(ln, R, d[0], d[1], d[2], d[3]);
-}
-#endif
 
 // ───────────────── the slow resolver's definition, in plain loops (CPU emulation) ─────────────────
 // One whole step from the raw bytes: lucky_anchor, else the longest match at the query suffix's
@@ -1087,11 +1053,7 @@ inline void lean_trip_cpu(LeanLane &ln, uint32_t *ring, const uint8_t *qbase, co
 	memcpy(y, lean_ptr(T, a.baseY, a.offY), 8);
 	switch (ln.ph) {
 		case LP_STEP: lean_step(ln, R, X, d, y[0], y[1]); break;
-#if PHY_STEP_FLAT
 		case LP_SEARCH: lean_step_any(ln, R, X, d, y[0], y[1], false); break; // (as the kernels digest it)
-#else
-		case LP_SEARCH: lean_search(ln, R, d[0], d[1], d[2], d[3]); break;
-#endif
 		case LP_SCAN: {
 			U4 r[4];
 			memcpy(r, d, 64);

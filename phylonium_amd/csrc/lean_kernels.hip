@@ -445,16 +445,8 @@ void launch_lean_work(const PhaseA &A, const LeanIndex &X, WorkItem *work, QDesc
 // STEP.  Same-box A/B on C3, anchor_spec / anchor_bridge: none 3.14 / 0.45 ms; 1 trip at 3/4 2.79 / 0.36; 2 at 1/2
 // 2.78 / 0.36; 4 at 1/2 2.76 / 0.345; 4 at 1/4 2.75 / 0.344; 8 at 1/4 2.91 / 0.37 (C5: 19.1 -> 16.4 / 0.74 -> 0.50;
 // c2like 0.568 -> 0.503; C4 11.7 -> 10.2).
-#ifndef PHY_FAST_TRIPS
-#define PHY_FAST_TRIPS 4
-#endif
-#ifndef PHY_FAST_NUM
-#define PHY_FAST_NUM 1
-#define PHY_FAST_DEN 4
-#endif
-#ifndef PHY_PRIO_ROT
-#define PHY_PRIO_ROT 16u // trips between two turns of the wavefronts' issue priorities (0: no rotation)
-#endif
+static const int FAST_TRIPS = 4, FAST_NUM = 1, FAST_DEN = 4;
+static const uint32_t PRIO_ROT = 16u; // trips between two turns of the wavefronts' issue priorities
 // Every chunk's exit state is continued into the chunk behind it until the continuation stands on a position that
 // chunk's own chain visited in an equivalent state (LeanBridge::begin_step).  Where that is the case at once — the
 // chunk's last match ran on into the next chunk and that chunk's chain found the same match — there is nothing to
@@ -514,13 +506,8 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 	WorkItem nx_w = {0, 0, 0, 0};
 	QDesc nx_d = {0, 0, 0, 0, 0, 0, 0, 0};
 	bool queue_empty = false;
-#if PHY_PRIO_ROT
 	const uint32_t prio_pass = (uint32_t)(((uint64_t)blockIdx.x * 4u) / gridDim.x);
-#endif
 	LeanAlloc alloc = {&A};
-#ifdef PHY_BRIDGE_CAP
-	uint32_t cap_steps = 0;
-#endif
 	ln.fin = false;
 	ln.ph = LP_STEP;
 	const uint32_t n_items = MODE == 0 ? A.nchunks : *A.bridge_todo;
@@ -553,14 +540,6 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 		if (active && ln.ph == LP_STEP) {
 			if constexpr (MODE == 0) active = L.begin_step(A, X, vis);
 			else active = L.begin_step(A, X, R);
-#ifdef PHY_BRIDGE_CAP // timing experiments (wrong results): no bridge walks more than this many steps
-			if constexpr (MODE == 1) {
-				if (active && ++cap_steps > (uint32_t)(PHY_BRIDGE_CAP)) {
-					L.finish(A, BRIDGE_END, 0);
-					active = false;
-				}
-			}
-#endif
 #ifdef PHY_LEAN_TIMING
 			if constexpr (MODE == 1) { // how many steps the bridges that end here took
 				if (active) {
@@ -635,9 +614,6 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 						w[4 * i] = v.x, w[4 * i + 1] = v.y, w[4 * i + 2] = v.z, w[4 * i + 3] = v.w;
 					}
 					L.unpack(A, w);
-#ifdef PHY_BRIDGE_CAP
-					cap_steps = 1;
-#endif
 #ifdef PHY_LEAN_TIMING
 					bsteps = 1;
 #endif
@@ -651,18 +627,17 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 		if (__all(done && !active)) break;
 		LEAN_TICK(0)
 
-#if PHY_FAST_TRIPS
 		// Fast trips.  A trip of the loop below carries the code of every phase one of the wavefront's lanes is in, five
 		// loads and their unpacking; most lanes, most of the time, are in STEP.  While nearly all of the wavefront's
-		// lanes are, up to PHY_FAST_TRIPS trips are taken here that know nothing else: window, the slot's 16 bytes (and
+		// lanes are, up to FAST_TRIPS trips are taken here that know nothing else: window, the slot's 16 bytes (and
 		// the lucky window), lean_step, and a finished step's bookkeeping.  The few lanes in another phase (an extension,
 		// a bucket walk, a refill, the slow resolver) sit these out and have their turn in the full trip that follows.
 		bool need_bs = false; // a lane whose step has finished and whose begin_step is still owed
-		for (int f = 0; f < PHY_FAST_TRIPS; f++) {
+		for (int f = 0; f < FAST_TRIPS; f++) {
 			bool go = active && !need_bs && ln.ph == LP_STEP && !X.force_slow;
 			if (go) go = lean_step_phase(ln, X) == LP_STEP;
 			const uint32_t n_go = (uint32_t)__popcll(__ballot(go)), n_act = (uint32_t)__popcll(__ballot(active));
-			if (!n_go || n_go * PHY_FAST_DEN < n_act * PHY_FAST_NUM) break;
+			if (!n_go || n_go * FAST_DEN < n_act * FAST_NUM) break;
 			const uint8_t *fA = s2_b, *fY = s2_b, *fV = s2_b;
 			if (go) {
 				const uint32_t w = ln.q >> 4;
@@ -699,7 +674,6 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 			}
 		}
 		if (__all(done && !active)) break;
-#endif
 		// which phase is the lane in this trip; a STEP needs its window from the ring
 		uint32_t ph = active ? ln.ph : (uint32_t)LP_SLOW + 8u;
 		if (active && ph == LP_STEP) {
@@ -753,18 +727,16 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 			}
 		}
 		trip++;
-#if PHY_PRIO_ROT
 		// The SIMD's arbiter breaks ties between ready wavefronts by age: of the three or four chain wavefronts a SIMD holds,
 		// the one dispatched first issues first, trip after trip, and the last one is left the gaps — same trips, 20 % longer
 		// (measured per wavefront).  Rotating priorities even that out.
-		if ((trip & (PHY_PRIO_ROT - 1u)) == 0u) {
-			const uint32_t pr = ((trip / PHY_PRIO_ROT) + prio_pass) & 3u;
+		if ((trip & (PRIO_ROT - 1u)) == 0u) {
+			const uint32_t pr = ((trip / PRIO_ROT) + prio_pass) & 3u;
 			if (pr == 0u) __builtin_amdgcn_s_setprio(0);
 			else if (pr == 1u) __builtin_amdgcn_s_setprio(1);
 			else if (pr == 2u) __builtin_amdgcn_s_setprio(2);
 			else __builtin_amdgcn_s_setprio(3);
 		}
-#endif
 		// one batch of loads for every phase
 		// (a STEP / SEARCH lane needs the 16 bytes of its slot only: the batch's other loads go to one address that
 		// every such lane shares)
@@ -813,21 +785,12 @@ __global__ __launch_bounds__(256) void lean_chain_kernel(PhaseA A, RefIndex R, L
 		}
 		LEAN_TICK(2)
 		// digest
-#if PHY_STEP_FLAT
 		if (ph == LP_STEP || ph == LP_SEARCH || ph == LP_LOOK) { // (one body for the three: lean_step_any)
 			if constexpr (MODE == 1) {
 				if (ph == LP_STEP) L.pv_base = L.vw_idx + 1u, L.pv0 = d[9], L.pv1 = d[10];
 			}
 			lean_step_any(ln, R, X, d, y[0], y[1], ph == LP_STEP);
 		} else if (ph == LP_EXT) {
-#else
-		if (ph == LP_STEP) {
-			if constexpr (MODE == 1) L.pv_base = L.vw_idx + 1u, L.pv0 = d[9], L.pv1 = d[10];
-			lean_step(ln, R, X, d, y[0], y[1]);
-		} else if (ph == LP_SEARCH || ph == LP_LOOK) {
-			lean_search(ln, R, d[0], d[1], d[2], d[3]);
-		} else if (ph == LP_EXT) {
-#endif
 			uint32_t sw[9];
 			ln.wb = (ln.q + (ln.e_pos - ((ln.q + ln.e_pos) & 15u))) >> 4;
 			ln.we = ln.wb + 8;
@@ -1145,7 +1108,7 @@ void launch_lean_spec(const PhaseA &A, const RefIndex &R, const LeanIndex &X, in
 // walks end within a few steps and a few run for dozens, so with a lane per bridge nearly every wavefront is soon left
 // with a handful of walkers and runs whole trips for them: fewer lanes, each taking bridge after bridge from the counter,
 // keep the wavefronts filled until the queue is empty and leave only the last walkers' tail.  How few is a matter of what
-// a trip costs — with the STEP-only trips (PHY_FAST_TRIPS) a block per CU, a third of a lane per chunk, at most three
+// a trip costs — with the STEP-only trips (FAST_TRIPS) a block per CU, a third of a lane per chunk, at most three
 // blocks on two CUs (C3, 742 blocks' worth of chunks: 0.41 ms at 96 blocks, 0.36 at 128, 0.325 at 192, 0.319 at 256,
 // 0.343 at 384; C4, 2230: 0.81 at 128, 0.66 at 192, 0.59 at 256, 0.56 at 384) — and twice the CUs with k = 14's
 // slot table, whose fetches want more of them in flight.

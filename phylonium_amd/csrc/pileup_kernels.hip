@@ -57,25 +57,10 @@ static __device__ __forceinline__ DevHom gload_hom(const DevHom *p)
 }
 
 static const uint32_t PROJ_TW = 64; // words per tile
-#ifndef PHY_PROJ_TG
-#define PHY_PROJ_TG 32
-#endif
-#ifndef PHY_PROJ_MINB
-#define PHY_PROJ_MINB 1 // blocks per CU the projection is compiled for (A/B builds: 5 caps the registers at 96 and spills)
-#endif
 // Branches the projection is better off without (same-box A/B, profiles/r05_ab_projection_micro*.txt; 0 restores them):
-#ifndef PHY_PROJ_ALWAYS_A
-#define PHY_PROJ_ALWAYS_A 1 // a window's first piece is added without a test of its mask (an empty mask adds nothing): C3 -4 %, C4 -6 %, C5 -8 %
-#endif
-#ifndef PHY_PROJ_REV_SELECT
-#define PHY_PROJ_REV_SELECT 1 // a reverse piece by selects instead of a branch: C3 -5 %, C4 -4 %, C5 -4 %
-#endif
 // (measured and left: the second piece without its test +1...5 %; v_alignbit instead of the 64-bit shifts 0...+2 %; the '!'
 // look-up's test as a scalar branch 0 %, or hoisted out of the pieces into one test per genome 0...+1 %)
-#ifndef PHY_PROJ_V2
-#define PHY_PROJ_V2 1 // the projection's covering-homology look-up without a loop (0: rounds 1-4's searching loop only; A/B builds)
-#endif
-static const uint32_t PROJ_TG = PHY_PROJ_TG; // genomes per tile (LDS with three planes: 3*64*(TG+1)*4 = 25 KB at 32 → 5 blocks per CU)
+static const uint32_t PROJ_TG = 32; // genomes per tile (LDS with three planes: 3*64*(TG+1)*4 = 25 KB at 32 → 5 blocks per CU)
 static const uint32_t PROJ_GPW = PROJ_TG / 4; // genomes per wavefront
 
 // Projection: one block per tile of 64 reference windows × 32 genomes.
@@ -144,7 +129,7 @@ static const uint32_t PROJ_HM = 256 / PROJ_TG; // homology descriptors cached pe
 // bang_list (FIVE = false only, may be null): every projected '!' as {genome | reverse << 31, reference position},
 // appended through the counter bang_flag[3]; more than bang_cap of them raise bit 1 of bang_flag[0].
 template <bool FIVE>
-__global__ __launch_bounds__(256, PHY_PROJ_MINB) void project_kernel(Pileup P, QuerySrc Q,
+__global__ __launch_bounds__(256) void project_kernel(Pileup P, QuerySrc Q,
 													   const DevHom *__restrict__ homs,
 													   const uint32_t *__restrict__ hom_rng,
 													   const uint32_t *__restrict__ first,
@@ -270,7 +255,6 @@ __global__ __launch_bounds__(256, PHY_PROJ_MINB) void project_kernel(Pileup P, Q
 		uint32_t a = (uint32_t)(((((uint64_t)w0 << 32) | w1) << sh) >> 32);
 		uint32_t b = (uint32_t)(((((uint64_t)w1 << 32) | w2) << sh) >> 32);
 		uint32_t hi, lo;
-#if PHY_PROJ_REV_SELECT
 		{
 			// a reverse piece: all 64 bits reversed — the codes run backwards and every code's two bits have changed places —
 			// and complemented.  Without a branch (nearly every wavefront holds a reverse piece somewhere and then runs both
@@ -282,19 +266,6 @@ __global__ __launch_bounds__(256, PHY_PROJ_MINB) void project_kernel(Pileup P, Q
 			lo = (rv ? pt : pf) ^ flip;
 			if (FIVE) D |= rv ? pc.mask : 0u;
 		}
-#else
-		if (pc.rev) {
-			// all 64 bits reversed: the codes run backwards and every code's two bits have changed places;
-			// the complement flips both
-			const uint32_t ra = __builtin_bitreverse32(b), rb = __builtin_bitreverse32(a);
-			hi = ~code_plane<false>(ra, rb);
-			lo = ~code_plane<true>(ra, rb);
-			if (FIVE) D |= pc.mask;
-		} else {
-			hi = code_plane<true>(a, b);
-			lo = code_plane<false>(a, b);
-		}
-#endif
 		V |= pc.mask;
 		N0 |= lo & pc.mask;
 		N1 |= hi & pc.mask;
@@ -322,7 +293,6 @@ __global__ __launch_bounds__(256, PHY_PROJ_MINB) void project_kernel(Pileup P, Q
 			}
 		}
 	};
-#if PHY_PROJ_V2
 	// Round 5.  The covering homology of a window without a loop: among the tile's cached descriptors (sorted, disjoint) it
 	// is the one whose index is the number of cached homologies that end at or before the window's first position — eight
 	// compares against wave-uniform LDS words.  A window takes that homology AND the one behind it (a window with a list
@@ -383,11 +353,7 @@ __global__ __launch_bounds__(256, PHY_PROJ_MINB) void project_kernel(Pileup P, Q
 		const uint32_t gi = wave + 4 * (u + half * HG), g = tg * PROJ_TG + gi;
 		uint32_t V = 0, N0 = 0, N1 = 0, D = 0, B = 0;
 		const int64_t q = (int64_t)Q.goff[g < P.N ? g : 0];
-#if PHY_PROJ_ALWAYS_A
 		add_piece(Piece{q + fa[u].rel, fa[u].mask, fa[u].rev, 0u}, gi, a0[u], a1[u], a2[u], V, N0, N1, D, B); // (an empty mask adds nothing)
-#else
-		if (fa[u].mask) add_piece(Piece{q + fa[u].rel, fa[u].mask, fa[u].rev, 0u}, gi, a0[u], a1[u], a2[u], V, N0, N1, D, B);
-#endif
 		if (fb[u].mask) add_piece(Piece{q + fb[u].rel, fb[u].mask, fb[u].rev, 0u}, gi, b0[u], b1[u], b2[u], V, N0, N1, D, B);
 		{
 			const uint32_t lo = hlo[gi], h1 = hend[gi];
@@ -401,37 +367,6 @@ __global__ __launch_bounds__(256, PHY_PROJ_MINB) void project_kernel(Pileup P, Q
 				h = more.next;
 			}
 		}
-#else
-	Piece pc[PROJ_GPW];
-	uint32_t d0[PROJ_GPW], d1[PROJ_GPW], d2[PROJ_GPW];
-#pragma unroll
-	for (uint32_t u = 0; u < PROJ_GPW; u++) {
-		const uint32_t gi = wave + 4 * u, g = tg * PROJ_TG + gi;
-		pc[u] = Piece{64, 0u, 0u, 0u};
-		if (g < P.N && w < P.W) pc[u] = find_piece(gi, (int64_t)Q.goff[g], hlo[gi], hlo[gi], hend[gi]);
-	}
-#pragma unroll
-	for (uint32_t u = 0; u < PROJ_GPW; u++) // mask == 0: pos is a valid position all the same, the data is ignored
-		fetch(pc[u], d0[u], d1[u], d2[u]);
-#pragma unroll
-	for (uint32_t u = 0; u < PROJ_GPW; u++) {
-		const uint32_t gi = wave + 4 * u, g = tg * PROJ_TG + gi;
-		uint32_t V = 0, N0 = 0, N1 = 0, D = 0, B = 0;
-		if (pc[u].mask) {
-			add_piece(pc[u], gi, d0[u], d1[u], d2[u], V, N0, N1, D, B);
-			const uint32_t lo = hlo[gi], h1 = hend[gi];
-			const int64_t q = (int64_t)Q.goff[g];
-			uint32_t h = pc[u].next;
-			while (h < h1) {
-				const Piece more = find_piece(gi, q, h, lo, h1);
-				if (!more.mask) break;
-				uint32_t e0, e1, e2;
-				fetch(more, e0, e1, e2);
-				add_piece(more, gi, e0, e1, e2, V, N0, N1, D, B);
-				h = more.next;
-			}
-		}
-#endif
 		any_bang |= B;
 		tile[0][lane][gi] = V;
 		tile[1][lane][gi] = N0;
@@ -441,9 +376,7 @@ __global__ __launch_bounds__(256, PHY_PROJ_MINB) void project_kernel(Pileup P, Q
 			tile[NP - 1][lane][gi] = B;
 		}
 	}
-#if PHY_PROJ_V2
 	} // half
-#endif
 	__syncthreads();
 	// rows [w][g0..g0+31] out: 128 contiguous bytes per row; a thread keeps its genome
 	// column and walks down the rows
@@ -566,16 +499,10 @@ __global__ __launch_bounds__(64) void pairs_kernel(Pileup P, const uint32_t *__r
 // i side and the j side.  Lane l holds genome l & 31 of a group of 32 genomes; lanes 0..31 take window w, lanes
 // 32..63 window w + 1: the instruction's two K blocks of 32.  A wavefront owns a tile of 64 x 64 genomes (2 x 2
 // instructions per channel and step) and a chunk of windows; two wavefronts per SIMD.
-#ifndef PHY_PAIRS_FENCE
-#define PHY_PAIRS_FENCE 1 // 0: the pair kernel's first loads in the scheduler's order (A/B builds)
-#endif
 typedef int pm_v8i __attribute__((ext_vector_type(8)));
 typedef float pm_v16f __attribute__((ext_vector_type(16)));
 static const int PM_G = 2;  // groups of 32 genomes per tile side
-#ifndef PHY_PAIRS_NB
-#define PHY_PAIRS_NB 3 // (A/B builds; with the waits counting: 2 sets C4 4.71 ms, 3 sets 4.36, 4 sets 4.41 — profiles/r05_ab_pairs_nb.txt)
-#endif
-static const int PM_NB = PHY_PAIRS_NB; // register sets of plane words in flight (a set is refilled right after its step has expanded it)
+static const int PM_NB = 3; // register sets of plane words in flight (a set is refilled right after its step has expanded it)
 
 static __device__ __forceinline__ void pm_expand_v(uint32_t V, uint32_t o[4])
 {
@@ -679,13 +606,11 @@ static __device__ __forceinline__ void pairs_mfma_body(const Pileup &P, uint32_t
 #pragma unroll
 		for (int k = 0; k < PM_NB; k++) {
 			load(x[k]);
-#if PHY_PAIRS_FENCE
 			// The sets are asked for one after the other, as the loop refills them.  Left to itself the scheduler sorts these 36
 			// loads by plane, the set the loop starts with has words among the last — and where the loop's first trip has to wait
 			// for every load in flight (s_waitcnt vmcnt(0)), the compiler makes every trip wait so: the two sets just asked for
 			// with it, a load's whole latency every three steps.  In order the waits count: vmcnt(35) ... (24), (12).
 			__builtin_amdgcn_sched_barrier(0);
-#endif
 		}
 		for (uint32_t w = w0; w < w1; w += 2 * PM_NB) {
 #pragma unroll

@@ -164,16 +164,15 @@ __global__ __launch_bounds__(256) void seqcmp_batch_kernel(const uint8_t *__rest
 
 // piece0[s]: the number of pieces of the segments before s (piece0[nseg] = all pieces); out[] zeroed by the caller.
 // Wavefront w takes the pieces w, w + nwaves, ...: neighbouring wavefronts read neighbouring 4 KiB at the same time.
-// A wavefront per SIMD, each with its next piece's loads in flight while it counts the current one: a launch of
-// tens of microseconds is over before thousands of blocks have been dealt out (measured, 2 x 64 MiB: 8 blocks per CU
-// 41 us without the pipelining; with it 6 per CU 36.7 us, 4: 34.1, 2: 30.6, 1: 29.3 — profiles/r05_seqcmp_bw.json).
+// A wavefront per SIMD: a launch of tens of microseconds is over before thousands of blocks have been dealt out
+// (measured, 2 x 64 MiB: 8 blocks per CU 40.4 us, 4: 32.5, 2: 29.4, 1: 27.9 — profiles/r05_seqcmp_bw.json).
 struct PieceAt {
 	const uint8_t *a, *b;
 	uint32_t n, o, m, seg;
 	bool rev;
 };
 // ONE: a batch of one segment (one seqcmp() / revseqcmp() call): it comes with the kernel's arguments, nothing is looked up
-template <bool ONE, bool PIPE>
+template <bool ONE>
 __global__ __launch_bounds__(256) void seqcmp_split_kernel(const uint8_t *__restrict__ base, const Segment *__restrict__ segs, uint32_t nseg,
 															const uint32_t *__restrict__ piece0, unsigned long long *__restrict__ out, Segment one)
 {
@@ -216,36 +215,13 @@ __global__ __launch_bounds__(256) void seqcmp_split_kernel(const uint8_t *__rest
 		}
 		cnt += piece_count(p.a, p.b, p.n, p.o, p.m, p.rev, lane, R);
 	};
-	uint32_t g = wave;
-	if (!PIPE) { // (measured, 2 x 64 MiB: 28.2 us against 27.7 with the next piece's loads issued ahead and waited for by count, 2 x 256 MiB 89.3
-				 // against 92.3 — profiles/r05_ab_seqcmp_pipe.txt: a launch this short is ramp and bandwidth, not a piece's latency)
-		for (; g < npieces; g += nwaves) {
-			PieceRegs R;
-			const PieceAt p = locate(g);
-			piece_load(p.a, p.b, p.n, p.o, p.m, p.rev, lane, R);
-			account(p, R);
-		}
-	} else if (g < npieces) {
-		// The next piece's loads are issued WHATEVER HAPPENS (past the last piece: that piece once more): the compiler places its
-		// waits by counting loads, and a load under a condition it cannot count — where the piece before is looked at it then
-		// waits for everything in flight (s_waitcnt vmcnt(0)), the piece just asked for with it, and the pipeline is none.
-		PieceRegs R0, R1;
-		PieceAt p0 = locate(g), p1 = p0;
-		piece_load(p0.a, p0.b, p0.n, p0.o, p0.m, p0.rev, lane, R0);
-		for (;;) {
-			g += nwaves;
-			const bool more1 = g < npieces;
-			if (more1) p1 = locate(g);
-			piece_load(p1.a, p1.b, p1.n, p1.o, p1.m, p1.rev, lane, R1);
-			account(p0, R0);
-			if (!more1) break;
-			g += nwaves;
-			const bool more0 = g < npieces;
-			if (more0) p0 = locate(g);
-			piece_load(p0.a, p0.b, p0.n, p0.o, p0.m, p0.rev, lane, R0);
-			account(p1, R1);
-			if (!more0) break;
-		}
+	// (the next piece's loads issued ahead and waited for by count were measured: 2 x 64 MiB 27.7 us against 28.2, 2 x 256 MiB 92.3
+	// against 89.3 — profiles/r05_ab_seqcmp_pipe.txt: a launch this short is ramp and bandwidth, not a piece's latency)
+	for (uint32_t g = wave; g < npieces; g += nwaves) {
+		PieceRegs R;
+		const PieceAt p = locate(g);
+		piece_load(p.a, p.b, p.n, p.o, p.m, p.rev, lane, R);
+		account(p, R);
 	}
 	// the block's wavefronts mostly end inside the same segment: one atomic for the four of them
 	const uint64_t tot = wave_sum(cnt);
@@ -268,9 +244,6 @@ __global__ __launch_bounds__(256) void seqcmp_split_kernel(const uint8_t *__rest
 	}
 }
 
-#ifndef PHY_SEQCMP_PIPE_DEFAULT
-#define PHY_SEQCMP_PIPE_DEFAULT 0 // 1: a piece's loads issued before the piece before is counted (A/B builds; measured below)
-#endif
 uint32_t seqcmp_split_waves(int n_cu) { return (uint32_t)n_cu * 8u * 4u; } // (what the per-segment launch has)
 
 void launch_seqcmp_batch(const uint8_t *base, const Segment *segs, uint32_t nseg, const uint32_t *piece0, uint32_t npieces, uint64_t *out,
@@ -283,15 +256,9 @@ void launch_seqcmp_batch(const uint8_t *base, const Segment *segs, uint32_t nseg
 		if (const char *e = getenv("PHY_SEQCMP_BPC")) per_cu = (uint32_t)std::max(1, atoi(e)); // experiments
 #endif
 		const uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)n_cu * per_cu, (npieces + 3u) / 4u));
-		bool pipe = PHY_SEQCMP_PIPE_DEFAULT != 0;
-#ifdef PHY_DEV_HOOKS
-		if (const char *e = getenv("PHY_SEQCMP_PIPE")) pipe = atoi(e) != 0; // experiments
-#endif
 		unsigned long long *o64 = (unsigned long long *)out;
-		if (one && pipe) hipLaunchKernelGGL((seqcmp_split_kernel<true, true>), dim3(blocks), dim3(256), 0, st, base, segs, nseg, piece0, o64, *one);
-		else if (one) hipLaunchKernelGGL((seqcmp_split_kernel<true, false>), dim3(blocks), dim3(256), 0, st, base, segs, nseg, piece0, o64, *one);
-		else if (pipe) hipLaunchKernelGGL((seqcmp_split_kernel<false, true>), dim3(blocks), dim3(256), 0, st, base, segs, nseg, piece0, o64, Segment{});
-		else hipLaunchKernelGGL((seqcmp_split_kernel<false, false>), dim3(blocks), dim3(256), 0, st, base, segs, nseg, piece0, o64, Segment{});
+		if (one) hipLaunchKernelGGL((seqcmp_split_kernel<true>), dim3(blocks), dim3(256), 0, st, base, segs, nseg, piece0, o64, *one);
+		else hipLaunchKernelGGL((seqcmp_split_kernel<false>), dim3(blocks), dim3(256), 0, st, base, segs, nseg, piece0, o64, Segment{});
 		return;
 	}
 	const uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)n_cu * 8u, (nseg + 3u) / 4u));

@@ -25,3 +25,29 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(HERE, "golden")
+
+
+# One value per run for the tests that draw a sample anew every run (PHY_SAMPLE_SEED pins it).  It is part of the
+# test id — a red run names its seed in the one line "FAILED ...[c4-sample_seed=123]" that survives any tail of the
+# log — and is written to gpurun_out/sample_seed.txt as well (that directory comes back from the GPU box).
+def _run_seed():
+    pinned = os.environ.get("PHY_SAMPLE_SEED")
+    return int(pinned) if pinned else int.from_bytes(os.urandom(4), "little")
+
+
+RUN_SEED = _run_seed()
+
+
+def pytest_generate_tests(metafunc):
+    if "sample_seed" in metafunc.fixturenames:
+        metafunc.parametrize("sample_seed", [RUN_SEED], ids=[f"sample_seed={RUN_SEED}"])
+
+
+def pytest_sessionstart(session):
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "sample_seed.txt"), "a") as f:
+            f.write(f"PHY_SAMPLE_SEED={RUN_SEED} pid={os.getpid()} argv={' '.join(sys.argv[1:])}\n")
+    except OSError:
+        pass
