@@ -45,6 +45,7 @@ WORKLOADS = {
 DUP = {"c3dup": (8, 8)}  # (byte-identical copies of the reference, near-identical genomes at d = 1e-4)
 CONTIGS = {"c5s": 50, "c5": 100}
 TREE = {"c3tree"}  # genomes mutated from their parent in a binary tree instead of all from genome 0
+MULTI_GPU_WORKLOAD = "c4"  # the 1024-genome set the several-GPU target is quoted on (fits one GPU: 5.1 GB of genomes)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 
 
@@ -222,6 +223,15 @@ def wallclock_leg(torch, holder, offs, lens, contigs_sep, want_text, n_gpus, run
             m = re.search(r"timing: (genomes .*)", err)
             res.append({"wall_s": round(wall, 4), "exit": pr.returncode, "timing": m.group(1) if m else err[-300:],
                         "matrix_identical": pr.stdout.decode(errors="replace") == want_text})
+        # like for like with earlier rounds (and with somebody who runs the program in a loop): no pause, and the runtime's
+        # orderly teardown instead of _exit — two runs back to back, the second one right behind the first one's exit
+        b2b = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            pr = subprocess.run(cmd[:1] + ["--teardown"] + cmd[1:], capture_output=True)
+            b2b.append(round(time.perf_counter() - t0, 4))
+            if pr.stdout.decode(errors="replace") != want_text:
+                b2b[-1] = None
         med = sorted(res, key=lambda r: r["wall_s"])[len(res) // 2]
         split = {}
         for key, pat in (("inside_main", r"total ([0-9.]+) s"), ("read", r"\| read ([0-9.]+)"), ("wait_for_device", r"wait-for-device ([0-9.]+)"),
@@ -234,11 +244,41 @@ def wallclock_leg(torch, holder, offs, lens, contigs_sep, want_text, n_gpus, run
         return {"wallclock_s": med["wall_s"], "unit": "s", "n_gpus": n_gpus, "what": "FASTA files in /dev/shm -> PHYLIP text on stdout, "
                 "`phylonium-amd --timing -r g0000.fasta <files>` as a fresh process, start to exit; median of %d runs" % runs,
                 "runs_s": [r["wall_s"] for r in res], "matrix_identical": all(r["matrix_identical"] for r in res),
-                "exit_status": med["exit"], "split_s": split, "fasta_bytes": fasta_bytes, "fasta_write_s": round(t_write, 2),
+                "exit_status": med["exit"], "split_s": split,
+                "pause_before_each_run_s": 2.0, "exit_mode": "_exit once the matrix is out (the driver's default)",
+                "back_to_back_with_teardown_s": b2b, "fasta_bytes": fasta_bytes, "fasta_write_s": round(t_write, 2),
                 "note": "exit status 1 is the reference's soft-warning status (src/io.cxx:106-139: a pair with < 20 % homology); "
                         "split_s is the driver's own --timing of the median run: process start-up and exit are the difference to wallclock_s"}
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def one_gpu_leg(torch, api, workload, seed, device, local, steps):
+    """One GPU's step (both phases as one call, phylo_anchor_compare) on another workload's genomes: `scaling_baseline`."""
+    n, length, d_range, indel, inv, desc = WORKLOADS[workload]
+    buf, offs, lens = make_genomes_gpu(torch, n, length, seed, device, d_range, indel, inv, contigs=CONTIGS.get(workload, 1),
+                                       tree=workload in TREE, dup=DUP.get(workload, (0, 0)))
+    torch.cuda.synchronize()
+    with api.Context(local) as c:
+        c.set_genomes_device(buf.data_ptr(), offs, lens)
+        c.set_reference(0)
+        c.result_open(None, ranks=1)
+        o = c.result_matrices()
+        for _ in range(2):
+            c.anchor_compare(out=o)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            c.anchor_compare(out=o)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+    bases = float(sum(lens))
+    del buf
+    torch.cuda.empty_cache()
+    return {"workload": f"{workload}: {desc}", "n_gpus": 1, "steps": steps, "ms_per_step": round(ms, 3),
+            "value": round(bases / (ms * 1e-3) / 1e9, 4), "unit": "Gbp/s",
+            "note": "the workload every `--gpus N > 1` line runs, on this one GPU (no HIP events around any kernel): the one-GPU point "
+                    "of the scaling curve; N > 1 lines carry the same measurement made in their own job (one_gpu_same_workload_ms)"}
 
 
 def verify_ranks(torch, api, dist, ctx, s, h, buf, offs, lens, ref_idx, world, local):
@@ -370,6 +410,8 @@ def main():
     ap.add_argument("--seed", type=int, default=20260101)
     ap.add_argument("--cpu-sample", type=int, default=63, help="queries in the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernels with HIP events")
+    ap.add_argument("--no-scaling-baseline", action="store_true", help="one rank on the default workload: skip the extra leg that times the "
+                    "several-GPU workload (c4) on this one GPU (`scaling_baseline` in the line)")
     ap.add_argument("--no-wallclock", action="store_true", help="skip the FASTA -> PHYLIP wall-clock leg (the C++ host driver as a child process)")
     ap.add_argument("--check", action="store_true", help="verify a sample of the result against the oracle")
     ap.add_argument("--verify-ranks", action="store_true", help="after the timed steps rank 0 checks the N-rank result by two other routes — "
@@ -394,8 +436,12 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args.gpus))
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    default_workload = args.workload is None
     if args.workload is None:
-        args.workload = "c3" if world_env == 1 else "c4"
+        # (one workload for the whole scaling curve: every line of a several-GPU run carries the same workload's one-GPU step
+        # measured in the same job — one_gpu_same_workload_ms, speedup_same_workload — and the one-GPU default run carries the
+        # several-GPU workload's step on this GPU as `scaling_baseline`: a 1/2/4/8 curve is never c4 at N over c3 at 1)
+        args.workload = "c3" if world_env == 1 else MULTI_GPU_WORKLOAD
 
     # stdout carries exactly one JSON line.  Libraries below (RCCL prints a version banner
     # through C stdio) write to fd 1 whenever they like: lend them stderr until the result
@@ -597,10 +643,19 @@ def main():
     if world > 1:
         td.barrier()
     dt = time.perf_counter() - t0
+    ranks_ms, rccl_ranks = None, None
     if world > 1:
+        own = torch.tensor([dt / args.steps * 1e3], dtype=torch.float64, device=coll_dev)
+        every = torch.empty(world, dtype=torch.float64, device=coll_dev)
+        td.all_gather_into_tensor(every, own)
+        ranks_ms = [round(float(x), 3) for x in every.cpu().tolist()]  # every rank's own clock around the K steps
         t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         dt = float(t.item())
+        if not shared:  # the ranks RCCL itself counts: a 1 from every rank of the communicator, summed on the devices
+            ones = torch.ones(1, dtype=torch.int32, device=device)
+            td.all_reduce(ones, op=td.ReduceOp.SUM)
+            rccl_ranks = int(ones.item())
     # the same K steps twice more: with HIP events around every kernel (the `kernels` table, roofline_mfma, the held clock),
     # and without any (reported beside the timed figure)
     dt_plain = None
@@ -653,6 +708,29 @@ def main():
         stats_keep = stats_all if not args.no_profile else None
 
     stats = stats_keep if stats_keep is not None else ctx.stats()
+    # several ranks: the same workload's step on ONE GPU, measured in this job — rank 0 alone runs both phases over all genomes
+    # (phylo_anchor_compare, what `--gpus 1 --workload <this one>` times), the other ranks idle at the barrier
+    one_gpu_ms = None
+    if world > 1 and not emu and not shared:
+        if rank == 0:  # (a context of its own: the ranks' lists in `ctx` stay what the exchange left, for --verify-ranks)
+            with api.Context(local) as c1:
+                c1.set_genomes_device(buf.data_ptr(), offs, lens)
+                c1.set_reference(ref_idx)
+                c1.result_open(None, ranks=1)
+                o1 = c1.result_matrices()
+                k1 = max(3, min(args.steps, 10))
+                for _ in range(2):
+                    c1.anchor_compare(out=o1)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(k1):
+                    c1.anchor_compare(out=o1)
+                torch.cuda.synchronize()
+                one_gpu_ms = (time.perf_counter() - t1) / k1 * 1e3
+                same = bool((np.asarray(o1[0]) == np.asarray(s)).all() and (np.asarray(o1[1]) == np.asarray(h)).all())
+                if not same:
+                    raise SystemExit("bench.py: the %d-rank result differs from one GPU's on the same genomes" % world)
+        td.barrier()
     if seg and rank == 0:
         print("# emulated rank, ms per step: " + "  ".join(f"{k} {v / args.steps * 1e3:.3f}" for k, v in seg.items()),
               file=sys.stderr, flush=True)
@@ -683,13 +761,13 @@ def main():
         kernels = {}
         if kern:
             alg = {"anchor_spec": bytes_a / shard, "anchor_bridge": 0.0, "anchor_fold": 0.0, "anchor_compact": 0.0,
-                   "pileup_project": total_bases, "pileup_project5": total_bases, "pileup_pairs": bytes_b / shard, "pileup_pairs_bang": bytes_b / shard,
-                   "pileup_pairs_mfma": bytes_b / shard,
-                   "seqcmp_batch": bytes_b / shard}
+                   "pileup_project": total_bases, "pileup_project5": total_bases, "seqcmp_batch": bytes_b / shard}
+            # (the pair kernels have no algorithmic bytes of their own: SURVEY 8d's bytes_B is what the byte kernels of seam B0
+            # would move, the pileup's pair kernels read bit planes — their bound is roofline_mfma / roofline_valu)
             for k in kern:
                 avg_ms = kern[k] / launches[k]
                 kernels[k] = {"avg_ms": round(avg_ms, 4), "launches_per_step": launches[k] / K,
-                              "alg_GBps": round(alg.get(k, 0.0) / (avg_ms * 1e-3) / 1e9, 2)}
+                              "alg_GBps": round(alg[k] / (avg_ms * 1e-3) / 1e9, 2) if alg.get(k) else None}
             # the kernel the HBM roofline is reported for: phase A's chain kernel, which carries ~15x the HBM bytes of
             # any other kernel and is the longest one at the metric's configuration; at N = 1024 the pair kernel takes
             # about as long, but it is bound by the vector ALUs (see `roofline_valu`), not by memory
@@ -712,6 +790,7 @@ def main():
                     traffic_current = pj.get("kernels_sha256_" + args.workload) == hh.hexdigest() if traffic else None
                 except Exception:
                     traffic = None
+            rq_dom = pj.get("read_requests_" + args.workload, {}).get(dom) if traffic else None
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "alg_bytes_per_launch": alg.get(dom, 0.0), "avg_launch_ms": round(avg_ms, 4),
@@ -720,6 +799,12 @@ def main():
                     "traffic_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic else None,
                     "traffic_frac": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                     "traffic_of_these_kernels": traffic_current,
+                    # the line-granularity cost as one number: what the memory carried over SURVEY 8d's algorithmic bytes, and the
+                    # bytes the kernel asked for — 16 B per memory-side read request (a slot or a record; 1.11e8 on c3 = one per
+                    # chain step) + the queries' 2-bit codes (|Q| / 4), each fetched as a 128-byte line
+                    "wasted_traffic_ratio": round(traffic / alg[dom], 2) if traffic and alg.get(dom) else None,
+                    "useful_bytes": (16.0 * rq_dom + total_bases / 4.0 / shard) if rq_dom else None,
+                    "useful_frac_of_traffic": round((16.0 * rq_dom + total_bases / 4.0 / shard) / traffic, 4) if rq_dom and traffic else None,
                     "traffic_source": "profiles/pmc_traffic.json (rocprofv3 PMC passes of this workload; its source_<workload> "
                                       "entry names the profile; traffic_of_these_kernels says whether the chain and phase-B kernels' sources are the ones "
                                       "the profile was taken on (sha256 recorded by tools/tools_pmc_traffic.py); regenerate "
@@ -734,7 +819,7 @@ def main():
                     "requests": (lambda rq: {"per_launch": rq, "achieved_G_per_s": round(rq / (avg_ms * 1e-3) / 1e9, 2), "peak_G_per_s": 55.0,
                                              "frac": round(rq / (avg_ms * 1e-3) / 1e9 / 55.0, 4),
                                              "peak_source": "profiles/r04_gather_bench.jsonl: 16-byte rows, 128 MB - 1 GB tables, 55-57 G rows/s"}
-                                 if rq else None)(pj.get("read_requests_" + args.workload, {}).get(dom) if traffic else None)}
+                                 if rq else None)(rq_dom)}
         # the pair kernel against the vector ALUs: 16 x 6 instructions per window and wavefront for its 16 x 64 pairs
         # (2 xor, and, bitop3, 2 popcount-accumulate) + 8 of loop and address work, one wavefront per tile of
         # 16 x 64 genomes holding a pair i < j; peak = CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction
@@ -826,6 +911,10 @@ def main():
                        "backend": ("none (one rank)" if world == 1 else
                                    "gloo: %d ranks share %d GPU(s), exchange through the host" % (world, ndev) if shared else
                                    "nccl (RCCL), one rank per GPU, device-resident exchange")},
+            # several ranks: what RCCL counts, every rank's own time, and the same workload on ONE GPU measured in this job
+            "rccl_ranks": rccl_ranks, "ranks_ms_per_step": ranks_ms,
+            "one_gpu_same_workload_ms": round(one_gpu_ms, 3) if one_gpu_ms else None,
+            "speedup_same_workload": round(one_gpu_ms / (dt / K * 1e3), 3) if one_gpu_ms else None,
             "ms_per_step_noprofile": round(dt_plain / K * 1e3, 3) if dt_plain else None,
             "ms_per_step_all_kernels_timed": round(dt_all / K * 1e3, 3) if dt_all else None,
             "timing_note": "value / ms_per_step: the K timed steps, HIP events around the chain kernel only (the roofline's kernel); "
@@ -843,31 +932,37 @@ def main():
                                   "ms:compare_hom_flatten", "ms:compare_hom_upload", "ms:stage_send_done", "ms:stage_all")},
             "kernels": kernels,
             "compared_sites": sites, "alg_bytes": {"anchor": bytes_a, "compare": bytes_b},
-            "path_alg_GBps": round((bytes_a + bytes_b) * K / dt / 1e9, 2),
-            # SURVEY §8d's whole-path and phase-B-only figures, next to the per-kernel `roofline` above.  Both
-            # exceed 1: the pileup moves 3/8 B per genome and reference position once instead of the reference
-            # layout's 2 B per compared site, so the measured HBM bytes are far below the algorithmic ones.
-            "roofline_path": {"achieved": round((bytes_a + bytes_b) * K / dt / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round((bytes_a + bytes_b) * K / dt / 1e9 / HBM_PEAK_GBS, 4),
-                              "note": "algorithmic bytes of the reference's layout over this run's time: above 1 because the "
-                                      "bit-plane pileup moves far fewer bytes than 2 B per compared site, not because HBM "
-                                      "ran beyond its peak"},
-            "roofline_phase_b": (lambda tb, tr: {"achieved": round(bytes_b / shard / (tb * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
-                                                 "unit": "GB/s", "frac": round(bytes_b / shard / (tb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            # SURVEY 8d's whole-path and phase-B-only HBM fractions are not reported (null): phase B does not move the
+            # reference layout's 2 B per compared site — the pileup reads 3 bits per genome and reference position once and
+            # contracts them on the matrix cores — so bytes_B over any time is not a bandwidth.  Phase B's bound is
+            # roofline_mfma (matrix cores + operand expansion); what its kernels do carry at the memory is `traffic`.
+            "roofline_path": {"bound": "mixed", "frac": None, "alg_bytes": bytes_a + bytes_b,
+                              "note": "no single roofline: phase A is bound by the memory's line rate (roofline: frac on SURVEY 8d's bytes, "
+                                      "traffic_frac on the bytes carried), phase B by the matrix cores (roofline_mfma); bytes_B of SURVEY "
+                                      "8d is not moved by this design, so (bytes_A + bytes_B) / time is not a bandwidth and is not printed"},
+            "roofline_phase_b": (lambda tb, tr: {"bound": "mfma", "frac": roof_mfma["frac"] if roof_mfma else None,
+                                                 "frac_at_held_clock": roof_mfma.get("frac_at_held_clock") if roof_mfma else None,
+                                                 "hbm_frac_on_alg_bytes": None, "alg_bytes_not_moved": bytes_b / shard,
                                                  "ms": round(tb, 3), "kernels": "pileup_project* + pileup_pairs*",
                                                  "traffic": tr,
                                                  "traffic_GBps": round(tr / (tb * 1e-3) / 1e9, 1) if tr else None,
                                                  "traffic_frac": round(tr / (tb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tr else None,
-                                                 "note": "achieved/frac price the reference layout's 2 B per compared site (above 1: "
-                                                         "see roofline_path); traffic = HBM-side bytes of these kernels from the "
-                                                         "PMC profile: the pair kernel is bound by its matrix and vector instructions "
-                                                         "(roofline_mfma; DESIGN.md, section 4), not by HBM"} if tb > 0 else None)(
+                                                 "note": "frac = roofline_mfma's (the pair kernel's multiply-adds against the dense FP4 peak); "
+                                                         "traffic = HBM-side bytes of these kernels from the PMC profile over this run's time"}
+                                 if tb > 0 else None)(
                 sum(kern[k] for k in kern if k.startswith("pileup_")) / K, phase_b_traffic),
             "phase_a_plan": {"chunk": stats.get("anchor:chunk"), "chunks": (stats.get("count:chunks") or 0) / max(1.0, stats.get("n:anchor_calls") or 1.0)},
             "setup_s": {"generate": round(t_gen, 2), "reference_index": round(t_ref, 2),
                         "suffix_array": round((ref_stats["ms:ref_suffix_array"] or 0) / 1e3, 3),
                         "suffix_array_builder": "device" if ref_stats["ref:sa_on_device"] else "host"},
         }
+        if emu:  # an emulation is not a bench result: no value, and the line says what it is
+            out["emulated_rank"] = "%d/%d" % emu
+            out["emulated_ms_per_step"] = out["ms_per_step"]
+            out["value"] = None
+            out["n_gpus"] = 1
+            out["note"] = ("rank %d of %d's share of every kernel, timed alone on ONE GPU%s: not a throughput figure of any job"
+                           % (emu[0], emu[1], " with a one-rank RCCL group standing in for the wire" if args.emulate_exchange else ""))
         if args.dump_matrix:
             np.savez(args.dump_matrix, subst=np.asarray(s), homologs=np.asarray(h))
         if verdict is not None:
@@ -883,6 +978,13 @@ def main():
     if out is not None and do_wall:
         want_text = api.format_phylip([f"g{j:04d}" for j in range(n)], np.asarray(s), np.asarray(h))
     ctx.close()
+    # one rank on the default workload: the several-GPU workload's step on THIS GPU — the baseline a 1/2/4/8 curve of
+    # `--gpus N` lines (which all run that workload) is to be divided by
+    if out is not None and world == 1 and not emu and default_workload and not args.no_scaling_baseline and args.workload != MULTI_GPU_WORKLOAD:
+        try:
+            out["scaling_baseline"] = one_gpu_leg(torch, api, MULTI_GPU_WORKLOAD, args.seed, device, local, max(3, min(args.steps, 20)))
+        except Exception as e:  # a report beside the metric, never a reason to lose the bench line
+            out["scaling_baseline"] = {"workload": MULTI_GPU_WORKLOAD, "ms_per_step": None, "note": f"failed: {e!r}"}
     if do_wall:
         holder = [buf]
         del buf

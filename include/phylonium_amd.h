@@ -265,6 +265,10 @@ int phylo_result_open(phylo_ctx *ctx, const char *shm_name, int create, size_t n
 int phylo_result_unlink(phylo_ctx *ctx);
 void phylo_result_close(phylo_ctx *ctx);
 int phylo_result_matrices(phylo_ctx *ctx, uint64_t **subst, uint64_t **homologs);
+/* A rank that gives a pass up after the others may already be waiting for its rows says so in the segment's header: their
+ * phylo_triangle_rows_to_result returns an error at once (otherwise after a minute).  The segment is closed and opened
+ * anew afterwards. */
+int phylo_result_abandon(phylo_ctx *ctx, size_t rank);
 int phylo_triangle_rows_to_result(phylo_ctx *ctx, const uint32_t *dev_tri, size_t row_begin, size_t row_end, size_t rank,
 								  size_t wait_ranks, uint32_t *report);
 

@@ -29,7 +29,7 @@ SYMBOLS = [
     "phylo_export_packed_device", "phylo_attach_packed_device", "phylo_compare_device",
     "phylo_ctx_set_stream", "phylo_ctx_device", "phylo_exchange_block_bytes", "phylo_export_block_device", "phylo_attach_blocks_device",
     "phylo_compare_triangle_device", "phylo_triangle_to_matrices", "phylo_triangle_words", "phylo_group_rank_begin", "phylo_host_device_count",
-    "phylo_anchor_block_device", "phylo_result_open", "phylo_result_unlink", "phylo_result_close", "phylo_result_matrices", "phylo_triangle_rows_to_result",
+    "phylo_anchor_block_device", "phylo_result_open", "phylo_result_unlink", "phylo_result_close", "phylo_result_matrices", "phylo_result_abandon", "phylo_triangle_rows_to_result",
     "phylo_group_create", "phylo_group_destroy", "phylo_group_last_error", "phylo_group_size", "phylo_group_ctx", "phylo_group_backend",
     "phylo_group_set_option", "phylo_group_get_stat", "phylo_group_set_genomes_packed", "phylo_group_set_reference", "phylo_group_anchor",
     "phylo_group_compare", "phylo_group_process",
@@ -104,6 +104,7 @@ def load():
     L.phylo_result_close.argtypes = [vp]
     L.phylo_result_close.restype = None
     L.phylo_result_matrices.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.phylo_result_abandon.argtypes = [vp, C.c_size_t]
     L.phylo_triangle_rows_to_result.argtypes = [vp, vp, sz, sz, sz, sz, vp]
     L.phylo_host_device_count.argtypes = [C.POINTER(C.c_int)]
     L.phylo_group_create.argtypes = [C.POINTER(vp), sz, vp]
@@ -217,6 +218,13 @@ class Context:
     def reset_stats(self):
         self._chk(self.L.phylo_reset_stats(self.h))
 
+    def _new_inputs(self):
+        """Other genomes or another reference: what dist.process_sharded_device remembers about this data set — the
+        exchange plan, and the route a pass had to be repeated on (phase A through the host, the vector-ALU pair
+        kernels) — no longer holds."""
+        self._xplan = None
+        self._route = None
+
     # genomes
     def set_genomes(self, genomes):
         arrs = [_u8(g) for g in genomes]
@@ -226,6 +234,7 @@ class Context:
         self._chk(self.L.phylo_set_genomes(self.h, n, ptrs, lens))
         self.n = n
         self.lengths = [a.size for a in arrs]
+        self._new_inputs()
 
     def set_genomes_packed(self, packed):
         """packed: (q2 words, length, separator positions) per genome, as read_fasta_packed returns them."""
@@ -239,6 +248,7 @@ class Context:
         self._chk(self.L.phylo_set_genomes_packed(self.h, n, qp, lens, bp, nb))
         self.n = n
         self.lengths = [int(p[1]) for p in packed]
+        self._new_inputs()
 
     def set_genomes_packed_device(self, dev_q2_ptr, offsets, lens, bad):
         """dev_q2_ptr: device buffer of 2-bit codes laid out as the arena's Q2 (word w = arena bytes [16w, 16w+16));
@@ -253,6 +263,7 @@ class Context:
                                                          ln.ctypes.data_as(C.c_void_p), bp, nb))
         self.n = n
         self.lengths = [int(x) for x in ln]
+        self._new_inputs()
 
     def get_genome(self, i):
         out = np.empty(self.lengths[i], np.uint8)
@@ -266,6 +277,7 @@ class Context:
                                                   off.ctypes.data_as(C.c_void_p), ln.ctypes.data_as(C.c_void_p)))
         self.n = off.size
         self.lengths = [int(x) for x in ln]
+        self._new_inputs()
 
     def set_reference(self, ref_idx, sa=None, threshold=0):
         sap = None
@@ -274,6 +286,7 @@ class Context:
             sap = self._sa.ctypes.data_as(C.c_void_p)
         self._chk(self.L.phylo_set_reference(self.h, ref_idx, sap, threshold))
         self.ref_idx = ref_idx
+        self._new_inputs()
 
     def reference_suffix_array(self):
         """The suffix array of S = reference + '#' + revcomp(reference) the index was built from (int64)."""
@@ -379,6 +392,10 @@ class Context:
 
     def result_close(self):
         self.L.phylo_result_close(self.h)
+
+    def result_abandon(self, rank):
+        """This rank gives the pass up: the ranks waiting for its rows return at once (phylo_result_abandon)."""
+        self.L.phylo_result_abandon(self.h, rank)
 
     def result_matrices(self):
         """The two n x n uint64 matrices of the result's home as numpy views (valid until result_close / close)."""
@@ -639,6 +656,7 @@ class Group:
         self._chk(self.L.phylo_group_set_genomes_packed(self.h, n, qp, lens, bp, nb))
         self.n = n
         self.lengths = [int(p[1]) for p in packed]
+        self._new_inputs()
 
     def set_reference(self, ref_idx, sa=None, threshold=0):
         sap = None

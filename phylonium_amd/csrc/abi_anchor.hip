@@ -369,7 +369,7 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, int defer)
 				launch_tile_index(TP, query_src(c), c->b_homs.p, c->b_hom_rng.p, c->b_first.p, j0, j1, sg);
 				KernelSpan s(c, c->eager_five ? "pileup_project5" : "pileup_project", sg);
 				launch_project(TP, c->eager_five, query_src(c), c->b_homs.p, c->b_hom_rng.p, c->b_first.p, c->b_flag.p,
-							   0, TP.Npad / tsz_q, sg, c->b_bang.p, c->bang_cap);
+							   0, TP.Npad / tsz_q, sg, c->b_bang.p, c->bang_cap, c->proj_resident);
 			}
 		}
 	}
@@ -602,7 +602,7 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, int defer)
 				launch_tile_index(EP, query_src(c), c->b_homs.p, c->b_hom_rng.p, c->b_first.p, (uint32_t)j0, (uint32_t)j1, st);
 				KernelSpan s(c, c->eager_five ? "pileup_project5" : "pileup_project");
 				launch_project(EP, c->eager_five, query_src(c), c->b_homs.p, c->b_hom_rng.p, c->b_first.p,
-							   c->b_flag.p, (uint32_t)(j0 / tsz), g + 1 == ngroups ? EP.Npad / (uint32_t)tsz : (uint32_t)(j1 / tsz), st, c->b_bang.p, c->bang_cap);
+							   c->b_flag.p, (uint32_t)(j0 / tsz), g + 1 == ngroups ? EP.Npad / (uint32_t)tsz : (uint32_t)(j1 / tsz), st, c->b_bang.p, c->bang_cap, c->proj_resident);
 			}
 		}
 		t_send_done = now_ms();

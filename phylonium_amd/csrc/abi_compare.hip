@@ -473,7 +473,7 @@ static int compare_pileup(phylo_ctx *c, size_t part, size_t nparts, uint64_t *su
 	auto project = [&](bool five) -> int {
 		KernelSpan s(c, five ? "pileup_project5" : "pileup_project");
 		launch_project(P, five, query_src(c), dev_homs, c->b_hom_rng.p, c->b_first.p, c->b_flag.p, 0, P.Npad / project_genomes_per_tile(), st,
-					   c->b_bang.p, c->bang_cap);
+					   c->b_bang.p, c->bang_cap, c->proj_resident);
 		return 0;
 	};
 	uint64_t *hs = c->h_mat.p;

@@ -41,6 +41,7 @@ int phylo_ctx_create(phylo_ctx **out, int device)
 #endif
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+	project_resident_blocks(c->proj_resident);
 	*out = c;
 	return 0;
 }

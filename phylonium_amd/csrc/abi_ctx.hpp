@@ -193,6 +193,7 @@ struct phylo_ctx {
 	int opt_pairs_kernel = 0; // option "pairs_kernel": 0 the matrix-core kernel when no projected position holds '!' (default), 1 the vector-ALU kernel always
 	std::string err;
 	int n_cu = 256;
+	int proj_resident[2] = {256, 256}; // blocks of the projection this device holds at once (project_resident_blocks)
 
 	// options
 	uint32_t opt_chunk = 0, opt_kmer = 0;

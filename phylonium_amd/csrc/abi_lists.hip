@@ -47,6 +47,7 @@ int phylo_set_homologies(phylo_ctx *c, size_t j, const phylo_homology *h, size_t
 	if (!c) return 1;
 	if (j >= c->n) return c->fail("genome index out of range");
 	if (n && !h) return c->fail("null homology list");
+	if (settle_anchor(c)) return 1; // (a phase A queued by phylo_anchor_block_device: its lists come in first, this one on top of them)
 	c->homs[j].assign(h, h + n);
 	c->homs_staged = false;
 	if (!c->host_stale.empty()) {
@@ -83,6 +84,7 @@ int phylo_import_homologies(phylo_ctx *c, size_t q_begin, size_t q_end, const ui
 {
 	if (!c) return 1;
 	if (q_begin > q_end || q_end > c->n || !counts) return c->fail("phylo_import_homologies: bad arguments");
+	if (settle_anchor(c)) return 1; // (as phylo_set_homologies)
 	if (!c->host_stale.empty()) {
 		if (ensure_host_lists(c, 0, q_begin) || ensure_host_lists(c, q_end, c->n)) return 1;
 		c->host_stale.clear();
@@ -150,6 +152,7 @@ int phylo_import_packed(phylo_ctx *c, size_t q_begin, size_t q_end, const uint64
 	if (!c) return 1;
 	if (q_begin > q_end || q_end > c->n || !counts) return c->fail("phylo_import_packed: bad arguments");
 	if (!c->have_ref) return c->fail("phylo_import_packed: no reference set");
+	if (settle_anchor(c)) return 1; // (as phylo_set_homologies)
 	if (!c->host_stale.empty()) {
 		for (size_t g = q_begin; g < q_end; g++) c->host_stale[g] = 0; // replaced below
 		if (ensure_host_lists(c, 0, q_begin) || ensure_host_lists(c, q_end, c->n)) return 1;
@@ -232,6 +235,9 @@ int phylo_attach_packed_device(phylo_ctx *c, const void *dev_records, const uint
 	if (!begin || !count || keep_begin > keep_end || keep_end > c->n) return c->fail("phylo_attach_packed_device: bad arguments");
 	if (!c->have_ref) return c->fail("phylo_attach_packed_device: no reference set");
 	HIPOK(c, hipSetDevice(c->device));
+	// a phase A queued by phylo_anchor_block_device is taken in first: its export kernel still writes h_rng, and a later
+	// settle would lay its lists over the ones attached here
+	if (settle_anchor(c)) return 1;
 	const size_t N = c->n;
 	HIPOK(c, c->h_rng.ensure(2 * N));
 	HIPOK(c, c->b_hom_rng.ensure(2 * N));

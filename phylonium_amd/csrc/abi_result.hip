@@ -20,6 +20,7 @@ using namespace phy;
 using namespace phyabi;
 
 static const size_t RES_HDR = 4096, RES_MAX_RANKS = 64;
+static const uint64_t RES_ABANDONED = ~0ull; // a rank's delivery counter once it has given a pass up
 
 extern "C" {
 
@@ -143,6 +144,17 @@ int phylo_result_unlink(phylo_ctx *c)
 	return 0;
 }
 
+// A rank that fails between the all-reduce and its delivery says so in its slot of the header: the ranks waiting for it in
+// phylo_triangle_rows_to_result return with an error at once instead of after their time-out.  The segment is of no use
+// afterwards (every later wait for this rank fails the same way): the ranks open a new one.
+int phylo_result_abandon(phylo_ctx *c, size_t rank)
+{
+	if (!c) return 1;
+	if (!c->res.map || rank >= c->res.ranks) return 0;
+	__atomic_store_n((uint64_t *)((char *)c->res.map + 64 * rank), RES_ABANDONED, __ATOMIC_RELEASE);
+	return 0;
+}
+
 int phylo_result_matrices(phylo_ctx *c, uint64_t **subst, uint64_t **homologs)
 {
 	if (!c || !subst || !homologs) return 1;
@@ -181,10 +193,12 @@ int phylo_triangle_rows_to_result(phylo_ctx *c, const uint32_t *dev_tri, size_t 
 	for (size_t r = 0; r < wait_ranks; r++) {
 		const uint64_t *f = (const uint64_t *)((const char *)c->res.map + 64 * r);
 		uint64_t spins = 0;
-		while (__atomic_load_n(f, __ATOMIC_ACQUIRE) < step) {
+		uint64_t seen;
+		while ((seen = __atomic_load_n(f, __ATOMIC_ACQUIRE)) < step) {
 			if ((++spins & 0xfffff) == 0 && now_ms() - t1 > 60000.0) return c->fail("phylo_triangle_rows_to_result: rank %zu has not delivered its rows", r);
 			__builtin_ia32_pause();
 		}
+		if (seen == RES_ABANDONED) return c->fail("phylo_triangle_rows_to_result: rank %zu gave the pass up (phylo_result_abandon)", r);
 	}
 	if (report) memcpy(report, tail, TRI_TAIL * 4);
 	c->stats["ms:result_rows"] += t1 - t0;

@@ -122,7 +122,10 @@ void launch_tile_index(const Pileup &P, const QuerySrc &Q, const DevHom *homs, c
 // position} each, counted in bang_flag[3], bit 1 of bang_flag[0] on overflow — for launch_bang_correct
 void launch_project(const Pileup &P, bool five_planes, const QuerySrc &Q, const DevHom *homs,
 					const uint32_t *hom_rng, const uint32_t *first, uint32_t *bang_flag, uint32_t tg0, uint32_t tg1,
-					hipStream_t st, uint32_t *bang_list = nullptr, uint32_t bang_cap = 0);
+					hipStream_t st, uint32_t *bang_list, uint32_t bang_cap, const int *resident_blocks);
+// blocks of the projection the current device holds at once, {three planes, five planes}: worked out once per context
+// (phylo_ctx_create) and handed to launch_project
+void project_resident_blocks(int out[2]);
 // the substitutions the three planes miss: '!' against 'A' in the same direction (one block per listed '!')
 void launch_bang_correct(const Pileup &P, const QuerySrc &Q, const DevHom *homs, const uint32_t *hom_rng, const uint32_t *list,
 						 const uint32_t *count, uint32_t cap, unsigned long long *subst, hipStream_t st);

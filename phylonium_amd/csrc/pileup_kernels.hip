@@ -775,25 +775,28 @@ void launch_tile_index(const Pileup &P, const QuerySrc &Q, const DevHom *homs, c
 	hipLaunchKernelGGL(tile_index_kernel, dim3((uint32_t)((entries + 255) / 256)), dim3(256), 0, st, P, Q, homs, hom_rng, first,
 					   g0, g1, zero_flags);
 }
+void project_resident_blocks(int out[2])
+{
+	int dev = 0;
+	hipDeviceProp_t prop;
+	if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
+	for (int five = 0; five < 2; five++) {
+		int per_cu = 0;
+		const void *fn = five ? (const void *)project_kernel<true> : (const void *)project_kernel<false>;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+		out[five] = per_cu * prop.multiProcessorCount;
+	}
+}
 void launch_project(const Pileup &P, bool five_planes, const QuerySrc &Q, const DevHom *homs,
 					const uint32_t *hom_rng, const uint32_t *first, uint32_t *bang_flag, uint32_t tg0, uint32_t tg1,
-					hipStream_t st, uint32_t *bang_list, uint32_t bang_cap)
+					hipStream_t st, uint32_t *bang_list, uint32_t bang_cap, const int *resident_blocks)
 {
 	uint32_t ntw = (P.W + PROJ_TW - 1) / PROJ_TW, ntg = P.Npad / PROJ_TG;
 	if (tg1 > ntg) tg1 = ntg;
 	if (!ntw || tg0 >= tg1) return;
 	const uint32_t ntiles = ntw * (tg1 - tg0);
 	// as many blocks as the chip holds at once (LDS: five per CU with three planes), each taking tile after tile
-	static int resident[2] = {0, 0};
-	int &res = resident[five_planes ? 1 : 0];
-	if (!res) {
-		int per_cu = 0, dev = 0;
-		hipDeviceProp_t prop;
-		const void *fn = five_planes ? (const void *)project_kernel<true> : (const void *)project_kernel<false>;
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-		if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
-		res = per_cu * prop.multiProcessorCount;
-	}
+	const int res = std::max(1, resident_blocks[five_planes ? 1 : 0]);
 	dim3 grid(std::min<uint32_t>(ntiles, (uint32_t)res));
 	if (five_planes)
 		hipLaunchKernelGGL(project_kernel<true>, grid, dim3(256), 0, st, P, Q, homs, hom_rng, first, bang_flag, tg0, ntiles, (uint32_t *)nullptr, 0u);

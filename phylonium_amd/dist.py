@@ -128,7 +128,11 @@ def _exchange_plan(ctx, n, rank, world, bounds, device):
     maxq = (maxq + 3) // 4 * 4 or 4
     nbytes = ctx.exchange_block_bytes(maxq, cap)
     shared = False
-    if _SHARED_RESULT:
+    seg = getattr(ctx, "_result_segment", None)
+    if _SHARED_RESULT and seg == (ctx.n, world):
+        shared = True  # a plan made again (lists that outgrew their blocks): the segment's size depends on n and world only,
+        # it stays mapped — views handed out with copy=False stay valid
+    elif _SHARED_RESULT:
         import os
         import time
         name = [None]
@@ -153,6 +157,7 @@ def _exchange_plan(ctx, n, rank, world, bounds, device):
         shared = bool(int(t.item()))
         if not shared:
             ctx.result_close()
+        ctx._result_segment = (ctx.n, world) if shared else None
     all_blocks = torch.empty(world * nbytes, dtype=torch.uint8, device=device)
     return {"maxq": maxq, "cap": cap, "bounds": tuple(bounds), "nbytes": nbytes, "shared_result": shared,
             "views": ctx.result_matrices() if shared else None,
@@ -195,7 +200,10 @@ def process_sharded_device(ctx, rank, world, bounds, device, out=None, result_ra
     if getattr(ctx, "_on_stream", None) != stream:
         ctx.set_stream(stream)
         ctx._on_stream = stream
-    slow_anchor, valu_pairs = False, False
+    # the route this data set needs is kept with the context (api.Context._new_inputs clears it): a set with a tied-start
+    # list, or more '!' than the lists hold, raises its report on every step — later steps start on the route that worked
+    route = getattr(ctx, "_route", None) or {}
+    slow_anchor, valu_pairs = bool(route.get("slow_anchor")), bool(route.get("valu_pairs"))
     for attempt in range(4):
         plan = getattr(ctx, "_xplan", None)
         usable = plan is not None and plan["bounds"] == tuple(bounds) and plan["tri"].numel() == ctx.triangle_words(n)
@@ -254,6 +262,9 @@ def process_sharded_device(ctx, rank, world, bounds, device, out=None, result_ra
             how = "plan" if "overflow" in msg and "scratch" not in msg else "anchor" if "needs the host" in msg else \
                 "pairs" if "pairs_kernel = 1" in msg else None
             if how is None:
+                if plan is not None and plan.get("shared_result"):
+                    ctx.result_abandon(rank)  # (the ranks that wait for this one's rows return at once, not after their time-out)
+                    ctx._result_segment = None
                 raise
         finally:
             if valu_pairs:
@@ -266,10 +277,12 @@ def process_sharded_device(ctx, rank, world, bounds, device, out=None, result_ra
             if slow_anchor:
                 raise RuntimeError("process_sharded_device: phase A failed on the host's route as well")
             slow_anchor = True
+            ctx._route = dict(route, slow_anchor=True, valu_pairs=valu_pairs)
         else:
             if valu_pairs:
                 raise RuntimeError("process_sharded_device: the vector-ALU pair kernels reported a '!' list overflow")
             valu_pairs = True
+            ctx._route = dict(route, slow_anchor=slow_anchor, valu_pairs=True)
     raise RuntimeError("process_sharded_device: the pass was repeated three times without a result")
 
 
