@@ -282,10 +282,14 @@ int phylo_anchor_compare(phylo_ctx *ctx, uint64_t *subst, uint64_t *homologs);
  * process() shards without a data-path collective inside either phase: phase A by query block (the loop at
  * src/process.cxx:433-434), phase B by range of reference windows (the pair loop at src/process.cxx:524-529 re-cut so
  * that projection and pair kernel both shrink with the ranks).  A group is one context and one host thread per rank;
- * the ranks meet three times per pass — the packed genomes (an all-gather of the blocks each rank uploaded), the
- * filtered lists after phase A (an all-gather of fixed-shape device blocks), the tallies after phase B (a reduce of
- * u32 triangles to rank 0) — over RCCL / xGMI when every rank has a GPU of its own (the library is loaded when a
- * group is made), by device-to-device copies when ranks share a GPU.  devices: n_ranks ordinals (NULL: rank r on
+ * the ranks meet three times — the packed genomes (an all-gather of the blocks each rank uploaded), the filtered lists
+ * after phase A (an all-gather of fixed-shape device blocks), the tallies after phase B (an all-reduce of u32 triangles,
+ * after which every rank's device writes its rows of the result into the node's page-locked home of it) — over RCCL /
+ * xGMI when every rank has a GPU of its own (the library is loaded when a group is made), by device-to-device copies
+ * when ranks share a GPU.  phylo_group_process queues a rank's whole pass on the rank's stream — phylo_anchor_block_device,
+ * all-gather in place, phylo_attach_blocks_device, phylo_compare_triangle_device, all-reduce, phylo_triangle_rows_to_result —
+ * and waits once; a pass whose summed report asks for it (blocks that overflowed, a list that needs the host's std::sort,
+ * more '!' than the lists hold) is repeated by all ranks the long way.  devices: n_ranks ordinals (NULL: rank r on
  * device r modulo the device count).  Results are identical to one context's for any number of ranks. */
 typedef struct phylo_group phylo_group;
 int phylo_group_create(phylo_group **out, size_t n_ranks, const int *devices);
@@ -300,15 +304,23 @@ const char *phylo_group_backend(const phylo_group *g);     /* "rccl", "device-to
  * outgrow a pinned capacity is repeated by phylo_group_process with a plan of its own) */
 int phylo_group_set_option(phylo_group *g, const char *key, long value);
 /* phylo_get_stat of a rank, plus "group:ms_anchor", "group:ms_exchange", "group:ms_compare", "group:ms_reduce" (the
- * rank's host-side milliseconds in the last pass) */
+ * rank's host-side milliseconds in the last pass: with a queued pass the first three are the time it took to queue the
+ * work), "group:ms_queued" (start of the pass to everything queued), "group:ms_step" (to the rank's rows delivered),
+ * "group:replans", "group:passes_repeated", "group:shared_result" (1: the node's shared home of the result is in use) */
 int phylo_group_get_stat(phylo_group *g, size_t rank, const char *key, double *out);
 /* the arguments of phylo_set_genomes_packed: rank r uploads its block of the genomes, one all-gather does the rest */
 int phylo_group_set_genomes_packed(phylo_group *g, size_t n, const uint32_t *const *q2, const size_t *len,
 								   const uint32_t *const *bad, const size_t *nbad);
 int phylo_group_set_reference(phylo_group *g, size_t ref_idx, const int64_t *sa, size_t threshold);
 int phylo_group_anchor(phylo_group *g);                                    /* phase A + the lists to every rank */
-int phylo_group_compare(phylo_group *g, uint64_t *subst, uint64_t *homologs); /* phase B + the sum on rank 0 */
-int phylo_group_process(phylo_group *g, uint64_t *subst, uint64_t *homologs); /* both */
+int phylo_group_compare(phylo_group *g, uint64_t *subst, uint64_t *homologs); /* phase B + the sum + the result */
+int phylo_group_process(phylo_group *g, uint64_t *subst, uint64_t *homologs); /* both, as one queue per rank */
+/* The group's own home of the result (several ranks, after the first pass): the two n x n matrices every rank's device
+ * writes its rows of.  Passed to phylo_group_process / phylo_group_compare as subst / homologs (or NULL, NULL) the result
+ * stays there — a caller's own matrices are filled by the ranks' threads, each copying its rows. */
+int phylo_group_result_matrices(phylo_group *g, uint64_t **subst, uint64_t **homologs);
+/* the ranks RCCL itself counts in the group's communicator (ncclCommCount; 0 when the ranks do not talk over RCCL) */
+size_t phylo_group_rccl_ranks(const phylo_group *g);
 
 /* ── B0 ── */
 size_t phylo_seqcmp(const char *begin, const char *other, size_t length);

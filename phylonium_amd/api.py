@@ -32,7 +32,7 @@ SYMBOLS = [
     "phylo_anchor_block_device", "phylo_result_open", "phylo_result_unlink", "phylo_result_close", "phylo_result_matrices", "phylo_result_abandon", "phylo_triangle_rows_to_result",
     "phylo_group_create", "phylo_group_destroy", "phylo_group_last_error", "phylo_group_size", "phylo_group_ctx", "phylo_group_backend",
     "phylo_group_set_option", "phylo_group_get_stat", "phylo_group_set_genomes_packed", "phylo_group_set_reference", "phylo_group_anchor",
-    "phylo_group_compare", "phylo_group_process",
+    "phylo_group_compare", "phylo_group_process", "phylo_group_result_matrices", "phylo_group_rccl_ranks",
     "phylo_complete_delete", "phylo_compare", "phylo_compare_all", "phylo_process", "phylo_anchor_compare", "phylo_seqcmp",
     "phylo_revseqcmp", "phylo_seqcmp_batch", "phylo_host_suffix_array", "phylo_host_reference_suffix_array", "phylo_host_min_anchor_length",
     "phylo_host_read_fasta", "phylo_host_read_fasta_packed", "phylo_host_free_packed", "phylo_host_free", "phylo_host_median_length_index",
@@ -127,6 +127,9 @@ def load():
     L.phylo_group_anchor.argtypes = [vp]
     L.phylo_group_compare.argtypes = [vp, vp, vp]
     L.phylo_group_process.argtypes = [vp, vp, vp]
+    L.phylo_group_result_matrices.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.phylo_group_rccl_ranks.restype = sz
+    L.phylo_group_rccl_ranks.argtypes = [vp]
     L.phylo_process.argtypes = [vp, sz, C.c_int, vp, vp]
     L.phylo_anchor_compare.argtypes = [vp, vp, vp]
     L.phylo_seqcmp.restype = sz
@@ -656,7 +659,6 @@ class Group:
         self._chk(self.L.phylo_group_set_genomes_packed(self.h, n, qp, lens, bp, nb))
         self.n = n
         self.lengths = [int(p[1]) for p in packed]
-        self._new_inputs()
 
     def set_reference(self, ref_idx, sa=None, threshold=0):
         sap = None
@@ -681,6 +683,20 @@ class Group:
         s, h = out if out is not None else (np.zeros((n, n), np.uint64), np.zeros((n, n), np.uint64))
         self._chk(self.L.phylo_group_process(self.h, s.ctypes.data_as(C.c_void_p), h.ctypes.data_as(C.c_void_p)))
         return s, h
+
+    def process_in_place(self):
+        """One pass whose result stays in the group's page-locked home (several ranks): returns views of the two matrices,
+        valid until the next pass (phylo_group_process(NULL, NULL) + phylo_group_result_matrices)."""
+        self._chk(self.L.phylo_group_process(self.h, None, None))
+        ps, ph = C.c_void_p(), C.c_void_p()
+        self._chk(self.L.phylo_group_result_matrices(self.h, C.byref(ps), C.byref(ph)))
+        n = self.n
+        mk = lambda p: np.frombuffer((C.c_uint64 * (n * n)).from_address(p.value), dtype=np.uint64).reshape(n, n)
+        return mk(ps), mk(ph)
+
+    @property
+    def rccl_ranks(self):
+        return int(self.L.phylo_group_rccl_ranks(self.h))
 
     def rank_context(self, rank):
         """A borrowed Context view of a rank's phylo_ctx (rank 0 holds every list after anchor())."""

@@ -321,6 +321,61 @@ Matrix process(Run &r, size_t ref_idx, const int64_t *sa = nullptr)
 	return m;
 }
 
+// --bench-steps K: K more passes of process() against the reference in place (phase A + phase B, the index and the genomes
+// resident), timed by this host's clock; one JSON line on stderr with the mean step, every step, and per rank the host-side
+// milliseconds the group keeps (queued: start of the pass to the last call returning; step: to the rank's rows delivered).
+// The result of every pass must be the matrix already printed.
+void bench_passes(Run &r, size_t K, const Matrix &want)
+{
+	const size_t N = r.q->size(), W = r.grp ? phylo_group_size(r.grp) : 1;
+	std::vector<uint64_t> s, h;
+	uint64_t *ps = nullptr, *ph = nullptr;
+	const bool in_place = r.grp && W > 1 && phylo_group_result_matrices(r.grp, &ps, &ph) == 0; // the group's own home of the result
+	if (!in_place) {
+		s.resize(N * N);
+		h.resize(N * N);
+		ps = s.data();
+		ph = h.data();
+	}
+	auto pass = [&]() {
+		if (r.grp) gok(r, phylo_group_process(r.grp, ps, ph));
+		else ok(r, phylo_anchor_compare(r.ctx, ps, ph));
+	};
+	for (int w = 0; w < 2; w++) pass();
+	std::vector<double> ms(K), q_sum(W, 0.0), st_sum(W, 0.0);
+	const double t0 = now_s();
+	for (size_t k = 0; k < K; k++) {
+		const double a = now_s();
+		pass();
+		ms[k] = (now_s() - a) * 1e3;
+		for (size_t rk = 0; r.grp && rk < W; rk++) {
+			double v = 0;
+			if (!phylo_group_get_stat(r.grp, rk, "group:ms_queued", &v)) q_sum[rk] += v;
+			if (!phylo_group_get_stat(r.grp, rk, "group:ms_step", &v)) st_sum[rk] += v;
+		}
+	}
+	const double mean = (now_s() - t0) * 1e3 / (double)K;
+	size_t diff = 0;
+	for (size_t k = 0; k < N * N; k++) diff += ps[k] != want[k].subst || ph[k] != want[k].homologs;
+	double bases = 0;
+	for (size_t l : GLEN) bases += (double)l;
+	std::vector<double> sorted = ms;
+	std::sort(sorted.begin(), sorted.end());
+	double rep = 0, sh = 0;
+	if (r.grp) {
+		phylo_group_get_stat(r.grp, 0, "group:passes_repeated", &rep);
+		phylo_group_get_stat(r.grp, 0, "group:shared_result", &sh);
+	}
+	fprintf(stderr, "bench-steps: {\"steps\": %zu, \"ranks\": %zu, \"backend\": \"%s\", \"rccl_ranks\": %zu, \"ms_per_step\": %.4f, \"median_ms\": %.4f, \"min_ms\": %.4f, "
+					"\"Gbp_per_s\": %.2f, \"result_in_place\": %s, \"shared_result\": %s, \"passes_repeated\": %.0f, \"identical_to_printed_matrix\": %s, \"per_rank_ms\": [",
+			K, W, r.grp ? phylo_group_backend(r.grp) : "one context", r.grp ? phylo_group_rccl_ranks(r.grp) : (size_t)0, mean, sorted[K / 2], sorted[0],
+			bases / (mean * 1e-3) / 1e9, in_place ? "true" : "false", sh != 0 ? "true" : "false", rep, diff == 0 ? "true" : "false");
+	for (size_t rk = 0; rk < W; rk++)
+		fprintf(stderr, "%s{\"rank\": %zu, \"queued\": %.4f, \"step\": %.4f}", rk ? ", " : "", rk, r.grp ? q_sum[rk] / (double)K : 0.0, r.grp ? st_sum[rk] / (double)K : mean);
+	fprintf(stderr, "]}\n");
+	if (diff) RETURN_CODE = 3;
+}
+
 // --verify-ranks: the matrix of an N-GPU run against two routes that share nothing with the exchange between the
 // ranks.  (1) The reference's row from rank 0's lists through seam B0 (phylo_seqcmp_batch: seqcmp / revseqcmp over the
 // resident genomes, libs/seqcmp.h:14, libs/revseqcmp.h:25, summed over each query's list).  (2) A sub-matrix of up to 32
@@ -424,6 +479,9 @@ bool verify_group_result(Run &r, const std::vector<PackedGenome> &pk, const std:
 		"  -d, --device=N       GPU ordinal (default 0; with --gpus: the first of them)\n"
 		"      --teardown       Release the device context(s) before exiting (default: exit as soon\n"
 		"                       as the output is written)\n"
+		"      --bench-steps=K  After the matrix is out: K more passes against the same reference, timed; one\n"
+		"                       JSON line on stderr (mean step, per-rank host times); exit status 3 if a pass's\n"
+		"                       result differs from the matrix printed\n"
 		"      --gpus=N         Shard the queries (phase A) and the reference's windows (phase B) over N\n"
 		"                       GPUs: one host thread and one context per GPU, RCCL between them\n"
 		"                       (ranks share GPUs when the machine has fewer)\n"
@@ -446,7 +504,7 @@ int main(int argc, char *argv[])
 	std::mt19937 prng(seed_env ? (std::mt19937::result_type)strtoul(seed_env, nullptr, 10) : rd());
 	int version_flag = 0, timing = 0, verify_ranks = 0, teardown = 0, flags = 0, device = 0, gpus = 0;
 	bool packed_ingest = true, host_sa = false;
-	long threads = 0;
+	long threads = 0, bench_steps = 0;
 	bool two_pass = false;
 	unsigned long bootstrap = 0;
 	std::string reference_name, refpos_file;
@@ -467,6 +525,7 @@ int main(int argc, char *argv[])
 										   {"ingest", required_argument, NULL, 0},
 										   {"sa", required_argument, NULL, 0},
 										   {"gpus", required_argument, NULL, 0},
+										   {"bench-steps", required_argument, NULL, 0},
 										   {0, 0, 0, 0}};
 	for (;;) {
 		int option_index = 0;
@@ -480,7 +539,10 @@ int main(int argc, char *argv[])
 					if (strcasecmp(optarg, "host") == 0) host_sa = true;
 					else if (strcasecmp(optarg, "device") != 0) usage(EXIT_FAILURE);
 				}
-				if (name == "gpus") {
+				if (name == "bench-steps") {
+					bench_steps = atol(optarg);
+					if (bench_steps < 1 || bench_steps > 100000) usage(EXIT_FAILURE);
+				} else if (name == "gpus") {
 					gpus = atoi(optarg);
 					if (gpus < 1 || gpus > 64) usage(EXIT_FAILURE);
 				}
@@ -642,6 +704,7 @@ int main(int argc, char *argv[])
 	print_matrix(q, m, flags, bootstrap, ref_idx, prng);
 	t_done = now_s();
 	if (verify_ranks && r.grp && !(flags & (F_COMPLETE_DELETION | F_POSITIONS)) && !verify_group_result(r, pk, pk_q2, ref_idx, m, device)) RETURN_CODE = 3;
+	if (bench_steps > 0 && !(flags & (F_COMPLETE_DELETION | F_POSITIONS))) bench_passes(r, (size_t)bench_steps, m);
 	if (timing) {
 		auto stat = [&](const char *k) {
 			double v = 0;

@@ -208,7 +208,7 @@ def test_fasta_reader_errors_in_command_line_order(tmp_path):
 def test_several_gpus_print_the_same(tmp_path, backend):
     """`phylonium-amd --gpus N` (one host thread and one context per rank, csrc/group.hip: the genomes' blocks
     all-gathered, phase A by query block, the lists exchanged as device blocks, phase B by window range, the u32
-    triangles reduced to rank 0) prints what one GPU prints — stdout, warnings and exit status — for N = 1, 2, 3, 5,
+    triangles all-reduced, every rank's device writing its rows of the result) prints what one GPU prints — stdout, warnings and exit status — for N = 1, 2, 3, 5,
     with a reference given or chosen, complete deletion, -p and the two-pass mode; on a box with fewer GPUs than
     ranks the ranks share them and the exchange is device-to-device copies."""
     env = dict(os.environ)
@@ -242,6 +242,17 @@ def test_several_gpus_print_the_same(tmp_path, backend):
     assert got == one and (tmp_path / "p1.txt").read_bytes() == (tmp_path / "p3.txt").read_bytes()
     rc, out, err = run_env(["--gpus", "3", "--timing", "-r", files[4], *files])
     assert out == want and "3 ranks over" in err
+    # --bench-steps K: K more passes (a rank's pass as one queue, the result left in the group's home), one JSON line
+    import json
+    for n in (1, 3, 8):
+        rc, out, err = run_env([*(["--gpus", str(n)] if n > 1 else []), "--bench-steps", "4", "-r", files[4], *files])
+        line = [l for l in err.splitlines() if l.startswith("bench-steps: ")]
+        assert rc == 1 and out == want and len(line) == 1, err[-2000:]
+        b = json.loads(line[0][len("bench-steps: "):])
+        assert b["steps"] == 4 and b["ranks"] == n and b["identical_to_printed_matrix"] and b["ms_per_step"] > 0 and len(b["per_rank_ms"]) == n
+        if n > 1:
+            assert b["shared_result"] and b["result_in_place"] and b["passes_repeated"] == 0
+            assert all(0 < x["queued"] <= x["step"] for x in b["per_rank_ms"])
 
 
 @pytest.mark.parametrize("ranks", [2, 8])

@@ -1035,7 +1035,8 @@ def test_result_matrices_written_by_the_device():
 @pytest.mark.parametrize("world", [1, 2, 4, 7])
 def test_group_of_ranks_gives_one_contexts_result(world):
     """phylo_group_* (csrc/group.hip): one context and one host thread per rank; the genomes' blocks all-gathered,
-    phase A by query block, lists exchanged as device blocks, phase B by window range, triangles reduced to rank 0.
+    phase A by query block, lists exchanged as device blocks, phase B by window range, triangles all-reduced, every rank's
+    device writing its rows of the result.
     Matrices and every list equal the oracle's for any number of ranks — more ranks than GPUs share them (device
     copies instead of RCCL) — over repeated passes (the planned block capacity is reused), after a change of
     reference, and when a later pass outgrows the plan."""
@@ -1080,6 +1081,56 @@ def test_group_of_ranks_gives_one_contexts_result(world):
             g.anchor()  # the failed comparison dropped the plan: the next pass fits
             s, h = g.compare()
             assert (s == so).all() and (h == ho).all()
+
+
+def _tied_query(gs, ref, rng):
+    """A query that carries stretches of genome `ref` once forward and once reverse-complemented between random flanks: the two
+    homologies of a stretch project onto the same reference interval — equal projected starts, which only the host's std::sort
+    orders as the reference does (process.cxx:438)."""
+    clean = gs[ref][gs[ref] != ord("!")]
+    pieces = []
+    for x in range(1000, 21000, 1000):
+        seg = clean[x:x + 500]
+        pieces += [synth.random_base(100, rng), seg, synth.random_base(100, rng), synth.revcomp(seg)]
+    return np.concatenate(pieces + [synth.random_base(200, rng)])
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_group_pass_is_one_queue_and_repeats_itself_the_long_way(world):
+    """phylo_group_process (csrc/group.hip): a rank's pass as one queue — phylo_anchor_block_device, all-gather in place, attach,
+    phylo_compare_triangle_device, all-reduce, the rank's rows into the node's shared home of the result — with one host wait.
+    The first pass against a reference has no plan and takes phase A with a wait; the following ones are queued (the
+    contexts count them).  A data set with a tied-start list raises the summed report's word 4 on its first queued pass:
+    every rank repeats that pass the long way, ONCE — the route is remembered until genomes or reference change.  The
+    result can stay in the group's own page-locked home (phylo_group_result_matrices).  All of it equals the oracle."""
+    gs = synth.make_genomes(13, 25000, seed=86, d_range=(0.01, 0.25), indel_per_mbp=300, inv_frac=0.08, contigs=2)
+    dup = _tied_query(gs, 5, np.random.default_rng(7))
+    with api.Group(world) as g:
+        for tied in (False, True):
+            g2 = gs + ([dup] if tied else [])
+            n, ref = len(g2), 5
+            r = O.Run(g2, ref).process()
+            so, ho = r.matrix()
+            g.set_genomes(g2)
+            g.set_reference(ref)
+            before = g.stat(0, "group:passes_repeated")
+            for rep in range(4):
+                s, h = g.process()
+                assert (s == so).all() and (h == ho).all(), (world, tied, rep)
+            assert g.stat(0, "group:shared_result") == 1
+            assert g.stat(0, "group:passes_repeated") - before == (1 if tied else 0), (world, tied)
+            if not tied:  # passes 2-4 were queued: their phase A was not waited for
+                assert g.rank_context(0).stat("n:anchor_calls_without_a_wait", 0) >= 3
+            vs, vh = g.process_in_place()
+            assert (vs == so).all() and (vh == ho).all(), (world, tied)
+            c0 = g.rank_context(world - 1)
+            for j in range(n):
+                assert hom_tuples_gpu(c0.homologies(j)) == hom_tuples_orc(r.homologies(j)), (world, tied, j)
+            assert g.stat(0, "group:ms_step") > 0 and g.stat(0, "group:ms_queued") > 0
+            # the two separate calls still give the same (phase A with a wait, the lists on every rank in between)
+            g.anchor()
+            s, h = g.compare()
+            assert (s == so).all() and (h == ho).all(), (world, tied)
 
 
 def _two_rank_worker(rank, world, port, out):
