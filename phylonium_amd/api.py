@@ -222,9 +222,9 @@ class Context:
         self._chk(self.L.phylo_reset_stats(self.h))
 
     def _new_inputs(self):
-        """Other genomes or another reference: what dist.process_sharded_device remembers about this data set — the
-        exchange plan, and the route a pass had to be repeated on (phase A through the host, the vector-ALU pair
-        kernels) — no longer holds."""
+        """Other genomes: what dist.process_sharded_device remembers about this data set — the exchange plan, and the
+        route a pass had to be repeated on (phase A through the host, the vector-ALU pair kernels) — no longer holds
+        (another reference drops the route only)."""
         self._xplan = None
         self._route = None
 
@@ -288,8 +288,9 @@ class Context:
             self._sa = np.ascontiguousarray(sa, dtype=np.int64)
             sap = self._sa.ctypes.data_as(C.c_void_p)
         self._chk(self.L.phylo_set_reference(self.h, ref_idx, sap, threshold))
+        if getattr(self, "ref_idx", None) != ref_idx:
+            self._route = None  # (the exchange plan stays: its blocks are checked against every pass's lists on the device)
         self.ref_idx = ref_idx
-        self._new_inputs()
 
     def reference_suffix_array(self):
         """The suffix array of S = reference + '#' + revcomp(reference) the index was built from (int64)."""

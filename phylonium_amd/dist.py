@@ -22,6 +22,46 @@ _LEGACY_DEVICE_EXCHANGE = False
 _SHARED_RESULT = True
 
 
+# The collectives of the device-resident pass go through this indirection: torch.distributed itself (None), or — tests on
+# a box with one GPU, where RCCL refuses two ranks on one device — HostStagedCollectives below.
+_COLL = None
+
+
+def _coll():
+    return _COLL if _COLL is not None else td
+
+
+class HostStagedCollectives:
+    """TEST-ONLY stand-in for RCCL when several rank PROCESSES share one GPU: the same calls on the same call sites of
+    process_sharded_device, each carried out as a copy to the host ON THE CURRENT STREAM (so everything the library queued
+    before it on that stream is complete, as before a real collective), the collective over gloo, and a copy back on the
+    current stream (so everything queued behind it sees the result).  Never used by bench.py's RCCL runs."""
+
+    @staticmethod
+    def _staged(t, fn):
+        if not t.is_cuda:
+            return fn(t)
+        host = t.detach().cpu()  # (waits for the current stream)
+        fn(host)
+        t.copy_(host)
+
+    def all_reduce(self, t, op=td.ReduceOp.SUM):
+        self._staged(t, lambda h: td.all_reduce(h, op=op))
+
+    def reduce(self, t, dst, op=td.ReduceOp.SUM):
+        self._staged(t, lambda h: td.reduce(h, dst=dst, op=op))
+
+    def all_gather_into_tensor(self, out, inp):
+        world = td.get_world_size()
+        host_in = inp.detach().cpu().contiguous()
+        parts = [torch.empty_like(host_in) for _ in range(world)]
+        td.all_gather(parts, host_in)
+        out.copy_(torch.cat([p.reshape(-1) for p in parts]).view(out.dtype).reshape(out.shape))
+
+    def broadcast_object_list(self, objs, src=0):
+        td.broadcast_object_list(objs, src=src)
+
+
 def query_shard(n, rank, world, lengths=None):
     """Contiguous block of queries for this rank, balanced by total length."""
     if lengths is None:
@@ -121,7 +161,7 @@ def _exchange_plan(ctx, n, rank, world, bounds, device):
     qb, qe = bounds[rank], bounds[rank + 1]
     own = int(ctx.hom_counts(qb, qe).sum())
     t = torch.tensor([own], dtype=torch.int64, device=device)
-    td.all_reduce(t, op=td.ReduceOp.MAX)
+    _coll().all_reduce(t, op=td.ReduceOp.MAX)
     cap = int(t.item())
     cap = cap + cap // 4 + 64
     maxq = max(bounds[r + 1] - bounds[r] for r in range(world))
@@ -144,14 +184,14 @@ def _exchange_plan(ctx, n, rank, world, bounds, device):
             except Exception:
                 ok = 0
         if world > 1:
-            td.broadcast_object_list(name, src=0)
+            _coll().broadcast_object_list(name, src=0)
         if rank != 0:
             try:
                 ctx.result_open(name[0], create=False, ranks=world)
             except Exception:
                 ok = 0
         t = torch.tensor([ok], dtype=torch.int64, device=device)
-        td.all_reduce(t, op=td.ReduceOp.MIN)
+        _coll().all_reduce(t, op=td.ReduceOp.MIN)
         if rank == 0 and ok:
             ctx.result_unlink()
         shared = bool(int(t.item()))
@@ -222,7 +262,7 @@ def process_sharded_device(ctx, rank, world, bounds, device, out=None, result_ra
                 ctx.export_block_device(qb, qe, plan["block"].data_ptr(), plan["maxq"], plan["cap"])
             if on_block is not None:  # (the self-check's tests damage a record here: bench.py --test-corrupt-rank)
                 on_block(plan["block"], plan["maxq"])
-            td.all_gather_into_tensor(plan["all"], plan["block"])
+            _coll().all_gather_into_tensor(plan["all"], plan["block"])
             ctx.attach_blocks_device(plan["all"].data_ptr(), bounds, plan["maxq"], plan["cap"], qb, qe)
             ctx._attached_records = plan["all"]  # still the source of the other ranks' lists should the caller ask for them
             # (the vector-ALU pair kernel, option pairs_kernel = 1, waits for its flags itself: a block that overflowed
@@ -230,7 +270,7 @@ def process_sharded_device(ctx, rank, world, bounds, device, out=None, result_ra
             ctx.compare_triangle_device(rank, world, plan["tri"].data_ptr())
             wants = result_rank is None or rank == result_rank
             if plan["shared_result"]:
-                td.all_reduce(plan["tri"], op=td.ReduceOp.SUM)
+                _coll().all_reduce(plan["tri"], op=td.ReduceOp.SUM)
                 rep = ctx.triangle_rows_to_result(plan["tri"].data_ptr(), n * rank // world, n * (rank + 1) // world, rank,
                                                   world if wants else 0)
                 _check_report(rep)
@@ -243,14 +283,14 @@ def process_sharded_device(ctx, rank, world, bounds, device, out=None, result_ra
                     return out[0], out[1]
                 return (s.copy(), h.copy()) if copy else (s, h)
             if result_rank is None:  # every rank gets the matrices
-                td.all_reduce(plan["tri"], op=td.ReduceOp.SUM)
+                _coll().all_reduce(plan["tri"], op=td.ReduceOp.SUM)
                 return ctx.triangle_to_matrices(plan["tri"].data_ptr(), out)
             # the job's one result, on one rank (as the reference prints one matrix): a reduce instead of the all-reduce, and
             # the other ranks neither copy 2 N^2 words home nor widen them on host cores the result's rank could use; the
             # parts' reports are all-reduced beside it (32 bytes), so that every rank learns of a pass to repeat
             report = plan["tri"][-8:].clone()
-            td.reduce(plan["tri"], dst=result_rank, op=td.ReduceOp.SUM)
-            td.all_reduce(report, op=td.ReduceOp.SUM)
+            _coll().reduce(plan["tri"], dst=result_rank, op=td.ReduceOp.SUM)
+            _coll().all_reduce(report, op=td.ReduceOp.SUM)
             _check_report(report.cpu().numpy())
             if rank == result_rank:
                 return ctx.triangle_to_matrices(plan["tri"].data_ptr(), out)

@@ -48,6 +48,12 @@ def test_two_ranks_started_by_bench_itself_equal_one_rank(tmp_path):
         assert line["config"]["workload"].startswith("small")
         if n == 2:
             assert "gloo" in line["config"]["backend"] or "nccl" in line["config"]["backend"]
+            # the scaling harness: every rank's own step time, and the same workload on ONE GPU measured in the same job
+            assert len(line["ranks_ms_per_step"]) == 2 and line["one_gpu_same_workload_ms"] > 0 and line["speedup_same_workload"] > 0
+            assert line["one_gpu_same_workload_identical"] is True
+            assert line["rccl_ranks"] in (None, 2)
+        else:
+            assert line["ranks_ms_per_step"] is None and line["one_gpu_same_workload_ms"] is None
         outs[n] = np.load(dump)
     assert (outs[1]["subst"] == outs[2]["subst"]).all() and (outs[1]["homologs"] == outs[2]["homologs"]).all()
     assert outs[1]["homologs"].sum() > 0

@@ -1167,6 +1167,101 @@ def test_two_process_sharded_run_on_gpu(tmp_path):
     assert (np.load(out + ".h.npy") == ho).all()
 
 
+def _queued_ranks_worker(rank, world, port, out):
+    """One rank PROCESS of `world` sharing the box's one GPU: dist.process_sharded_device — the code an 8-GPU bench run
+    executes — with dist.HostStagedCollectives standing in for RCCL on the same call sites."""
+    import torch
+    import torch.distributed as td
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from phylonium_amd import dist
+    dist._COLL = dist.HostStagedCollectives()
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))  # the library's kernels and the staged collectives on one stream of their own
+    gs = synth.make_genomes(13, 25000, seed=86, d_range=(0.01, 0.25), indel_per_mbp=300, inv_frac=0.08, contigs=2)
+    dup = _tied_query(gs, 5, np.random.default_rng(7))
+    log = {}
+    c = api.Context(0)
+    for tied in (False, True):
+        g2 = gs + ([dup] if tied else [])
+        n, ref = len(g2), 5
+        with api.Context(0) as one:  # the one-context result, computed by this very process
+            one.set_genomes(g2)
+            so, ho = one.process(ref)
+        c.set_genomes(g2)
+        c.set_reference(ref)
+        c.reset_stats()
+        for step in range(4):  # the first pass plans (phase A with a wait), the others are queued; every rank gets the result
+            s, h = dist.process_sharded(c, ref, rank, world, device=dev, set_reference=False)
+            assert (s == so).all() and (h == ho).all(), (rank, tied, step)
+        plan = c._xplan
+        assert plan["shared_result"] and c.stat("ms:result_rows") is not None  # `world` mappers of one segment
+        if tied:  # word 4 of the summed report on the first queued pass: every rank repeats it the long way, once
+            assert c._route and c._route["slow_anchor"], rank
+        else:
+            assert c.stat("n:anchor_calls_without_a_wait", 0) >= 3 and not c._route, rank
+        # the result on one rank only (bench.py --gpus N): the others get nothing, views of the segment stay valid across a re-plan
+        s, h = dist.process_sharded(c, ref, rank, world, device=dev, set_reference=False, result_rank=0, copy=False)
+        assert (rank == 0 and (s == so).all() and (h == ho).all()) or (rank != 0 and s is None)
+        views = plan["views"]
+        # exchange blocks that have become too small: the overflow mark comes back in the summed report — or, with the
+        # vector-ALU pair kernels, as the comparison's own error — and every rank plans again and repeats the pass
+        for pairs_kernel in (0, 1):
+            p = c._xplan
+            nbytes = c.exchange_block_bytes(p["maxq"], 16)
+            small = dict(p)
+            blocks = torch.empty(world * nbytes, dtype=torch.uint8, device=dev)
+            small.update({"cap": 16, "nbytes": nbytes, "all": blocks, "block": blocks[rank * nbytes:(rank + 1) * nbytes]})
+            c._xplan = small
+            c.set_option("pairs_kernel", pairs_kernel)
+            s, h = dist.process_sharded(c, ref, rank, world, device=dev, set_reference=False)
+            c.set_option("pairs_kernel", 0)
+            assert (s == so).all() and (h == ho).all() and c._xplan["cap"] > 16, (rank, tied, pairs_kernel)
+            assert c._xplan["views"][0].ctypes.data == views[0].ctypes.data  # the same segment, still mapped
+        if rank == 0:
+            assert (views[0] == so).all() and (views[1] == ho).all()
+        td.barrier()
+        # every list, on every rank, as the one context has it
+        with api.Context(0) as one:
+            one.set_genomes(g2)
+            one.set_reference(ref)
+            one.anchor()
+            for j in range(n):
+                assert hom_tuples_gpu(c.homologies(j)) == hom_tuples_gpu(one.homologies(j)), (rank, tied, j)
+        log[str(tied)] = {"calls_without_a_wait": c.stat("n:anchor_calls_without_a_wait", 0), "route": c._route}
+    td.barrier()
+    c.close()
+    if rank == world - 1:
+        import json
+        with open(out, "w") as f:
+            json.dump(log, f)
+    td.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 8])
+def test_queued_pass_of_several_rank_processes_on_one_gpu(tmp_path, world):
+    """dist.process_sharded_device with MORE THAN ONE RANK, as separate processes: the plan, the
+    queued passes (phase A never waited for), the in-place all-gather of a view of its own output, `world` processes
+    mapping and registering the one shared result segment and each writing its rows, the result on every rank and on one
+    rank only, the repeat protocol — a tied-start list (report word 4), exchange blocks that overflow (word 2, and the
+    vector-ALU kernels' own error) — with views of the segment surviving a re-plan.  RCCL refuses two ranks on one
+    device, so dist.HostStagedCollectives carries the collectives over gloo on the same call sites and stream order.
+    Every rank compares matrices and lists with a one-context run of its own."""
+    import json
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = str(tmp_path / "log.json")
+    mp.spawn(_queued_ranks_worker, args=(world, port, out), nprocs=world, join=True)
+    log = json.load(open(out))
+    assert log["False"]["calls_without_a_wait"] >= 3 and log["True"]["route"]["slow_anchor"]
+
+
 def _shared_home_worker(rank, world, name, out):
     import time
     import torch
