@@ -290,7 +290,8 @@ struct phylo_ctx {
 	uint32_t bang_cap = 0;    // as many as the genomes hold separators (a separator is projected at most once)
 	DevBuf<Segment> s_segs;
 	DevBuf<uint64_t> s_out;
-	DevBuf<uint32_t> s_piece0; // a batch of few, long segments: their pieces' prefix sums (seqcmp_kernels.hip)
+	DevBuf<uint32_t> s_piece0; // a batch's segments: their rounds' prefix sums (seqcmp_kernels.hip)
+	DevBuf<uint8_t> s_rounds;  //   and the rounds' descriptors, written by the device
 	PinBuf<uint32_t> h_piece0;
 
 	// host staging and workers

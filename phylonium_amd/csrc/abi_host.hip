@@ -28,9 +28,8 @@ int phylo_seqcmp_batch(phylo_ctx *c, size_t n, const uint32_t *ga, const uint64_
 	return run_segments(c, c->d_genomes, segs.data(), n, out, "seqcmp_batch");
 }
 
-// A batch of segments through the byte kernels.  With fewer segments than a launch has wavefronts — one seqcmp() of
-// megabytes, a handful of long homologies — the segments' 4 KiB pieces are dealt out over all wavefronts instead of
-// a segment per wavefront (seqcmp_kernels.hip); the pieces' prefix sums are made here.
+// A batch of segments through the byte kernels (seqcmp_kernels.hip): a single segment — one seqcmp() of megabytes — comes
+// with the kernel's arguments; any other batch is cut into rounds of 63 chunks on the device, from the prefix sums made here.
 int phyabi::run_segments(phylo_ctx *c, const uint8_t *base, const Segment *segs, size_t n, uint64_t *out, const char *span)
 {
 	if (!n) return 0;
@@ -38,26 +37,32 @@ int phyabi::run_segments(phylo_ctx *c, const uint8_t *base, const Segment *segs,
 	HIPOK(c, c->s_segs.ensure(n));
 	HIPOK(c, c->s_out.ensure(n));
 	hipStream_t st = c->stream;
-	HIPOK(c, hipMemcpyAsync(c->s_segs.p, segs, n * sizeof(Segment), hipMemcpyHostToDevice, st));
-	const uint32_t *piece0 = nullptr;
-	uint64_t npieces = 0;
-	if (n < seqcmp_split_waves(c->n_cu)) {
-		HIPOK(c, c->h_piece0.ensure(n + 1));
+	uint64_t nrounds = 0;
+	if (n > 1) {
+		HIPOK(c, hipMemcpyAsync(c->s_segs.p, segs, n * sizeof(Segment), hipMemcpyHostToDevice, st));
+		// the rounds' prefix sums, and for every pass of four rounds the segment its first round lies in
+		const uint32_t rpp = seqcmp_rounds_per_pass();
+		uint64_t total = 0;
+		for (size_t s = 0; s < n; s++) total += (segs[s].len + SEQCMP_ROUND - 1) / SEQCMP_ROUND;
+		if (total >= 0xfffffff0ull) return c->fail("more than 2^32 KiB in one batch of segments");
+		const size_t npasses = (size_t)((total + rpp - 1) / rpp);
+		HIPOK(c, c->h_piece0.ensure(n + 1 + npasses));
+		uint32_t *r0 = c->h_piece0.p, *hint = c->h_piece0.p + n + 1;
+		size_t pass = 0;
 		for (size_t s = 0; s < n; s++) {
-			c->h_piece0.p[s] = (uint32_t)npieces;
-			npieces += (segs[s].len + SEQCMP_PIECE - 1) / SEQCMP_PIECE;
+			r0[s] = (uint32_t)nrounds;
+			nrounds += (segs[s].len + SEQCMP_ROUND - 1) / SEQCMP_ROUND;
+			for (; pass < npasses && pass * rpp < nrounds; pass++) hint[pass] = (uint32_t)s;
 		}
-		c->h_piece0.p[n] = (uint32_t)npieces;
-		if (npieces > 2 * n && npieces < 0xffffffffull) { // (else: nothing to deal out)
-			HIPOK(c, c->s_piece0.ensure(n + 1));
-			HIPOK(c, hipMemcpyAsync(c->s_piece0.p, c->h_piece0.p, (n + 1) * 4, hipMemcpyHostToDevice, st));
-			HIPOK(c, hipMemsetAsync(c->s_out.p, 0, n * 8, st));
-			piece0 = c->s_piece0.p;
-		}
+		r0[n] = (uint32_t)nrounds;
+		HIPOK(c, c->s_piece0.ensure(n + 1 + npasses));
+		HIPOK(c, hipMemcpyAsync(c->s_piece0.p, c->h_piece0.p, (n + 1 + npasses) * 4, hipMemcpyHostToDevice, st));
+		HIPOK(c, c->s_rounds.ensure(seqcmp_rounds_bytes(nrounds)));
 	}
+	HIPOK(c, hipMemsetAsync(c->s_out.p, 0, n * 8, st));
 	{
 		KernelSpan s(c, span);
-		launch_seqcmp_batch(base, c->s_segs.p, (uint32_t)n, piece0, (uint32_t)npieces, c->s_out.p, c->n_cu, st, n == 1 ? segs : nullptr);
+		launch_seqcmp_batch(base, c->s_segs.p, (uint32_t)n, c->s_piece0.p, c->s_piece0.p + n + 1, (uint32_t)nrounds, c->s_rounds.p, c->s_out.p, c->n_cu, st, n == 1 ? segs : nullptr);
 	}
 	HIPOK(c, hipGetLastError());
 	HIPOK(c, hipMemcpyAsync(out, c->s_out.p, n * 8, hipMemcpyDeviceToHost, st));

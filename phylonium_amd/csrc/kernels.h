@@ -80,14 +80,17 @@ struct Segment {
 // words behind a part's u32 triangle (phylo_triangle_words): {the projection's list of '!' overflowed, a gathered list is not
 // sorted and disjoint, a gathered block overflowed its capacity, 1 per part, a rank's phase A needs the host, 0, 0, 0}
 static const uint32_t TRI_TAIL = 8;
-static const uint32_t SEQCMP_PIECE = 4096; // bytes a wavefront compares per round: four 16-byte chunks per lane and string
-uint32_t seqcmp_split_waves(int n_cu);     // wavefronts of a full launch: with fewer segments than that the pieces are dealt out instead
-// out[s] = seqcmp / revseqcmp of segment s.  piece0 = nullptr: a wavefront per segment.  piece0 = device array of nseg + 1
-// prefix sums of the segments' pieces (ceil(len / SEQCMP_PIECE)), npieces = piece0[nseg]: the pieces over all wavefronts,
-// which add to out[] (zeroed by the caller).
-// one: the batch's only segment, as the host holds it (split launches: spares the kernel its look-ups)
-void launch_seqcmp_batch(const uint8_t *base, const Segment *segs, uint32_t nseg, const uint32_t *piece0, uint32_t npieces, uint64_t *out,
-						 int n_cu, hipStream_t st, const Segment *one = nullptr);
+static const uint32_t SEQCMP_PIECE = 4096; // bytes of either string a wavefront has in flight: four 16-byte chunks per lane and string
+static const uint32_t SEQCMP_ROUND = 1008; // a round: 63 chunks (lane 63 provides its neighbour's fifth dword); a batch's segments are cut into rounds, four rounds a pass
+// out[s] = seqcmp / revseqcmp of segment s, ADDED to out[] (zeroed by the caller).
+// one != nullptr: the batch's only segment, as the host holds it (it comes with the kernel's arguments: nothing is looked up).
+// Otherwise round0 = device array of nseg + 1 prefix sums of the segments' rounds (ceil(len / SEQCMP_ROUND)), nrounds =
+// round0[nseg]; hint = device array with the segment round seqcmp_rounds_per_pass() * p lies in, for every pass p; rounds =
+// device scratch of seqcmp_rounds_bytes(nrounds) for the rounds' descriptors.
+uint32_t seqcmp_rounds_per_pass();
+size_t seqcmp_rounds_bytes(uint64_t nrounds);
+void launch_seqcmp_batch(const uint8_t *base, const Segment *segs, uint32_t nseg, const uint32_t *round0, const uint32_t *hint, uint32_t nrounds,
+						 void *rounds, uint64_t *out, int n_cu, hipStream_t st, const Segment *one = nullptr);
 
 // pileup_kernels.hip
 struct DevHom {

@@ -54,6 +54,7 @@ static double stat(phylo_ctx *c, const char *k)
 int main(int argc, char **argv)
 {
 	const size_t LEN = (argc > 1 ? atol(argv[1]) : 64) << 20, PAIRS = 8, REPS = argc > 2 ? atol(argv[2]) : 40;
+	const uint64_t ALIGN = argc > 3 ? (uint64_t)atol(argv[3]) : 1; // experiments: the batch's segments start on multiples of this
 	phylo_ctx *c = nullptr;
 	if (phylo_ctx_create(&c, 0)) {
 		fprintf(stderr, "%s\n", phylo_last_error(nullptr));
@@ -98,7 +99,8 @@ int main(int argc, char **argv)
 			   rev ? "revseqcmp" : "seqcmp", LEN, stat(c, "n:seqcmp_batch"), ms, 2.0 * LEN / (ms * 1e-3) / 1e9, 2.0 * LEN / (ms * 1e-3) / 8e12,
 			   LEN / (ms * 1e-3), ok ? "true" : "false", (double)(n * LEN) / (1u << 30));
 	}
-	{
+	// the batch three times: a tenth of the segments reverse (what a pair grid holds), all forward, all reverse
+	for (int mode = 0; mode < 3; mode++) {
 		const size_t NS = 100000;
 		std::mt19937_64 rng(99);
 		std::vector<uint32_t> ga(NS), gb(NS);
@@ -112,9 +114,10 @@ int main(int argc, char **argv)
 			ln[s] = l;
 			ga[s] = (uint32_t)(rng() % n);
 			gb[s] = (uint32_t)(rng() % n);
-			oa[s] = rng() % (LEN - l);
-			ob[s] = rng() % (LEN - l);
-			rv[s] = (rng() % 10) == 0;
+			oa[s] = rng() % (LEN - l) / ALIGN * ALIGN;
+			ob[s] = rng() % (LEN - l) / ALIGN * ALIGN;
+			const bool r10 = (rng() % 10) == 0;
+			rv[s] = mode == 0 ? r10 : mode == 2;
 			tot += (double)l;
 		}
 		PK(c, phylo_reset_stats(c));
@@ -132,10 +135,10 @@ int main(int argc, char **argv)
 			if (w != out[s]) ok = false;
 		}
 		const double ms = stat(c, "ms:seqcmp_batch") / stat(c, "n:seqcmp_batch");
-		printf(" {\"shape\": \"batch\", \"segments\": %zu, \"mean_length\": %.0f, \"reverse_share\": 0.1, \"launches\": %.0f, \"kernel_ms\": %.5f, "
-			   "\"alg_GBps\": %.1f, \"frac_of_8TBps\": %.4f, \"sites_per_s\": %.4g, \"count_ok\": %s}\n]\n",
-			   NS, tot / NS, stat(c, "n:seqcmp_batch"), ms, 2.0 * tot / (ms * 1e-3) / 1e9, 2.0 * tot / (ms * 1e-3) / 8e12, tot / (ms * 1e-3),
-			   ok ? "true" : "false");
+		printf(" {\"shape\": \"batch\", \"segments\": %zu, \"mean_length\": %.0f, \"reverse_share\": %s, \"launches\": %.0f, \"kernel_ms\": %.5f, "
+			   "\"alg_GBps\": %.1f, \"frac_of_8TBps\": %.4f, \"sites_per_s\": %.4g, \"count_ok\": %s}%s\n",
+			   NS, tot / NS, mode == 0 ? "0.1" : mode == 1 ? "0" : "1", stat(c, "n:seqcmp_batch"), ms, 2.0 * tot / (ms * 1e-3) / 1e9, 2.0 * tot / (ms * 1e-3) / 8e12, tot / (ms * 1e-3),
+			   ok ? "true" : "false", mode == 2 ? "\n]" : ",");
 	}
 	phylo_ctx_destroy(c);
 	CK(hipFree(d));
