@@ -5,7 +5,7 @@
 set -x
 cd $GRAFT_REPO_ROOT
 timeout 900 python -m pytest tests -x -q -m gpu > gpurun_out/final_pytest.log 2>&1; tail -3 gpurun_out/final_pytest.log
-R=r05
+R=r06
 mkdir -p gpurun_out/final
 python bench.py > gpurun_out/final/${R}_bench_c3.json 2> gpurun_out/final/c3.err
 python bench.py --workload c4 --steps 20 --warmup 3 --check > gpurun_out/final/${R}_bench_c4.json 2> gpurun_out/final/c4.err
@@ -32,5 +32,10 @@ for r in 0 3; do bash tools/tools_rank_timeline.sh c4 $r/8 $GRAFT_REPO_ROOT/gpur
 ./build/seqcmp_bw 256 20 > gpurun_out/final/${R}_seqcmp_bw_256MiB.json 2>> gpurun_out/final/seqcmp_bw.err
 ( cd /tmp && export TMPDIR=/tmp && rm -rf $GRAFT_REPO_ROOT/gpurun_out/final/prof_seqcmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/final/prof_seqcmp --output-format csv -- $GRAFT_REPO_ROOT/build/seqcmp_bw > /dev/null 2>&1 )
 head -4 $(find gpurun_out/final/prof_seqcmp -name "*kernel_stats.csv" | head -1) > gpurun_out/final/${R}_seqcmp_bw_rocprof_stats.csv; rm -rf gpurun_out/final/prof_seqcmp
+./build/unaligned 1024 2 > gpurun_out/final/${R}_unaligned_loads.json 2>> gpurun_out/final/seqcmp_bw.err
+# the C++ host's pass (phylonium-amd --bench-steps: csrc/group.hip) on c4, one context and 2 / 8 ranks sharing this box's GPU
+bash tools/tools_cpp_bench.sh c4 "2 8" gpurun_out/final/${R}_cpp_bench_c4.txt 10 > /dev/null 2>&1
+# what a rank's step cannot shed: the kernels behind the chains for 128 ... 1 queries
+python tools/tools_floor.py c4 3/8 > gpurun_out/final/${R}_floor_c4_rank3of8.json 2> gpurun_out/final/floor.err
 python tools/tools_round_summary.py gpurun_out/final
 grep -h "emulated\|check" gpurun_out/final/*.err | head
