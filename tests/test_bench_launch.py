@@ -54,6 +54,16 @@ def test_two_ranks_started_by_bench_itself_equal_one_rank(tmp_path):
             assert line["rccl_ranks"] in (None, 2)
         else:
             assert line["ranks_ms_per_step"] is None and line["one_gpu_same_workload_ms"] is None
+        # no fraction of the line exceeds 1: what SURVEY 8d's bytes cannot express (phase B, the whole path) is null, not 42
+        def fracs(o, path=""):
+            if isinstance(o, dict):
+                for k, v in o.items():
+                    if "frac" in k and isinstance(v, (int, float)):
+                        yield path + "/" + k, v
+                    yield from fracs(v, path + "/" + k)
+        assert all(0 <= v <= 1.0 for _, v in fracs(line)), [kv for kv in fracs(line) if not 0 <= kv[1] <= 1.0]
+        assert line["roofline_path"]["frac"] is None and line["roofline_phase_b"]["hbm_frac_on_alg_bytes"] is None
+        assert line["roofline_phase_b"]["bound"] == "mfma"
         outs[n] = np.load(dump)
     assert (outs[1]["subst"] == outs[2]["subst"]).all() and (outs[1]["homologs"] == outs[2]["homologs"]).all()
     assert outs[1]["homologs"].sum() > 0

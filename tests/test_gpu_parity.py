@@ -1296,6 +1296,46 @@ def _shared_home_worker(rank, world, name, out):
     c.close()
 
 
+def test_a_rank_that_gives_up_releases_the_ranks_waiting_for_it():
+    """phylo_result_abandon: a rank that fails between the all-reduce and its delivery says so in its slot of the shared
+    segment's header; the rank waiting for every rank's rows (wait_ranks > 0) returns with an error at once — not after its
+    minute's time-out — and the segment can be opened anew."""
+    import time
+    import torch
+    gs = synth.make_genomes(6, 15000, seed=73, d_range=(0.01, 0.2))
+    n = len(gs)
+    name = "/phylonium_amd_test3_%d" % os.getpid()
+    a, b = api.Context(0), api.Context(0)
+    try:
+        for c in (a, b):
+            c.set_genomes(gs)
+            c.set_reference(1)
+            c.anchor()
+        a.result_open(name, create=True, ranks=2)
+        b.result_open(name, create=False, ranks=2)
+        a.result_unlink()
+        tri = torch.empty(a.triangle_words(), dtype=torch.int32, device="cuda:0")
+        a.compare_triangle_device(0, 1, tri.data_ptr())
+        b.result_abandon(1)
+        t0 = time.time()
+        with pytest.raises(api.PhyloniumError, match="gave the pass up"):
+            a.triangle_rows_to_result(tri.data_ptr(), 0, n // 2, 0, 2)
+        assert time.time() - t0 < 5
+        for c in (a, b):
+            c.result_close()
+        a.result_open(name, create=True, ranks=2)  # a new segment under the same name: the old one is gone
+        b.result_open(name, create=False, ranks=2)
+        a.result_unlink()
+        rep = b.triangle_rows_to_result(tri.data_ptr(), n // 2, n, 1, 0)
+        rep = a.triangle_rows_to_result(tri.data_ptr(), 0, n // 2, 0, 2)
+        s, h = a.result_matrices()
+        so, ho = O.Run(gs, 1).process().matrix()
+        assert (s == so).all() and (h == ho).all() and int(rep[3]) == 1
+    finally:
+        a.close()
+        b.close()
+
+
 def test_two_processes_write_their_rows_of_one_shared_result(tmp_path):
     """The result's shared page-locked home across processes (phylo_result_open with a POSIX shared-memory name): two
     processes on the test box's one GPU map and register the same segment, each one's device writes its half of the rows

@@ -18,8 +18,8 @@ NAMES = [  # substring of the kernel's name -> the name bench.py and the library
     ("project_kernel<true>", "pileup_project5"), ("project_kernel", "pileup_project"), ("tile_index_kernel", "pileup_tile_index"),
     ("pairs_mfma_kernel", "pileup_pairs_mfma"), ("bang_correct_kernel", "pileup_bang_correct"),
     ("pairs_kernel<true>", "pileup_pairs_bang"), ("pairs_kernel<false>", "pileup_pairs"), ("pack_triangle_kernel", "result_pack_triangle"),
-    ("sym32_from", "result_sym32"), ("symmetrise_kernel", "result_symmetrise"), ("seqcmp_batch_kernel", "seqcmp_batch"),
-    ("seqcmp_split_kernel", "seqcmp_split"), ("triangle_rows_kernel", "result_rows"), ("matrices_to_home_kernel", "result_to_home"),
+    ("sym32_from", "result_sym32"), ("symmetrise_kernel", "result_symmetrise"), ("seqcmp_pass_kernel", "seqcmp_pass"),
+    ("seqcmp_rounds_kernel", "seqcmp_rounds"), ("seqcmp_one_kernel", "seqcmp_one"), ("triangle_rows_kernel", "result_rows"), ("matrices_to_home_kernel", "result_to_home"),
     ("triangle_to_host_kernel", "result_triangle_to_host"), ("lean_bridge_prepare_kernel", "anchor_bridge_prepare"),
     ("phase_a_report_kernel", "anchor_report"), ("lean_work_kernel", "anchor_work_items"),
 ]
