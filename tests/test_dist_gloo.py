@@ -136,3 +136,48 @@ def test_two_rank_sharded_process_matches_unsharded(tmp_path):
     so, ho = O.Run(gs, 2).process().matrix()
     assert (np.load(out + ".s.npy") == so).all()
     assert (np.load(out + ".h.npy") == ho).all()
+
+
+def _staged_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as td
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from phylonium_amd import dist
+    c = dist.HostStagedCollectives()
+    # the in-place all-gather of process_sharded_device: a rank's own block is a view of the gathered buffer
+    allb = torch.zeros(world * 5, dtype=torch.uint8)
+    own = allb[rank * 5:(rank + 1) * 5]
+    own[:] = torch.arange(5, dtype=torch.uint8) + 10 * rank
+    c.all_gather_into_tensor(allb, own)
+    assert allb.tolist() == [v + 10 * r for r in range(world) for v in range(5)]
+    t = torch.tensor([rank + 1, 7], dtype=torch.int32)
+    c.all_reduce(t, op=td.ReduceOp.SUM)
+    assert t.tolist() == [world * (world + 1) // 2, 7 * world]
+    m = torch.tensor([rank], dtype=torch.int64)
+    c.all_reduce(m, op=td.ReduceOp.MAX)
+    assert int(m) == world - 1
+    r = torch.tensor([1], dtype=torch.int32)
+    c.reduce(r, dst=0, op=td.ReduceOp.SUM)
+    assert rank != 0 or int(r) == world
+    name = ["x%d" % rank]
+    c.broadcast_object_list(name, src=0)
+    assert name == ["x0"]
+    if rank == 0:
+        open(out, "w").write("ok")
+    td.destroy_process_group()
+
+
+def test_staged_collectives_keep_torch_distributeds_semantics(tmp_path):
+    """dist.HostStagedCollectives — the stand-in that lets several rank processes share one GPU in the -m gpu tests of
+    dist.process_sharded_device — behaves like the torch.distributed calls it replaces (CPU tensors here: the staging copy is
+    the identity): the in-place all-gather of a view of its own output, all-reduce (sum, max), reduce, object broadcast."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "ok")
+    mp.spawn(_staged_worker, args=(2, port, out), nprocs=2, join=True)
+    assert open(out).read() == "ok"

@@ -131,8 +131,9 @@ def test_seqcmp_batch_all_lengths_and_alignments(ctx):
     b[idx] = rng.choice(alpha, int(idx.sum()))
     ctx.set_genomes([a, b])
     ga, oa, gb, ob, ln, rv, want = [], [], [], [], [], [], []
-    for n in list(range(0, 301)) + [511, 512, 513, 1023, 1024, 1025, 4096, 5000]:
-        for offa, offb in ((0, 0), (1, 0), (3, 7), (13, 2), (64, 65)):
+    # (a round of the batch kernel is 63 chunks = 1008 bytes, a wavefront's pass four rounds: lengths around both)
+    for n in list(range(0, 301)) + [511, 512, 513, 991, 992, 993, 1007, 1008, 1009, 1023, 1024, 1025, 2015, 2016, 2017, 4031, 4032, 4033, 4096, 5000]:
+        for offa, offb in ((0, 0), (1, 0), (3, 7), (13, 2), (64, 65), (2, 2), (6, 1)):
             if max(offa, offb) + n > 6000:
                 continue
             for rev in (0, 1):
@@ -144,9 +145,10 @@ def test_seqcmp_batch_all_lengths_and_alignments(ctx):
 
 
 def test_seqcmp_batch_few_long_segments_are_split_over_the_wavefronts(ctx):
-    """Fewer segments than the launch has wavefronts, and long ones: their 4 KiB pieces are dealt out over all wavefronts
-    (seqcmp_split_kernel) — lengths around the piece size, an empty segment between others, every alignment, both
-    directions, a segment of megabytes beside one of a byte; and one call with a single segment (one seqcmp())."""
+    """A few long segments: their rounds are dealt out over all wavefronts, four rounds a pass (seqcmp_pass_kernel) — lengths
+    around the pass's size, empty segments between others (the rounds' hint walks over them), every alignment, both
+    directions, a segment of megabytes beside one of a byte; and one call with a single segment (one seqcmp():
+    seqcmp_one_kernel)."""
     rng = np.random.default_rng(11)
     alpha = np.frombuffer(b"ACGT!", np.uint8)
     L = 3_600_000
@@ -169,6 +171,33 @@ def test_seqcmp_batch_few_long_segments_are_split_over_the_wavefronts(ctx):
     for rev in (0, 1):
         got = ctx.seqcmp_batch([0], [5], [1], [2], [L - 5], [rev])
         assert got.tolist() == [(O.revseqcmp if rev else O.seqcmp)(a[5:], b[2:L - 3], L - 5)]
+
+
+def test_seqcmp_batch_of_ragged_short_segments(ctx):
+    """The shape evo_model::account produces (src/evo_model.cxx:55): thousands of segments of 0.1-10 kbp at any byte offset,
+    a tenth reversed, empty ones among them, '!' in the strings — a wavefront's pass holds rounds of up to four different
+    segments, every lane's 16 bytes are cut out of dword-aligned loads and its neighbour's; every tally against the oracle."""
+    rng = np.random.default_rng(12)
+    alpha = np.frombuffer(b"ACGT!", np.uint8)
+    L = 400_000
+    gs = [rng.choice(alpha, L, p=[.24, .24, .24, .24, .04]) for _ in range(3)]
+    gs[1][::7] = gs[0][::7]
+    gs[2] = synth.revcomp(gs[0])  # (so that reversed segments meet complements)
+    ctx.set_genomes(gs)
+    NS = 6000
+    ln = np.minimum(10000, np.maximum(0, rng.exponential(2600, NS))).astype(np.int64)
+    ln[rng.random(NS) < 0.03] = 0
+    short = rng.random(NS) < 0.05
+    ln[short] = rng.integers(1, 40, int(short.sum()))
+    ga, gb = rng.integers(0, 3, NS), rng.integers(0, 3, NS)
+    oa = (rng.random(NS) * (L - ln)).astype(np.int64)
+    ob = (rng.random(NS) * (L - ln)).astype(np.int64)
+    rv = (rng.random(NS) < 0.1).astype(np.uint8)
+    got = ctx.seqcmp_batch(ga, oa, gb, ob, ln, rv)
+    for s in range(NS):
+        x, y = gs[ga[s]][oa[s]:oa[s] + ln[s]], gs[gb[s]][ob[s]:ob[s] + ln[s]]
+        want = O.revseqcmp(x, y, int(ln[s])) if rv[s] else O.seqcmp(x, y, int(ln[s]))
+        assert int(got[s]) == want, (s, int(ln[s]), int(oa[s]) % 4, int(ob[s]) % 4, int(rv[s]))
 
 
 def test_b0_reference_signatures(ctx):
