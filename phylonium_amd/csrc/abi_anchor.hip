@@ -347,7 +347,12 @@ int phyabi::anchor_impl(phylo_ctx *c, size_t q_begin, size_t q_end, int defer)
 			// 0.12 ms; counted with the subject it was one block each, 0.19 ms — on the rank that also fetches the result.)
 			uint32_t fold_nb = c->opt_fold_blocks;
 			const uint32_t nq_real = std::max<uint32_t>(1, (uint32_t)c->plan_nq_real);
-			if (!fold_nb) fold_nb = 2 * nq_real <= (uint32_t)c->n_cu ? (uint32_t)std::min<size_t>(8, (size_t)c->n_cu / nq_real) : 1u;
+			// (a power of two up to sixteen — round 6: eight queries of 100 Mbp, a rank's eighth of C5: 8 blocks each 0.746 ms, 12: 0.735,
+			// 16: 0.607, 24: 0.604, 32: 1.14; c5s's sixteen queries 0.238 -> 0.201; four queries of 5 Mbp the same)
+			if (!fold_nb) {
+				fold_nb = 1;
+				while (2 * fold_nb <= 16 && 2 * fold_nb * nq_real <= (uint32_t)c->n_cu) fold_nb *= 2;
+			}
 			launch_fold(A, j0, j1, c->L, c->threshold, c->a_raw.p, c->a_out_base.p, c->a_out_cap.p, c->a_out_cnt.p, sg, fold_nb, nch == 0);
 		}
 		if (device_filter) {

@@ -813,7 +813,7 @@ def test_device_resident_exchange_between_two_contexts():
             c.close()
 
 
-@pytest.mark.parametrize("blocks", [1, 2, 5, 8])
+@pytest.mark.parametrize("blocks", [1, 2, 5, 8, 16])
 def test_fold_with_several_blocks_per_query(ctx, blocks):
     """Queries of 1.2 Mbp at low divergence leave tens of thousands of anchors in one window of chunks: the fold's
     iterations are split over `blocks` blocks per query, each finding the carry in front of its part (last anchor, its
