@@ -1405,6 +1405,48 @@ def test_fuzz_small_random_sets(ctx, seed):
     check_process(ctx, gs, ref, chunk=chunk, kmer=kmer, backend=backend, threshold=threshold)
 
 
+@pytest.mark.parametrize("world", [2, 3, 5, 6])
+def test_fuzz_group_passes(world):
+    """The C++ group's pass (csrc/group.hip) over randomised sets — genome count (fewer genomes than ranks among them: ranks
+    with an empty block), lengths, divergence, contigs, duplicates, an unrelated short genome, a tied-start query — and
+    randomised options: four passes each (the first plans, the others are queued), against the oracle's matrices and lists;
+    one group serves all sets (the plan, the route and the result's home follow the changes of genomes and reference)."""
+    with api.Group(world) as g:
+        for seed in range(8):
+            rng = np.random.default_rng(7000 + 31 * world + seed)
+            n = int(rng.integers(2, 12))
+            length = int(rng.integers(400, 20000))
+            gs = synth.make_genomes(n, length, seed=3000 + seed, d_range=(0.001, float(rng.choice([0.02, 0.1, 0.3]))), tree=bool(rng.integers(0, 2)),
+                                    indel_per_mbp=float(rng.choice([0, 500, 3000])), inv_frac=float(rng.choice([0, 0.05, 0.3])),
+                                    contigs=int(rng.choice([1, 2, 5])) if length > 2000 else 1, inv_len=(50, max(60, length // 10)))
+            if rng.random() < 0.4:
+                gs.append(gs[int(rng.integers(0, n))].copy())
+            if rng.random() < 0.3:
+                gs.append(synth.random_base(int(rng.integers(1, 400)), rng))
+            ref = int(rng.integers(0, len(gs)))
+            if rng.random() < 0.3 and len(gs[ref]) > 3000:  # forward + reverse copies of stretches of the reference: tied projected starts
+                clean = gs[ref][gs[ref] != ord("!")]
+                pieces = []
+                for x in range(200, len(clean) - 600, 700):
+                    seg = clean[x:x + 300]
+                    pieces += [synth.random_base(60, rng), seg, synth.random_base(60, rng), synth.revcomp(seg)]
+                gs.append(np.concatenate(pieces + [synth.random_base(100, rng)]))
+            r = O.Run(gs, ref).process()
+            so, ho = r.matrix()
+            g.set_genomes(gs)
+            g.set_option("chunk", int(rng.choice([0, 64, 128, 448])))
+            g.set_option("kmer", int(rng.choice([0, 0, 3, 5])))
+            g.set_reference(ref)
+            for rep in range(4):
+                s, h = g.process() if rep != 2 else g.process_in_place()
+                assert (s == so).all() and (h == ho).all(), (world, seed, rep)
+            c = g.rank_context(int(rng.integers(0, world)))
+            for j in range(len(gs)):
+                assert hom_tuples_gpu(c.homologies(j)) == hom_tuples_orc(r.homologies(j)), (world, seed, j)
+            g.set_option("chunk", 0)
+            g.set_option("kmer", 0)
+
+
 def _nccl_one_rank_worker(rank, world, port, out):
     import torch
     import torch.distributed as td
