@@ -281,6 +281,48 @@ def one_gpu_leg(torch, api, workload, seed, device, local, steps):
                     "of the scaling curve; N > 1 lines carry the same measurement made in their own job (one_gpu_same_workload_ms)"}
 
 
+def b0_leg(ctx, s, h, lens, ref_idx, max_queries=256, reps=5):
+    """Seam B0 on the workload's own segments (the kernel north_star asks an HBM fraction for): the reference's row as
+    evo_model::account / account_rev would call it (src/evo_model.cxx:53-75) — one seqcmp / revseqcmp per homology of up to
+    `max_queries` queries, reference bytes against query bytes — through phylo_seqcmp_batch over the resident genomes.
+    The kernels' time is the library's HIP-event span around them, measured live; 2 bytes per compared site over it is
+    `achieved`; the tallies must add up to the matrix's row."""
+    n = len(lens)
+    qs = [j for j in range(n) if j != ref_idx][:max_queries]
+    ga, oa, gb, ob, ln, rv, cuts = [], [], [], [], [], [], [0]
+    for j in qs:
+        hom = ctx.homologies(j)
+        m = hom.size
+        ga.append(np.full(m, ref_idx, np.uint32))
+        oa.append(hom["index_reference_projected"].astype(np.uint64))
+        gb.append(np.full(m, j, np.uint32))
+        ob.append(hom["index_query"].astype(np.uint64))
+        ln.append(hom["length"].astype(np.uint64))
+        rv.append((hom["direction"] != 0).astype(np.uint8))
+        cuts.append(cuts[-1] + m)
+    ga, oa, gb, ob, ln, rv = (np.concatenate(x) for x in (ga, oa, gb, ob, ln, rv))
+    ctx.set_option("profile", 1)
+    for _ in range(2):
+        sub = ctx.seqcmp_batch(ga, oa, gb, ob, ln, rv)
+    ctx.reset_stats()
+    for _ in range(reps):
+        sub = ctx.seqcmp_batch(ga, oa, gb, ob, ln, rv)
+    ms = ctx.stat("ms:seqcmp_batch") / max(1.0, ctx.stat("n:seqcmp_batch") or 1.0)
+    ok = all(int(sub[cuts[t]:cuts[t + 1]].sum()) == int(s[ref_idx, j]) and int(ln[cuts[t]:cuts[t + 1]].sum()) == int(h[ref_idx, j])
+             for t, j in enumerate(qs))
+    sites = float(ln.sum())
+    return {"bound": "hbm", "kernel": "seqcmp_rounds + seqcmp_pass (csrc/seqcmp_kernels.hip)", "achieved": round(2.0 * sites / (ms * 1e-3) / 1e9, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(2.0 * sites / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms, 4),
+            "segments": int(ln.size), "mean_length": round(sites / max(1, ln.size), 1), "reverse_share": round(float(rv.mean()), 4) if rv.size else 0.0,
+            "alg_bytes_per_launch": 2.0 * sites, "queries": len(qs), "row_identical_to_matrix": bool(ok),
+            "note": "off the default path (phase B is the pileup): the reference's row of the result recomputed by the byte kernels over "
+                    "each query's homologies, 2 B per compared site (SURVEY 8d) over the kernels' HIP-event span, measured in this run.  "
+                    "Of the two strings of a segment the reference's is re-read by every query and stays in the L2 / Infinity Cache "
+                    "(5 MB at c3), so the HBM interface carries about half of these bytes; segments between two queries at random "
+                    "places, where nothing is re-read, run at 0.67 (profiles/r06_seqcmp_bw.json; PMC traffic 1.06 x the algorithmic "
+                    "bytes: profiles/r06_seqcmp_pmc.txt)"}
+
+
 def verify_ranks(torch, api, dist, ctx, s, h, buf, offs, lens, ref_idx, world, local):
     """The result of an N-rank run against two routes that share nothing with the exchange between the ranks:
     (1) the reference's row from rank 0's lists through seam B0 (seqcmp / revseqcmp over the resident genomes, summed over
@@ -412,6 +454,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not time kernels with HIP events")
     ap.add_argument("--no-scaling-baseline", action="store_true", help="one rank on the default workload: skip the extra leg that times the "
                     "several-GPU workload (c4) on this one GPU (`scaling_baseline` in the line)")
+    ap.add_argument("--no-b0", action="store_true", help="skip the seam-B0 leg (the byte kernels over the reference row's own segments: `roofline_b0`)")
     ap.add_argument("--no-wallclock", action="store_true", help="skip the FASTA -> PHYLIP wall-clock leg (the C++ host driver as a child process)")
     ap.add_argument("--check", action="store_true", help="verify a sample of the result against the oracle")
     ap.add_argument("--verify-ranks", action="store_true", help="after the timed steps rank 0 checks the N-rank result by two other routes — "
@@ -890,6 +933,12 @@ def main():
                 cpu = {"value": None, "unit": "Gbp/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
         if args.verify_ranks:
             verdict = verify_ranks(torch, api, dist, ctx, s, h, buf, offs, lens, ref_idx, world, local)
+        roof_b0 = None
+        if world == 1 and not emu and not args.no_b0:
+            try:
+                roof_b0 = b0_leg(ctx, s, h, lens, ref_idx)
+            except Exception as e:  # a report beside the metric, never a reason to lose the bench line
+                roof_b0 = {"bound": "hbm", "frac": None, "note": f"failed: {e!r}"}
         if args.check:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as O
@@ -924,7 +973,7 @@ def main():
             "timing_note": "value / ms_per_step: the K timed steps, HIP events around the chain kernel only (the roofline's kernel); "
                            "`kernels`, roofline_mfma and the held clock come from K more steps with events around every kernel "
                            "(ms_per_step_all_kernels_timed), ms_per_step_noprofile from K steps without any",
-            "roofline": roof, "roofline_valu": roof_valu, "roofline_mfma": roof_mfma, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_valu": roof_valu, "roofline_mfma": roof_mfma, "roofline_b0": roof_b0, "cpu_baseline": cpu,
             "phases_note": ("one rank queues both phases as one call (phylo_anchor_compare): anchor_total is the host's part of "
                             "phase A, compare_total ends with the one wait for both phases' kernels; the kernels' own times "
                             "are under `kernels`") if stats.get("n:anchor_calls_without_a_wait") else None,

@@ -18,5 +18,5 @@ for f in sorted(glob.glob(os.path.join(d, "*.json"))):
         print(name, "unreadable:", e)
         continue
     print(name, b["value"], "Gbp/s", b["ms_per_step"], "ms", "no-profile", b.get("ms_per_step_noprofile"), "n_gpus", b["n_gpus"],
-          "frac", (b.get("roofline") or {}).get("frac"), "valu", (b.get("roofline_valu") or {}).get("frac"),
+          "frac", (b.get("roofline") or {}).get("frac"), "b0", (b.get("roofline_b0") or {}).get("frac"), "valu", (b.get("roofline_valu") or {}).get("frac"),
           "cpu", (b.get("cpu_baseline") or {}).get("value"), {k: round(v["avg_ms"], 3) for k, v in b["kernels"].items()})
