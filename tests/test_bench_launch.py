@@ -54,6 +54,8 @@ def test_two_ranks_started_by_bench_itself_equal_one_rank(tmp_path):
             assert line["rccl_ranks"] in (None, 2)
         else:
             assert line["ranks_ms_per_step"] is None and line["one_gpu_same_workload_ms"] is None
+            # seam B0 measured live on the workload's own segments: the reference's row recomputed by the byte kernels
+            assert line["roofline_b0"]["row_identical_to_matrix"] is True and 0 < line["roofline_b0"]["frac"] <= 1
         # no fraction of the line exceeds 1: what SURVEY 8d's bytes cannot express (phase B, the whole path) is null, not 42
         def fracs(o, path=""):
             if isinstance(o, dict):
