@@ -13,6 +13,7 @@
 // point that does the path's arithmetic launches HIP kernels and fails if no device is usable.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -50,23 +51,53 @@ double now_ms()
 	return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
+#ifdef PHY_DEV_HOOKS
+// PHY_DEBUG_ALLOC=1 (development builds): every device / page-locked allocation and release on stderr, with the process id
+inline void debug_alloc(const char *what, const void *p, size_t bytes)
+{
+	static const bool on = getenv("PHY_DEBUG_ALLOC") != nullptr;
+	if (on) fprintf(stderr, "[phylonium_amd alloc %d] %s %p .. %p (%zu bytes)\n", (int)getpid(), what, p, (const char *)p + bytes, bytes);
+}
+// PHY_DEBUG_POISON=<byte> (development builds): every new device buffer is filled with that byte — a kernel that reads what
+// nobody has written yet (fresh memory is zero in a new process, and whatever was there in a warm one) then fails every time
+inline void debug_poison(void *p, size_t bytes)
+{
+	static const char *e = getenv("PHY_DEBUG_POISON");
+	if (e && p) {
+		(void)hipMemset(p, (int)strtol(e, nullptr, 0), bytes);
+		(void)hipDeviceSynchronize();
+	}
+}
+#else
+inline void debug_alloc(const char *, const void *, size_t) {}
+inline void debug_poison(void *, size_t) {}
+#endif
+
 template <class T> struct DevBuf {
 	T *p = nullptr;
 	size_t cap = 0; // elements
 	hipError_t ensure(size_t n)
 	{
 		if (n <= cap) return hipSuccess;
-		if (p) (void)hipFree(p);
+		if (p) {
+			debug_alloc("free  ", p, cap * sizeof(T));
+			(void)hipFree(p);
+		}
 		p = nullptr;
 		cap = 0;
 		size_t want = n + n / 8 + 16;
 		hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
 		if (e == hipSuccess) cap = want;
+		debug_alloc("malloc", p, want * sizeof(T));
+		if (e == hipSuccess) debug_poison(p, want * sizeof(T));
 		return e;
 	}
 	void release()
 	{
-		if (p) (void)hipFree(p);
+		if (p) {
+			debug_alloc("free  ", p, cap * sizeof(T));
+			(void)hipFree(p);
+		}
 		p = nullptr;
 		cap = 0;
 	}
@@ -91,6 +122,7 @@ template <class T> struct PinBuf {
 		size_t want = n + n / 4 + 64;
 		hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
 		if (e == hipSuccess) cap = want;
+		debug_alloc("pinned", p, want * sizeof(T));
 		return e;
 	}
 	void release()
