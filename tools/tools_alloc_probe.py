@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""dev: one cold one-context process() of thirteen 25 kbp genomes — with the development build and PHY_DEBUG_ALLOC=1 every
+device / page-locked allocation of that call on stderr (addresses, sizes); PHY_DEBUG_POISON=0xff fills new buffers:
+    PHYLONIUM_AMD_LIB=phylonium_amd/libphylonium_amd_dev.so PHY_DEBUG_ALLOC=1 python tools/tools_alloc_probe.py"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
