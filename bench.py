@@ -569,7 +569,13 @@ def main():
         if int(lo.item()) != int(hi.item()):
             raise SystemExit("bench.py: the ranks generated different genomes")
     t_ref = time.time()
-    ctx.set_reference(ref_idx)  # host suffix array + tables: outside the metric
+    if shared:  # (ranks sharing a GPU, tests only: their first — cold — calls of the library in turn, profiles/EXPERIMENTS.md round 6)
+        for turn in range(world):
+            if turn == rank:
+                ctx.set_reference(ref_idx)
+            td.barrier()
+    else:
+        ctx.set_reference(ref_idx)  # suffix array + tables: outside the metric
     t_ref = time.time() - t_ref
     ref_stats = {k: ctx.stat(k) for k in ("ms:ref_suffix_array", "ms:ref_lcp_table", "ms:ref_total", "ms:ref_fetch", "ref:sa_on_device", "ref:sa_rounds")}
     if os.environ.get("BENCH_REF_STATS"):
