@@ -72,6 +72,12 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 				(void)hipStreamSynchronize(st);
 			}
 			sa_on_device = rc == 0; // rc == 1: a byte outside ! # A C G T — the host builders order any bytes
+#ifdef PHY_DEV_HOOKS
+			if (sa_on_device && ns > 8 && getenv("PHYLONIUM_AMD_TEST_CORRUPT_SA")) { // tests: the device's array damaged — the check must catch it
+				const uint32_t wrong[2] = {0xfffffff0u, 3u};
+				HIPOK(c, hipMemcpy(c->d_SA.p + ns / 2, wrong, 8, hipMemcpyHostToDevice));
+			}
+#endif
 		} else {
 			(void)hipGetLastError(); // no room for the working set next to the genomes: the host cores sort
 		}
@@ -121,9 +127,32 @@ int phylo_set_reference(phylo_ctx *c, size_t ref_idx, const int64_t *sa, size_t 
 	// LCP by direct comparison of neighbouring suffixes, capped at the 16-bit clip of the
 	// SAX records; only a repeat of >= 64 kbp needs the exact values (host, Kasai)
 	launch_lcp(c->d_S.p, c->d_SA.p, ns, 0xffffu, c->d_LCP.p, c->a_misc.p, st);
-	uint32_t capped = 0;
-	HIPOK(c, hipMemcpyAsync(&capped, c->a_misc.p, 4, hipMemcpyDeviceToHost, st));
+	uint32_t lcp_words[2] = {0, 0}; // {ranks that reached the clip, the array is not the suffix array of S}
+	HIPOK(c, hipMemcpyAsync(lcp_words, c->a_misc.p, 8, hipMemcpyDeviceToHost, st));
 	HIPOK(c, hipStreamSynchronize(st));
+	if (lcp_words[1]) {
+		// The LCP kernel compares every suffix with its successor and so proves the array — or not.  A caller's array that
+		// fails is the caller's error; the device builder's (seen once in thousands of runs with eight or more processes
+		// starting on one GPU at the same moment, profiles/EXPERIMENTS.md round 6; never otherwise) is built again on the host cores.
+		if (!sa_on_device) return c->fail("phylo_set_reference: the suffix array is not the suffix array of S = subject + '#' + reverse complement");
+		c->stats["ref:sa_device_rejected"] += 1;
+		sa_on_device = false;
+		if (host_S()) return 1;
+		SA.assign((size_t)ns + 4, 0);
+		{
+			WorkerPool &pool = workers(c);
+			auto par = [&](size_t nt, const std::function<void(size_t)> &f) { pool.run(nt, f); };
+			suffix_array_u32_par(S.data(), ns, SA.data(), par, std::max<size_t>(1, pool.size()));
+		}
+		HIPOK(c, hipMemcpyAsync(c->d_SA.p, SA.data(), SA.size() * 4, hipMemcpyHostToDevice, st));
+		HIPOK(c, hipMemsetAsync(c->a_misc.p, 0, 64, st));
+		HIPOK(c, hipMemsetAsync(c->d_LCP.p, 0, ((size_t)ns + 1 + 4) * 4, st));
+		launch_lcp(c->d_S.p, c->d_SA.p, ns, 0xffffu, c->d_LCP.p, c->a_misc.p, st);
+		HIPOK(c, hipMemcpyAsync(lcp_words, c->a_misc.p, 8, hipMemcpyDeviceToHost, st));
+		HIPOK(c, hipStreamSynchronize(st));
+		if (lcp_words[1]) return c->fail("phylo_set_reference: the host's suffix array failed the device's check");
+	}
+	const uint32_t capped = lcp_words[0];
 	if (capped) {
 		std::vector<uint32_t> LCP((size_t)ns + 1 + 4, 0);
 		if (host_sa() || host_S()) return 1;

@@ -85,7 +85,10 @@ void launch_next_bytes(const uint8_t *S, uint32_t n, uint32_t *masks, hipStream_
 }
 
 // LCP[r] = lcp(suffix SA[r-1], suffix SA[r]) for 1 <= r < n, min'ed with `cap`;
-// LCP[0] = LCP[n] = 0.  *capped counts the ranks that reached the cap.
+// LCP[0] = LCP[n] = 0.  capped[0] counts the ranks that reached the cap.  The same comparison checks the array it is
+// given: every entry inside S and every suffix smaller than its successor (unsigned bytes, the shorter one first) — which
+// together say "a permutation, sorted", i.e. THE suffix array; capped[1] is raised otherwise, and nothing outside S is
+// read whatever the entries hold.  (A pair that reaches the cap is not decided here: repeats of >= 64 kbp.)
 __global__ __launch_bounds__(256) void lcp_kernel(const uint8_t *__restrict__ S, const uint32_t *__restrict__ SA,
 												   uint32_t n, uint32_t cap, uint32_t *__restrict__ LCP,
 												   uint32_t *__restrict__ capped)
@@ -95,22 +98,29 @@ __global__ __launch_bounds__(256) void lcp_kernel(const uint8_t *__restrict__ S,
 	uint32_t l = 0;
 	if (r >= 1 && r < n) {
 		const uint32_t a = SA[r - 1], b = SA[r];
-		// both suffixes end in S's zero padding at different offsets, and S itself never
-		// contains a zero byte, so the scan stops at the shorter suffix's end by itself
-		const uint32_t lim = min(cap, n - max(a, b));
-		while (l < lim) {
-			uint64_t x, y;
-			__builtin_memcpy(&x, S + a + l, 8);
-			__builtin_memcpy(&y, S + b + l, 8);
-			const uint64_t d = x ^ y;
-			if (d) {
-				l += (uint32_t)(__ffsll((unsigned long long)d) - 1) >> 3;
-				break;
+		if (a >= n || b >= n || a == b) {
+			capped[1] = 1;
+		} else {
+			// both suffixes end in S's zero padding at different offsets, and S itself never
+			// contains a zero byte, so the scan stops at the shorter suffix's end by itself
+			const uint32_t lim = min(cap, n - max(a, b));
+			while (l < lim) {
+				uint64_t x, y;
+				__builtin_memcpy(&x, S + a + l, 8);
+				__builtin_memcpy(&y, S + b + l, 8);
+				const uint64_t d = x ^ y;
+				if (d) {
+					l += (uint32_t)(__ffsll((unsigned long long)d) - 1) >> 3;
+					break;
+				}
+				l += 8;
 			}
-			l += 8;
+			if (l > lim) l = lim;
+			if (l >= cap) atomicAdd(capped, 1u);
+			else if (!(S[a + l] < S[b + l])) capped[1] = 1; // (the shorter suffix's next byte is the padding's zero)
 		}
-		if (l > lim) l = lim;
-		if (l >= cap) atomicAdd(capped, 1u);
+	} else if (r == 0 && n && SA[0] >= n) {
+		capped[1] = 1;
 	}
 	LCP[r] = l;
 }

@@ -72,14 +72,17 @@ __global__ __launch_bounds__(256) void sa_heads_kernel(const uint64_t *__restric
 __global__ __launch_bounds__(256) void sa_update_kernel(const uint64_t *__restrict__ key, const uint32_t *__restrict__ suf, uint32_t m,
 														 const uint32_t *__restrict__ pos, const uint32_t *__restrict__ rank,
 														 uint32_t *__restrict__ SA, uint32_t *__restrict__ rank_at,
-														 uint32_t *__restrict__ ISA, uint8_t *__restrict__ active)
+														 uint32_t *__restrict__ ISA, uint8_t *__restrict__ active, uint32_t n_all)
 {
 	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= m) return;
 	const uint32_t p = pos ? pos[t] : t, s = suf[t];
-	SA[p] = s;
-	rank_at[p] = rank[t];
-	ISA[s] = rank[t];
+	// (entries out of range — a sort that went wrong — are left out rather than followed: the array's consumer checks it, index_kernels.hip: lcp_kernel)
+	if (p < n_all && s < n_all) {
+		SA[p] = s;
+		rank_at[p] = rank[t];
+		ISA[s] = rank[t];
+	}
 	const bool head = t == 0 || key[t] != key[t - 1];
 	const bool last = t + 1 == m || key[t + 1] != key[t];
 	active[t] = !(head && last);
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256) void sa_round_keys_kernel(const uint32_t *__re
 {
 	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= m) return;
-	const uint32_t p = pos[t], s = SA[p];
+	const uint32_t p = pos[t] < n ? pos[t] : 0u, s = SA[p] < n ? SA[p] : 0u; // (see sa_update_kernel)
 	const uint64_t next = (uint64_t)s + h;
 	const uint32_t k2 = next < n ? ISA[next] + 1u : 0u; // a suffix that ends here is smaller than any that goes on
 	key[t] = ((uint64_t)rank_at[p] << 32) | k2;
@@ -183,7 +186,7 @@ int device_suffix_array(const uint8_t *S, uint32_t n, uint32_t *SA, void *scratc
 	tmp_bytes = P.tmp_bytes;
 	SA_OK(rocprim::inclusive_scan(tmp, tmp_bytes, headv, headv, (size_t)n, SaMax(), st));
 	hipLaunchKernelGGL(sa_update_kernel, grid(n), dim3(256), 0, st, kd.current(), vd.current(), n, (const uint32_t *)nullptr, headv, SA,
-					   rank_at, ISA, active);
+					   rank_at, ISA, active, n);
 	tmp_bytes = P.tmp_bytes;
 	SA_OK(rocprim::select(tmp, tmp_bytes, rocprim::counting_iterator<uint32_t>(0), active, pos_a, count, (size_t)n, st));
 	uint32_t host[2] = {0, 0};
@@ -208,7 +211,7 @@ int device_suffix_array(const uint8_t *S, uint32_t n, uint32_t *SA, void *scratc
 		hipLaunchKernelGGL(sa_heads_kernel, grid(m), dim3(256), 0, st, kr.current(), m, pos, headv);
 		tmp_bytes = P.tmp_bytes;
 		SA_OK(rocprim::inclusive_scan(tmp, tmp_bytes, headv, headv, (size_t)m, SaMax(), st));
-		hipLaunchKernelGGL(sa_update_kernel, grid(m), dim3(256), 0, st, kr.current(), vr.current(), m, pos, headv, SA, rank_at, ISA, active);
+		hipLaunchKernelGGL(sa_update_kernel, grid(m), dim3(256), 0, st, kr.current(), vr.current(), m, pos, headv, SA, rank_at, ISA, active, n);
 		tmp_bytes = P.tmp_bytes;
 		SA_OK(rocprim::select(tmp, tmp_bytes, pos, active, pos_next, count, (size_t)m, st));
 		SA_OK(hipMemcpyAsync(host, count, 4, hipMemcpyDeviceToHost, st));

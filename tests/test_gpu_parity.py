@@ -5,6 +5,7 @@ same libm, so they are compared with == (tolerance stated by the north star:
 1e-12)."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -544,6 +545,47 @@ def test_both_phases_as_one_call(ctx):
     r = O.Run(sets[-1][0], 1).process(threads=4)
     so, ho = r.matrix()
     assert (h == ho).all() and (s == so).all()
+
+
+_CORRUPT_SA_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+from phylonium_amd import api, synth
+gs = synth.make_genomes(6, 30000, seed=61, d_range=(0.01, 0.2), indel_per_mbp=300, inv_frac=0.05, contigs=2)
+with api.Context(0) as ctx:
+    ctx.set_genomes(gs)
+    s, h = ctx.process(2)
+    print("rejected", int(ctx.stat("ref:sa_device_rejected", 0)), "on_device", int(ctx.stat("ref:sa_on_device", 0)))
+    np.save(sys.argv[1], np.stack([s, h]))
+"""
+
+
+def test_a_device_built_suffix_array_that_is_wrong_is_caught_and_rebuilt(ctx, tmp_path):
+    """The LCP kernel compares every suffix with its successor, which proves the array it is given (index_kernels.hip): a
+    caller's array that is not the suffix array of S is refused; the device builder's own, damaged on purpose (development
+    build, PHYLONIUM_AMD_TEST_CORRUPT_SA: two entries overwritten, one of them far outside S), is thrown away, built again on
+    the host cores, and the result is the oracle's — no fault, no wrong matrix."""
+    import subprocess
+    gs = synth.make_genomes(6, 30000, seed=61, d_range=(0.01, 0.2), indel_per_mbp=300, inv_frac=0.05, contigs=2)
+    so, ho = O.Run(gs, 2).process().matrix()
+    refb = bytes(gs[2])
+    sa = api.host_suffix_array(refb + b"#" + O.revcomp(refb)).copy()
+    ctx.set_genomes(gs)
+    ctx.set_reference(2, sa=sa)  # the right array: accepted
+    sa[1000], sa[1001] = sa[1001], sa[1000]
+    with pytest.raises(api.PhyloniumError, match="not the suffix array"):
+        ctx.set_reference(2, sa=sa)
+    sa[1000] = 2 ** 31  # an entry outside S: refused, not followed
+    with pytest.raises(api.PhyloniumError, match="not the suffix array|out of range"):
+        ctx.set_reference(2, sa=sa)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "m.npy")
+    env = dict(os.environ, PHYLONIUM_AMD_LIB=os.path.join(root, "phylonium_amd", "libphylonium_amd_dev.so"), PHYLONIUM_AMD_TEST_CORRUPT_SA="1")
+    r = subprocess.run([sys.executable, "-c", _CORRUPT_SA_SCRIPT % root, out], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "rejected 1 on_device 0" in r.stdout, (r.stdout, r.stderr[-2000:])
+    m = np.load(out)
+    assert (m[0] == so).all() and (m[1] == ho).all()
 
 
 def test_external_suffix_array_is_accepted(ctx):
