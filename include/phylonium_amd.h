@@ -129,7 +129,9 @@ int phylo_get_genome(phylo_ctx *ctx, size_t i, char *buf);
  * exactly what divsufsort64 returns at src/esa.cxx:74; NULL builds it on the
  * device (option "sa_builder" = 1, the default: prefix doubling over radix sorts, csrc/sa_kernels.hip) or on the
  * host cores ("sa_builder" = 0: bucket sort / SA-IS). threshold 0 computes
- * min_anchor_length(0.025, gc, 2L+1) as src/process.cxx:416-417. */
+ * min_anchor_length(0.025, gc, 2L+1) as src/process.cxx:416-417.  The array is checked on the device while the LCP
+ * values are made (every suffix against its successor): one that is not the suffix array of S makes the call fail; a
+ * device-built one that fails is built again on the host cores. */
 int phylo_set_reference(phylo_ctx *ctx, size_t ref_idx, const int64_t *sa, size_t threshold);
 size_t phylo_threshold(const phylo_ctx *ctx);
 /* The suffix array the current reference's index was built from (2L+1 entries, as divsufsort64 would return
